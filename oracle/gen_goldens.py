@@ -1,0 +1,374 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (run only in the build container).
+
+TEST INFRASTRUCTURE ONLY.  Imports /root/reference (read-only) with three import stubs from
+oracle/_stubs (cv2, seaborn: never called on this path; loralib: restated 0.1.1 Conv2d, PARITY
+UNPINNED), drives the reference's own ``YNetTrainer._train`` / ``train_epoch`` / ``evaluate`` on
+seeded synthetic scenes, checks that oracle/ynet_oracle.py reproduces every captured quantity, and
+writes inputs + expected outputs as fixtures.  Fixtures are data only: no reference source travels.
+
+    python oracle/gen_goldens.py            # rewrites tests/golden/
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pandas as pd
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(HERE, "_stubs"), REF, ROOT]
+
+from models.trainer import YNetTrainer                                   # noqa: E402  (reference)
+from utils.train_epoch import train_epoch as ref_train_epoch             # noqa: E402  (reference)
+from utils.evaluate import evaluate as ref_evaluate                      # noqa: E402  (reference)
+from utils.image_utils import (create_dist_mat, create_gaussian_heatmap_template,   # noqa: E402
+                               get_patch as ref_get_patch)
+from utils.softargmax import SoftArgmax2D as RefSoftArgmax               # noqa: E402
+
+from oracle import ynet_oracle as O                                      # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+FULL_LIMIT = 40000
+STRIDE = 5
+
+
+def pack(store, name, t):
+    a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    if a.size <= FULL_LIMIT:
+        store[name] = a
+    else:
+        flat = a.reshape(-1)
+        store[name + "__strided"] = flat[::STRIDE].copy()
+        store[name + "__shape"] = np.array(a.shape)
+        store[name + "__sum"] = np.array(flat.astype(np.float64).sum())
+        store[name + "__sqsum"] = np.array((flat.astype(np.float64) ** 2).sum())
+
+
+def check(name, got, want, rtol=1e-5, atol=1e-6):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max() if got.size else 0.0
+    ok = np.allclose(got, want, rtol=rtol, atol=atol)
+    print(f"    oracle vs reference {name:42s} max|d|={err:.3e} {'ok' if ok else 'MISMATCH'}")
+    assert ok, name
+    return err
+
+
+def ref_params(cfg, batch_size, lr=1e-3, n_goal=20, n_traj=1):
+    return dict(
+        obs_len=cfg.obs_len, pred_len=cfg.pred_len, segmentation_model_fp=None, use_features_only=False,
+        n_semantic_classes=cfg.n_classes, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
+        waypoints=list(cfg.waypoints), train_net=cfg.train_net, position=list(cfg.position),
+        network=cfg.network, n_fusion=cfg.n_fusion, resize_factor=cfg.resize_factor,
+        ckpt_path=None, dataset_name="sdd", batch_size=batch_size, lr=lr, n_epoch=1, n_goal=n_goal,
+        n_traj=n_traj, kernlen=cfg.kernlen, nsig=cfg.nsig, e_unfreeze=10000, loss_scale=cfg.loss_scale,
+        temperature=cfg.temperature, use_raw_data=False, save_every_n=1000, fine_tune=True,
+        augment=False, ynet_bias=False, use_CWS=False, CWS_params=None, steps=[20], n_round=1,
+        rel_threshold=0.01, use_TTST=False)
+
+
+def loader_for(traj):
+    meta = pd.DataFrame({"metaId": np.arange(traj.shape[0])})
+    return [(traj.clone(), [meta], "scene0")]
+
+
+class Capture:
+    """Forward hooks on the reference model; keeps the FIRST call of each sub-network."""
+
+    def __init__(self, model):
+        self.data, self.soft = {}, []
+        def keep(key, fn):
+            def hook(m, i, o):
+                if key not in self.data:
+                    self.data[key] = fn(o)
+            return hook
+
+        def soft(m, i, o):
+            self.soft.append(o.detach().clone())
+
+        self.h = [
+            model.encoder.register_forward_hook(keep("features", lambda o: [t.detach().clone() for t in o])),
+            model.goal_decoder.register_forward_hook(keep("goal_map", lambda o: o.detach().clone())),
+            model.traj_decoder.register_forward_hook(keep("traj_map", lambda o: o.detach().clone())),
+            model.softargmax_.register_forward_hook(soft),
+        ]
+
+    def close(self):
+        for h in self.h:
+            h.remove()
+
+
+def make_case(tag, cfg, H, W, B, seed, lora_b_std=0.05, lr=1e-3, n_goal=20, do_epoch=True, do_eval=True):
+    print(f"[{tag}] network={cfg.network} train_net={cfg.train_net} position={list(cfg.position)} {H}x{W} B={B}")
+    store = {}
+    sd0 = O.make_state_dict(cfg, seed=seed, lora_b_std=lora_b_std)
+    scene = O.synthetic_scene(cfg, H, W, seed)
+    traj = O.synthetic_trajectories(cfg, B, H, W, seed)
+    S = cfg.template_size
+    meta = dict(obs_len=cfg.obs_len, pred_len=cfg.pred_len, waypoints=list(cfg.waypoints), enc=list(cfg.enc),
+                dec=list(cfg.dec), network=cfg.network, n_fusion=cfg.n_fusion or 0, train_net=cfg.train_net,
+                position=list(cfg.position), resize_factor=cfg.resize_factor, temperature=cfg.temperature,
+                loss_scale=cfg.loss_scale, H=H, W=W, B=B, seed=seed, lr=lr, n_goal=n_goal,
+                lora_source="oracle/_stubs/loralib (restated 0.1.1, PARITY UNPINNED)")
+    store["meta"] = np.array(repr(meta))
+    for k, v in sd0.items():
+        store["sd/" + k] = v.numpy()
+    store["scene"] = scene.numpy()
+    store["traj"] = traj.numpy()
+
+    # -------- one step through the reference's YNetTrainer._train (freeze policy + Adam + ckpt) --------
+    params = ref_params(cfg, batch_size=B, lr=lr, n_goal=n_goal)
+    with contextlib.redirect_stdout(io.StringIO()) as log:
+        trainer = YNetTrainer(params, device=torch.device("cpu"))
+    missing = trainer.model.load_state_dict(sd0, strict=True)
+    images = {"scene0": scene[0].clone()}
+    trainer.prepare_data = lambda *a, **k: (images, loader_for(traj), None)
+    cap = Capture(trainer.model)
+    with tempfile.TemporaryDirectory() as tmp:
+        params["ckpt_path"] = tmp
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()) as log:
+            trainer._train(None, None, None, None, "exp", **{k: v for k, v in params.items()})
+        ck = torch.load(os.path.join(tmp, "exp.pt"), weights_only=False)
+        ck_keys = list(ck.keys())
+        ck_is_param = [isinstance(v, torch.nn.Parameter) for v in ck.values()]
+    cap.close()
+    out = log.getvalue()
+    n_train_line = [l for l in out.splitlines() if "number of trainable parameters" in l][0]
+    n_trainable = int(n_train_line.split(":")[1])
+    model = trainer.model
+    tr_names = [n for n, p in model.named_parameters() if p.requires_grad]
+    # oracle
+    in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+    ref_in_t = torch.Tensor(create_dist_mat(size=S))
+    ref_gt_t = torch.Tensor(create_gaussian_heatmap_template(size=S, kernlen=cfg.kernlen, nsig=cfg.nsig, normalize=False))
+    assert torch.equal(in_t, ref_in_t), "dist template not bit-exact"
+    assert torch.equal(gt_t, ref_gt_t), "gaussian template not bit-exact"
+    o_names = O.trainable_names(cfg, sd0)
+    assert o_names == tr_names, (o_names, tr_names)
+    assert n_trainable == sum(sd0[n].numel() for n in o_names)
+    st = O.train_step(sd0, cfg, scene, traj, in_t, gt_t, o_names, keep_maps=True)
+    for i, (a, b) in enumerate(zip(st["features"], cap.data["features"])):
+        check(f"features[{i}]", a, b)
+        pack(store, f"step/features{i}", b)
+    check("goal_map", st["goal_map"], cap.data["goal_map"])
+    check("traj_map", st["traj_map"], cap.data["traj_map"])
+    pack(store, "step/goal_map", cap.data["goal_map"])
+    pack(store, "step/traj_map", cap.data["traj_map"])
+    check("softargmax(traj)", st["pred_traj"], cap.soft[0])
+    check("softargmax(goal)", st["pred_goal"], cap.soft[1])
+    store["step/pred_traj"], store["step/pred_goal"] = cap.soft[0].numpy(), cap.soft[1].numpy()
+    named = dict(model.named_parameters())
+    for n in tr_names:
+        check("grad " + n, st["grads"][n], named[n].grad, rtol=1e-4, atol=1e-6)
+        store["step/grad/" + n] = named[n].grad.numpy()
+        m0 = torch.zeros_like(sd0[n])
+        p1, _, _ = O.adam_update(sd0[n], st["grads"][n], m0, m0.clone(), 1, lr)
+        # _train reloads nothing when best_epoch == 0, so the model holds the post-step weights
+        check("adam " + n, p1, named[n].detach(), rtol=1e-5, atol=1e-7)
+        store["step/after/" + n] = named[n].detach().numpy()
+    store["step/trainable"] = np.array(tr_names)
+    store["step/n_trainable"] = np.array(n_trainable)
+    store["step/ckpt_keys"] = np.array(ck_keys)
+    store["step/ckpt_is_parameter"] = np.array(ck_is_param)
+    # scalar losses straight from the reference's train_epoch on a fresh copy of the weights
+    tr2 = fresh_reference(cfg, sd0, B, lr, o_names)
+    opt = torch.optim.Adam(tr2.parameters(), lr=lr)
+    ade, fde, loss = ref_train_epoch(
+        tr2, loader_for(traj), images, opt, torch.nn.BCEWithLogitsLoss(), cfg.loss_scale, torch.device("cpu"),
+        "sdd", None, ref_gt_t, ref_in_t, list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B, 10000,
+        cfg.resize_factor, cfg.network, False)
+    check("step loss", st["loss"], loss, rtol=1e-6)
+    check("step ADE", st["ade"].mean(), ade, rtol=1e-6)
+    check("step FDE", st["fde"].mean(), fde, rtol=1e-6)
+    store["step/loss"], store["step/ade"], store["step/fde"] = np.array(loss), np.array(ade), np.array(fde)
+    store["step/goal_loss"], store["step/traj_loss"] = st["goal_loss"].numpy(), st["traj_loss"].numpy()
+
+    # -------- a ragged epoch: N = 2B+1 trajectories, batch_size B -> 3 Adam steps --------
+    if do_epoch:
+        N = 2 * B + 1
+        traj_e = O.synthetic_trajectories(cfg, N, H, W, seed + 7)
+        tr3 = fresh_reference(cfg, sd0, B, lr, o_names)
+        opt = torch.optim.Adam(tr3.parameters(), lr=lr)
+        ade, fde, loss = ref_train_epoch(
+            tr3, loader_for(traj_e), images, opt, torch.nn.BCEWithLogitsLoss(), cfg.loss_scale, torch.device("cpu"),
+            "sdd", None, ref_gt_t, ref_in_t, list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B, 10000,
+            cfg.resize_factor, cfg.network, False)
+        # oracle epoch
+        sd = {k: v.clone() for k, v in sd0.items()}
+        ms = {n: torch.zeros_like(sd[n]) for n in o_names}
+        vs = {n: torch.zeros_like(sd[n]) for n in o_names}
+        ades, fdes, tot = [], [], 0.0
+        for step, i in enumerate(range(0, N, B), 1):
+            r = O.train_step(sd, cfg, scene, traj_e[i:i + B], in_t, gt_t, o_names)
+            for n in o_names:
+                sd[n], ms[n], vs[n] = O.adam_update(sd[n], r["grads"][n], ms[n], vs[n], step, lr)
+            ades.append(r["ade"]); fdes.append(r["fde"]); tot = tot + r["loss"]
+        check("epoch ADE", torch.cat(ades).mean(), ade, rtol=1e-5)
+        check("epoch FDE", torch.cat(fdes).mean(), fde, rtol=1e-5)
+        check("epoch loss", tot, loss, rtol=1e-5)
+        named3 = dict(tr3.named_parameters())
+        for n in o_names:
+            check("epoch param " + n, sd[n], named3[n].detach(), rtol=1e-4, atol=1e-6)
+            store["epoch/after/" + n] = named3[n].detach().numpy()
+        store["epoch/traj"] = traj_e.numpy()
+        store["epoch/ade"], store["epoch/fde"], store["epoch/loss"] = np.array(ade), np.array(fde), np.array(loss)
+
+    # -------- evaluation sweep (K = n_goal) with the reference's own sampling --------
+    if do_eval:
+        tr4 = fresh_reference(cfg, sd0, B, lr, o_names)
+        cap = Capture(tr4)
+        torch.manual_seed(seed + 3)
+        ade, fde, df, td = ref_evaluate(
+            tr4, loader_for(traj), images, torch.device("cpu"), "sdd", None, ref_in_t, list(cfg.waypoints), "test",
+            n_goal, 1, cfg.obs_len, B, cfg.resize_factor, cfg.temperature, False, False, 0.01, None,
+            return_preds=True, return_samples=True, network=cfg.network)
+        cap.close()
+        wps = torch.from_numpy(td["waypoint_sample"]).permute(2, 0, 1, 3).contiguous()   # [K,B,nwp,2]
+        ev = O.eval_batch(sd0, cfg, scene, traj, in_t, n_goal=n_goal, waypoint_samples=wps)
+        check("eval goal_map", ev["goal_map"], td["goal_map"])
+        check("eval trajs", ev["trajs"], torch.stack(cap.soft), rtol=1e-5, atol=2e-5)
+        check("eval ade/traj", ev["ade"], df["ade"].to_numpy(), rtol=1e-5, atol=2e-5)
+        check("eval fde/traj", ev["fde"], df["fde"].to_numpy(), rtol=1e-5, atol=2e-5)
+        # the sampler itself, re-seeded: multinomial on the oracle's sigmoid map must redraw the same points
+        torch.manual_seed(seed + 3)
+        ev2 = O.eval_batch(sd0, cfg, scene, traj, in_t, n_goal=n_goal)
+        assert torch.equal(ev2["waypoint_samples"], wps), "sampling restatement diverges from the reference"
+        store["eval/waypoint_samples"] = wps.numpy()
+        pack(store, "eval/goal_map", torch.from_numpy(td["goal_map"]))
+        store["eval/trajs"] = torch.stack(cap.soft).numpy()
+        store["eval/ade_per_traj"], store["eval/fde_per_traj"] = df["ade"].to_numpy(), df["fde"].to_numpy()
+        store["eval/ade"], store["eval/fde"] = np.array(ade), np.array(fde)
+        store["eval/seed"] = np.array(seed + 3)
+
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def fresh_reference(cfg, sd0, B, lr, trainable):
+    with contextlib.redirect_stdout(io.StringIO()):
+        t = YNetTrainer(ref_params(cfg, B, lr), device=torch.device("cpu"))
+    t.model.load_state_dict(sd0, strict=True)
+    for n, p in t.model.named_parameters():
+        p.requires_grad = n in set(trainable)
+    return t.model
+
+
+def kernel_vectors():
+    """Op-level vectors from the reference's leaf functions (soft-argmax, get_patch, templates)."""
+    store = {}
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 4, 24, 40, generator=g) * 3
+    x[0, 0] = -20
+    x[0, 0, 5, 7] = 50.0                                   # known answer: (7, 5)
+    x[1, 1] *= 10                                          # peaky
+    store["softargmax/x"] = x.numpy()
+    store["softargmax/out"] = RefSoftArgmax(normalized_coordinates=False)(x).numpy()
+    check("softargmax", O.softargmax2d(x), store["softargmax/out"])
+    S = 210
+    dm = torch.Tensor(create_dist_mat(size=S))
+    gm = torch.Tensor(create_gaussian_heatmap_template(size=S, kernlen=31, nsig=4, normalize=False))
+    assert torch.equal(dm, O.dist_template(S)) and torch.equal(gm, O.gaussian_template(S, 31, 4))
+    store["template/dist_S210_sum"] = np.array(float(dm.double().sum()))
+    store["template/gauss_S210_sum"] = np.array(float(gm.double().sum()))
+    store["template/gauss_S210_peak"] = np.array(float(gm.max()))
+    for S_full in (1050, 1386):
+        dmf = torch.Tensor(create_dist_mat(size=S_full))
+        assert torch.equal(dmf, O.dist_template(S_full))
+        store[f"template/dist_S{S_full}_sum"] = np.array(float(dmf.double().sum()))
+        store[f"template/dist_S{S_full}_diag"] = torch.diagonal(dmf).numpy()
+    xy = np.array([[10.5, 3.5], [11.5, 4.5], [0.0, 0.0], [39.49, 23.51], [12.3, 7.8], [2.5, 0.5]], dtype=np.float32)
+    patches = torch.stack(ref_get_patch(dm, xy, 24, 40))
+    assert torch.equal(patches, O.crop_patches(dm, xy, 24, 40))
+    store["patch/xy"] = xy
+    store["patch/dist"] = patches.numpy()
+    store["patch/gauss"] = torch.stack(ref_get_patch(gm, xy, 24, 40)).numpy()
+    np.savez_compressed(os.path.join(OUT, "kernels.npz"), **store)
+    print("  wrote kernels.npz")
+
+
+def fullsize_scalars():
+    """Loss / ADE / FDE / grad norms at the BASELINE.json shapes (small B) for the GPU-side tests."""
+    rows = {}
+    pos5 = ["0", "1", "2", "3", "4"]
+    cases = {
+        "C1_sdd_short_train": (O.sdd_short(train_net="train"), 256, 256, 2),
+        "C2_sdd_short_mosa1": (O.sdd_short(train_net="mosa_1", position=pos5), 256, 256, 2),
+        "C3_sdd_short_mosa4": (O.sdd_short(train_net="mosa_4", position=pos5), 256, 256, 2),
+        "C4_ind_long_fusion_mosa3_scene": (O.ind_long(network="fusion", n_fusion=2, train_net="mosa_3", position=["scene"]), 512, 512, 1),
+        "C5_sdd_long_eval": (O.sdd_long(train_net="train"), 256, 256, 2),
+    }
+    store = {}
+    for tag, (cfg, H, W, B) in cases.items():
+        print(f"[{tag}]")
+        sd0 = O.make_state_dict(cfg, seed=3, lora_b_std=0.05)
+        scene, traj = O.synthetic_scene(cfg, H, W, 3), O.synthetic_trajectories(cfg, B, H, W, 3)
+        S = cfg.template_size
+        in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+        names = O.trainable_names(cfg, sd0)
+        model = fresh_reference(cfg, sd0, B, 1e-3, names)
+        images = {"scene0": scene[0].clone()}
+        store[tag + "/weight_checksum"] = np.array(sum(float(v.double().abs().sum()) for v in sd0.values()))
+        if tag.startswith("C5"):
+            cap = Capture(model)
+            torch.manual_seed(5)
+            ade, fde, df, td = ref_evaluate(
+                model, loader_for(traj), images, torch.device("cpu"), "sdd", None, in_t, list(cfg.waypoints), "test",
+                20, 1, cfg.obs_len, B, cfg.resize_factor, cfg.temperature, False, False, 0.01, None,
+                return_preds=True, return_samples=True, network=cfg.network)
+            cap.close()
+            wps = torch.from_numpy(td["waypoint_sample"]).permute(2, 0, 1, 3).contiguous()
+            ev = O.eval_batch(sd0, cfg, scene, traj, in_t, waypoint_samples=wps)
+            check("eval trajs", ev["trajs"], torch.stack(cap.soft), rtol=1e-5, atol=5e-5)
+            store[tag + "/waypoint_samples"] = wps.numpy()
+            store[tag + "/trajs"] = torch.stack(cap.soft).numpy()
+            store[tag + "/ade_per_traj"], store[tag + "/fde_per_traj"] = df["ade"].to_numpy(), df["fde"].to_numpy()
+            store[tag + "/ade"], store[tag + "/fde"] = np.array(ade), np.array(fde)
+            continue
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        ade, fde, loss = ref_train_epoch(
+            model, loader_for(traj), images, opt, torch.nn.BCEWithLogitsLoss(), cfg.loss_scale, torch.device("cpu"),
+            "sdd", None, gt_t, in_t, list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B, 10000,
+            cfg.resize_factor, cfg.network, False)
+        st = O.train_step(sd0, cfg, scene, traj, in_t, gt_t, names)
+        check("loss", st["loss"], loss, rtol=1e-6)
+        check("ADE", st["ade"].mean(), ade, rtol=1e-6)
+        named = dict(model.named_parameters())
+        gn = []
+        for n in names:
+            check("grad " + n, st["grads"][n], named[n].grad, rtol=1e-4, atol=1e-6)
+            gn.append(float(named[n].grad.double().norm()))
+        store[tag + "/loss"], store[tag + "/ade"], store[tag + "/fde"] = np.array(loss), np.array(ade), np.array(fde)
+        store[tag + "/grad_names"], store[tag + "/grad_norms"] = np.array(names), np.array(gn)
+        small = [n for n in names if sd0[n].numel() <= 4096][:12]
+        for n in small:
+            store[tag + "/grad/" + n] = named[n].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "fullsize_scalars.npz"), **store)
+    print("  wrote fullsize_scalars.npz")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    tiny = dict(enc=(8, 8, 16, 16, 16), dec=(16, 16, 16, 8, 8))
+    pos5 = ["0", "1", "2", "3", "4"]
+    kernel_vectors()
+    make_case("tiny_short_train", O.sdd_short(train_net="train", **tiny), 32, 64, 2, seed=1)
+    make_case("tiny_short_mosa1", O.sdd_short(train_net="mosa_1", position=pos5, **tiny), 32, 64, 2, seed=2)
+    make_case("tiny_short_mosa4_partial", O.sdd_short(train_net="mosa_4", position=["0", "2", "4"], **tiny), 64, 32, 3, seed=3, do_eval=False)
+    make_case("tiny_long_fusion_mosa3_scene", O.ind_long(network="fusion", n_fusion=2, train_net="mosa_3", position=["scene"], **tiny), 32, 64, 2, seed=4)
+    make_case("tiny_long_train", O.sdd_long(train_net="train", **tiny), 64, 64, 2, seed=5, do_epoch=False)
+    make_case("tiny_short_encoder_pos", O.sdd_short(train_net="encoder", position=["1", "3"], **tiny), 32, 32, 2, seed=6, do_eval=False)
+    make_case("tiny_fusion_scene_only", O.sdd_short(network="fusion", n_fusion=2, train_net="scene", **tiny), 32, 32, 2, seed=7, do_eval=False, do_epoch=False)
+    make_case("tiny_short_bias", O.sdd_short(train_net="bias", **tiny), 32, 32, 2, seed=8, do_eval=False, do_epoch=False)
+    fullsize_scalars()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,465 @@
+"""CPU oracle for the Y-Net (+MoSA/LoRA) forward/backward path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``motion-style-transfer_amd/`` may import this file; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do, and only as the
+checker / the timed CPU baseline — never as the shipped path.
+
+It is a *functional* restatement (a state dict of plain tensors + stock ``torch.nn.functional`` ops on
+CPU — the very ATen ops the reference dispatches) of these reference symbols:
+
+  * models/ynet.py:134-151      get_conv2d / loralib.Conv2d      -> :func:`effective_weight`, :func:`conv`
+  * models/ynet.py:170-234      YNetEncoder / YNetEncoderL       -> :func:`encoder`
+  * models/ynet.py:286-395      YNetEncoderFusion (Y-Net-Mod)    -> :func:`encoder`
+  * models/ynet.py:398-471      YNetDecoder                      -> :func:`decoder`
+  * utils/softargmax.py:55-81   SoftArgmax2D.forward             -> :func:`softargmax2d`
+  * utils/image_utils.py:7-63   gkern / templates / get_patch    -> :func:`gaussian_template`,
+                                                                    :func:`dist_template`, :func:`crop_patches`
+  * utils/image_utils.py:110-135 sampling                        -> :func:`sample_coords`
+  * utils/train_epoch.py:44-126 one training step                -> :func:`train_step`
+  * utils/evaluate.py:109-291   one evaluation batch (no TTST/CWS) -> :func:`eval_batch`
+  * models/trainer.py:116-195   freeze policy                    -> :func:`trainable_names`
+  * torch.optim.Adam (trainer.py:197)                            -> :func:`adam_update`
+
+Pinned against the reference itself: ``oracle/gen_goldens.py`` imports /root/reference in the build
+container, runs both on identical seeded inputs, asserts agreement and writes ``tests/golden/*.npz``
+(checked again by ``tests/test_oracle_golden.py`` without the reference).  The LoRA boundary is
+"parity unpinned": loralib 0.1.1 is absent from the tree, see ``oracle/_stubs/loralib``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class Cfg:
+    obs_len: int = 8
+    pred_len: int = 12
+    n_classes: int = 6
+    enc: Sequence[int] = (32, 32, 64, 64, 64)
+    dec: Sequence[int] = (64, 64, 64, 32, 32)
+    waypoints: Sequence[int] = (11,)
+    network: str = "original"          # 'original' | 'fusion'
+    n_fusion: Optional[int] = None
+    train_net: str = "train"
+    position: Sequence[str] = field(default_factory=list)
+    resize_factor: float = 0.25
+    temperature: float = 1.0
+    loss_scale: float = 1000.0
+    kernlen: int = 31
+    nsig: float = 4.0
+
+    @property
+    def n_wp(self) -> int:
+        return len(self.waypoints)
+
+    @property
+    def rank(self) -> Optional[int]:
+        # models/ynet.py:186-189
+        if "mosa" not in self.train_net:
+            return None
+        parts = self.train_net.split("_")
+        return int(parts[1]) if len(parts) > 1 else 1
+
+    @property
+    def template_size(self) -> int:
+        return int(4200 * self.resize_factor)  # models/trainer.py:61
+
+
+def sdd_short(**kw) -> Cfg:
+    return Cfg(obs_len=8, pred_len=12, waypoints=(11,), resize_factor=0.25, temperature=1.0, **kw)
+
+
+def sdd_long(**kw) -> Cfg:
+    return Cfg(obs_len=5, pred_len=30, waypoints=(14, 29), resize_factor=0.25, temperature=1.8, **kw)
+
+
+def ind_long(**kw) -> Cfg:
+    return Cfg(obs_len=5, pred_len=30, waypoints=(14, 29), resize_factor=0.33, temperature=1.8, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# layer tables (state-dict contract)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class ConvSpec:
+    name: str      # state-dict prefix
+    cin: int
+    cout: int
+    k: int
+    layer: str     # the 'l' passed to get_conv2d ('' for decoder convs: never adapted)
+
+
+def encoder_specs(cfg: Cfg) -> List[ConvSpec]:
+    ch = list(cfg.enc)
+    out: List[ConvSpec] = []
+    if cfg.network == "fusion":
+        nsep = len(ch) - cfg.n_fusion - 1
+        for br, cin0 in (("scene", cfg.n_classes), ("motion", cfg.obs_len)):
+            out.append(ConvSpec(f"encoder.{br}_stages.0.0", cin0, ch[0] // 2, 3, br))
+            for i in range(nsep):
+                out.append(ConvSpec(f"encoder.{br}_stages.{i + 1}.1", ch[i] // 2, ch[i + 1] // 2, 3, br))
+                out.append(ConvSpec(f"encoder.{br}_stages.{i + 1}.3", ch[i + 1] // 2, ch[i + 1] // 2, 3, br))
+        for j, i in enumerate(range(nsep, len(ch) - 1)):
+            out.append(ConvSpec(f"encoder.fusion_stages.{j}.1", ch[i], ch[i + 1], 3, "fusion"))
+            out.append(ConvSpec(f"encoder.fusion_stages.{j}.3", ch[i + 1], ch[i + 1], 3, "fusion"))
+    else:
+        out.append(ConvSpec("encoder.stages.0.0", cfg.n_classes + cfg.obs_len, ch[0], 3, "0"))
+        for i in range(len(ch) - 1):
+            out.append(ConvSpec(f"encoder.stages.{i + 1}.1", ch[i], ch[i + 1], 3, str(i + 1)))
+            out.append(ConvSpec(f"encoder.stages.{i + 1}.3", ch[i + 1], ch[i + 1], 3, str(i + 1)))
+    return out
+
+
+def decoder_specs(cfg: Cfg, which: str) -> List[ConvSpec]:
+    extra = cfg.n_wp if which == "traj_decoder" else 0
+    enc = [c + extra for c in cfg.enc][::-1]
+    dec = list(cfg.dec)
+    center = enc[0]
+    out = [ConvSpec(f"{which}.center.0", center, 2 * center, 3, ""),
+           ConvSpec(f"{which}.center.2", 2 * center, 2 * center, 3, "")]
+    up_in = [2 * center] + dec[:-1]
+    up_out = [c // 2 for c in up_in]
+    for i, (a, b) in enumerate(zip(up_in, up_out)):
+        out.append(ConvSpec(f"{which}.upsample_conv.{i}", a, b, 3, ""))
+    for i, (e, u, d) in enumerate(zip(enc, up_out, dec)):
+        out.append(ConvSpec(f"{which}.decoder.{i}.0", e + u, d, 3, ""))
+        out.append(ConvSpec(f"{which}.decoder.{i}.2", d, d, 3, ""))
+    out.append(ConvSpec(f"{which}.predictor", dec[-1], cfg.pred_len, 1, ""))
+    return out
+
+
+def all_specs(cfg: Cfg) -> List[ConvSpec]:
+    return encoder_specs(cfg) + decoder_specs(cfg, "goal_decoder") + decoder_specs(cfg, "traj_decoder")
+
+
+def is_adapted(cfg: Cfg, spec: ConvSpec) -> bool:
+    # models/ynet.py:139-144: lora conv iff 'mosa' in train_net and str(l) in position
+    return cfg.rank is not None and spec.layer != "" and spec.layer in [str(p) for p in cfg.position]
+
+
+def make_state_dict(cfg: Cfg, seed: int = 0, lora_b_std: float = 0.0) -> Dict[str, Tensor]:
+    """Deterministic random-init weights (CPU generator): conv weight/bias ~ U(+-1/sqrt(fan_in)) like
+    nn.Conv2d's default, lora_A ~ U(+-1/sqrt(fan_in)), lora_B ~ N(0, lora_b_std) (0 => identity)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+    for s in all_specs(cfg):
+        bound = 1.0 / math.sqrt(s.cin * s.k * s.k)
+        sd[s.name + ".weight"] = (torch.rand(s.cout, s.cin, s.k, s.k, generator=g) * 2 - 1) * bound
+        sd[s.name + ".bias"] = (torch.rand(s.cout, generator=g) * 2 - 1) * bound
+        if is_adapted(cfg, s):
+            r = cfg.rank
+            ba = 1.0 / math.sqrt(s.cin * s.k)
+            sd[s.name + ".lora_A"] = (torch.rand(r * s.k, s.cin * s.k, generator=g) * 2 - 1) * ba
+            sd[s.name + ".lora_B"] = torch.randn(s.cout * s.k, r * s.k, generator=g) * lora_b_std
+    return sd
+
+
+def trainable_names(cfg: Cfg, sd: Dict[str, Tensor], ynet_bias: bool = False) -> List[str]:
+    """Freeze policy of models/trainer.py:116-195 restricted to the Y-Net parameters."""
+    tn, pos = cfg.train_net, [str(p) for p in cfg.position]
+    names = list(sd.keys())
+    enc = [n for n in names if n.startswith("encoder.")]
+    if tn in ("all", "train"):
+        out = names
+    elif tn == "encoder" and not pos:
+        out = enc
+    elif tn == "encoder":
+        out = [n for n in enc if n[len("encoder."):].split(".")[1] in pos]
+    elif "mosa" in tn:
+        # loralib freezes the adapted conv's weight; trainer.py:137-139 enables names containing 'lora'
+        out = [n for n in enc if "lora" in n]
+    elif cfg.network == "fusion" and tn in ("scene", "motion", "fusion", "scene_fusion", "motion_fusion",
+                                            "scene_motion", "scene_motion_fusion"):
+        parts = tn.split("_")
+        out = [n for n in enc if n.split(".")[1].replace("_stages", "") in parts]
+    elif tn == "biasEncoder":
+        out = [n for n in enc if "bias" in n]
+    elif tn == "biasGoal":
+        out = [n for n in names if n.startswith("goal_decoder.") and "bias" in n]
+    elif tn == "biasTraj":
+        out = [n for n in names if n.startswith("traj_decoder.") and "bias" in n]
+    elif tn == "bias":
+        out = [n for n in names if "bias" in n]
+    else:
+        raise NotImplementedError(tn)
+    if ynet_bias and tn not in ("all", "train"):
+        out = out + [n for n in names if "bias" in n and n not in out]
+    return [n for n in names if n in set(out)]
+
+
+# ----------------------------------------------------------------------------------------------
+# network
+# ----------------------------------------------------------------------------------------------
+def effective_weight(sd: Dict[str, Tensor], name: str) -> Tensor:
+    """loralib 0.1.1 Conv2d: W + (B @ A).view(W.shape) * (lora_alpha / r), lora_alpha = 1.
+    The .view is a FLAT reshape of the [Cout*k, Cin*k] matrix."""
+    w = sd[name + ".weight"]
+    a = sd.get(name + ".lora_A")
+    if a is None:
+        return w
+    b = sd[name + ".lora_B"]
+    k = w.shape[-1]
+    r = a.shape[0] // k
+    return w + (b @ a).view(w.shape) * (1.0 / r)
+
+
+def conv(sd, name: str, x: Tensor, relu: bool) -> Tensor:
+    w = effective_weight(sd, name)
+    y = F.conv2d(x, w, sd[name + ".bias"], stride=1, padding=w.shape[-1] // 2)
+    return F.relu(y) if relu else y
+
+
+def _stage(sd, prefix: str, x: Tensor, first: bool) -> Tensor:
+    if first:
+        return conv(sd, prefix + ".0", x, True)
+    x = F.max_pool2d(x, 2, 2)
+    x = conv(sd, prefix + ".1", x, True)
+    return conv(sd, prefix + ".3", x, True)
+
+
+def encoder(sd, cfg: Cfg, scene: Tensor, motion: Tensor) -> List[Tensor]:
+    ch = list(cfg.enc)
+    feats: List[Tensor] = []
+    if cfg.network == "fusion":
+        nsep = len(ch) - cfg.n_fusion - 1
+        branches = []
+        for br, x in (("scene", scene), ("motion", motion)):
+            fs = []
+            for i in range(nsep + 1):
+                x = _stage(sd, f"encoder.{br}_stages.{i}", x, i == 0)
+                fs.append(x)
+            branches.append(fs)
+        feats = [torch.cat([s, m], dim=1) for s, m in zip(*branches)]
+        x = feats[-1]
+        for j in range(cfg.n_fusion):
+            x = _stage(sd, f"encoder.fusion_stages.{j}", x, False)
+            feats.append(x)
+        feats.append(F.max_pool2d(x, 2, 2))
+    else:
+        x = torch.cat([scene, motion], dim=1)
+        for i in range(len(ch)):
+            x = _stage(sd, f"encoder.stages.{i}", x, i == 0)
+            feats.append(x)
+        feats.append(F.max_pool2d(x, 2, 2))
+    return feats
+
+
+def decoder(sd, cfg: Cfg, which: str, feats: List[Tensor]) -> Tensor:
+    fr = feats[::-1]
+    x = conv(sd, f"{which}.center.0", fr[0], True)
+    x = conv(sd, f"{which}.center.2", x, True)
+    for i, skip in enumerate(fr[1:]):
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        x = conv(sd, f"{which}.upsample_conv.{i}", x, False)   # the only 3x3 conv without ReLU
+        x = torch.cat([x, skip], dim=1)
+        x = conv(sd, f"{which}.decoder.{i}.0", x, True)
+        x = conv(sd, f"{which}.decoder.{i}.2", x, True)
+    return conv(sd, f"{which}.predictor", x, False)
+
+
+def waypoint_pyramid(wp_map: Tensor, n_levels: int) -> List[Tensor]:
+    # utils/train_epoch.py:97-100
+    return [wp_map] + [F.avg_pool2d(wp_map, 2 ** i, 2 ** i) for i in range(1, n_levels)]
+
+
+def traj_inputs(feats: List[Tensor], wp_map: Tensor) -> List[Tensor]:
+    return [torch.cat([f, g], dim=1) for f, g in zip(feats, waypoint_pyramid(wp_map, len(feats)))]
+
+
+# ----------------------------------------------------------------------------------------------
+# soft-argmax, loss, templates, patches, sampling
+# ----------------------------------------------------------------------------------------------
+def softargmax2d(x: Tensor, eps: float = 1e-6) -> Tensor:
+    """[B,C,H,W] -> [B,C,2] in (x, y) order, unnormalised pixel coordinates."""
+    if x.dim() != 4:
+        raise ValueError(f"expected BxCxHxW, got {tuple(x.shape)}")
+    b, c, h, w = x.shape
+    flat = x.reshape(b, c, -1)
+    e = torch.exp(flat - flat.max(dim=-1, keepdim=True)[0])
+    inv = 1.0 / (e.sum(dim=-1, keepdim=True) + eps)
+    ys = torch.arange(h, dtype=x.dtype).view(h, 1).expand(h, w).reshape(-1)
+    xs = torch.arange(w, dtype=x.dtype).view(1, w).expand(h, w).reshape(-1)
+    ey = ((ys * e) * inv).sum(dim=-1, keepdim=True)
+    ex = ((xs * e) * inv).sum(dim=-1, keepdim=True)
+    return torch.cat([ex, ey], dim=-1)
+
+
+def bce_logits_mean(x: Tensor, t: Tensor) -> Tensor:
+    return F.binary_cross_entropy_with_logits(x, t)
+
+
+def gaussian_kernel(kernlen: int, nsig: float) -> np.ndarray:
+    ax = np.linspace(-(kernlen - 1) / 2.0, (kernlen - 1) / 2.0, kernlen)
+    sq = ax[None, :] ** 2 + ax[:, None] ** 2
+    k = np.exp(-0.5 * sq / (nsig ** 2))
+    return k / k.sum()
+
+
+def gaussian_template(size: int, kernlen: int = 31, nsig: float = 4.0, normalize: bool = False) -> Tensor:
+    """float64 NumPy, then cast to fp32 (trainer.py:210-211 passes normalize=False)."""
+    t = np.zeros((size, size))
+    k = gaussian_kernel(kernlen, nsig)
+    lo = size // 2 - kernlen // 2
+    hi = size // 2 + (kernlen + 1) // 2
+    t[lo:hi, lo:hi] = k
+    if normalize:
+        t = t / t.max()
+    return torch.from_numpy(t.astype(np.float32))
+
+
+def dist_template(size: int, normalize: bool = True) -> Tensor:
+    r = np.arange(size, dtype=np.int64) - size // 2
+    d = np.sqrt((r[:, None] ** 2 + r[None, :] ** 2).astype(np.float64))
+    if normalize:
+        d = d / d.max() * 2
+    return torch.from_numpy(d.astype(np.float32))
+
+
+def round_coords(xy: np.ndarray):
+    """np.round = round-half-to-even, as in utils/image_utils.py:52-53."""
+    return np.round(xy[:, 0]).astype(np.int64), np.round(xy[:, 1]).astype(np.int64)
+
+
+def crop_patches(template: Tensor, xy, H: int, W: int) -> Tensor:
+    """[N,2] (x,y) -> [N,H,W]; window template[S/2-y : S/2+H-y, S/2-x : S/2+W-x]."""
+    xy = np.asarray(xy, dtype=np.float32).reshape(-1, 2)
+    xs, ys = round_coords(xy)
+    cy, cx = template.shape[0] // 2, template.shape[1] // 2
+    out = torch.empty(len(xs), H, W, dtype=template.dtype)
+    for n, (x, y) in enumerate(zip(xs, ys)):
+        out[n] = template[cy - y:cy - y + H, cx - x:cx - x + W]
+    return out
+
+
+def sample_coords(prob: Tensor, num_samples: int, generator=None) -> Tensor:
+    """[B,C,H,W] -> [B,C,K,2] float (x,y): multinomial without replacement on the flat plane."""
+    b, c, h, w = prob.shape
+    idx = torch.multinomial(prob.reshape(b * c, -1), num_samples, replacement=False, generator=generator)
+    idx = idx.view(b, c, num_samples).float()
+    return torch.stack([idx % w, torch.floor(idx / w)], dim=-1)
+
+
+def displacement_error(gt: Tensor, pred: Tensor, resize: float) -> Tensor:
+    return ((((gt - pred) / resize) ** 2).sum(dim=-1) ** 0.5)
+
+
+# ----------------------------------------------------------------------------------------------
+# one training step / one evaluation batch
+# ----------------------------------------------------------------------------------------------
+def build_maps(cfg: Cfg, traj: Tensor, H: int, W: int, in_tmpl: Tensor, gt_tmpl: Optional[Tensor]):
+    b = traj.shape[0]
+    obs = traj[:, :cfg.obs_len].reshape(-1, 2).numpy()
+    observed = crop_patches(in_tmpl, obs, H, W).reshape(b, cfg.obs_len, H, W)
+    fut = traj[:, cfg.obs_len:]
+    gt_map = wp_map = None
+    if gt_tmpl is not None:
+        gt_map = crop_patches(gt_tmpl, fut.reshape(-1, 2).numpy(), H, W).reshape(b, cfg.pred_len, H, W)
+        wps = fut[:, list(cfg.waypoints)]
+        wp_map = crop_patches(in_tmpl, wps.reshape(-1, 2).numpy(), H, W).reshape(b, cfg.n_wp, H, W)
+    return observed, gt_map, wp_map
+
+
+def train_step(sd: Dict[str, Tensor], cfg: Cfg, scene: Tensor, traj: Tensor, in_tmpl: Tensor,
+               gt_tmpl: Tensor, trainable: Sequence[str], loss_weight: float = 1.0,
+               keep_maps: bool = False) -> Dict[str, object]:
+    """utils/train_epoch.py:54-126 for ONE batch (no optimizer step).  ``scene`` is [1,C,H,W].
+    ``loss_weight`` scales the loss (B_local/B_global in data-parallel runs)."""
+    H, W = scene.shape[-2:]
+    b = traj.shape[0]
+    params = {k: v.detach().clone().requires_grad_(k in set(trainable)) for k, v in sd.items()}
+    observed, gt_map, wp_map = build_maps(cfg, traj, H, W, in_tmpl, gt_tmpl)
+    sem = scene.expand(b, -1, -1, -1)
+    feats = encoder(params, cfg, sem, observed)
+    goal_map = decoder(params, cfg, "goal_decoder", feats)
+    goal_loss = bce_logits_mean(goal_map, gt_map) * cfg.loss_scale
+    traj_map = decoder(params, cfg, "traj_decoder", traj_inputs(feats, wp_map))
+    traj_loss = bce_logits_mean(traj_map, gt_map) * cfg.loss_scale
+    loss = goal_loss + traj_loss
+    names = [n for n in sd if n in set(trainable)]
+    grads = torch.autograd.grad(loss * loss_weight, [params[n] for n in names], allow_unused=True)
+    with torch.no_grad():
+        fut = traj[:, cfg.obs_len:]
+        pred_traj = softargmax2d(traj_map)
+        pred_goal = softargmax2d(goal_map[:, -1:])
+        ade = displacement_error(fut, pred_traj, cfg.resize_factor).mean(dim=1)
+        fde = displacement_error(fut[:, -1:], pred_goal[:, -1:], cfg.resize_factor).mean(dim=1)
+    out = {"loss": loss.detach(), "goal_loss": goal_loss.detach(), "traj_loss": traj_loss.detach(),
+           "grads": {n: (g if g is not None else torch.zeros_like(sd[n])) for n, g in zip(names, grads)},
+           "ade": ade, "fde": fde, "pred_traj": pred_traj, "pred_goal": pred_goal}
+    if keep_maps:
+        out.update(features=[f.detach() for f in feats], goal_map=goal_map.detach(),
+                   traj_map=traj_map.detach(), observed=observed, gt_map=gt_map, wp_map=wp_map)
+    return out
+
+
+def adam_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+                b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+    """torch.optim.Adam defaults (no weight decay, no amsgrad); returns (p, m, v)."""
+    m = m * b1 + g * (1 - b1)
+    v = v * b2 + g * g * (1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    return p - (lr / bc1) * (m / denom), m, v
+
+
+@torch.no_grad()
+def eval_batch(sd, cfg: Cfg, scene: Tensor, traj: Tensor, in_tmpl: Tensor, n_goal: int = 20,
+               n_traj: int = 1, waypoint_samples: Optional[Tensor] = None,
+               generator=None) -> Dict[str, Tensor]:
+    """utils/evaluate.py:109-291 (use_TTST=False, use_CWS=False) for ONE batch.
+    ``waypoint_samples`` [K,B,nwp,2] teacher-forces the sampled goals/waypoints."""
+    H, W = scene.shape[-2:]
+    b = traj.shape[0]
+    observed, _, _ = build_maps(cfg, traj, H, W, in_tmpl, None)
+    fut = traj[:, cfg.obs_len:]
+    feats = encoder(sd, cfg, scene.expand(b, -1, -1, -1), observed)
+    goal_map = decoder(sd, cfg, "goal_decoder", feats)
+    wp_logits = goal_map[:, list(cfg.waypoints)]
+    wp_sig = torch.sigmoid(wp_logits / cfg.temperature)
+    if waypoint_samples is None:
+        goals = sample_coords(wp_sig[:, -1:], n_goal, generator).permute(2, 0, 1, 3)
+        if cfg.n_wp > 1:
+            wps = sample_coords(wp_sig[:, :-1], n_goal * n_traj, generator).permute(2, 0, 1, 3)
+            waypoint_samples = torch.cat([wps, goals.repeat(n_traj, 1, 1, 1)], dim=2)
+        else:
+            waypoint_samples = goals
+    trajs = []
+    for wp in waypoint_samples:
+        wp_map = crop_patches(in_tmpl, wp.reshape(-1, 2).numpy(), H, W).reshape(b, cfg.n_wp, H, W)
+        tmap = decoder(sd, cfg, "traj_decoder", traj_inputs(feats, wp_map))
+        trajs.append(softargmax2d(tmap))
+    trajs = torch.stack(trajs)
+    ade_k = displacement_error(fut, trajs, cfg.resize_factor).mean(dim=2)             # [K,B]
+    fde_k = displacement_error(fut[:, -1:], waypoint_samples[:, :, -1:], cfg.resize_factor)  # [K,B,1]
+    return {"goal_map": goal_map, "wp_sigmoid": wp_sig, "waypoint_samples": waypoint_samples,
+            "trajs": trajs, "ade_k": ade_k, "fde_k": fde_k[:, :, 0],
+            "ade": ade_k.min(dim=0)[0], "fde": fde_k.min(dim=0)[0][:, 0], "features": feats}
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic workload (SURVEY 8d / BASELINE.md section 3)
+# ----------------------------------------------------------------------------------------------
+def synthetic_scene(cfg: Cfg, H: int, W: int, seed: int = 0) -> Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.softmax(torch.randn(cfg.n_classes, H, W, generator=g), dim=0).unsqueeze(0)
+
+
+def synthetic_trajectories(cfg: Cfg, n: int, H: int, W: int, seed: int = 0) -> Tensor:
+    g = torch.Generator().manual_seed(seed + 1)
+    t = cfg.obs_len + cfg.pred_len
+    start = torch.rand(n, 1, 2, generator=g) * torch.tensor([0.4 * W, 0.4 * H]) + torch.tensor([0.3 * W, 0.3 * H])
+    steps = torch.randn(n, t, 2, generator=g) * 2.0
+    steps[:, 0] = 0
+    return (start + steps.cumsum(dim=1)).float()
