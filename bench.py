@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X Y-Net(+LoRA) training step — BASELINE.json's metric.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (N=1): BASELINE.json configs[1] "SDD shortterm Y-Net + LoRA rank=1 on encoder[0-4],
+batch=32, 256x256 raster, obs=8 pred=12".  One "step" = one batch iteration of train_epoch:
+{3x gather_patch, encoder, goal decoder, BCE, waypoint pyramid, trajectory decoder, BCE, backward,
+RCCL all-reduce of the adapter gradients (N>1), Adam step, 2x soft-argmax}.  N>1 is WEAK scaling:
+every rank keeps 32 trajectories per step (global batch 32*N sharded by dist.DataParallel).
+Inputs are synthetic and resident in HBM before the timed region, except the
+[B, 20, 2] trajectory coordinates that train_epoch receives on the host like the reference does.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : the dominant kernel (the MFMA conv), timed live with HIP events on the launch stream
+                 in a separate instrumented step; achieved = algorithmic FLOPs / kernel time
+  cpu_baseline : the CPU oracle (torch-CPU restatement of the reference, "port") on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "motion-style-transfer_amd"
+
+import numpy as np  # noqa: E402
+import pandas as pd  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def pkg(sub):
+    return importlib.import_module(PKG + "." + sub)
+
+
+def make_cfg(O, name):
+    pos5 = ["0", "1", "2", "3", "4"]
+    if name == "C2":
+        return O.sdd_short(train_net="mosa_1", position=pos5), 256, 256, \
+            "C2: SDD shortterm Y-Net + LoRA rank=1 on encoder[0-4], 256x256 raster, obs=8 pred=12"
+    if name == "C1":
+        return O.sdd_short(train_net="train"), 256, 256, "C1: SDD shortterm Y-Net, all weights trainable, 256x256"
+    if name == "C3":
+        return O.sdd_short(train_net="mosa_4", position=pos5), 256, 256, "C3: SDD ped->biker MoSA, LoRA rank=4, 256x256"
+    if name == "C4":
+        return O.ind_long(network="fusion", n_fusion=2, train_net="mosa_3", position=["scene"]), 512, 512, \
+            "C4: inD longterm Y-Net-Mod, scene adapter only (LoRA r=3), 512x512, obs=5 pred=30"
+    raise SystemExit(f"unknown config {name}")
+
+
+def loader_for(traj):
+    return [(traj, [pd.DataFrame({"metaId": np.arange(traj.shape[0])})], "scene0")]
+
+
+class ConvTimer:
+    """Wraps ops.conv2d_raw with HIP-event pairs (same stream as the launch) for ONE instrumented step."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.rec = ops, ops.conv2d_raw, []
+
+    def __enter__(self):
+        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu)
+            e1.record()
+            cin = sum(s[1] for s in srcs)
+            dl = list(dsts)
+            while len(dl) > 1 and dl[-1][0] is None:      # unwanted trailing outputs are not computed
+                dl.pop()
+            cout = sum(d[1] for d in dl)
+            flops = 2.0 * B * H * W * cin * cout * K * K
+            byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]))
+            self.rec.append((f"conv_mfma_kernel<{K},{2 if cout > 32 else 1},4,{ {1: 16, 3: 8, 5: 4}[K] }>", e0, e1, flops, byts))
+        self.ops.conv2d_raw = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.conv2d_raw = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1, fl, by in self.rec:
+            d = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return agg
+
+
+def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0):
+    """CPU oracle (port of the reference's ATen-op path) on the host cores: bounded sample."""
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.05)
+    scene = O.synthetic_scene(cfg, H, W, 0)
+    S = cfg.template_size
+    in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+    names = O.trainable_names(cfg, sd)
+    ms = {n: torch.zeros_like(sd[n]) for n in names}
+    vs = {n: torch.zeros_like(sd[n]) for n in names}
+    times = []
+    t_start = time.perf_counter()
+    step = 0
+    while True:
+        traj = O.synthetic_trajectories(cfg, batch, H, W, 100 + step)
+        t0 = time.perf_counter()
+        r = O.train_step(sd, cfg, scene, traj, in_t, gt_t, names)
+        for n in names:
+            sd[n], ms[n], vs[n] = O.adam_update(sd[n], r["grads"][n], ms[n], vs[n], step + 1, 1e-3)
+        dt = time.perf_counter() - t0
+        step += 1
+        if step > 1:                    # first step = warm-up
+            times.append(dt)
+        if step >= 2 and (time.perf_counter() - t_start > seconds_budget or len(times) >= 5):
+            break
+    med = float(np.median(times))
+    return {"value": batch / med, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} steps of batch {batch} after 1 warm-up (oracle/ynet_oracle.py train_step + Adam, "
+                      f"same config and raster size), median step {med * 1e3:.0f} ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU per step")
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4"])
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from oracle import ynet_oracle as O      # cpu_baseline leg + synthetic-input generators only
+    D = pkg("dist")
+    rank, local, world = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    ynet, trainer, te, ops = pkg("models.ynet"), pkg("models.trainer"), pkg("utils.train_epoch"), pkg("ops")
+    cfg, H, W, workload = make_cfg(O, args.config)
+    B, N = args.batch, world
+    sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.05)
+    model = ynet.YNet(cfg.obs_len, cfg.pred_len, None, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
+                      n_waypoints=len(cfg.waypoints), train_net=cfg.train_net, position=list(cfg.position),
+                      network=cfg.network, n_fusion=cfg.n_fusion)
+    model.load_state_dict(sd, strict=True)
+    trainer.apply_freeze_policy(model, cfg.train_net, cfg.position, cfg.network)
+    model.to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    dp = D.DataParallel(model.parameters()) if world > 1 else None
+    crit = trainer.HipBCEWithLogitsLoss()
+    S = cfg.template_size
+    in_t, gt_t = O.dist_template(S).to(dev), O.gaussian_template(S, cfg.kernlen, cfg.nsig).to(dev)
+    images = {"scene0": O.synthetic_scene(cfg, H, W, 0)[0].to(dev)}
+
+    def run(n_steps, seed):
+        traj = O.synthetic_trajectories(cfg, B * N * n_steps, H, W, seed)
+        return te.train_epoch(model, loader_for(traj), images, opt, crit, cfg.loss_scale, dev, "sdd", None, gt_t, in_t,
+                              list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B * N, 10000, cfg.resize_factor,
+                              cfg.network, False, dp=dp)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup, 1)
+    fence()
+    t0 = time.perf_counter()
+    ade, fde, loss = run(args.steps, 2)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = B * N * args.steps / elapsed
+
+    out = {
+        "metric": "trajectories/sec fwd+bwd (Y-Net+LoRA, SDD shortterm)", "value": value, "unit": "trajectories/s",
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * N, "raster": f"{H}x{W}",
+                   "obs_len": cfg.obs_len, "pred_len": cfg.pred_len, "train_net": cfg.train_net,
+                   "parallelism": f"dp{N}", "trainable_floats": sum(p.numel() for p in model.parameters() if p.requires_grad)},
+        "final_loss": loss,
+    }
+
+    if args.no_roofline:
+        pass
+    elif rank == 0:
+        with ConvTimer(ops) as ct:
+            run(1, 3)
+        agg = ct.summary()
+        name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get(name)
+        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                           "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                           "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                           "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
+        out["conv_kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}
+        total_conv_ms = sum(v["ms"] for v in agg.values())
+        out["conv_share_of_step"] = total_conv_ms / out["ms_per_step"]
+    else:
+        run(1, 3)      # keep ranks in lock-step with rank 0's instrumented step (collectives inside)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(O, cfg, H, W, args.cpu_batch)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+/* libynet_hip.so — C ABI of the MI355X (gfx950) Y-Net forward/backward kernels.
+ *
+ * The reference (vita-epfl/motion-style-transfer) is pure Python on stock PyTorch and has no FFI
+ * of its own: the seam is the nn.Module surface of models/ynet.py and the ATen ops it dispatches
+ * (SURVEY.md section 8b).  Each entry point below therefore replaces one ATen op (or a fused group)
+ * at the reference call site cited next to it.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned memory (PyTorch allocations); fp32, NCHW,
+ *    contiguous inside one image plane; batch strides are explicit where concatenation is fused;
+ *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); calls only enqueue
+ *    work: no allocation, no synchronisation, no host<->device copies, no global state;
+ *  - return 0 on success, non-zero on error; ynet_last_error() returns the message (thread local);
+ *  - results are bitwise reproducible run to run (no float atomics anywhere).
+ */
+#ifndef YNET_HIP_H
+#define YNET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int ynet_abi_version(void);
+const char* ynet_last_error(void);
+
+/* ---- convolution ----------------------------------------------------------------------------
+ * Filters are consumed in a packed layout [cin_pad16][K*K][cout_pad64] built by ynet_pack_weight
+ * from the checkpoint layout [Cout][Cin][K][K] (models/ynet.py state-dict contract).
+ *   mode 0: forward filter.   mode 1: data-gradient filter (taps flipped, cin/cout swapped).
+ */
+long long ynet_packed_weight_floats(int cout, int cin, int K, int mode);
+int ynet_pack_weight(const float* w, float* wp, int cout, int cin, int K, int mode, void* stream);
+
+/* nn.Conv2d(K in {1,3,5}, stride 1, padding K/2) [+ nn.ReLU] with the channel concatenation of its
+ * input fused in — replaces conv2d at models/ynet.py:150,192-211,420-451,464,467,469 and the
+ * torch.cat calls at models/ynet.py:387,466,574, utils/train_epoch.py:103-104,
+ * utils/evaluate.py:259-260.  The same entry point computes the data gradient
+ * (convolution_backward -> grad_input) when handed a mode-1 filter, the incoming gradient as the
+ * source, `mask` = the post-ReLU activation of the layer (gradient kept where mask > 0) and one
+ * destination per concatenated input (NULL = not wanted).
+ *   src[i]:   nsrc (1..4) sources, src_c[i] channels, batch stride src_bs[i] elements (0 = broadcast)
+ *   dst[i]:   ndst (1..4) destinations, dst_c[i] channels, batch stride dst_bs[i]
+ *   cin = sum(src_c), cout = sum(dst_c); wp packed for (cout, cin); bias [cout] or NULL
+ */
+int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
+                const float* mask, long long mask_bs, const float* wp, const float* bias,
+                float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
+                int B, int H, int W, int K, int relu, void* stream);
+
+/* convolution_backward -> grad_weight [Cout][Cin][K][K] and grad_bias [Cout] (db may be NULL).
+ * x = concat(src...), dy = incoming gradient, mask = post-ReLU activation of this layer or NULL.
+ * workspace: ynet_conv2d_wgrad_workspace_floats(...) floats.
+ */
+long long ynet_conv2d_wgrad_workspace_floats(int B, int H, int W, int cout, int cin, int K);
+int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
+                      const float* dy, long long dy_bs, const float* mask, long long mask_bs,
+                      float* dw, float* db, float* workspace, int B, int H, int W, int cout, int K,
+                      void* stream);
+
+/* ---- MoSA / LoRA (loralib==0.1.1 Conv2d, call site models/ynet.py:141-144) -------------------
+ * lora_a [r*K][cin*K], lora_b [cout*K][r*K], scale = lora_alpha / r (lora_alpha = 1).
+ *   compose: w_eff = w + (lora_b @ lora_a).view(w.shape) * scale
+ *   grad:    d_a = scale * lora_b^T @ dWm,  d_b = scale * dWm @ lora_a^T,  dWm = dw.view(cout*K, cin*K)
+ */
+int ynet_lora_compose(const float* w, const float* lora_a, const float* lora_b, float scale, float* w_eff,
+                      int cout, int cin, int K, int r, void* stream);
+int ynet_lora_grad(const float* dw, const float* lora_a, const float* lora_b, float scale, float* d_a, float* d_b,
+                   int cout, int cin, int K, int r, void* stream);
+
+/* ---- pooling / resampling ------------------------------------------------------------------- */
+/* nn.MaxPool2d(2,2) (models/ynet.py:202,215,326,340,354,367); N = B*C planes of H x W. */
+int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream);
+int ynet_maxpool2_bwd(const float* x, const float* dy, float* dx, long long N, int H, int W, void* stream);
+/* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (models/ynet.py:463);
+ * H, W are the LOW-resolution sizes in both directions. */
+int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream);
+int ynet_upsample2x_bwd(const float* dy, float* dx, long long N, int H, int W, void* stream);
+/* [x] + [AvgPool2d(2^i)(x) for i = 1..nlev] (utils/train_epoch.py:97-100, utils/evaluate.py:255-257);
+ * outs[i-1] receives level i; H, W multiples of 32. */
+int ynet_avgpool_pyramid(const float* x, float* const* outs, int nlev, long long N, int H, int W, void* stream);
+
+/* ---- loss ----------------------------------------------------------------------------------- */
+/* nn.BCEWithLogitsLoss() (models/trainer.py:206; utils/train_epoch.py:94,106): loss[0] = mean.
+ * workspace: ynet_bce_workspace_bytes() bytes.  bwd: dx = (sigmoid(x) - t) * grad_out[0] / n. */
+long long ynet_bce_workspace_bytes(void);
+int ynet_bce_logits_fwd(const float* x, const float* t, long long n, float* loss, void* workspace, void* stream);
+int ynet_bce_logits_bwd(const float* x, const float* t, const float* grad_out, float* dx, long long n, void* stream);
+
+/* ---- goal / trajectory read-out -------------------------------------------------------------- */
+/* SoftArgmax2D.forward (utils/softargmax.py:55-81; models/ynet.py:582-583): x [B][C][H][W] with
+ * batch stride `batch_stride` elements (so a channel slice such as pred_goal_map[:, -1:] needs no
+ * copy) -> out [B][C][2] = (E[x], E[y]) in pixels. */
+int ynet_softargmax2d(const float* x, float* out, long long B, int C, long long batch_stride, int H, int W,
+                      void* stream);
+/* sigmoid(pred_goal_map[:, sel] / temperature) (utils/evaluate.py:128-131; models/ynet.py:585-586):
+ * x [B][C][HW] -> y [B][nsel][HW]; sel is a HOST array of nsel (<= 8) channel indices. */
+int ynet_sigmoid_temp(const float* x, float* y, long long B, int C, long long HW, const int* sel, int nsel,
+                      float temperature, void* stream);
+
+/* ---- heat-map construction -------------------------------------------------------------------- */
+/* get_patch + torch.stack (utils/image_utils.py:40-63; utils/train_epoch.py:63-78;
+ * utils/evaluate.py:112-114,250-253): out[n] = tmpl[SH/2 - ry : +H, SW/2 - rx : +W] with
+ * (rx, ry) = rint(xy[n]) (round-half-even like np.round); xy [N][2] fp32 on the device.
+ * *status (device int, zero it first) becomes 1 if any window leaves the template. */
+int ynet_gather_patch(const float* tmpl, int SH, int SW, const float* xy, float* out, int N, int H, int W,
+                      int* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YNET_HIP_H */

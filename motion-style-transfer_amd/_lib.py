@@ -1,0 +1,82 @@
+"""ctypes binding of libynet_hip.so (the C ABI declared in include/ynet_hip.h).
+
+There is NO fallback: if the library is missing or a symbol is absent, importing the ops fails
+loudly with the build command.  Loading needs no GPU (the CPU test-suite checks every symbol).
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libynet_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ynet_hip.h")
+
+c_fp = ctypes.c_void_p       # device pointers travel as plain addresses
+c_i = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_f = ctypes.c_float
+PP = ctypes.POINTER(ctypes.c_void_p)
+PI = ctypes.POINTER(ctypes.c_int)
+PLL = ctypes.POINTER(ctypes.c_longlong)
+
+# name -> (restype, argtypes); must list every function of include/ynet_hip.h
+SIGNATURES = {
+    "ynet_abi_version": (c_i, []),
+    "ynet_last_error": (ctypes.c_char_p, []),
+    "ynet_packed_weight_floats": (c_ll, [c_i, c_i, c_i, c_i]),
+    "ynet_pack_weight": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_conv2d": (c_i, [PP, PI, PLL, c_i, c_fp, c_ll, c_fp, c_fp, PP, PI, PLL, c_i,
+                          c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_conv2d_wgrad_workspace_floats": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "ynet_conv2d_wgrad": (c_i, [PP, PI, PLL, c_i, c_fp, c_ll, c_fp, c_ll, c_fp, c_fp, c_fp,
+                                c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_lora_compose": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_lora_grad": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_maxpool2_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
+    "ynet_maxpool2_bwd": (c_i, [c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
+    "ynet_upsample2x_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
+    "ynet_upsample2x_bwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
+    "ynet_avgpool_pyramid": (c_i, [c_fp, PP, c_i, c_ll, c_i, c_i, c_fp]),
+    "ynet_bce_workspace_bytes": (c_ll, []),
+    "ynet_bce_logits_fwd": (c_i, [c_fp, c_fp, c_ll, c_fp, c_fp, c_fp]),
+    "ynet_bce_logits_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_fp]),
+    "ynet_softargmax2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, c_i, c_i, c_fp]),
+    "ynet_sigmoid_temp": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, PI, c_i, c_f, c_fp]),
+    "ynet_gather_patch": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/ynet_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ynet_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the library and bind every symbol; raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built and there is no fallback path. "
+            f"Build it with `make -C {os.path.dirname(LIB_PATH)}` (or `python -c 'import __graft_entry__ as g; g.build()'`).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        raise RuntimeError("libynet_hip: " + lib.ynet_last_error().decode(errors="replace"))

@@ -1,0 +1,293 @@
+// Direct convolution as an implicit GEMM on the gfx950 fp32 matrix cores.
+//
+// Replaces the ATen conv2d / convolution_backward(dgrad) calls of the reference's Y-Net
+// (models/ynet.py:150,192-211,420-451; K1/K2/K3 in SURVEY.md section 2.1).  One kernel serves
+//   * forward:  y = [relu](conv(cat(src0,src1,src2), W) + bias)       (fused concat, bias, ReLU)
+//   * dgrad:    dx_i = conv(dy * [y > 0], W^T flipped)                (fused ReLU mask, split outputs)
+// because dgrad of a stride-1 "same" convolution is a convolution with the flipped, transposed filter;
+// the two differ only in the packed filter handed in (see ynet_pack_weight).
+//
+// Mapping (v_mfma_f32_32x32x2_f32, exact fp32 = an fmaf chain, 64 FLOP/clk/SIMD):
+//   M = 32 output channels   -> A operand = packed filter  [cin][tap][cout]   (LDS, cout fastest)
+//   N = 32 consecutive x     -> B operand = input tile row (LDS, x fastest)   -> coalesced NCHW stores
+//   K = 2 input channels at one filter tap per instruction (lanes 0-31: channel c, 32-63: c+1)
+// A workgroup = 4 waves computes a 32(x) x 4R(y) pixel tile for 32*NCB output channels; each wave
+// owns R rows, so one A fragment feeds R MFMAs and one B fragment NCB MFMAs.  The input tile
+// (with halo) and the filter slice for CC input channels are staged in LDS per chunk; 2-4 resident
+// workgroups per CU overlap one group's staging with another's MFMAs.
+#include "ynet_common.h"
+
+struct ConvArgs {
+    YSrc src[YNET_MAX_SRC];
+    int nsrc, cin;
+    const float* mask;      // optional ReLU mask source (same layout as src[0]); value kept where mask > 0
+    long long mask_bs;
+    const float* wp;        // packed filter [cin_pad][K*K][cout_pad], zero padded
+    const float* bias;      // [cout] or NULL
+    YDst dst[YNET_MAX_SRC];
+    int ndst;
+    int B, H, W, cout, cout_pad, relu;
+    int tiles_x, tiles_y, cgroups;
+};
+
+template <int KS, int NCB, int R, int CC>
+struct ConvCfg {
+    static constexpr int PAD = KS / 2, KK = KS * KS;
+    static constexpr int TH = 4 * R, TW = 32;
+    static constexpr int TROWS = TH + KS - 1, TCOLS = TW + KS - 1, PLANE = TROWS * TCOLS;
+    static constexpr int CB = 32 * NCB;
+    static constexpr int XS_FLOATS = ((CC * PLANE + 3) / 4) * 4;
+    static constexpr int WS_FLOATS = CC * KK * CB;
+    static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
+};
+
+template <int KS, int NCB, int R, int CC>
+__global__ __launch_bounds__(256, (NCB == 1 ? 4 : 3)) void conv_mfma_kernel(const ConvArgs a) {
+    using C = ConvCfg<KS, NCB, R, CC>;
+    constexpr int PAD = C::PAD, KK = C::KK, TH = C::TH, TW = C::TW;
+    constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                  // [CC][TROWS][TCOLS]
+    float* ws = smem + C::XS_FLOATS;   // [CC][KK][CB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    int bid = blockIdx.x;
+    const int cg = bid % a.cgroups;
+    bid /= a.cgroups;
+    const int txi = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int tyi = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int x0 = txi * TW, y0 = tyi * TH;
+    const int HW = a.H * a.W;
+
+    f32x16 acc[NCB][R];
+#pragma unroll
+    for (int i = 0; i < NCB; ++i)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][r][q] = 0.f;
+
+    const int nchunks = (a.cin + CC - 1) / CC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CC;
+        __syncthreads();
+        // ---- stage the input tile (+halo) of CC channels; zero outside the image / past cin
+#pragma unroll 1
+        for (int c = 0; c < CC; ++c) {
+            const float* base = nullptr;
+            const float* mbase = nullptr;
+            const int cc = c0 + c;
+            if (cc < a.cin) {
+                int s = 0, rel = cc;
+                while (s < a.nsrc - 1 && rel >= a.src[s].c) {
+                    rel -= a.src[s].c;
+                    ++s;
+                }
+                base = a.src[s].p + (long long)b * a.src[s].bs + (long long)rel * HW;
+                if (a.mask) mbase = a.mask + (long long)b * a.mask_bs + (long long)rel * HW;
+            }
+            for (int i = tid; i < PLANE; i += 256) {
+                const int ty = i / TCOLS, tx = i - ty * TCOLS;
+                const int gy = y0 + ty - PAD, gx = x0 + tx - PAD;
+                float v = 0.f;
+                if (base != nullptr && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    v = base[gy * a.W + gx];
+                    if (mbase != nullptr) v = mbase[gy * a.W + gx] > 0.f ? v : 0.f;
+                }
+                xs[c * PLANE + i] = v;
+            }
+        }
+        // ---- stage the filter slice [CC][KK][CB] (rows of CB floats, 16-byte vectors)
+        {
+            constexpr int ROW4 = CB / 4;
+            const float* wsrc = a.wp + (long long)c0 * KK * a.cout_pad + cg * CB;
+            for (int i = tid; i < CC * KK * ROW4; i += 256) {
+                const int row = i / ROW4, j4 = i - row * ROW4;
+                reinterpret_cast<float4*>(ws)[i] =
+                    *reinterpret_cast<const float4*>(wsrc + (long long)row * a.cout_pad + j4 * 4);
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over (channel pair, tap)
+        const int rem = a.cin - c0;
+        const int npairs = rem >= CC ? CC / 2 : (rem + 1) / 2;
+        const float* xb = xs + half * PLANE + (wave * R) * TCOLS + l31;
+        const float* wb = ws + half * KK * CB + l31;
+#pragma unroll 1
+        for (int p = 0; p < npairs; ++p) {
+            const float* xp = xb + 2 * p * PLANE;
+            const float* wq = wb + 2 * p * KK * CB;
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                const int ky = t / KS, kx = t % KS;
+                float av[NCB];
+#pragma unroll
+                for (int i = 0; i < NCB; ++i) av[i] = wq[t * CB + i * 32];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float bv = xp[(r + ky) * TCOLS + kx];
+#pragma unroll
+                    for (int i = 0; i < NCB; ++i)
+                        acc[i][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][r], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, ReLU, scatter to the (possibly split) destination
+    const int gx = x0 + l31;
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = cg * CB + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+            if (co >= a.cout) continue;
+            const float bsv = a.bias ? a.bias[co] : 0.f;
+            int d = 0, rel = co;
+            while (d < a.ndst - 1 && rel >= a.dst[d].c) {
+                rel -= a.dst[d].c;
+                ++d;
+            }
+            float* dp = a.dst[d].p;
+            if (dp == nullptr) continue;
+            dp += (long long)b * a.dst[d].bs + (long long)rel * HW;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int gy = y0 + wave * R + r;
+                if (gy < a.H && gx < a.W) {
+                    float v = acc[i][r][q] + bsv;
+                    if (a.relu) v = v < 0.f ? 0.f : v;
+                    dp[gy * a.W + gx] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int NCB, int R, int CC>
+static int launch_conv(ConvArgs& a, hipStream_t st) {
+    using C = ConvCfg<KS, NCB, R, CC>;
+    a.tiles_x = ceil_div(a.W, C::TW);
+    a.tiles_y = ceil_div(a.H, C::TH);
+    a.cgroups = ceil_div(a.cout, C::CB);
+    const long long nblk = (long long)a.tiles_x * a.tiles_y * a.cgroups * a.B;
+    YNET_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv2d: grid of %lld blocks is out of range", nblk);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, NCB, R, CC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, NCB, R, CC>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    return ynet_check_launch("conv2d");
+}
+
+static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
+    const bool wide = a.cout > 32;
+    switch (K) {
+        case 1: return wide ? launch_conv<1, 2, 4, 16>(a, st) : launch_conv<1, 1, 4, 16>(a, st);
+        case 3: return wide ? launch_conv<3, 2, 4, 8>(a, st) : launch_conv<3, 1, 4, 8>(a, st);
+        case 5: return wide ? launch_conv<5, 2, 4, 4>(a, st) : launch_conv<5, 1, 4, 4>(a, st);
+        default: ynet_set_error("conv2d: kernel size %d not supported (1, 3, 5)", K); return 1;
+    }
+}
+
+// The largest CC used above: the packed filter is zero padded to a multiple of it along cin.
+#define YNET_CIN_PAD 16
+#define YNET_COUT_PAD 64
+
+// ------------------------------------------------------------------------------------------------
+// filter packing: checkpoint layout [Cout][Cin][K][K] -> [cin_pad][K*K][cout_pad] (zero padded)
+//   mode 0 (forward): wp[ci][t][co] = w[co][ci][t]
+//   mode 1 (dgrad):   wp[co][t][ci] = w[co][ci][K*K-1-t]   (roles of cin/cout swapped, taps flipped)
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin,
+                                   int KK, int mode, int rows /*K-dim channels*/, int cols /*M-dim channels*/,
+                                   int rows_pad, int cols_pad) {
+    const long long n = (long long)rows_pad * KK * cols_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % cols_pad);
+        const int t = (int)((i / cols_pad) % KK);
+        const int k = (int)(i / ((long long)cols_pad * KK));
+        float v = 0.f;
+        if (k < rows && m < cols) {
+            v = mode == 0 ? w[((long long)m * cin + k) * KK + t] : w[((long long)k * cin + m) * KK + (KK - 1 - t)];
+        }
+        wp[i] = v;
+    }
+}
+
+extern "C" {
+
+long long ynet_packed_weight_floats(int cout, int cin, int K, int mode) {
+    const int rows = mode == 0 ? cin : cout, cols = mode == 0 ? cout : cin;
+    const long long rp = (long long)ceil_div(rows, YNET_CIN_PAD) * YNET_CIN_PAD;
+    const long long cp = (long long)ceil_div(cols, YNET_COUT_PAD) * YNET_COUT_PAD;
+    return rp * K * K * cp;
+}
+
+int ynet_pack_weight(const float* w, float* wp, int cout, int cin, int K, int mode, void* stream) {
+    YNET_REQUIRE(w && wp, "pack_weight: null pointer");
+    YNET_REQUIRE(mode == 0 || mode == 1, "pack_weight: mode must be 0 (forward) or 1 (dgrad)");
+    YNET_REQUIRE(cout > 0 && cin > 0 && (K == 1 || K == 3 || K == 5), "pack_weight: bad shape %d %d %d", cout, cin, K);
+    const int rows = mode == 0 ? cin : cout, cols = mode == 0 ? cout : cin;
+    const int rp = ceil_div(rows, YNET_CIN_PAD) * YNET_CIN_PAD, cp = ceil_div(cols, YNET_COUT_PAD) * YNET_COUT_PAD;
+    const long long n = (long long)rp * K * K * cp;
+    const int grid = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp, cout, cin, K * K,
+                       mode, rows, cols, rp, cp);
+    return ynet_check_launch("pack_weight");
+}
+
+// y[dst...] = [relu](conv(cat(src...) [masked], wp) + bias); cin = sum of source channels,
+// cout = sum of destination channels.  See include/ynet_hip.h.
+int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
+                const float* mask, long long mask_bs, const float* wp, const float* bias,
+                float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
+                int B, int H, int W, int K, int relu, void* stream) {
+    YNET_REQUIRE(nsrc >= 1 && nsrc <= YNET_MAX_SRC && ndst >= 1 && ndst <= YNET_MAX_SRC,
+                 "conv2d: 1..%d sources/destinations supported (got %d/%d)", YNET_MAX_SRC, nsrc, ndst);
+    YNET_REQUIRE(B > 0 && H > 0 && W > 0, "conv2d: empty problem B=%d H=%d W=%d", B, H, W);
+    YNET_REQUIRE(wp != nullptr, "conv2d: packed filter is null");
+    YNET_REQUIRE(mask == nullptr || nsrc == 1, "conv2d: a ReLU mask needs a single source");
+    ConvArgs a{};
+    a.nsrc = nsrc;
+    a.cin = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        YNET_REQUIRE(src[i] != nullptr && src_c[i] > 0, "conv2d: source %d is null/empty", i);
+        a.src[i] = YSrc{src[i], src_c[i], src_bs[i]};
+        a.cin += src_c[i];
+    }
+    a.ndst = ndst;
+    a.cout = 0;
+    for (int i = 0; i < ndst; ++i) {
+        YNET_REQUIRE(dst_c[i] > 0, "conv2d: destination %d has no channels", i);
+        a.dst[i] = YDst{dst[i], dst_c[i], dst_bs[i]};
+        a.cout += dst_c[i];
+    }
+    // trailing destinations that are not wanted need not be computed at all
+    while (a.ndst > 1 && a.dst[a.ndst - 1].p == nullptr) {
+        a.cout -= a.dst[a.ndst - 1].c;
+        --a.ndst;
+    }
+    {   // the packed filter was padded for the FULL cout
+        int full = 0;
+        for (int i = 0; i < ndst; ++i) full += dst_c[i];
+        a.cout_pad = ceil_div(full, YNET_COUT_PAD) * YNET_COUT_PAD;
+    }
+    a.mask = mask;
+    a.mask_bs = mask_bs;
+    a.wp = wp;
+    a.bias = bias;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.relu = relu;
+    return conv_dispatch(a, K, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,536 @@
+// HBM-bound kernels of the Y-Net path: pooling, bilinear x2, waypoint pyramid, BCE-with-logits,
+// soft-argmax, sigmoid(x/T), heat-map patch gather.  One pass over the data each, coalesced
+// (16-byte where alignment allows), wavefront (64-lane) shuffles for reductions.
+// Reference call sites are cited per kernel; the public C ABI is include/ynet_hip.h.
+#include "ynet_common.h"
+
+static inline int grid_for(long long n, int block, int cap = 2048 * 4) {
+    long long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(2,2) forward / backward   (models/ynet.py:202,215,326,340,354,367)
+// backward recomputes the argmax from x with ATen's rule: first maximum in window scan order.
+// ------------------------------------------------------------------------------------------------
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long N, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long total = N * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo);
+        const int yo = (int)((i / Wo) % Ho);
+        const long long n = i / ((long long)Wo * Ho);
+        const float* p = x + (n * H + 2 * yo) * W + 2 * xo;
+        float m = p[0];
+        float v = p[1];
+        m = (v > m || v != v) ? v : m;
+        v = p[W];
+        m = (v > m || v != v) ? v : m;
+        v = p[W + 1];
+        m = (v > m || v != v) ? v : m;
+        y[i] = m;
+    }
+}
+
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    float* __restrict__ dx, long long N, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;   // cover odd trailing row/col with zeros
+    const long long total = N * Hc * Wc;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wc);
+        const int yo = (int)((i / Wc) % Hc);
+        const long long n = i / ((long long)Wc * Hc);
+        const long long base = (n * H + 2 * yo) * W + 2 * xo;
+        if (yo < Ho && xo < Wo) {
+            const float* p = x + base;
+            float m = p[0];
+            int arg = 0;
+            float v = p[1];
+            if (v > m || v != v) { m = v; arg = 1; }
+            v = p[W];
+            if (v > m || v != v) { m = v; arg = 2; }
+            v = p[W + 1];
+            if (v > m || v != v) { m = v; arg = 3; }
+            const float g = dy[(n * Ho + yo) * Wo + xo];
+            dx[base] = arg == 0 ? g : 0.f;
+            dx[base + 1] = arg == 1 ? g : 0.f;
+            dx[base + W] = arg == 2 ? g : 0.f;
+            dx[base + W + 1] = arg == 3 ? g : 0.f;
+        } else {
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    if (2 * yo + a < H && 2 * xo + b < W) dx[base + a * W + b] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False)   (models/ynet.py:463)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up2_src(int o, int in, int& i0, int& i1, float& l0, float& l1) {
+    float s = 0.5f * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long N, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = N * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo);
+        const int oy = (int)((i / Wo) % Ho);
+        const long long n = i / ((long long)Wo * Ho);
+        int h0, h1, w0, w1;
+        float hl0, hl1, wl0, wl1;
+        up2_src(oy, H, h0, h1, hl0, hl1);
+        up2_src(ox, W, w0, w1, wl0, wl1);
+        const float* p = x + n * H * W;
+        y[i] = hl0 * (wl0 * p[h0 * W + w0] + wl1 * p[h0 * W + w1]) +
+               hl1 * (wl0 * p[h1 * W + w0] + wl1 * p[h1 * W + w1]);
+    }
+}
+
+// dx[i][j] = sum over the (at most 4x4) output pixels whose stencil touches (i,j)
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long N, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = N * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % W);
+        const int iy = (int)((i / W) % H);
+        const long long n = i / ((long long)W * H);
+        const float* g = dy + n * Ho * Wo;
+        float wy[4], wx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int o = 2 * iy - 1 + k, a0, a1;
+            float l0, l1;
+            wy[k] = 0.f;
+            if (o >= 0 && o < Ho) {
+                up2_src(o, H, a0, a1, l0, l1);
+                wy[k] = (a0 == iy ? l0 : 0.f) + (a1 == iy ? l1 : 0.f);
+            }
+            o = 2 * ix - 1 + k;
+            wx[k] = 0.f;
+            if (o >= 0 && o < Wo) {
+                up2_src(o, W, a0, a1, l0, l1);
+                wx[k] = (a0 == ix ? l0 : 0.f) + (a1 == ix ? l1 : 0.f);
+            }
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oy = 2 * iy - 1 + a;
+            if (wy[a] == 0.f) continue;
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ox = 2 * ix - 1 + b;
+                if (wx[b] != 0.f) row += wx[b] * g[oy * Wo + ox];
+            }
+            acc += wy[a] * row;
+        }
+        dx[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AvgPool2d(2^i) pyramid of the waypoint map, i = 1..nlev  (utils/train_epoch.py:97-100,
+// utils/evaluate.py:255-257): one pass, one 32x32 tile per workgroup, levels chained through LDS.
+// ------------------------------------------------------------------------------------------------
+struct PyrArgs {
+    const float* x;
+    float* out[5];
+    int nlev, H, W;
+    long long N;
+};
+
+__global__ __launch_bounds__(256) void avgpool_pyramid_kernel(const PyrArgs a) {
+    __shared__ float t[32 * 33];
+    __shared__ float l1[16 * 16], l2[8 * 8], l3[4 * 4], l4[2 * 2];
+    const int tid = threadIdx.x;
+    const int tiles_x = a.W / 32, tiles_y = a.H / 32;
+    long long bid = blockIdx.x;
+    const int txi = (int)(bid % tiles_x);
+    const int tyi = (int)((bid / tiles_x) % tiles_y);
+    const long long n = bid / ((long long)tiles_x * tiles_y);
+    const float* p = a.x + (n * a.H + tyi * 32) * a.W + txi * 32;
+    for (int i = tid; i < 1024; i += 256) t[(i >> 5) * 33 + (i & 31)] = p[(i >> 5) * (long long)a.W + (i & 31)];
+    __syncthreads();
+    {
+        const int oy = tid >> 4, ox = tid & 15;
+        const float s = (t[(2 * oy) * 33 + 2 * ox] + t[(2 * oy) * 33 + 2 * ox + 1]) +
+                        (t[(2 * oy + 1) * 33 + 2 * ox] + t[(2 * oy + 1) * 33 + 2 * ox + 1]);
+        l1[tid] = s;
+        a.out[0][(n * (a.H / 2) + tyi * 16 + oy) * (a.W / 2) + txi * 16 + ox] = s * 0.25f;
+    }
+    if (a.nlev < 2) return;
+    __syncthreads();
+    if (tid < 64) {
+        const int oy = tid >> 3, ox = tid & 7;
+        const float s = (l1[(2 * oy) * 16 + 2 * ox] + l1[(2 * oy) * 16 + 2 * ox + 1]) +
+                        (l1[(2 * oy + 1) * 16 + 2 * ox] + l1[(2 * oy + 1) * 16 + 2 * ox + 1]);
+        l2[tid] = s;
+        a.out[1][(n * (a.H / 4) + tyi * 8 + oy) * (a.W / 4) + txi * 8 + ox] = s * (1.f / 16.f);
+    }
+    if (a.nlev < 3) return;
+    __syncthreads();
+    if (tid < 16) {
+        const int oy = tid >> 2, ox = tid & 3;
+        const float s = (l2[(2 * oy) * 8 + 2 * ox] + l2[(2 * oy) * 8 + 2 * ox + 1]) +
+                        (l2[(2 * oy + 1) * 8 + 2 * ox] + l2[(2 * oy + 1) * 8 + 2 * ox + 1]);
+        l3[tid] = s;
+        a.out[2][(n * (a.H / 8) + tyi * 4 + oy) * (a.W / 8) + txi * 4 + ox] = s * (1.f / 64.f);
+    }
+    if (a.nlev < 4) return;
+    __syncthreads();
+    if (tid < 4) {
+        const int oy = tid >> 1, ox = tid & 1;
+        const float s = (l3[(2 * oy) * 4 + 2 * ox] + l3[(2 * oy) * 4 + 2 * ox + 1]) +
+                        (l3[(2 * oy + 1) * 4 + 2 * ox] + l3[(2 * oy + 1) * 4 + 2 * ox + 1]);
+        l4[tid] = s;
+        a.out[3][(n * (a.H / 16) + tyi * 2 + oy) * (a.W / 16) + txi * 2 + ox] = s * (1.f / 256.f);
+    }
+    if (a.nlev < 5) return;
+    __syncthreads();
+    if (tid == 0) {
+        const float s = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+        a.out[4][(n * (a.H / 32) + tyi) * (a.W / 32) + txi] = s * (1.f / 1024.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wavefront / block reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BCEWithLogitsLoss(reduction='mean')  (models/trainer.py:206, utils/train_epoch.py:94,106)
+//   l = (1 - t) * x - log_sigmoid(x),  log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+//   dl/dx = (sigmoid(x) - t) * g / n
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                      long long n, double* __restrict__ partial) {
+    __shared__ double ws[4];
+    double acc = 0.0;
+    const long long n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* t4 = reinterpret_cast<const float4*>(t);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float4 xv = x4[i], tv = t4[i];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float ls = fminf(xs[k], 0.f) - log1pf(expf(-fabsf(xs[k])));
+            s += (1.f - ts[k]) * xs[k] - ls;
+        }
+        acc += (double)s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        const float ls = fminf(x[i], 0.f) - log1pf(expf(-fabsf(x[i])));
+        acc += (double)((1.f - t[i]) * x[i] - ls);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(256) void bce_finish_kernel(const double* __restrict__ partial, int nparts, long long n,
+                                                         float* __restrict__ loss) {
+    __shared__ double ws[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((ws[0] + ws[1]) + (ws[2] + ws[3])) / (double)n);
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                      const float* __restrict__ gout, float* __restrict__ dx,
+                                                      long long n) {
+    const float g = gout[0] / (float)n;
+    const long long n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* t4 = reinterpret_cast<const float4*>(t);
+    float4* d4 = reinterpret_cast<float4*>(dx);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float4 xv = x4[i], tv = t4[i];
+        float4 o;
+        o.x = (1.f / (1.f + expf(-xv.x)) - tv.x) * g;
+        o.y = (1.f / (1.f + expf(-xv.y)) - tv.y) * g;
+        o.z = (1.f / (1.f + expf(-xv.z)) - tv.z) * g;
+        o.w = (1.f / (1.f + expf(-xv.w)) - tv.w) * g;
+        d4[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        dx[i] = (1.f / (1.f + expf(-x[i])) - t[i]) * g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SoftArgmax2D  (utils/softargmax.py:55-81): one workgroup per (b,c) plane, ONE pass over HBM with
+// an online (running-max) softmax; per-thread fp32 partials over <= a few hundred pixels, combined
+// across the wavefront and the workgroup in fp64.  out[plane] = (E[x], E[y]).
+// ------------------------------------------------------------------------------------------------
+struct SoftAcc {
+    float m;        // running max
+    float s, sx, sy;
+};
+
+__device__ __forceinline__ void soft_add(SoftAcc& a, float v, float px, float py) {
+    if (v > a.m) {
+        const float r = expf(a.m - v);   // a.m = -inf on the first element -> 0
+        a.s *= r;
+        a.sx *= r;
+        a.sy *= r;
+        a.m = v;
+    }
+    const float e = expf(v - a.m);
+    a.s += e;
+    a.sx += e * px;
+    a.sy += e * py;
+}
+
+__global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         int C, long long bs, int H, int W, float eps) {
+    __shared__ float wm[4];
+    __shared__ double wsum[4][3];
+    const long long plane = blockIdx.x;
+    const float* p = x + (plane / C) * bs + (plane % C) * (long long)H * W;
+    const int tid = threadIdx.x;
+    SoftAcc a{-INFINITY, 0.f, 0.f, 0.f};
+    const int n = H * W;
+    if ((W & 3) == 0) {
+        const int w4 = W >> 2, n4 = n >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int i = tid; i < n4; i += 256) {
+            const float4 v = p4[i];
+            const int row = i / w4, col = (i - row * w4) << 2;
+            // rescale at most once per 16-byte vector
+            const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+            if (mx > a.m) {
+                const float r = expf(a.m - mx);
+                a.s *= r;
+                a.sx *= r;
+                a.sy *= r;
+                a.m = mx;
+            }
+            const float e0 = expf(v.x - a.m), e1 = expf(v.y - a.m), e2 = expf(v.z - a.m), e3 = expf(v.w - a.m);
+            const float es = (e0 + e1) + (e2 + e3);
+            a.s += es;
+            a.sx += (e0 * (float)col + e1 * (float)(col + 1)) + (e2 * (float)(col + 2) + e3 * (float)(col + 3));
+            a.sy += es * (float)row;
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) {
+            const int row = i / W, col = i - row * W;
+            soft_add(a, p[i], (float)col, (float)row);
+        }
+    }
+    // combine: block max, then rescaled sums in fp64
+    float m = wave_max(a.m);
+    if ((tid & 63) == 0) wm[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    const double r = (a.m == -INFINITY) ? 0.0 : (double)expf(a.m - m);
+    double s = wave_sum((double)a.s * r), sx = wave_sum((double)a.sx * r), sy = wave_sum((double)a.sy * r);
+    if ((tid & 63) == 0) {
+        wsum[tid >> 6][0] = s;
+        wsum[tid >> 6][1] = sx;
+        wsum[tid >> 6][2] = sy;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        s = (wsum[0][0] + wsum[1][0]) + (wsum[2][0] + wsum[3][0]);
+        sx = (wsum[0][1] + wsum[1][1]) + (wsum[2][1] + wsum[3][1]);
+        sy = (wsum[0][2] + wsum[1][2]) + (wsum[2][2] + wsum[3][2]);
+        const double inv = 1.0 / (s + (double)eps);
+        out[plane * 2 + 0] = (float)(sx * inv);
+        out[plane * 2 + 1] = (float)(sy * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sigmoid(x[:, sel] / T)   (utils/evaluate.py:128-131, models/ynet.py:585-586): channel gather fused
+// ------------------------------------------------------------------------------------------------
+struct SigArgs {
+    const float* x;
+    float* y;
+    int sel[8];
+    int nsel, C;
+    long long B, HW;
+    float T;
+};
+
+__global__ void sigmoid_temp_kernel(const SigArgs a) {
+    const long long total = a.B * a.nsel * a.HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long px = i % a.HW;
+        const int k = (int)((i / a.HW) % a.nsel);
+        const long long b = i / (a.HW * a.nsel);
+        const float v = a.x[(b * a.C + a.sel[k]) * a.HW + px] / a.T;
+        a.y[i] = 1.f / (1.f + expf(-v));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_patch + torch.stack  (utils/image_utils.py:40-63; utils/train_epoch.py:63-78):
+//   out[n,y,x] = tmpl[cy - ry_n + y][cx - rx_n + x],  r = rint(coord) (round-half-even = np.round)
+// coords: [N,2] (x,y) fp32 on the device; `status` (int, device) is set to 1 if a window leaves the
+// template (the reference would silently produce a ragged patch and fail in torch.stack).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_patch_kernel(const float* __restrict__ tmpl, int SH, int SW,
+                                                           const float* __restrict__ xy, float* __restrict__ out,
+                                                           int H, int W, int* __restrict__ status) {
+    const int n = blockIdx.y;
+    const int rx = (int)rintf(xy[2 * n]), ry = (int)rintf(xy[2 * n + 1]);
+    const int ox = SW / 2 - rx, oy = SH / 2 - ry;
+    if (ox < 0 || oy < 0 || ox + W > SW || oy + H > SH) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(status, 1);
+        return;
+    }
+    float* o = out + (long long)n * H * W;
+    const int total = H * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int y = i / W, x = i - y * W;
+        o[i] = tmpl[(long long)(oy + y) * SW + ox + x];
+    }
+}
+
+extern "C" {
+
+int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
+    YNET_REQUIRE(x && y && N > 0 && H >= 2 && W >= 2, "maxpool2_fwd: bad arguments");
+    const long long total = N * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
+    return ynet_check_launch("maxpool2_fwd");
+}
+
+int ynet_maxpool2_bwd(const float* x, const float* dy, float* dx, long long N, int H, int W, void* stream) {
+    YNET_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2, "maxpool2_bwd: bad arguments");
+    const long long total = N * ((H + 1) / 2) * ((W + 1) / 2);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W);
+    return ynet_check_launch("maxpool2_bwd");
+}
+
+int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
+    YNET_REQUIRE(x && y && N > 0 && H > 0 && W > 0, "upsample2x_fwd: bad arguments");
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(N * H * W * 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
+    return ynet_check_launch("upsample2x_fwd");
+}
+
+int ynet_upsample2x_bwd(const float* dy, float* dx, long long N, int H, int W, void* stream) {
+    YNET_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0, "upsample2x_bwd: bad arguments");
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+    return ynet_check_launch("upsample2x_bwd");
+}
+
+int ynet_avgpool_pyramid(const float* x, float* const* outs, int nlev, long long N, int H, int W, void* stream) {
+    YNET_REQUIRE(x && outs && nlev >= 1 && nlev <= 5, "avgpool_pyramid: 1..5 levels supported (got %d)", nlev);
+    YNET_REQUIRE(N > 0 && H % 32 == 0 && W % 32 == 0 && H > 0 && W > 0,
+                 "avgpool_pyramid: H and W must be multiples of 32 (got %dx%d)", H, W);
+    PyrArgs a{};
+    a.x = x;
+    for (int i = 0; i < nlev; ++i) {
+        YNET_REQUIRE(outs[i] != nullptr, "avgpool_pyramid: output %d is null", i);
+        a.out[i] = outs[i];
+    }
+    a.nlev = nlev;
+    a.H = H;
+    a.W = W;
+    a.N = N;
+    const long long nblk = N * (H / 32) * (W / 32);
+    hipLaunchKernelGGL(avgpool_pyramid_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a);
+    return ynet_check_launch("avgpool_pyramid");
+}
+
+#define YNET_BCE_PARTS 1024
+
+long long ynet_bce_workspace_bytes(void) { return YNET_BCE_PARTS * (long long)sizeof(double); }
+
+int ynet_bce_logits_fwd(const float* x, const float* t, long long n, float* loss, void* workspace, void* stream) {
+    YNET_REQUIRE(x && t && loss && workspace && n > 0, "bce_logits_fwd: bad arguments");
+    YNET_REQUIRE((((uintptr_t)x | (uintptr_t)t) & 15) == 0, "bce_logits_fwd: inputs must be 16-byte aligned");
+    const int parts = grid_for(n / 4 + 1, 256, YNET_BCE_PARTS);
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, x, t, n, (double*)workspace);
+    hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, parts, n, loss);
+    return ynet_check_launch("bce_logits_fwd");
+}
+
+int ynet_bce_logits_bwd(const float* x, const float* t, const float* grad_out, float* dx, long long n, void* stream) {
+    YNET_REQUIRE(x && t && grad_out && dx && n > 0, "bce_logits_bwd: bad arguments");
+    YNET_REQUIRE((((uintptr_t)x | (uintptr_t)t | (uintptr_t)dx) & 15) == 0, "bce_logits_bwd: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, t, grad_out, dx, n);
+    return ynet_check_launch("bce_logits_bwd");
+}
+
+int ynet_softargmax2d(const float* x, float* out, long long B, int C, long long batch_stride, int H, int W,
+                      void* stream) {
+    YNET_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, "softargmax2d: bad arguments");
+    const long long planes = B * C;
+    YNET_REQUIRE(planes < (1ll << 31), "softargmax2d: too many planes");
+    YNET_REQUIRE((W & 3) != 0 || ((((uintptr_t)x) & 15) == 0 && (batch_stride & 3) == 0 && (((long long)H * W) & 3) == 0),
+                 "softargmax2d: input must be 16-byte aligned");
+    hipLaunchKernelGGL(softargmax_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, out, C,
+                       batch_stride, H, W, 1e-6f);
+    return ynet_check_launch("softargmax2d");
+}
+
+int ynet_sigmoid_temp(const float* x, float* y, long long B, int C, long long HW, const int* sel, int nsel,
+                      float temperature, void* stream) {
+    YNET_REQUIRE(x && y && sel && B > 0 && C > 0 && HW > 0, "sigmoid_temp: bad arguments");
+    YNET_REQUIRE(nsel >= 1 && nsel <= 8, "sigmoid_temp: 1..8 selected channels supported (got %d)", nsel);
+    YNET_REQUIRE(temperature != 0.f, "sigmoid_temp: temperature must be non-zero");
+    SigArgs a{};
+    a.x = x;
+    a.y = y;
+    for (int i = 0; i < nsel; ++i) {
+        YNET_REQUIRE(sel[i] >= 0 && sel[i] < C, "sigmoid_temp: channel %d out of range [0,%d)", sel[i], C);
+        a.sel[i] = sel[i];
+    }
+    a.nsel = nsel;
+    a.C = C;
+    a.B = B;
+    a.HW = HW;
+    a.T = temperature;
+    hipLaunchKernelGGL(sigmoid_temp_kernel, dim3(grid_for(B * nsel * HW, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return ynet_check_launch("sigmoid_temp");
+}
+
+int ynet_gather_patch(const float* tmpl, int SH, int SW, const float* xy, float* out, int N, int H, int W,
+                      int* status, void* stream) {
+    YNET_REQUIRE(tmpl && xy && out && status, "gather_patch: null pointer");
+    YNET_REQUIRE(N > 0 && N < 65536 && H > 0 && W > 0 && SH >= H && SW >= W, "gather_patch: bad shape N=%d %dx%d in %dx%d", N, H, W, SH, SW);
+    int gx = (H * W + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(gather_patch_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, tmpl, SH, SW, xy, out, H, W, status);
+    return ynet_check_launch("gather_patch");
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// MoSA / LoRA adapter algebra on the fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// Restates loralib==0.1.1 `Conv2d` (call site models/ynet.py:141-144; third-party, not in the
+// reference tree -> "parity unpinned", see oracle/_stubs/loralib):
+//   W_eff = W + (lora_B @ lora_A).view(W.shape) * (lora_alpha / r)          (compose, K5)
+//   dA = s * B^T @ dWm,   dB = s * dWm @ A^T,   dWm = dW.view(Cout*k, Cin*k)  (grad,    K6)
+// The .view is a FLAT reshape of the [Cout*k, Cin*k] product, so both are plain row-major GEMMs
+// over the flat weight.  These are the "dense LoRA down/up projections" of the north star; they
+// are tiny (inner dimension r*k = 3..12), one wavefront per 16x16 output tile, operands straight
+// from global memory (L2-resident).
+#include "ynet_common.h"
+
+struct GemmArgs {
+    const float* A;   // element (m,k) at A[m*sam + k*sak]
+    const float* B;   // element (k,n) at B[k*sbk + n*sbn]
+    const float* D;   // optional addend, row-major [M][N]
+    float* C;         // row-major [M][N]:  C = alpha * A@B + D
+    int M, N, K;
+    long long sam, sak, sbk, sbn;
+    float alpha;
+};
+
+__global__ __launch_bounds__(64) void small_gemm_mfma_kernel(const GemmArgs g) {
+    const int lane = threadIdx.x;
+    const int tiles_n = (g.N + 15) / 16;
+    const int m0 = (blockIdx.x / tiles_n) * 16, n0 = (blockIdx.x % tiles_n) * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int am = m0 + r, bn = n0 + r;
+    for (int k0 = 0; k0 < g.K; k0 += 4) {
+        const int k = k0 + kq;
+        const float a = (am < g.M && k < g.K) ? g.A[am * g.sam + k * g.sak] : 0.f;
+        const float b = (bn < g.N && k < g.K) ? g.B[k * g.sbk + bn * g.sbn] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + kq * 4 + q, n = n0 + r;
+        if (m < g.M && n < g.N) {
+            const long long i = (long long)m * g.N + n;
+            g.C[i] = g.alpha * acc[q] + (g.D ? g.D[i] : 0.f);
+        }
+    }
+}
+
+static int run_gemm(const GemmArgs& g, hipStream_t st, const char* what) {
+    const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+    hipLaunchKernelGGL(small_gemm_mfma_kernel, dim3(tiles), dim3(64), 0, st, g);
+    return ynet_check_launch(what);
+}
+
+extern "C" {
+
+int ynet_lora_compose(const float* w, const float* lora_a, const float* lora_b, float scale, float* w_eff,
+                      int cout, int cin, int K, int r, void* stream) {
+    YNET_REQUIRE(w && lora_a && lora_b && w_eff, "lora_compose: null pointer");
+    YNET_REQUIRE(cout > 0 && cin > 0 && K > 0 && r > 0, "lora_compose: bad shape");
+    GemmArgs g{};
+    g.M = cout * K;
+    g.N = cin * K;
+    g.K = r * K;
+    g.A = lora_b;   // [M][Kd]
+    g.sam = g.K;
+    g.sak = 1;
+    g.B = lora_a;   // [Kd][N]
+    g.sbk = g.N;
+    g.sbn = 1;
+    g.D = w;
+    g.C = w_eff;
+    g.alpha = scale;
+    return run_gemm(g, (hipStream_t)stream, "lora_compose");
+}
+
+int ynet_lora_grad(const float* dw, const float* lora_a, const float* lora_b, float scale, float* d_a, float* d_b,
+                   int cout, int cin, int K, int r, void* stream) {
+    YNET_REQUIRE(dw && lora_a && lora_b && d_a && d_b, "lora_grad: null pointer");
+    YNET_REQUIRE(cout > 0 && cin > 0 && K > 0 && r > 0, "lora_grad: bad shape");
+    const int M = cout * K, N = cin * K, Kd = r * K;
+    GemmArgs ga{};   // dA[Kd][N] = s * B^T[Kd][M] @ dWm[M][N]
+    ga.M = Kd;
+    ga.N = N;
+    ga.K = M;
+    ga.A = lora_b;
+    ga.sam = 1;
+    ga.sak = Kd;
+    ga.B = dw;
+    ga.sbk = N;
+    ga.sbn = 1;
+    ga.C = d_a;
+    ga.alpha = scale;
+    int rc = run_gemm(ga, (hipStream_t)stream, "lora_grad(dA)");
+    if (rc) return rc;
+    GemmArgs gb{};   // dB[M][Kd] = s * dWm[M][N] @ A^T[N][Kd]
+    gb.M = M;
+    gb.N = Kd;
+    gb.K = N;
+    gb.A = dw;
+    gb.sam = N;
+    gb.sak = 1;
+    gb.B = lora_a;
+    gb.sbk = 1;
+    gb.sbn = N;
+    gb.C = d_b;
+    gb.alpha = scale;
+    return run_gemm(gb, (hipStream_t)stream, "lora_grad(dB)");
+}
+
+}  // extern "C"

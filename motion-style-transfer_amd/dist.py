@@ -1,0 +1,98 @@
+"""Data-parallel sharding of a scene batch over the GPUs of one node (new: the reference is
+single-process).
+
+One process per GPU (torchrun); backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests.
+Every batch of trajectories is split into contiguous row shards; the semantic map, templates and
+weights are replicated.  BCE is a mean over B*pred*H*W (models/trainer.py:206), so a rank scales its
+local loss by B_local / B_global and ONE all-reduce(SUM) of the flat trainable-gradient buffer per
+step (32 KB for mosa_1 ... 6.6 MB full model) reproduces the single-GPU gradient; every rank then
+applies the identical Adam update.  The flat buffer is persistent and ``p.grad`` are views into it,
+so the collective runs in place on the compute stream with no packing copies.
+"""
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, params, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("DataParallel needs an initialised torch.distributed process group")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self._views = []
+        off = 0
+        for p in self.params:
+            self._views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.bind()
+
+    # -- sharding ---------------------------------------------------------------------------
+    def shard(self, n: int) -> Tuple[int, int]:
+        """Rows [lo, hi) of an n-row batch owned by this rank (ragged tails allowed, may be empty)."""
+        base, extra = divmod(n, self.world)
+        lo = self.rank * base + min(self.rank, extra)
+        return lo, lo + base + (1 if self.rank < extra else 0)
+
+    # -- gradients --------------------------------------------------------------------------
+    def bind(self):
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+
+    def zero_grad(self):
+        self.flat.zero_()
+        self.bind()
+
+    def allreduce_grads(self):
+        for p, v in zip(self.params, self._views):      # a rank with an empty shard never ran backward
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def sum_scalar(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            t = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def gather_rows(self, t: torch.Tensor, sizes: List[int]) -> torch.Tensor:
+        """Concatenate per-rank row blocks of (possibly different) length sizes[r] on every rank."""
+        if self.world == 1:
+            return t
+        m = max(sizes)
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        pad[:t.shape[0]] = t
+        out = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(out, pad, group=self.group)
+        return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+    def shard_sizes(self, n: int) -> List[int]:
+        base, extra = divmod(n, self.world)
+        return [base + (1 if r < extra else 0) for r in range(self.world)]
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """torchrun-style bring-up: returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world

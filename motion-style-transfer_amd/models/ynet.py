@@ -1,0 +1,333 @@
+"""Y-Net on MI355X: host-side mirror of the reference's models/ynet.py.
+
+Same public classes, constructor signatures, attribute tree and state-dict keys as the reference
+(``encoder.stages.{i}.{j}.{weight,bias,lora_A,lora_B}``, ``{goal,traj}_decoder.{center,
+upsample_conv,decoder,predictor}...`` — SURVEY.md A.2), so reference checkpoints load unchanged.
+The arithmetic runs in the hand-written gfx950 kernels behind ``..ops``:
+
+  * nn.Conv2d + nn.ReLU            -> one fused MFMA implicit-GEMM launch (ops.conv2d)
+  * loralib.Conv2d (MoSA)          -> MFMA compose of W + BA*s, then the same conv (LoRAConv2d)
+  * torch.cat of skip / waypoint   -> never materialised; the conv reads its parts (ops.LazyCat)
+  * MaxPool2d, bilinear x2, soft-argmax, sigmoid -> dedicated HBM-bound kernels
+
+Reference: models/ynet.py:134-151 (get_conv2d), 170-234 (YNetEncoder/L), 286-395
+(YNetEncoderFusion), 398-471 (YNetDecoder), 474-600 (YNet).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.softargmax import SoftArgmax2D, create_meshgrid
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d (stride 1, 'same' padding, K in {1,3,5}) executed by ynet_conv2d."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=None, bias=True):
+        if isinstance(kernel_size, (tuple, list)):
+            if kernel_size[0] != kernel_size[1]:
+                raise ValueError("only square kernels are supported")
+            kernel_size = kernel_size[0]
+        if isinstance(stride, (tuple, list)):
+            stride = stride[0]
+        if isinstance(padding, (tuple, list)):
+            padding = padding[0]
+        if padding is None:
+            padding = kernel_size // 2
+        if stride != 1 or padding != kernel_size // 2 or kernel_size not in (1, 3, 5):
+            raise ValueError(f"HipConv2d supports stride 1, padding k//2, k in (1,3,5); got k={kernel_size} "
+                             f"stride={stride} padding={padding}")
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
+        self._packed = {}
+
+    def forward(self, x, relu=False):
+        return ops.conv2d(x, self.weight, self.bias, relu, self._packed)
+
+
+class LoRAConv2d(HipConv2d):
+    """loralib==0.1.1 ``Conv2d`` semantics (parameters weight, bias, lora_A, lora_B on the conv
+    itself; scaling = lora_alpha / r; base weight frozen).  Restated from the published algorithm:
+    loralib is not part of the reference tree (requirements.txt:11) -> parity unpinned."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, r=0, lora_alpha=1, lora_dropout=0.0,
+                 merge_weights=True, **kwargs):
+        self._lora_ready = False
+        super().__init__(in_channels, out_channels, kernel_size, **kwargs)
+        assert type(kernel_size) is int
+        self.r, self.lora_alpha, self.merged, self.merge_weights = r, lora_alpha, False, merge_weights
+        if r > 0:
+            self.lora_A = nn.Parameter(self.weight.new_zeros((r * kernel_size, in_channels * kernel_size)))
+            self.lora_B = nn.Parameter(self.weight.new_zeros((out_channels * kernel_size, r * kernel_size)))
+            self.scaling = self.lora_alpha / self.r
+            self.weight.requires_grad = False
+        self._lora_ready = True
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.Conv2d.reset_parameters(self)
+        if getattr(self, "_lora_ready", False) and hasattr(self, "lora_A"):
+            nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+            nn.init.zeros_(self.lora_B)
+
+    def forward(self, x, relu=False):
+        if self.r > 0:
+            return ops.conv2d(x, self.weight, self.bias, relu, self._packed, self.lora_A, self.lora_B, self.scaling)
+        return ops.conv2d(x, self.weight, self.bias, relu, self._packed)
+
+
+class HipMaxPool2d(nn.MaxPool2d):
+    def forward(self, x):
+        if self.kernel_size != 2 or self.stride != 2 or self.padding != 0 or self.ceil_mode:
+            raise ValueError("HipMaxPool2d supports kernel 2 / stride 2 / no padding only")
+        return ops.max_pool2(x)
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential with the reference's child indices, executing Conv2d+ReLU pairs as one launch."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, HipConv2d):
+                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = m(x, relu=fuse)
+                i += 2 if fuse else 1
+            else:
+                if isinstance(m, nn.ReLU):
+                    raise NotImplementedError("a stand-alone ReLU is not on the Y-Net path (it is fused into the conv)")
+                x = m(x)
+                i += 1
+        return x
+
+
+def get_conv2d(train_net, l, position, kernel_size, in_channels, out_channels=None, rank=None, stride=1,
+               padding=None):
+    """models/ynet.py:134-151."""
+    if out_channels is None:
+        out_channels = in_channels
+    if padding is None:
+        padding = kernel_size // 2
+    l = str(l)
+    position = [str(i) for i in position] if position is not None else []
+    if "mosa" in train_net and l in position:
+        assert rank != 0 and rank is not None
+        return LoRAConv2d(in_channels, out_channels, kernel_size=kernel_size, r=rank, stride=stride, padding=padding)
+    if "Layer" in train_net and l in position:
+        raise NotImplementedError(f"adapter layers ({train_net}) are not on the MI355X hot path yet")
+    return HipConv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
+
+
+def _mosa_rank(train_net):
+    if "mosa" in train_net:
+        parts = train_net.split("_")
+        return int(parts[1]) if len(parts) > 1 else 1
+    return None
+
+
+def _stage(train_net, l, position, cin, cout, rank, first):
+    if first:
+        return FusedSequential(get_conv2d(train_net, l, position, 3, cin, cout, rank), nn.ReLU(inplace=False))
+    return FusedSequential(
+        HipMaxPool2d(kernel_size=2, stride=2, padding=0, dilation=1, ceil_mode=False),
+        get_conv2d(train_net, l, position, 3, cin, cout, rank), nn.ReLU(inplace=False),
+        get_conv2d(train_net, l, position, 3, cout, cout, rank), nn.ReLU(inplace=False))
+
+
+class YNetEncoder(nn.Module):
+    def __init__(self, in_channels, channels=(64, 128, 256, 512, 512), train_net=None, position=[]):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, channels
+        self.train_net, self.position = train_net, position
+        self.rank = _mosa_rank(train_net)
+        self.stages = nn.ModuleList([_stage(train_net, 0, position, in_channels, channels[0], self.rank, True)])
+        for i in range(len(channels) - 1):
+            self.stages.append(_stage(train_net, i + 1, position, channels[i], channels[i + 1], self.rank, False))
+        self.stages.append(FusedSequential(HipMaxPool2d(kernel_size=2, stride=2, padding=0, dilation=1, ceil_mode=False)))
+
+    def forward(self, x):
+        features = []
+        for stage in self.stages:
+            x = stage(x)
+            features.append(x)
+        return features
+
+
+class YNetEncoderL(YNetEncoder):
+    pass
+
+
+class YNetEncoderB(YNetEncoder):
+    """Reference models/ynet.py:237-283.  Without serial/parallel adapters it is the plain encoder."""
+
+    def __init__(self, in_channels, channels=(64, 128, 256, 512, 512), train_net=None, position=[]):
+        if "serial" in train_net or "parallel" in train_net:
+            raise NotImplementedError(f"adapter blocks ({train_net}) are not on the MI355X hot path yet")
+        super().__init__(in_channels, channels, train_net, [int(i) for i in position])
+
+
+class YNetEncoderFusion(nn.Module):
+    """Y-Net-Mod: separate scene / motion branches, concatenated, then fused stages (ynet.py:286-395)."""
+
+    def __init__(self, scene_channel, motion_channel, channels, train_net=None, position=[], n_fusion=2):
+        super().__init__()
+        self.scene_channel, self.motion_channel, self.channels = scene_channel, motion_channel, channels
+        self.train_net, self.position = train_net, position
+        self.rank = _mosa_rank(train_net)
+        assert not any(i % 2 for i in channels), f"Odd value in channels={channels}"
+        assert n_fusion <= len(channels) - 1, "The number of fusion exceeds the total number of layer in encoder"
+        n_sep = len(channels) - n_fusion - 1
+        half = [c // 2 for c in channels]
+        self.scene_stages = nn.ModuleList([_stage(train_net, "scene", position, scene_channel, half[0], self.rank, True)])
+        self.motion_stages = nn.ModuleList([_stage(train_net, "motion", position, motion_channel, half[0], self.rank, True)])
+        self.fusion_stages = nn.ModuleList()
+        for i in range(n_sep):
+            self.scene_stages.append(_stage(train_net, "scene", position, half[i], half[i + 1], self.rank, False))
+        for i in range(n_sep):
+            self.motion_stages.append(_stage(train_net, "motion", position, half[i], half[i + 1], self.rank, False))
+        for i in range(n_sep, len(channels) - 1):
+            self.fusion_stages.append(_stage(train_net, "fusion", position, channels[i], channels[i + 1], self.rank, False))
+        self.fusion_stages.append(FusedSequential(HipMaxPool2d(kernel_size=2, stride=2, padding=0, dilation=1, ceil_mode=False)))
+
+    def forward(self, scene_map, motion_map):
+        scene, motion = [], []
+        x = scene_map
+        for stage in self.scene_stages:
+            x = stage(x)
+            scene.append(x)
+        x = motion_map
+        for stage in self.motion_stages:
+            x = stage(x)
+            motion.append(x)
+        features = [ops.lazy_cat([s, m]) for s, m in zip(scene, motion)]
+        x = features[-1]
+        for i, stage in enumerate(self.fusion_stages):
+            if i == 0:
+                # first fused stage starts with a max-pool of the concatenation = concat of the pools
+                mods = list(stage)
+                pooled = ops.lazy_cat([mods[0](p) for p in x.parts])
+                x = pooled
+                j = 1
+                while j < len(mods):
+                    fuse = j + 1 < len(mods) and isinstance(mods[j + 1], nn.ReLU)
+                    x = mods[j](x, relu=fuse)
+                    j += 2 if fuse else 1
+                if isinstance(x, ops.LazyCat):      # n_fusion == 0: only the final pool
+                    x = x.materialize()
+            else:
+                x = stage(x)
+            features.append(x)
+        return features
+
+
+class YNetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels, output_len, traj=False):
+        super().__init__()
+        if traj:
+            encoder_channels = [c + traj for c in encoder_channels]
+        encoder_channels = encoder_channels[::-1]
+        center = encoder_channels[0]
+        self.center = FusedSequential(
+            HipConv2d(center, center * 2, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1)), nn.ReLU(inplace=False),
+            HipConv2d(center * 2, center * 2, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1)), nn.ReLU(inplace=False))
+        up_in = [center * 2] + decoder_channels[:-1]
+        up_out = [c // 2 for c in up_in]
+        self.upsample_conv = nn.ModuleList([
+            HipConv2d(a, b, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1)) for a, b in zip(up_in, up_out)])
+        in_channels = [e + d for e, d in zip(encoder_channels, up_out)]
+        self.decoder = nn.ModuleList([
+            FusedSequential(
+                HipConv2d(a, b, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1)), nn.ReLU(inplace=False),
+                HipConv2d(b, b, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1)), nn.ReLU(inplace=False))
+            for a, b in zip(in_channels, decoder_channels)])
+        self.predictor = HipConv2d(decoder_channels[-1], output_len, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, features):
+        features = features[::-1]
+        x = self.center(features[0])
+        for f, d, up in zip(features[1:], self.decoder, self.upsample_conv):
+            x = ops.upsample2x(x)
+            x = up(x)
+            x = d(ops.lazy_cat([x, f]))
+        return self.predictor(x)
+
+
+class YNet(nn.Module):
+    def __init__(self, obs_len, pred_len, segmentation_model_fp, use_features_only=False, n_semantic_classes=6,
+                 encoder_channels=[], decoder_channels=[], n_waypoints=1, train_net=None, position=[],
+                 network=None, n_fusion=None):
+        super().__init__()
+        self.train_net = train_net
+        if segmentation_model_fp is not None:
+            # frozen backbone, run once per scene (out of the hot path): loaded exactly as the reference does
+            self.semantic_segmentation = torch.load(
+                segmentation_model_fp, map_location=None if torch.cuda.is_available() else torch.device("cpu"),
+                weights_only=False)
+            print("Loaded segmentation model to GPU" if torch.cuda.is_available() else "Loaded segmentation model to CPU")
+            if use_features_only:
+                self.semantic_segmentation.segmentation_head = nn.Identity()
+                n_semantic_classes = 16
+        else:
+            self.semantic_segmentation = nn.Identity()
+        self.feature_channels = n_semantic_classes + obs_len
+        self.network = network
+        if "semantic" in train_net:
+            kernel_size = int(train_net.split("_")[-1].split("x")[0])
+            self.semantic_adapter = get_conv2d(train_net, None, None, kernel_size, n_semantic_classes, n_semantic_classes)
+            nn.init.zeros_(self.semantic_adapter.weight)
+            nn.init.zeros_(self.semantic_adapter.bias)
+        if network == "fusion":
+            assert n_fusion is not None
+            self.encoder = YNetEncoderFusion(n_semantic_classes, obs_len, encoder_channels, train_net=train_net,
+                                             position=position, n_fusion=n_fusion)
+        elif network == "original":
+            cls = YNetEncoderL if ("mosa" in train_net or "Layer" in train_net) else YNetEncoderB
+            self.encoder = cls(in_channels=self.feature_channels, channels=encoder_channels, train_net=train_net,
+                               position=position)
+        elif network == "embed":
+            raise NotImplementedError("network='embed' is not on the MI355X hot path")
+        else:
+            raise ValueError("No network parameter is provided")
+        self.goal_decoder = YNetDecoder(encoder_channels, decoder_channels, output_len=pred_len)
+        self.traj_decoder = YNetDecoder(encoder_channels, decoder_channels, output_len=pred_len, traj=n_waypoints)
+        self.softargmax_ = SoftArgmax2D(normalized_coordinates=False)
+        self.encoder_channels = encoder_channels
+
+    def segmentation(self, image):
+        return self.semantic_segmentation(image)
+
+    def adapt_semantic(self, semantic_img):
+        if "semantic" in self.train_net:
+            return self.semantic_adapter(semantic_img) + semantic_img
+        return semantic_img
+
+    def pred_goal(self, features):
+        return self.goal_decoder(features)
+
+    def pred_traj(self, features):
+        return self.traj_decoder(features)
+
+    def pred_features(self, scene_map, motion_map):
+        if self.network == "fusion":
+            return self.encoder(scene_map, motion_map)
+        return self.encoder(ops.lazy_cat([scene_map, motion_map]))
+
+    def softmax(self, x):
+        return nn.Softmax(2)(x.view(*x.size()[:2], -1)).view_as(x)
+
+    def softargmax(self, output):
+        return self.softargmax_(output)
+
+    def sigmoid(self, output):
+        c = output.shape[1]
+        return ops.sigmoid_temp(output, list(range(c)), 1.0) if c <= 8 else torch.sigmoid(output)
+
+    def softargmax_on_softmax_map(self, x):
+        pos_y, pos_x = create_meshgrid(x, normalized_coordinates=False)
+        x = x.flatten(2)
+        ex = torch.sum(pos_x.reshape(-1) * x, dim=-1, keepdim=True)
+        ey = torch.sum(pos_y.reshape(-1) * x, dim=-1, keepdim=True)
+        return torch.cat([ex, ey], dim=-1)

@@ -1,0 +1,448 @@
+"""Operators of the MI355X Y-Net path: thin autograd wrappers over the C ABI (include/ynet_hip.h).
+
+Every function here enqueues hand-written gfx950 kernels from csrc/ on the current torch HIP
+stream.  There is no CPU path and no ATen fallback: host tensors raise.  torch is used for device
+memory (torch.empty), streams and autograd bookkeeping only.
+"""
+import ctypes
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+MAX_SRC = 4
+_VP = ctypes.c_void_p
+
+
+def _lib():
+    return L.load()
+
+
+def _stream():
+    return _VP(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t: torch.Tensor, what: str):
+    if not torch.is_tensor(t):
+        raise TypeError(f"{what}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the MI355X path runs on HIP devices only "
+                           f"(no CPU fallback exists by design)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: fp32 expected, got {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------------------
+# lazy channel concatenation (fused into the consumer conv; replaces torch.cat at
+# models/ynet.py:387,466,574, utils/train_epoch.py:103-104, utils/evaluate.py:259-260)
+# ------------------------------------------------------------------------------------------------
+class LazyCat:
+    """A channel concatenation that is never materialised: conv kernels read its parts directly.
+    Any other torch function receives the materialised tensor (``__torch_function__``)."""
+
+    def __init__(self, parts: Sequence[torch.Tensor]):
+        flat: List[torch.Tensor] = []
+        for p in parts:
+            flat.extend(p.parts if isinstance(p, LazyCat) else [p])
+        b, _, h, w = flat[0].shape
+        for p in flat:
+            if p.dim() != 4 or p.shape[0] != b or p.shape[2:] != (h, w):
+                raise ValueError(f"lazy_cat: incompatible shapes {[tuple(q.shape) for q in flat]}")
+        self.parts = flat
+
+    @property
+    def shape(self):
+        p = self.parts[0]
+        return torch.Size((p.shape[0], sum(q.shape[1] for q in self.parts), p.shape[2], p.shape[3]))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 4
+
+    @property
+    def device(self):
+        return self.parts[0].device
+
+    @property
+    def dtype(self):
+        return self.parts[0].dtype
+
+    def materialize(self) -> torch.Tensor:
+        return torch.cat([p.contiguous() for p in self.parts], dim=1)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.cat:
+            seq = args[0] if args else kwargs["tensors"]
+            dim = args[1] if len(args) > 1 else kwargs.get("dim", kwargs.get("axis", 0))
+            if dim == 1:
+                return LazyCat(list(seq))
+
+        def mat(o):
+            if isinstance(o, LazyCat):
+                return o.materialize()
+            if isinstance(o, (list, tuple)):
+                return type(o)(mat(i) for i in o)
+            return o
+        return func(*mat(args), **{k: mat(v) for k, v in kwargs.items()})
+
+
+def lazy_cat(parts: Sequence[torch.Tensor]):
+    return parts[0] if len(parts) == 1 and not isinstance(parts[0], LazyCat) else LazyCat(parts)
+
+
+def _parts(x) -> List[torch.Tensor]:
+    return list(x.parts) if isinstance(x, LazyCat) else [x]
+
+
+def _plane_desc(t: torch.Tensor, what: str):
+    """-> (tensor kept alive, C, batch stride) with planes contiguous and channel stride H*W."""
+    _need_gpu(t, what)
+    if t.dim() != 4:
+        raise ValueError(f"{what}: expected BxCxHxW, got {tuple(t.shape)}")
+    b, c, h, w = t.shape
+    st = t.stride()
+    ok = (w == 1 or st[3] == 1) and (h == 1 or st[2] == w) and (c == 1 or st[1] == h * w)
+    if not ok:
+        t = t.contiguous()
+        st = t.stride()
+    return t, c, (st[0] if b > 1 else c * h * w)
+
+
+def _arrays(descs):
+    n = len(descs)
+    ptrs = (_VP * n)(*[d[0] for d in descs])
+    cs = (ctypes.c_int * n)(*[d[1] for d in descs])
+    bss = (ctypes.c_longlong * n)(*[d[2] for d in descs])
+    return ctypes.cast(ptrs, L.PP), cs, bss
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution (+ fused concat / bias / ReLU / LoRA) with hand-written backward
+# ------------------------------------------------------------------------------------------------
+def pack_weight(w: torch.Tensor, mode: int) -> torch.Tensor:
+    _need_gpu(w, "pack_weight")
+    cout, cin, k, _ = w.shape
+    lib = _lib()
+    out = torch.empty(lib.ynet_packed_weight_floats(cout, cin, k, mode), device=w.device, dtype=torch.float32)
+    L.check(lib.ynet_pack_weight(w.data_ptr(), out.data_ptr(), cout, cin, k, mode, _stream()), lib)
+    return out
+
+
+def lora_compose(w, lora_a, lora_b, scale: float) -> torch.Tensor:
+    for t, n in ((w, "weight"), (lora_a, "lora_A"), (lora_b, "lora_B")):
+        _need_gpu(t, "lora_compose " + n)
+    cout, cin, k, _ = w.shape
+    r = lora_a.shape[0] // k
+    if tuple(lora_a.shape) != (r * k, cin * k) or tuple(lora_b.shape) != (cout * k, r * k):
+        raise ValueError(f"lora_compose: lora_A {tuple(lora_a.shape)} / lora_B {tuple(lora_b.shape)} do not fit "
+                         f"weight {tuple(w.shape)}")
+    out = torch.empty_like(w, memory_format=torch.contiguous_format)
+    lib = _lib()
+    L.check(lib.ynet_lora_compose(w.contiguous().data_ptr(), lora_a.contiguous().data_ptr(),
+                                  lora_b.contiguous().data_ptr(), scale, out.data_ptr(), cout, cin, k, r, _stream()), lib)
+    return out
+
+
+def lora_grad(dw, lora_a, lora_b, scale: float):
+    cout, cin, k, _ = dw.shape
+    r = lora_a.shape[0] // k
+    d_a, d_b = torch.empty_like(lora_a), torch.empty_like(lora_b)
+    lib = _lib()
+    L.check(lib.ynet_lora_grad(dw.data_ptr(), lora_a.contiguous().data_ptr(), lora_b.contiguous().data_ptr(), scale,
+                               d_a.data_ptr(), d_b.data_ptr(), cout, cin, k, r, _stream()), lib)
+    return d_a, d_b
+
+
+def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
+    """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None."""
+    lib = _lib()
+    sp, sc, sb = _arrays(srcs)
+    dp, dc, db = _arrays(dsts)
+    L.check(lib.ynet_conv2d(sp, sc, sb, len(srcs), mask[0] if mask else None, mask[1] if mask else 0,
+                            wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                            dp, dc, db, len(dsts), B, H, W, K, 1 if relu else 0, _stream()), lib)
+
+
+def _weight_key(weight, lora_a, lora_b):
+    key = (weight.data_ptr(), weight._version)
+    if lora_a is not None:
+        key += (lora_a.data_ptr(), lora_a._version, lora_b.data_ptr(), lora_b._version)
+    return key
+
+
+def _cached(cache: dict, weight, lora_a, lora_b, scale, what: str):
+    """Per-layer cache of w_eff and the two packed filters, invalidated when a parameter changes."""
+    key = _weight_key(weight, lora_a, lora_b)
+    if cache.get("key") != key:
+        cache.clear()
+        cache["key"] = key
+    if "w_eff" not in cache:
+        with torch.no_grad():
+            w = weight.detach()
+            cache["w_eff"] = lora_compose(w, lora_a.detach(), lora_b.detach(), scale) if lora_a is not None \
+                else (w if w.is_contiguous() else w.contiguous())
+    if what == "w_eff":
+        return cache["w_eff"]
+    if what not in cache:
+        cache[what] = pack_weight(cache["w_eff"], 0 if what == "fwd" else 1)
+    return cache[what]
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, weight, bias, lora_a, lora_b, *srcs):
+        relu, scale, cache = meta["relu"], meta.get("scale", 1.0), meta["cache"]
+        _need_gpu(weight, "conv2d weight")
+        cout, cin, k, _ = weight.shape
+        descs, keep = [], []
+        for i, s in enumerate(srcs):
+            t, c, bs = _plane_desc(s, f"conv2d input {i}")
+            keep.append(t)
+            descs.append((t.data_ptr(), c, bs))
+        if len(descs) > MAX_SRC:
+            raise ValueError(f"conv2d: at most {MAX_SRC} concatenated inputs (got {len(descs)})")
+        if sum(d[1] for d in descs) != cin:
+            raise ValueError(f"conv2d: inputs carry {sum(d[1] for d in descs)} channels, weight expects {cin}")
+        B, _, H, W = keep[0].shape
+        wp = _cached(cache, weight, lora_a, lora_b, scale, "fwd")
+        y = torch.empty((B, cout, H, W), device=weight.device, dtype=torch.float32)
+        b = bias.detach() if bias is not None else None
+        conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu)
+        ctx.meta = meta
+        ctx.n_src = len(srcs)
+        ctx.has_bias = bias is not None
+        ctx.has_lora = lora_a is not None
+        ctx.save_for_backward(weight, lora_a, lora_b, y if relu else None, *keep)
+        ctx.w_key = _weight_key(weight, lora_a, lora_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, lora_a, lora_b, y, *srcs = ctx.saved_tensors
+        meta = ctx.meta
+        relu, scale, cache = meta["relu"], meta.get("scale", 1.0), meta["cache"]
+        cout, cin, k, _ = weight.shape
+        dy = dy.contiguous()
+        B, _, H, W = dy.shape
+        mask = (y.data_ptr(), cout * H * W) if relu else None
+        need = ctx.needs_input_grad
+        need_src = list(need[5:5 + ctx.n_src])
+        d_srcs = [None] * ctx.n_src
+        if any(need_src):
+            if ctx.w_key != _weight_key(weight, lora_a, lora_b):
+                raise RuntimeError("conv2d backward: a parameter was modified in place between forward and backward")
+            wp_d = _cached(cache, weight, lora_a, lora_b, scale, "dgrad")
+            dsts = []
+            for i, s in enumerate(srcs):
+                c = s.shape[1]
+                if need_src[i]:
+                    if s.stride(0) == 0 and s.shape[0] > 1:
+                        raise NotImplementedError("conv2d backward: gradient of a batch-broadcast input")
+                    d_srcs[i] = torch.empty((B, c, H, W), device=dy.device, dtype=torch.float32)
+                    dsts.append((d_srcs[i].data_ptr(), c, c * H * W))
+                else:
+                    dsts.append((None, c, 0))
+            conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False)
+        d_w = d_b = d_a = d_bm = None
+        want_w = need[1] or (ctx.has_lora and (need[3] or need[4]))
+        want_b = ctx.has_bias and need[2]
+        if want_w or want_b:
+            lib = _lib()
+            descs = [(s.data_ptr(), s.shape[1], (s.stride(0) if s.shape[0] > 1 else s.shape[1] * H * W)) for s in srcs]
+            sp, sc, sb = _arrays(descs)
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            d_b = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_b else None
+            ws = torch.empty(lib.ynet_conv2d_wgrad_workspace_floats(B, H, W, cout, cin, k), device=dy.device,
+                             dtype=torch.float32)
+            L.check(lib.ynet_conv2d_wgrad(sp, sc, sb, len(descs), dy.data_ptr(), cout * H * W,
+                                          mask[0] if mask else None, mask[1] if mask else 0,
+                                          dw.data_ptr(), d_b.data_ptr() if want_b else None, ws.data_ptr(),
+                                          B, H, W, cout, k, _stream()), lib)
+            if ctx.has_lora and (need[3] or need[4]):
+                d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
+            if need[1]:
+                d_w = dw
+        return (None, d_w, d_b, d_a if need[3] else None, d_bm if need[4] else None, *d_srcs)
+
+
+def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0):
+    """[ReLU](conv(cat(x), W_eff) + bias); x is a tensor or a LazyCat."""
+    meta = {"relu": bool(relu), "scale": float(scale), "cache": cache}
+    return _Conv2dFn.apply(meta, weight, bias, lora_a, lora_b, *_parts(x))
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / resampling
+# ------------------------------------------------------------------------------------------------
+class _MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x, "max_pool2d")
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        lib = _lib()
+        L.check(lib.ynet_maxpool2_fwd(x.data_ptr(), y.data_ptr(), B * C, H, W, _stream()), lib)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        lib = _lib()
+        L.check(lib.ynet_maxpool2_bwd(x.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), B * C, H, W, _stream()), lib)
+        return dx
+
+
+def max_pool2(x):
+    return _MaxPool2Fn.apply(x)
+
+
+class _Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x, "upsample2x")
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        lib = _lib()
+        L.check(lib.ynet_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B * C, H, W, _stream()), lib)
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.float32)
+        lib = _lib()
+        L.check(lib.ynet_upsample2x_bwd(dy.contiguous().data_ptr(), dx.data_ptr(), B * C, H, W, _stream()), lib)
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2xFn.apply(x)
+
+
+def avgpool_pyramid(x: torch.Tensor, n_levels: int) -> List[torch.Tensor]:
+    """[x, AvgPool2d(2)(x), ..., AvgPool2d(2**(n_levels-1))(x)] in one pass (no gradient)."""
+    _need_gpu(x, "avgpool_pyramid")
+    x = x.detach().contiguous()
+    B, C, H, W = x.shape
+    outs = [torch.empty((B, C, H >> i, W >> i), device=x.device, dtype=torch.float32) for i in range(1, n_levels)]
+    if outs:
+        lib = _lib()
+        ptrs = (_VP * len(outs))(*[o.data_ptr() for o in outs])
+        L.check(lib.ynet_avgpool_pyramid(x.data_ptr(), ctypes.cast(ptrs, L.PP), len(outs), B * C, H, W, _stream()), lib)
+    return [x] + outs
+
+
+# ------------------------------------------------------------------------------------------------
+# BCE-with-logits (mean)
+# ------------------------------------------------------------------------------------------------
+class _BCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t):
+        _need_gpu(x, "bce_with_logits input")
+        _need_gpu(t, "bce_with_logits target")
+        if x.shape != t.shape:
+            raise ValueError(f"Target size ({tuple(t.shape)}) must be the same as input size ({tuple(x.shape)})")
+        x, t = x.contiguous(), t.contiguous()
+        lib = _lib()
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.ynet_bce_workspace_bytes() // 8, device=x.device, dtype=torch.float64)
+        L.check(lib.ynet_bce_logits_fwd(x.data_ptr(), t.data_ptr(), x.numel(), loss.data_ptr(), ws.data_ptr(), _stream()), lib)
+        ctx.save_for_backward(x, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        lib = _lib()
+        g = g.contiguous().float()
+        L.check(lib.ynet_bce_logits_bwd(x.data_ptr(), t.data_ptr(), g.data_ptr(), dx.data_ptr(), x.numel(), _stream()), lib)
+        return dx, None
+
+
+def bce_with_logits(x, t):
+    return _BCEFn.apply(x, t)
+
+
+# ------------------------------------------------------------------------------------------------
+# read-out and heat-map construction (no gradient on this path)
+# ------------------------------------------------------------------------------------------------
+def softargmax2d(x: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] -> [B,C,2] (x, y) in pixels (utils/softargmax.py:55-81)."""
+    if not torch.is_tensor(x):
+        raise TypeError(f"Input input type is not a torch.Tensor. Got {type(x)}")
+    if x.dim() != 4:
+        raise ValueError(f"Invalid input shape, we expect BxCxHxW. Got: {x.shape}")
+    t, c, bs = _plane_desc(x.detach(), "softargmax")
+    B, _, H, W = t.shape
+    if W % 4 == 0 and (bs % 4 or (H * W) % 4 or t.data_ptr() % 16):
+        t = t.contiguous()
+        bs = c * H * W
+    out = torch.empty((B, c, 2), device=t.device, dtype=torch.float32)
+    lib = _lib()
+    L.check(lib.ynet_softargmax2d(t.data_ptr(), out.data_ptr(), B, c, bs, H, W, _stream()), lib)
+    return out
+
+
+def sigmoid_temp(x: torch.Tensor, channels: Sequence[int], temperature: float) -> torch.Tensor:
+    """sigmoid(x[:, channels] / temperature) (utils/evaluate.py:128-131) in one pass."""
+    _need_gpu(x, "sigmoid_temp")
+    x = x.detach().contiguous()
+    B, C, H, W = x.shape
+    sel = [int(c) % C for c in channels]
+    y = torch.empty((B, len(sel), H, W), device=x.device, dtype=torch.float32)
+    lib = _lib()
+    arr = (ctypes.c_int * len(sel))(*sel)
+    L.check(lib.ynet_sigmoid_temp(x.data_ptr(), y.data_ptr(), B, C, H * W, arr, len(sel), float(temperature), _stream()), lib)
+    return y
+
+
+_patch_status = {}
+
+
+def gather_patches(template: torch.Tensor, xy, H: int, W: int) -> torch.Tensor:
+    """[N,2] (x,y) coordinates -> [N,H,W] windows of `template` (utils/image_utils.py:40-63)."""
+    _need_gpu(template, "get_patch template")
+    if template.dim() != 2:
+        raise ValueError("get_patch: template must be 2-D")
+    template = template.contiguous()
+    SH, SW = template.shape
+    dev = template.device
+    if torch.is_tensor(xy) and xy.is_cuda:
+        coords = xy.detach().reshape(-1, 2).float().contiguous()
+    else:
+        host = np.ascontiguousarray(np.asarray(xy.detach().cpu() if torch.is_tensor(xy) else xy, dtype=np.float32).reshape(-1, 2))
+        rx, ry = np.round(host[:, 0]).astype(np.int64), np.round(host[:, 1]).astype(np.int64)
+        ox, oy = SW // 2 - rx, SH // 2 - ry
+        if ((ox < 0) | (oy < 0) | (ox + W > SW) | (oy + H > SH)).any():
+            raise ValueError(f"get_patch: a {H}x{W} window around one of the coordinates leaves the {SH}x{SW} template")
+        coords = torch.from_numpy(host).to(dev, non_blocking=True)
+    n = coords.shape[0]
+    out = torch.empty((n, H, W), device=dev, dtype=torch.float32)
+    st = _patch_status.get(dev)
+    if st is None:
+        st = _patch_status[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
+    lib = _lib()
+    L.check(lib.ynet_gather_patch(template.data_ptr(), SH, SW, coords.data_ptr(), out.data_ptr(), n, H, W,
+                                  st.data_ptr(), _stream()), lib)
+    return out
+
+
+def check_patch_status():
+    """Raise if a device-side coordinate ever left the template (checked at sync points)."""
+    for dev, st in _patch_status.items():
+        if int(st.item()) != 0:
+            st.zero_()
+            raise ValueError("get_patch: a window left the template (device-side coordinates)")

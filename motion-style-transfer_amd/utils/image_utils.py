@@ -1,0 +1,91 @@
+"""Heat-map templates, patch gathering and goal sampling (mirror of utils/image_utils.py).
+
+  create_dist_mat / create_gaussian_heatmap_template : float64 NumPy, bit-identical to the reference
+      (utils/image_utils.py:7-37); they are built once per run, not on the hot path.
+  get_patch        : same signature/return type as the reference (a list of [H,W] tensors) but the
+      windows come from ONE ynet_gather_patch launch (utils/image_utils.py:40-63).
+  gather_patches   : the same without the list, [N,H,W] contiguous (what train_epoch/evaluate use).
+  sampling         : torch.multinomial on the device (utils/image_utils.py:110-135); kept in torch
+      so the RNG stream stays torch's.
+Image file I/O (resize / pad / preprocess_image_for_segmentation) needs cv2 + smp and is out of scope.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def gkern(kernlen=31, nsig=4):
+    half = (kernlen - 1) / 2.0
+    ax = np.linspace(-half, half, kernlen)
+    g = np.exp(-0.5 * (ax[None, :] ** 2 + ax[:, None] ** 2) / np.square(nsig))
+    return g / np.sum(g)
+
+
+def create_gaussian_heatmap_template(size, kernlen=81, nsig=4, normalize=True):
+    template = np.zeros([size, size])
+    kernel = gkern(kernlen=kernlen, nsig=nsig)
+    m = kernel.shape[0]
+    lo, hi = size // 2 - m // 2, size // 2 + (m + 1) // 2
+    template[lo:hi, lo:hi] = kernel
+    return template / template.max() if normalize else template
+
+
+def create_dist_mat(size, normalize=True):
+    off = np.arange(size, dtype=np.int64) - size // 2
+    dist = np.sqrt((off[:, None] ** 2 + off[None, :] ** 2).astype(np.float64))
+    return dist / dist.max() * 2 if normalize else dist
+
+
+def gather_patches(template, traj, H, W):
+    """template [S,S] (device), traj [N,2] (x,y) -> [N,H,W] device tensor."""
+    return ops.gather_patches(template, traj, H, W)
+
+
+def get_patch(template, traj, H, W):
+    return list(gather_patches(template, traj, H, W).unbind(0))
+
+
+def sampling(probability_map, num_samples, rel_threshold=None, replacement=False):
+    b, c, h, w = probability_map.shape
+    prob = probability_map.reshape(b * c, -1)
+    if rel_threshold is not None:
+        keep = prob >= prob.max(dim=1, keepdim=True)[0] * rel_threshold
+        prob = prob * keep.int()
+        prob = prob / prob.sum()
+    idx = torch.multinomial(prob, num_samples=num_samples, replacement=replacement)
+    idx = idx.view(b, c, -1).float()
+    return torch.stack([idx % w, torch.floor(idx / w)], dim=3)
+
+
+def image2world(image_coords, scene, homo_mat, resize):
+    """ETH/UCY pixel -> world coordinates (utils/image_utils.py:138-162)."""
+    pts = image_coords.clone()
+    if pts.dim() == 4:
+        pts = pts.reshape(-1, image_coords.shape[2], 2)
+    if scene in ["eth", "hotel"]:
+        pts = pts.flip(-1)
+    pts = pts / resize
+    pts = torch.cat([pts, torch.ones_like(pts[..., :1])], dim=-1).reshape(-1, 3)
+    pts = (homo_mat[scene] @ pts.T).T
+    pts = pts[:, :2] / pts[:, 2:]
+    return pts.view_as(image_coords)
+
+
+def swap_pavement_terrain(semantic_img):
+    if semantic_img.dim() != 4:
+        raise ValueError(f"semanctic image has shape {semantic_img.shape} but should have 4 dimensions")
+    semantic_img[:, [1, 2]] = semantic_img[:, [2, 1]]
+    return semantic_img
+
+
+def _needs_cv2(name):
+    def fn(*a, **k):
+        raise ImportError(f"{name} needs OpenCV / segmentation_models_pytorch image I/O, which is outside the "
+                          f"MI355X hot path; pre-process scene images with the reference and pass tensors")
+    return fn
+
+
+resize = _needs_cv2("resize")
+pad = _needs_cv2("pad")
+preprocess_image_for_segmentation = _needs_cv2("preprocess_image_for_segmentation")

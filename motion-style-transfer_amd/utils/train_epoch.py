@@ -1,0 +1,97 @@
+"""One training epoch (mirror of utils/train_epoch.py:8-136, same signature and return value).
+
+Per batch: heat-maps by one gather launch each (instead of a Python list of slices + torch.stack),
+encoder -> goal decoder -> BCE, waypoint pyramid in one pass, trajectory decoder (concat fused into
+the convs) -> BCE, backward through the hand-written dgrad/wgrad/LoRA kernels, optimizer step,
+soft-argmax ADE/FDE.  ``dp`` (optional, not in the reference) shards every batch over ranks.
+"""
+import torch
+
+from .. import ops
+from .image_utils import gather_patches, swap_pavement_terrain
+
+
+def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_scale, device, dataset_name, homo_mat,
+                gt_template, input_template, waypoints, epoch, obs_len, pred_len, batch_size, e_unfreeze,
+                resize_factor, network=None, swap_semantic=False, dp=None):
+    train_loss = 0
+    train_ADE, train_FDE = [], []
+    model.train()
+    waypoints = list(waypoints)
+
+    for trajectory, meta, scene in train_loader:
+        if epoch < e_unfreeze:
+            model.eval()
+            scene_image = model.segmentation(train_images[scene].to(device).unsqueeze(0))
+            model.train()
+
+        for i in range(0, len(trajectory), batch_size):
+            if epoch >= e_unfreeze:
+                scene_image = model.segmentation(train_images[scene].to(device).unsqueeze(0))
+            semantic_img = model.adapt_semantic(scene_image)
+            if swap_semantic:
+                semantic_img = swap_pavement_terrain(semantic_img)
+            _, _, H, W = scene_image.shape
+
+            batch = trajectory[i:i + batch_size]
+            n_global = len(batch)
+            if dp is not None:
+                lo, hi = dp.shard(n_global)
+                batch = batch[lo:hi]
+            n_local = len(batch)
+
+            if dp is not None:
+                dp.zero_grad()
+            else:
+                optimizer.zero_grad()
+
+            if n_local > 0:
+                # heat-maps: distance map per observed step, Gaussian blob per future step, distance map per waypoint
+                observed_map = gather_patches(input_template, batch[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
+                gt_future = batch[:, obs_len:].to(device)
+                gt_future_map = gather_patches(gt_template, batch[:, obs_len:].reshape(-1, 2), H, W).view(-1, pred_len, H, W)
+                gt_waypoints = batch[:, obs_len:][:, waypoints]
+                gt_waypoint_map = gather_patches(input_template, gt_waypoints.reshape(-1, 2), H, W).view(-1, len(waypoints), H, W)
+                if network == "embed":
+                    raise NotImplementedError("network='embed' is not on the MI355X hot path")
+
+                semantic_map = semantic_img.expand(n_local, -1, -1, -1)
+                features = model.pred_features(semantic_map, observed_map)
+                pred_goal_map = model.pred_goal(features)
+                goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
+
+                pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
+                traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]   # concat fused into the convs
+                pred_traj_map = model.pred_traj(traj_input)
+                traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
+
+                loss = goal_loss + traj_loss
+                if dp is not None:
+                    loss = loss * (n_local / n_global)      # BCE is a mean: weight by the shard's share
+                loss.backward()
+            else:
+                loss = torch.zeros((), device=device)
+            if dp is not None:
+                dp.allreduce_grads()
+                loss = dp.sum_scalar(loss.detach())
+            optimizer.step()
+
+            with torch.no_grad():
+                train_loss += loss
+                if n_local > 0:
+                    pred_traj = model.softargmax(pred_traj_map)
+                    pred_goal = model.softargmax(pred_goal_map[:, -1:])
+                    ade = ((((gt_future - pred_traj) / resize_factor) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
+                    fde = ((((gt_future[:, -1:] - pred_goal[:, -1:]) / resize_factor) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
+                else:
+                    ade = fde = torch.zeros(0, device=device)
+                if dp is not None:
+                    sizes = dp.shard_sizes(n_global)
+                    ade, fde = dp.gather_rows(ade, sizes), dp.gather_rows(fde, sizes)
+                train_ADE.append(ade)
+                train_FDE.append(fde)
+
+    train_ADE = torch.cat(train_ADE).mean()
+    train_FDE = torch.cat(train_FDE).mean()
+    ops.check_patch_status()
+    return train_ADE.item(), train_FDE.item(), train_loss.item()

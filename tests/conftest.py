@@ -1,0 +1,89 @@
+import ast
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PKG = "motion-style-transfer_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pkg(sub=""):
+    return importlib.import_module(PKG + (("." + sub) if sub else ""))
+
+
+class Golden:
+    """A tests/golden/*.npz fixture (inputs + the REFERENCE's outputs, see oracle/gen_goldens.py)."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        self.meta = ast.literal_eval(str(self.z["meta"])) if "meta" in self.z.files else {}
+
+    def __contains__(self, k):
+        return k in self.z.files or (k + "__strided") in self.z.files
+
+    def keys(self, prefix):
+        return [k[len(prefix):] for k in self.z.files if k.startswith(prefix)]
+
+    def t(self, k):
+        return torch.from_numpy(np.array(self.z[k]))
+
+    def state_dict(self):
+        return {k: self.t("sd/" + k) for k in self.keys("sd/")}
+
+    def cfg(self):
+        from oracle import ynet_oracle as O
+        m = self.meta
+        return O.Cfg(obs_len=m["obs_len"], pred_len=m["pred_len"], enc=tuple(m["enc"]), dec=tuple(m["dec"]),
+                     waypoints=tuple(m["waypoints"]), network=m["network"], n_fusion=m["n_fusion"] or None,
+                     train_net=m["train_net"], position=list(m["position"]), resize_factor=m["resize_factor"],
+                     temperature=m["temperature"], loss_scale=m["loss_scale"])
+
+    def compare(self, k, got, rtol, atol):
+        """Compare against a full or a strided+checksum entry."""
+        got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, dtype=np.float64)
+        if k in self.z.files:
+            want = self.z[k].astype(np.float64)
+            assert got.shape == want.shape, (k, got.shape, want.shape)
+            np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=k)
+        else:
+            assert tuple(self.z[k + "__shape"]) == got.shape, (k, got.shape)
+            flat = got.reshape(-1)
+            np.testing.assert_allclose(flat[::5], self.z[k + "__strided"].astype(np.float64), rtol=rtol, atol=atol, err_msg=k)
+            n = flat.size
+            np.testing.assert_allclose(flat.sum(), float(self.z[k + "__sum"]), rtol=1e-4, atol=atol * n ** 0.5, err_msg=k + " sum")
+            np.testing.assert_allclose((flat ** 2).sum(), float(self.z[k + "__sqsum"]), rtol=1e-4, atol=atol, err_msg=k + " sqsum")
+
+
+TINY_CASES = ["tiny_short_train", "tiny_short_mosa1", "tiny_short_mosa4_partial", "tiny_long_fusion_mosa3_scene",
+              "tiny_long_train", "tiny_short_encoder_pos", "tiny_fusion_scene_only", "tiny_short_bias"]
+
+
+def build_model(cfg, sd=None, device="cpu"):
+    """The product YNet for an oracle Cfg (state dict optionally loaded, freeze policy applied)."""
+    ynet = pkg("models.ynet")
+    trainer = pkg("models.trainer")
+    m = ynet.YNet(cfg.obs_len, cfg.pred_len, None, use_features_only=False, n_semantic_classes=cfg.n_classes,
+                  encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec), n_waypoints=len(cfg.waypoints),
+                  train_net=cfg.train_net, position=list(cfg.position), network=cfg.network, n_fusion=cfg.n_fusion)
+    if sd is not None:
+        m.load_state_dict(sd, strict=True)
+    trainer.apply_freeze_policy(m, cfg.train_net, list(cfg.position), cfg.network)
+    return m.to(device)
+
+
+@pytest.fixture(scope="session")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

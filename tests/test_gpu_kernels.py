@@ -1,0 +1,249 @@
+"""Per-kernel parity on the MI355X: every entry point of the C ABI against the CPU oracle / stock
+torch ops on the same seeded inputs, plus the reference-generated vectors in golden/kernels.npz.
+
+Tolerances (fp32): activations rtol 2e-5 / atol 2e-5 (different accumulation order than MKL-DNN);
+gradients rtol 2e-4 relative to the tensor's scale; integer-like ops (max-pool, gather) bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import Golden, pkg
+from oracle import ynet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, want, rtol=2e-5, atol=2e-5, scale_rel=None, msg=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (msg, got.shape, want.shape)
+    if scale_rel is not None:
+        atol = max(atol, scale_rel * float(want.abs().max()))
+    err = (got - want).abs()
+    bad = err > atol + rtol * want.abs()
+    assert not bool(bad.any()), f"{msg}: max err {float(err.max()):.3e} (atol {atol:.2e}), {int(bad.sum())} bad of {bad.numel()}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # B, H, W, [source channels], cout, K, relu
+    (2, 16, 32, [14], 32, 3, True),
+    (1, 64, 64, [32], 32, 3, True),
+    (2, 32, 64, [32, 16, 1], 32, 3, True),      # decoder conv: up + skip + waypoint map
+    (2, 8, 8, [65], 130, 3, True),              # trajectory-decoder centre (odd channels, tiny map)
+    (3, 24, 40, [5, 3], 16, 3, False),          # ragged tile edges, no ReLU
+    (2, 32, 32, [32], 12, 1, False),            # 1x1 predictor
+    (1, 16, 16, [7], 9, 5, True),               # 5x5 (adapter kernels)
+    (2, 16, 16, [64, 33], 64, 3, True),
+    (1, 40, 72, [16, 16, 8, 2], 48, 3, True),   # 4 sources
+]
+
+
+@pytest.mark.parametrize("B,H,W,cs,cout,K,relu", CONV_CASES)
+def test_conv2d_forward_backward(dev, B, H, W, cs, cout, K, relu):
+    ops = pkg("ops")
+    cin = sum(cs)
+    xs = [rnd(B, c, H, W, seed=i + 1) for i, c in enumerate(cs)]
+    w = rnd(cout, cin, K, K, seed=10, scale=1.0 / (cin * K * K) ** 0.5)
+    b = rnd(cout, seed=11, scale=0.1)
+    gy = rnd(B, cout, H, W, seed=12)
+    # oracle: stock torch on CPU
+    xc = [x.clone().requires_grad_(True) for x in xs]
+    wc, bc = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(torch.cat(xc, 1), wc, bc, padding=K // 2)
+    y = F.relu(y) if relu else y
+    y.backward(gy)
+    # HIP
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    yd = ops.conv2d(ops.lazy_cat(xd), wd, bd, relu, {})
+    yd.backward(gy.to(dev))
+    close(yd, y, msg="y")
+    for i, (a, c) in enumerate(zip(xd, xc)):
+        close(a.grad, c.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx{i}")
+    close(wd.grad, wc.grad, rtol=1e-4, scale_rel=5e-6, msg="dW")
+    close(bd.grad, bc.grad, rtol=1e-4, scale_rel=5e-6, msg="db")
+
+
+def test_conv2d_broadcast_source_and_partial_grads(dev):
+    """Semantic map shared by the batch (stride-0 expand) + only some inputs wanting gradients."""
+    ops = pkg("ops")
+    B, H, W = 3, 32, 32
+    sem = rnd(1, 6, H, W, seed=1)
+    mot = rnd(B, 8, H, W, seed=2)
+    w, b = rnd(32, 14, 3, 3, seed=3, scale=0.1), rnd(32, seed=4, scale=0.1)
+    y = F.relu(F.conv2d(torch.cat([sem.expand(B, -1, -1, -1), mot], 1), w, b, padding=1))
+    motd = mot.to(dev).requires_grad_(True)
+    yd = ops.conv2d(ops.lazy_cat([sem.to(dev).expand(B, -1, -1, -1), motd]), w.to(dev), b.to(dev), True, {})
+    close(yd, y, msg="broadcast")
+    yd.sum().backward()            # first source wants no gradient, second does
+    mc = mot.clone().requires_grad_(True)
+    F.relu(F.conv2d(torch.cat([sem.expand(B, -1, -1, -1), mc], 1), w, b, padding=1)).sum().backward()
+    close(motd.grad, mc.grad, rtol=1e-4, scale_rel=2e-6, msg="partial grad")
+
+
+def test_conv2d_is_deterministic(dev):
+    ops = pkg("ops")
+    x, w, b = rnd(2, 33, 40, 40, seed=1).to(dev), rnd(40, 33, 3, 3, seed=2).to(dev).requires_grad_(True), rnd(40, seed=3).to(dev)
+    outs = []
+    for _ in range(2):
+        w.grad = None
+        y = ops.conv2d(x, w, b, True, {})
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), w.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("cout,cin,r", [(32, 14, 1), (64, 32, 4), (16, 6, 3), (64, 64, 1)])
+def test_lora_compose_and_grad(dev, cout, cin, r):
+    ops = pkg("ops")
+    k = 3
+    w, a, bm = rnd(cout, cin, k, k, seed=1), rnd(r * k, cin * k, seed=2), rnd(cout * k, r * k, seed=3, scale=0.1)
+    sd = {"l.weight": w, "l.lora_A": a, "l.lora_B": bm}
+    want = O.effective_weight(sd, "l")
+    got = ops.lora_compose(w.to(dev), a.to(dev), bm.to(dev), 1.0 / r)
+    close(got, want, rtol=1e-5, atol=1e-6, msg="w_eff")
+    dw = rnd(cout, cin, k, k, seed=4)
+    ac, bc = a.clone().requires_grad_(True), bm.clone().requires_grad_(True)
+    ((bc @ ac).view(w.shape) * (1.0 / r) * dw).sum().backward()
+    d_a, d_b = ops.lora_grad(dw.to(dev), a.to(dev), bm.to(dev), 1.0 / r)
+    close(d_a, ac.grad, rtol=1e-4, scale_rel=2e-6, msg="dA")
+    close(d_b, bc.grad, rtol=1e-4, scale_rel=2e-6, msg="dB")
+
+
+def test_lora_conv_end_to_end_and_identity_at_init(dev):
+    """loralib semantics through the conv: grads of lora_A/B; zero lora_B == base conv bit-exactly
+    (the reference's --init_check, train.py:46-59)."""
+    ops = pkg("ops")
+    B, cin, cout, H, W, r = 2, 14, 32, 32, 32, 2
+    x = rnd(B, cin, H, W, seed=1)
+    w, b = rnd(cout, cin, 3, 3, seed=2, scale=0.1), rnd(cout, seed=3, scale=0.1)
+    a, bm = rnd(r * 3, cin * 3, seed=4, scale=0.2), rnd(cout * 3, r * 3, seed=5, scale=0.05)
+    ac, bc = a.clone().requires_grad_(True), bm.clone().requires_grad_(True)
+    y = F.relu(F.conv2d(x, w + (bc @ ac).view(w.shape) / r, b, padding=1))
+    gy = rnd(B, cout, H, W, seed=6)
+    y.backward(gy)
+    ad, bd = a.to(dev).requires_grad_(True), bm.to(dev).requires_grad_(True)
+    yd = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), True, {}, ad, bd, 1.0 / r)
+    yd.backward(gy.to(dev))
+    close(yd, y, msg="lora y")
+    close(ad.grad, ac.grad, rtol=2e-4, scale_rel=5e-6, msg="dA")
+    close(bd.grad, bc.grad, rtol=2e-4, scale_rel=5e-6, msg="dB")
+    y0 = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), True, {}, a.to(dev), torch.zeros_like(bm).to(dev), 1.0 / r)
+    y1 = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), True, {})
+    assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 32), (1, 5, 10, 14), (2, 2, 7, 9)])
+def test_maxpool(dev, shape):
+    ops = pkg("ops")
+    x = rnd(*shape, seed=1)
+    x[0, 0, :2, :2] = 0.0                       # ties: the first maximum takes the gradient
+    xc = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xc, 2, 2)
+    gy = rnd(*y.shape, seed=2)
+    y.backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    yd = ops.max_pool2(xd)
+    yd.backward(gy.to(dev))
+    assert torch.equal(yd.cpu(), y.detach())
+    assert torch.equal(xd.grad.cpu(), xc.grad)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 16), (1, 2, 1, 1), (1, 4, 5, 3), (2, 16, 32, 32)])
+def test_upsample2x(dev, shape):
+    ops = pkg("ops")
+    x = rnd(*shape, seed=1)
+    xc = x.clone().requires_grad_(True)
+    y = F.interpolate(xc, scale_factor=2, mode="bilinear", align_corners=False)
+    gy = rnd(*y.shape, seed=2)
+    y.backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    yd = ops.upsample2x(xd)
+    yd.backward(gy.to(dev))
+    close(yd, y, rtol=1e-6, atol=1e-6, msg="up fwd")
+    close(xd.grad, xc.grad, rtol=1e-5, atol=1e-5, msg="up bwd")
+
+
+def test_avgpool_pyramid(dev):
+    ops = pkg("ops")
+    x = rnd(3, 2, 64, 96, seed=1).abs()
+    got = ops.avgpool_pyramid(x.to(dev), 6)
+    want = O.waypoint_pyramid(x, 6)
+    assert len(got) == 6
+    for g, w in zip(got, want):
+        close(g, w, rtol=1e-6, atol=1e-6, msg="pyramid")
+
+
+def test_bce_with_logits(dev):
+    ops = pkg("ops")
+    x = rnd(2, 12, 32, 64, seed=1, scale=4.0)
+    t = torch.rand(2, 12, 32, 64, generator=torch.Generator().manual_seed(2)) * 0.01
+    xc = x.clone().requires_grad_(True)
+    loss = F.binary_cross_entropy_with_logits(xc, t) * 1000
+    loss.backward()
+    xd = x.to(dev).requires_grad_(True)
+    ld = ops.bce_with_logits(xd, t.to(dev)) * 1000
+    ld.backward()
+    close(ld, loss.detach(), rtol=2e-6, atol=1e-6, msg="loss")
+    close(xd.grad, xc.grad, rtol=1e-5, atol=1e-9, msg="dlogits")
+    zero = ops.bce_with_logits(torch.zeros(1, 1, 8, 8, device=dev), torch.zeros(1, 1, 8, 8, device=dev)) * 1000
+    assert abs(float(zero) - 1000 * np.log(2)) < 1e-3      # known answer
+
+
+def test_softargmax_golden_and_slices(dev):
+    ops = pkg("ops")
+    g = Golden("kernels")
+    x = g.t("softargmax/x")
+    got = ops.softargmax2d(x.to(dev))
+    close(got, g.t("softargmax/out"), rtol=1e-5, atol=2e-5, msg="softargmax vs reference")
+    assert abs(float(got[0, 0, 0]) - 7) < 1e-4 and abs(float(got[0, 0, 1]) - 5) < 1e-4   # known answer
+    # channel slice without a copy, odd width (scalar path), and fp64 truth
+    sl = ops.softargmax2d(x.to(dev)[:, -1:])
+    close(sl, g.t("softargmax/out")[:, -1:], rtol=1e-5, atol=2e-5, msg="slice")
+    y = rnd(2, 3, 17, 23, seed=3, scale=3.0)
+    close(ops.softargmax2d(y.to(dev)), O.softargmax2d(y.double()).float(), rtol=1e-5, atol=2e-5, msg="odd width")
+    with pytest.raises(ValueError):
+        ops.softargmax2d(torch.zeros(3, 4, 4, device=dev))
+    with pytest.raises(TypeError):
+        ops.softargmax2d([1, 2])
+
+
+def test_softargmax_accuracy_vs_fp64(dev):
+    """Closer to the fp64 truth than (or as close as) the fp32 reference on flat and peaky maps."""
+    ops = pkg("ops")
+    for scale in (0.5, 8.0):
+        x = rnd(4, 12, 256, 256, seed=5, scale=scale)
+        truth = O.softargmax2d(x.double())
+        ref32 = O.softargmax2d(x)
+        got = ops.softargmax2d(x.to(dev)).cpu()
+        e_ref = float((ref32.double() - truth).abs().max())
+        e_got = float((got.double() - truth).abs().max())
+        assert e_got <= max(2 * e_ref, 2e-5), (scale, e_got, e_ref)
+
+
+def test_sigmoid_temp(dev):
+    ops = pkg("ops")
+    x = rnd(3, 30, 16, 32, seed=1, scale=3.0)
+    for sel, T in (([14, 29], 1.8), ([11], 1.0)):
+        got = ops.sigmoid_temp(x.to(dev), sel, T)
+        want = torch.sigmoid(x[:, sel] / T)
+        close(got, want, rtol=1e-6, atol=1e-7, msg="sigmoid")
+
+
+def test_gather_patch_golden(dev):
+    ops = pkg("ops")
+    g = Golden("kernels")
+    xy = g.t("patch/xy")
+    for name, tmpl in (("dist", O.dist_template(210)), ("gauss", O.gaussian_template(210, 31, 4))):
+        want = g.t("patch/" + name)
+        for coords in (xy.numpy(), xy, xy.to(dev)):       # host array, host tensor, device tensor
+            got = ops.gather_patches(tmpl.to(dev), coords, 24, 40)
+            assert torch.equal(got.cpu(), want), name       # bit-exact incl. round-half-even (10.5 -> 10, 11.5 -> 12)
+    with pytest.raises(ValueError):
+        ops.gather_patches(O.dist_template(64).to(dev), np.array([[40.0, 0.0]], dtype=np.float32), 32, 32)
