@@ -80,7 +80,8 @@ class ConvTimer:
             cout = sum(d[1] for d in dl)
             flops = 2.0 * B * H * W * cin * cout * K * K
             byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]))
-            self.rec.append((f"conv_mfma_kernel<{K},{2 if cout > 32 else 1},4,{ {1: 16, 3: 8, 5: 4}[K] }>", e0, e1, flops, byts))
+            name = f"conv_mfma_kernel<{K}, {2 if cout > 32 else 1}, 4, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}>"
+            self.rec.append((name, e0, e1, flops, byts))
         self.ops.conv2d_raw = timed
         return self
 

@@ -36,18 +36,34 @@ struct ConvCfg {
     static constexpr int TH = 4 * R, TW = 32;
     static constexpr int TROWS = TH + KS - 1, TCOLS = TW + KS - 1, PLANE = TROWS * TCOLS;
     static constexpr int CB = 32 * NCB;
-    static constexpr int XS_FLOATS = ((CC * PLANE + 3) / 4) * 4;
+    static constexpr int XI = (PLANE + 255) / 256;            // tile elements per thread per channel
+    static constexpr int CHS = XI * 256;                      // LDS channel stride (>= PLANE): unconditional staging stores
+    static constexpr int XS_FLOATS = CC * CHS;
     static constexpr int WS_FLOATS = CC * KK * CB;
     static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
 };
 
-template <int KS, int NCB, int R, int CC>
-__global__ __launch_bounds__(256, (NCB == 1 ? 4 : 3)) void conv_mfma_kernel(const ConvArgs a) {
+// Buffer descriptor for one image plane.  The inputs are wave-uniform; readfirstlane makes that
+// provable to hipcc, which otherwise wraps every buffer_load in a waterfall loop (guide T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* p, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(p ? bytes : 0u);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+template <int KS, int NCB, int R, int CC, bool MASK>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<KS, NCB, R, CC>;
     constexpr int PAD = C::PAD, KK = C::KK, TH = C::TH, TW = C::TW;
-    constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB;
+    constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB, CHS = C::CHS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                  // [CC][TROWS][TCOLS]
+    float* xs = smem;                  // [CC][CHS] (a TROWS x TCOLS plane per channel)
     float* ws = smem + C::XS_FLOATS;   // [CC][KK][CB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,7 +76,7 @@ __global__ __launch_bounds__(256, (NCB == 1 ? 4 : 3)) void conv_mfma_kernel(cons
     const int tyi = bid % a.tiles_y;
     const int b = bid / a.tiles_y;
     const int x0 = txi * TW, y0 = tyi * TH;
-    const int HW = a.H * a.W;
+    const int HW = __builtin_amdgcn_readfirstlane(a.H * a.W);   // keep plane arithmetic on the scalar unit
 
     f32x16 acc[NCB][R];
 #pragma unroll
@@ -70,55 +86,99 @@ __global__ __launch_bounds__(256, (NCB == 1 ? 4 : 3)) void conv_mfma_kernel(cons
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][r][q] = 0.f;
 
-    const int nchunks = (a.cin + CC - 1) / CC;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * CC;
-        __syncthreads();
-        // ---- stage the input tile (+halo) of CC channels; zero outside the image / past cin
-#pragma unroll 1
+    // Register-staged software pipeline: the global loads of chunk ch+1 are issued before the MFMA
+    // loop of chunk ch and written to LDS after it, so their latency hides under ~10-18k MFMA cycles.
+    constexpr int XI = C::XI;
+    constexpr int ROW4 = CB / 4;
+    constexpr int WI = (CC * KK * ROW4 + 255) / 256;       // filter float4 per thread
+    float xr[CC][XI], mr[MASK ? CC : 1][MASK ? XI : 1];
+    float wr[WI][4];     // (a float4 array is not promoted to registers by hipcc here: scratch)
+
+    // per-thread byte offsets of its XI tile elements inside an image plane (same for every channel
+    // and chunk); out-of-image elements get an offset past the buffer: the hardware range check of
+    // buffer_load returns 0 for them, so the staging loop has no branches.
+    unsigned goff[XI];
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const int i = tid + k * 256;
+        const int ty = i / TCOLS, tx = i - ty * TCOLS;
+        const int gy = y0 + ty - PAD, gx = x0 + tx - PAD;
+        const bool ok = i < PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0xFFFFFFF0u;
+    }
+    const unsigned plane_bytes = (unsigned)HW * 4u;
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
         for (int c = 0; c < CC; ++c) {
             const float* base = nullptr;
-            const float* mbase = nullptr;
             const int cc = c0 + c;
             if (cc < a.cin) {
-                int s = 0, rel = cc;
-                while (s < a.nsrc - 1 && rel >= a.src[s].c) {
-                    rel -= a.src[s].c;
-                    ++s;
+                int rel = cc;
+#pragma unroll
+                for (int s = 0; s < YNET_MAX_SRC; ++s) {      // static indices only: keeps the args in SGPRs
+                    if (base == nullptr && s < a.nsrc) {
+                        if (rel < a.src[s].c || s == a.nsrc - 1)
+                            base = a.src[s].p + (long long)b * a.src[s].bs + (long long)rel * HW;
+                        else
+                            rel -= a.src[s].c;
+                    }
                 }
-                base = a.src[s].p + (long long)b * a.src[s].bs + (long long)rel * HW;
-                if (a.mask) mbase = a.mask + (long long)b * a.mask_bs + (long long)rel * HW;
             }
-            for (int i = tid; i < PLANE; i += 256) {
-                const int ty = i / TCOLS, tx = i - ty * TCOLS;
-                const int gy = y0 + ty - PAD, gx = x0 + tx - PAD;
-                float v = 0.f;
-                if (base != nullptr && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                    v = base[gy * a.W + gx];
-                    if (mbase != nullptr) v = mbase[gy * a.W + gx] > 0.f ? v : 0.f;
-                }
-                xs[c * PLANE + i] = v;
+            const __amdgpu_buffer_rsrc_t rx = plane_rsrc(base, plane_bytes);
+#pragma unroll
+            for (int k = 0; k < XI; ++k) xr[c][k] = buf_load(rx, goff[k]);
+            if (MASK) {
+                const float* mbase = cc < a.cin ? a.mask + (long long)b * a.mask_bs + (long long)cc * HW : nullptr;
+                const __amdgpu_buffer_rsrc_t rm = plane_rsrc(mbase, plane_bytes);
+#pragma unroll
+                for (int k = 0; k < XI; ++k) mr[MASK ? c : 0][MASK ? k : 0] = buf_load(rm, goff[k]);
             }
         }
-        // ---- stage the filter slice [CC][KK][CB] (rows of CB floats, 16-byte vectors)
-        {
-            constexpr int ROW4 = CB / 4;
-            const float* wsrc = a.wp + (long long)c0 * KK * a.cout_pad + cg * CB;
-            for (int i = tid; i < CC * KK * ROW4; i += 256) {
-                const int row = i / ROW4, j4 = i - row * ROW4;
-                reinterpret_cast<float4*>(ws)[i] =
-                    *reinterpret_cast<const float4*>(wsrc + (long long)row * a.cout_pad + j4 * 4);
-            }
+        const float* wsrc = a.wp + (long long)c0 * KK * a.cout_pad + cg * CB;
+#pragma unroll
+        for (int k = 0; k < WI; ++k) {
+            int i = tid + k * 256;
+            i = i < CC * KK * ROW4 ? i : CC * KK * ROW4 - 1;      // clamp (keeps wr[] in registers)
+            const int row = i / ROW4, j4 = i - row * ROW4;
+            const float4 v4 = *reinterpret_cast<const float4*>(wsrc + (long long)row * a.cout_pad + j4 * 4);
+            wr[k][0] = v4.x;
+            wr[k][1] = v4.y;
+            wr[k][2] = v4.z;
+            wr[k][3] = v4.w;
         }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+#pragma unroll
+            for (int k = 0; k < XI; ++k) {
+                const int i = tid + k * 256;
+                xs[c * CHS + i] = (!MASK || mr[MASK ? c : 0][MASK ? k : 0] > 0.f) ? xr[c][k] : 0.f;
+            }
+#pragma unroll
+        for (int k = 0; k < WI; ++k) {
+            const int i = tid + k * 256;
+            if (i < CC * KK * ROW4) reinterpret_cast<float4*>(ws)[i] = make_float4(wr[k][0], wr[k][1], wr[k][2], wr[k][3]);
+        }
+    };
+
+    const int nchunks = (a.cin + CC - 1) / CC;
+    load_chunk(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CC;
+        __syncthreads();            // every wave finished reading the previous chunk
+        store_chunk();
         __syncthreads();
+        if (ch + 1 < nchunks) load_chunk(c0 + CC);
         // ---- MFMA over (channel pair, tap)
         const int rem = a.cin - c0;
         const int npairs = rem >= CC ? CC / 2 : (rem + 1) / 2;
-        const float* xb = xs + half * PLANE + (wave * R) * TCOLS + l31;
+        const float* xb = xs + half * CHS + (wave * R) * TCOLS + l31;
         const float* wb = ws + half * KK * CB + l31;
 #pragma unroll 1
         for (int p = 0; p < npairs; ++p) {
-            const float* xp = xb + 2 * p * PLANE;
+            const float* xp = xb + 2 * p * CHS;
             const float* wq = wb + 2 * p * KK * CB;
 #pragma unroll
             for (int t = 0; t < KK; ++t) {
@@ -146,14 +206,23 @@ __global__ __launch_bounds__(256, (NCB == 1 ? 4 : 3)) void conv_mfma_kernel(cons
             const int co = cg * CB + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
             if (co >= a.cout) continue;
             const float bsv = a.bias ? a.bias[co] : 0.f;
-            int d = 0, rel = co;
-            while (d < a.ndst - 1 && rel >= a.dst[d].c) {
-                rel -= a.dst[d].c;
-                ++d;
+            float* dp = nullptr;
+            {
+                int rel = co;
+                bool found = false;
+#pragma unroll
+                for (int d = 0; d < YNET_MAX_SRC; ++d) {
+                    if (!found && d < a.ndst) {
+                        if (rel < a.dst[d].c || d == a.ndst - 1) {
+                            found = true;
+                            if (a.dst[d].p != nullptr) dp = a.dst[d].p + (long long)b * a.dst[d].bs + (long long)rel * HW;
+                        } else {
+                            rel -= a.dst[d].c;
+                        }
+                    }
+                }
             }
-            float* dp = a.dst[d].p;
             if (dp == nullptr) continue;
-            dp += (long long)b * a.dst[d].bs + (long long)rel * HW;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int gy = y0 + wave * R + r;
@@ -167,8 +236,8 @@ __global__ __launch_bounds__(256, (NCB == 1 ? 4 : 3)) void conv_mfma_kernel(cons
     }
 }
 
-template <int KS, int NCB, int R, int CC>
-static int launch_conv(ConvArgs& a, hipStream_t st) {
+template <int KS, int NCB, int R, int CC, bool MASK>
+static int launch_conv_m(ConvArgs& a, hipStream_t st) {
     using C = ConvCfg<KS, NCB, R, CC>;
     a.tiles_x = ceil_div(a.W, C::TW);
     a.tiles_y = ceil_div(a.H, C::TH);
@@ -177,12 +246,17 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     YNET_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv2d: grid of %lld blocks is out of range", nblk);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, NCB, R, CC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, NCB, R, CC, MASK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, NCB, R, CC>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, NCB, R, CC, MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
     return ynet_check_launch("conv2d");
+}
+
+template <int KS, int NCB, int R, int CC>
+static int launch_conv(ConvArgs& a, hipStream_t st) {
+    return a.mask ? launch_conv_m<KS, NCB, R, CC, true>(a, st) : launch_conv_m<KS, NCB, R, CC, false>(a, st);
 }
 
 static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
