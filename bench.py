@@ -80,8 +80,9 @@ class ConvTimer:
             cout = sum(d[1] for d in dl)
             flops = 2.0 * B * H * W * cin * cout * K * K
             byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]))
-            name = f"conv_mfma_kernel<{K}, {2 if cout > 32 else 1}, 4, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}>"
-            self.rec.append((name, e0, e1, flops, byts))
+            rows = self.ops._lib().ynet_conv2d_plan_rows(B, H, W, cout, K)
+            name = f"conv_mfma_kernel<{K}, {2 if cout > 32 else 1}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}>"
+            self.rec.append((name, e0, e1, flops, byts, (B, H, W, cin, cout, K, bool(mask))))
         self.ops.conv2d_raw = timed
         return self
 
@@ -91,7 +92,7 @@ class ConvTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, e0, e1, fl, by in self.rec:
+        for name, e0, e1, fl, by, _shape in self.rec:
             d = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -142,6 +143,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print one line per conv launch of the instrumented step (stderr)")
     args = ap.parse_args()
 
     from oracle import ynet_oracle as O      # cpu_baseline leg + synthetic-input generators only
@@ -212,6 +214,10 @@ def main():
         with ConvTimer(ops) as ct:
             run(1, 3)
         agg = ct.summary()
+        if args.layers:
+            for name, e0, e1, fl, by, shape in ct.rec:
+                ms = e0.elapsed_time(e1)
+                print(f"LAYER B,H,W,cin,cout,K,mask={shape} {ms * 1e3:8.1f} us {fl / ms / 1e9:7.2f} TF/s", file=sys.stderr)
         name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
         traffic = None

@@ -16,6 +16,7 @@
 // (with halo) and the filter slice for CC input channels are staged in LDS per chunk; 2-4 resident
 // workgroups per CU overlap one group's staging with another's MFMAs.
 #include "ynet_common.h"
+#include <stdlib.h>
 
 struct ConvArgs {
     YSrc src[YNET_MAX_SRC];
@@ -259,11 +260,33 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     return a.mask ? launch_conv_m<KS, NCB, R, CC, true>(a, st) : launch_conv_m<KS, NCB, R, CC, false>(a, st);
 }
 
+// Rows per wave (R): 4 gives the most operand reuse; small feature maps (8^2 .. 64^2) take R = 2 or 1
+// so that the launch still spreads over the 256 CUs (a workgroup's run time is its MFMA count).
+static int pick_rows(const ConvArgs& a, int ncb) {
+    static const int forced = getenv("YNET_CONV_R") ? atoi(getenv("YNET_CONV_R")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    const long long per_img_x = ceil_div(a.W, 32), cg = ceil_div(a.cout, 32 * ncb);
+    for (int r = 4; r > 1; r >>= 1) {
+        const long long nblk = per_img_x * ceil_div(a.H, 4 * r) * cg * a.B;
+        if (nblk >= 1024) return r;
+    }
+    return 1;
+}
+
+template <int KS, int NCB, int CC>
+static int launch_conv_r(ConvArgs& a, hipStream_t st) {
+    switch (pick_rows(a, NCB)) {
+        case 4: return launch_conv<KS, NCB, 4, CC>(a, st);
+        case 2: return launch_conv<KS, NCB, 2, CC>(a, st);
+        default: return launch_conv<KS, NCB, 1, CC>(a, st);
+    }
+}
+
 static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
     const bool wide = a.cout > 32;
     switch (K) {
-        case 1: return wide ? launch_conv<1, 2, 4, 16>(a, st) : launch_conv<1, 1, 4, 16>(a, st);
-        case 3: return wide ? launch_conv<3, 2, 4, 8>(a, st) : launch_conv<3, 1, 4, 8>(a, st);
+        case 1: return wide ? launch_conv_r<1, 2, 16>(a, st) : launch_conv_r<1, 1, 16>(a, st);
+        case 3: return wide ? launch_conv_r<3, 2, 8>(a, st) : launch_conv_r<3, 1, 8>(a, st);
         case 5: return wide ? launch_conv<5, 2, 4, 4>(a, st) : launch_conv<5, 1, 4, 4>(a, st);
         default: ynet_set_error("conv2d: kernel size %d not supported (1, 3, 5)", K); return 1;
     }
@@ -296,6 +319,18 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 }
 
 extern "C" {
+
+// rows per wave the dispatcher picks for this problem (1, 2 or 4): names the kernel instantiation
+// conv_mfma_kernel<K, cout>32 ? 2 : 1, rows, CC, mask> that a profile will show.
+int ynet_conv2d_plan_rows(int B, int H, int W, int cout, int K) {
+    if (K == 5) return 4;
+    ConvArgs a{};
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.cout = cout;
+    return pick_rows(a, cout > 32 ? 2 : 1);
+}
 
 long long ynet_packed_weight_floats(int cout, int cin, int K, int mode) {
     const int rows = mode == 0 ? cin : cout, cols = mode == 0 ? cout : cin;
