@@ -8,9 +8,10 @@
 // the two differ only in the packed filter handed in (see ynet_pack_weight).
 //
 // Mapping (v_mfma_f32_32x32x2_f32, exact fp32 = an fmaf chain, 64 FLOP/clk/SIMD):
-//   M = 32 output channels   -> A operand = packed filter  [cin][tap][cout]   (LDS, cout fastest)
-//   N = 32 consecutive x     -> B operand = input tile row (LDS, x fastest)   -> coalesced NCHW stores
+//   M = 32 consecutive x     -> A operand = input tile row (LDS, x fastest)
+//   N = 32 output channels   -> B operand = packed filter  [cin][tap][cout]   (LDS, cout fastest)
 //   K = 2 input channels at one filter tap per instruction (lanes 0-31: channel c, 32-63: c+1)
+//   D: a lane owns one output channel and 4 consecutive pixels per register quad -> 16-byte NCHW stores
 // A workgroup = 4 waves computes a 32(x) x 4R(y) pixel tile for 32*NCB output channels; each wave
 // owns R rows, so one A fragment feeds R MFMAs and one B fragment NCB MFMAs.  The input tile
 // (with halo) and the filter slice for CC input channels are staged in LDS per chunk; 2-4 resident
@@ -177,60 +178,91 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         const int npairs = rem >= CC ? CC / 2 : (rem + 1) / 2;
         const float* xb = xs + half * CHS + (wave * R) * TCOLS + l31;
         const float* wb = ws + half * KK * CB + l31;
+        // Operands of tap t+1 are read from LDS while the MFMAs of tap t run (explicit two-stage
+        // register pipeline; sched_group_barrier pins "reads first, then MFMAs" so that no MFMA waits
+        // on an LDS read issued just before it).
+        float a_cur[NCB], b_cur[R], a_nxt[NCB], b_nxt[R];
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) a_cur[i] = wb[i * 32];
+#pragma unroll
+        for (int r = 0; r < R; ++r) b_cur[r] = xb[r * TCOLS];
 #pragma unroll 1
         for (int p = 0; p < npairs; ++p) {
             const float* xp = xb + 2 * p * CHS;
             const float* wq = wb + 2 * p * KK * CB;
 #pragma unroll
             for (int t = 0; t < KK; ++t) {
-                const int ky = t / KS, kx = t % KS;
-                float av[NCB];
+                const int tn = (t + 1) % KK;                     // next tap (of the next pair when t is the last)
+                const float* xn = t + 1 < KK ? xp : xp + 2 * CHS;
+                const float* wn = t + 1 < KK ? wq : wq + 2 * KK * CB;
+                const int kyn = tn / KS, kxn = tn % KS;
+                if (t + 1 < KK || p + 1 < npairs) {
 #pragma unroll
-                for (int i = 0; i < NCB; ++i) av[i] = wq[t * CB + i * 32];
+                    for (int i = 0; i < NCB; ++i) a_nxt[i] = wn[tn * CB + i * 32];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float bv = xp[(r + ky) * TCOLS + kx];
+                    for (int r = 0; r < R; ++r) b_nxt[r] = xn[(r + kyn) * TCOLS + kxn];
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, NCB + R, 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int i = 0; i < NCB; ++i)
-                        acc[i][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][r], 0, 0, 0);
-                }
+                        acc[i][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[r], a_cur[i], acc[i][r], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, NCB * R, 0);
+#pragma unroll
+                for (int i = 0; i < NCB; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+                for (int r = 0; r < R; ++r) b_cur[r] = b_nxt[r];
             }
         }
     }
 
-    // ---- epilogue: bias, ReLU, scatter to the (possibly split) destination
-    const int gx = x0 + l31;
+    // ---- epilogue: bias, ReLU, scatter to the (possibly split) destination.
+    // D = pixels x cout: lane (l31, half) owns output channel l31 of the block and, in registers
+    // 4g..4g+3, the four consecutive pixels x0 + 8g + 4*half .. +3  ->  one 16-byte store each.
+    const bool vec_ok = (a.W & 3) == 0;
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
+        const int co = cg * CB + i * 32 + l31;
+        float* dp = nullptr;
+        if (co < a.cout) {
+            int rel = co;
+            bool found = false;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int co = cg * CB + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-            if (co >= a.cout) continue;
-            const float bsv = a.bias ? a.bias[co] : 0.f;
-            float* dp = nullptr;
-            {
-                int rel = co;
-                bool found = false;
-#pragma unroll
-                for (int d = 0; d < YNET_MAX_SRC; ++d) {
-                    if (!found && d < a.ndst) {
-                        if (rel < a.dst[d].c || d == a.ndst - 1) {
-                            found = true;
-                            if (a.dst[d].p != nullptr) dp = a.dst[d].p + (long long)b * a.dst[d].bs + (long long)rel * HW;
-                        } else {
-                            rel -= a.dst[d].c;
-                        }
+            for (int d = 0; d < YNET_MAX_SRC; ++d) {
+                if (!found && d < a.ndst) {
+                    if (rel < a.dst[d].c || d == a.ndst - 1) {
+                        found = true;
+                        if (a.dst[d].p != nullptr) dp = a.dst[d].p + (long long)b * a.dst[d].bs + (long long)rel * HW;
+                    } else {
+                        rel -= a.dst[d].c;
                     }
                 }
             }
-            if (dp == nullptr) continue;
+        }
+        if (dp == nullptr) continue;
+        const float bsv = a.bias ? a.bias[co] : 0.f;
+        const bool vec = vec_ok && ((reinterpret_cast<uintptr_t>(dp) & 15) == 0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int gy = y0 + wave * R + r;
-                if (gy < a.H && gx < a.W) {
-                    float v = acc[i][r][q] + bsv;
-                    if (a.relu) v = v < 0.f ? 0.f : v;
-                    dp[gy * a.W + gx] = v;
+        for (int r = 0; r < R; ++r) {
+            const int gy = y0 + wave * R + r;
+            if (gy >= a.H) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int gx = x0 + 8 * g + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][r][4 * g + e] + bsv;
+                    if (a.relu) v[e] = v[e] < 0.f ? 0.f : v[e];
+                }
+                float* o = dp + (long long)gy * a.W + gx;
+                if (vec && gx + 3 < a.W) {
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gx + e < a.W) o[e] = v[e];
                 }
             }
         }

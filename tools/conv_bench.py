@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single conv / wgrad launches (development tool, GPU only).
+
+    python tools/conv_bench.py --shape 32,256,256,32,32,3 --mask 0 --iters 50
+Prints the average launch time (HIP events on the launch stream) and the algorithmic TFLOP/s.
+"""
+import argparse
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+ops = importlib.import_module("motion-style-transfer_amd.ops")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="32,256,256,32,32,3", help="B,H,W,cin,cout,K")
+    ap.add_argument("--mask", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--wgrad", action="store_true")
+    ap.add_argument("--nostore", action="store_true", help="ablation: compute but skip the epilogue stores")
+    ap.add_argument("--dstbs0", action="store_true", help="ablation: every batch item writes the same image (cache-resident writes)")
+    ap.add_argument("--srcbs0", action="store_true", help="ablation: every batch item reads the same image")
+    a = ap.parse_args()
+    B, H, W, cin, cout, K = map(int, a.shape.split(","))
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    x = torch.randn(B, cin, H, W, device=dev)
+    w = torch.randn(cout, cin, K, K, device=dev) * 0.05
+    b = torch.randn(cout, device=dev)
+    y = torch.empty(B, cout, H, W, device=dev)
+    m = torch.randn(B, cin, H, W, device=dev) if a.mask else None
+    wp = ops.pack_weight(w, 0)
+    lib = ops._lib()
+
+    def run():
+        if a.wgrad:
+            raise SystemExit("use bench.py for wgrad")
+        ops.conv2d_raw([(x.data_ptr(), cin, 0 if a.srcbs0 else cin * H * W)], (m.data_ptr(), cin * H * W) if a.mask else None, wp, b,
+                       [(None if a.nostore else y.data_ptr(), cout, 0 if a.dstbs0 else cout * H * W)], B, H, W, K, True)
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / a.iters
+    fl = 2.0 * B * H * W * cin * cout * K * K
+    rows = lib.ynet_conv2d_plan_rows(B, H, W, cout, K)
+    print(f"shape {a.shape} mask {a.mask} rows {rows}: {us:9.1f} us  {fl / us / 1e6:7.2f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
