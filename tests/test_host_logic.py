@@ -1,0 +1,169 @@
+"""Host-side logic of the product (no GPU): state-dict contract, freeze policy, LoRA module
+semantics/init, lazy concatenation, templates, sampling, dataset contract, checkpoint format."""
+import io
+import contextlib
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import Golden, TINY_CASES, build_model, pkg, ROOT
+from oracle import ynet_oracle as O
+
+
+@pytest.mark.parametrize("case", TINY_CASES)
+def test_state_dict_contract_and_freeze_policy(case):
+    g = Golden(case)
+    cfg = g.cfg()
+    sd = g.state_dict()
+    model = build_model(cfg, sd)                       # strict load: key names and shapes are the reference's
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    trainable = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert trainable == [str(s) for s in g.z["step/trainable"]]
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == int(g.z["step/n_trainable"])
+
+
+def test_fullsize_parameter_counts():
+    cfg = O.sdd_short(train_net="mosa_4", position=["0", "1", "2", "3", "4"])
+    m = build_model(cfg)
+    assert sum(p.numel() for n, p in m.named_parameters() if "lora" not in n) == 1641381
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 32760
+    cfg = O.ind_long(network="fusion", n_fusion=2, train_net="mosa_3", position=["scene"])
+    m = build_model(cfg)
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 5346
+    assert m.encoder.scene_stages[0][0].lora_A.shape == (9, 18)
+
+
+def test_unknown_modes_raise_like_the_reference():
+    ynet, trainer = pkg("models.ynet"), pkg("models.trainer")
+    kw = dict(encoder_channels=[8, 8, 16, 16, 16], decoder_channels=[16, 16, 16, 8, 8])
+    with pytest.raises(ValueError, match="No network parameter"):
+        ynet.YNet(8, 12, None, train_net="train", network=None, **kw)
+    m = ynet.YNet(8, 12, None, train_net="train", network="original", **kw)
+    with pytest.raises(NotImplementedError):
+        trainer.apply_freeze_policy(m, "nonsense")
+    with pytest.raises(AssertionError):
+        ynet.YNetEncoderFusion(6, 8, [8, 9, 16], train_net="train", n_fusion=1)
+
+
+def test_lora_conv_matches_loralib_restatement_init_and_names():
+    """Same seed -> the same parameters as the (restated) loralib 0.1.1 Conv2d the reference builds."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_stubs"))
+    import loralib
+    ynet = pkg("models.ynet")
+    torch.manual_seed(5)
+    a = loralib.Conv2d(14, 32, kernel_size=3, r=2, stride=1, padding=1)
+    torch.manual_seed(5)
+    b = ynet.LoRAConv2d(14, 32, kernel_size=3, r=2, stride=1, padding=1)
+    assert [n for n, _ in a.named_parameters()] == [n for n, _ in b.named_parameters()]
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
+        assert p.requires_grad == q.requires_grad, n
+    assert b.scaling == 0.5 and not b.weight.requires_grad and float(b.lora_B.abs().sum()) == 0.0
+
+
+def test_model_init_consumes_rng_like_the_reference_layout():
+    """Two product models built under one seed are identical and depend on the seed."""
+    cfg = O.sdd_short(train_net="mosa_1", position=["0", "2"], enc=(8, 8, 16, 16, 16), dec=(16, 16, 16, 8, 8))
+    torch.manual_seed(3)
+    a = build_model(cfg)
+    torch.manual_seed(3)
+    b = build_model(cfg)
+    torch.manual_seed(4)
+    c = build_model(cfg)
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+    assert not all(torch.equal(p, q) for p, q in zip(a.parameters(), c.parameters()))
+    assert hasattr(a.encoder.stages[0][0], "lora_A") and not hasattr(a.encoder.stages[1][1], "lora_A")
+
+
+def test_lazy_cat_protocol():
+    ops = pkg("ops")
+    a, b, c = torch.rand(2, 3, 4, 5), torch.rand(2, 1, 4, 5), torch.rand(2, 2, 4, 5)
+    lc = ops.lazy_cat([a, b])
+    assert isinstance(lc, ops.LazyCat) and lc.shape == (2, 4, 4, 5) and lc.dim() == 4 and lc.size(1) == 4
+    nested = torch.cat([lc, c], dim=1)                     # stays lazy through torch.cat(dim=1)
+    assert isinstance(nested, ops.LazyCat) and [p.shape[1] for p in nested.parts] == [3, 1, 2]
+    assert torch.equal(nested.materialize(), torch.cat([a, b, c], 1))
+    assert torch.equal(torch.flatten(lc, 2), torch.cat([a, b], 1).flatten(2))     # any other op materialises
+    assert ops.lazy_cat([a]) is a
+    with pytest.raises(ValueError):
+        ops.lazy_cat([a, torch.rand(2, 1, 4, 6)])
+
+
+def test_templates_and_sampling_match_oracle():
+    iu = pkg("utils.image_utils")
+    for S in (210, 1050):
+        assert torch.equal(torch.Tensor(iu.create_dist_mat(size=S)), O.dist_template(S))
+        assert torch.equal(torch.Tensor(iu.create_gaussian_heatmap_template(size=S, kernlen=31, nsig=4, normalize=False)),
+                           O.gaussian_template(S, 31, 4))
+    t = iu.create_gaussian_heatmap_template(size=101, kernlen=31, nsig=4, normalize=True)
+    assert t.max() == 1.0 and abs(iu.gkern(31, 4).sum() - 1.0) < 1e-12
+    prob = torch.rand(3, 2, 16, 24)
+    torch.manual_seed(1)
+    a = iu.sampling(prob, 7)
+    torch.manual_seed(1)
+    b = O.sample_coords(prob, 7)
+    assert a.shape == (3, 2, 7, 2) and torch.equal(a, b)
+    assert float(a[..., 0].max()) < 24 and float(a[..., 1].max()) < 16
+    x = torch.arange(2 * 3 * 2 * 2, dtype=torch.float32).view(2, 3, 2, 2)
+    y = iu.swap_pavement_terrain(x.clone())
+    assert torch.equal(y[:, 1], x[:, 2]) and torch.equal(y[:, 2], x[:, 1]) and torch.equal(y[:, 0], x[:, 0])
+    with pytest.raises(ImportError):
+        iu.pad({}, 32)
+
+
+def test_scene_dataset_contract():
+    dl = pkg("utils.dataloader")
+    rows = []
+    for scene, n in (("a", 3), ("b", 2)):
+        for m in range(n):
+            for t in range(20):
+                rows.append(dict(sceneId=scene, metaId=f"{scene}{m}", x=float(4 * t + m), y=float(8 * t)))
+    ds = dl.SceneDataset(pd.DataFrame(rows), resize=0.25, total_len=20)
+    assert len(ds) == 2
+    traj, meta, scene = dl.scene_collate([ds[0]])
+    assert scene == "a" and traj.shape == (3, 20, 2) and traj.dtype == torch.float32
+    assert float(traj[1, 2, 0]) == (4 * 2 + 1) * 0.25 and len(meta[0]) == 60
+
+
+def test_trainer_checkpoint_format_cpu(tmp_path):
+    """save_params: full state dict (minus segmentation) for train/all; only requires_grad Parameters otherwise."""
+    trn = pkg("models.trainer")
+    g = Golden("tiny_short_mosa1")
+    cfg = g.cfg()
+    params = dict(obs_len=8, pred_len=12, segmentation_model_fp=None, use_features_only=False, n_semantic_classes=6,
+                  encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec), waypoints=[11],
+                  train_net=cfg.train_net, position=list(cfg.position), network="original", n_fusion=None,
+                  resize_factor=0.25)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t = trn.YNetTrainer(params, device=torch.device("cpu"))
+    assert t.template_size == 1050 and t.division_factor == 32
+    t.model.load_state_dict(g.state_dict(), strict=True)
+    trn.apply_freeze_policy(t.model, cfg.train_net, cfg.position, "original")
+    t.save_params(str(tmp_path / "delta.pt"), cfg.train_net)
+    ck = torch.load(tmp_path / "delta.pt", weights_only=False)
+    assert list(ck.keys()) == [str(k) for k in g.z["step/ckpt_keys"]]
+    assert all(isinstance(v, torch.nn.Parameter) for v in ck.values())
+    t.save_params(str(tmp_path / "full.pt"), "train")
+    full = torch.load(tmp_path / "full.pt", weights_only=False)
+    assert list(full.keys()) == list(g.state_dict().keys())
+    with contextlib.redirect_stdout(io.StringIO()):
+        t2 = trn.YNetTrainer(params, device=torch.device("cpu"))
+        t2.load_separated_params(str(tmp_path / "full.pt"), str(tmp_path / "delta.pt"))
+    for (n, p), (_, q) in zip(t.model.named_parameters(), t2.model.named_parameters()):
+        assert torch.equal(p, q), n
+    with pytest.raises(ImportError):
+        t.prepare_data(pd.DataFrame(), "some/dir", "sdd", "train", 8, 12, 0.25, False)
+    with pytest.raises(ValueError):
+        t.prepare_data(pd.DataFrame(), {}, "kitti", "train", 8, 12, 0.25, False)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    L = pkg("_lib")
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no fallback"):
+        L.load()

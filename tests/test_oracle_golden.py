@@ -1,0 +1,123 @@
+"""The CPU oracle (oracle/ynet_oracle.py) against the fixtures generated FROM THE REFERENCE
+(oracle/gen_goldens.py): this is what pins the oracle.  Runs without a GPU and without /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, TINY_CASES
+from oracle import ynet_oracle as O
+
+TIGHT = dict(rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", TINY_CASES)
+def test_train_step(case):
+    g = Golden(case)
+    cfg, m = g.cfg(), g.meta
+    sd = g.state_dict()
+    S = cfg.template_size
+    in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+    names = O.trainable_names(cfg, sd)
+    assert names == [str(s) for s in g.z["step/trainable"]]
+    assert sum(sd[n].numel() for n in names) == int(g.z["step/n_trainable"])
+    st = O.train_step(sd, cfg, g.t("scene"), g.t("traj"), in_t, gt_t, names, keep_maps=True)
+    for i, f in enumerate(st["features"]):
+        g.compare(f"step/features{i}", f, **TIGHT)
+    g.compare("step/goal_map", st["goal_map"], **TIGHT)
+    g.compare("step/traj_map", st["traj_map"], **TIGHT)
+    g.compare("step/pred_traj", st["pred_traj"], rtol=1e-5, atol=2e-5)
+    g.compare("step/pred_goal", st["pred_goal"], rtol=1e-5, atol=2e-5)
+    assert abs(float(st["loss"]) - float(g.z["step/loss"])) <= 1e-6 * abs(float(g.z["step/loss"]))
+    assert abs(float(st["ade"].mean()) - float(g.z["step/ade"])) <= 1e-5
+    assert abs(float(st["fde"].mean()) - float(g.z["step/fde"])) <= 1e-5
+    for n in names:
+        g.compare("step/grad/" + n, st["grads"][n], rtol=1e-4, atol=1e-6)
+        z = torch.zeros_like(sd[n])
+        p1, _, _ = O.adam_update(sd[n], st["grads"][n], z, z.clone(), 1, m["lr"])
+        g.compare("step/after/" + n, p1, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", [c for c in TINY_CASES if "epoch/ade" in Golden(c).z.files])
+def test_ragged_epoch(case):
+    g = Golden(case)
+    cfg, m = g.cfg(), g.meta
+    sd = g.state_dict()
+    S = cfg.template_size
+    in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+    names = O.trainable_names(cfg, sd)
+    ms = {n: torch.zeros_like(sd[n]) for n in names}
+    vs = {n: torch.zeros_like(sd[n]) for n in names}
+    traj, B = g.t("epoch/traj"), m["B"]
+    ades, fdes, tot = [], [], 0.0
+    for step, i in enumerate(range(0, traj.shape[0], B), 1):
+        r = O.train_step(sd, cfg, g.t("scene"), traj[i:i + B], in_t, gt_t, names)
+        for n in names:
+            sd[n], ms[n], vs[n] = O.adam_update(sd[n], r["grads"][n], ms[n], vs[n], step, m["lr"])
+        ades.append(r["ade"]); fdes.append(r["fde"]); tot += float(r["loss"])
+    assert abs(float(torch.cat(ades).mean()) - float(g.z["epoch/ade"])) <= 1e-4
+    assert abs(float(torch.cat(fdes).mean()) - float(g.z["epoch/fde"])) <= 1e-4
+    assert abs(tot - float(g.z["epoch/loss"])) <= 1e-5 * abs(float(g.z["epoch/loss"]))
+    for n in names:
+        g.compare("epoch/after/" + n, sd[n], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", [c for c in TINY_CASES if "eval/trajs" in Golden(c).z.files])
+def test_eval_sweep(case):
+    g = Golden(case)
+    cfg, m = g.cfg(), g.meta
+    sd = g.state_dict()
+    in_t = O.dist_template(cfg.template_size)
+    ev = O.eval_batch(sd, cfg, g.t("scene"), g.t("traj"), in_t, n_goal=m["n_goal"],
+                      waypoint_samples=g.t("eval/waypoint_samples"))
+    g.compare("eval/goal_map", ev["goal_map"], **TIGHT)
+    np.testing.assert_allclose(ev["trajs"].numpy(), g.z["eval/trajs"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(ev["ade"].numpy(), g.z["eval/ade_per_traj"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(ev["fde"].numpy(), g.z["eval/fde_per_traj"], rtol=1e-5, atol=2e-5)
+    # the sampler: same seed -> the reference's own draws
+    torch.manual_seed(int(g.z["eval/seed"]))
+    ev2 = O.eval_batch(sd, cfg, g.t("scene"), g.t("traj"), in_t, n_goal=m["n_goal"])
+    assert torch.equal(ev2["waypoint_samples"], g.t("eval/waypoint_samples"))
+
+
+def test_leaf_vectors():
+    g = Golden("kernels")
+    np.testing.assert_allclose(O.softargmax2d(g.t("softargmax/x")).numpy(), g.z["softargmax/out"], rtol=1e-6, atol=1e-6)
+    dm, gm = O.dist_template(210), O.gaussian_template(210, 31, 4)
+    assert abs(float(dm.double().sum()) - float(g.z["template/dist_S210_sum"])) < 1e-6
+    assert abs(float(gm.double().sum()) - float(g.z["template/gauss_S210_sum"])) < 1e-9
+    assert float(gm.max()) == float(g.z["template/gauss_S210_peak"])
+    for S in (1050, 1386):
+        d = O.dist_template(S)
+        assert abs(float(d.double().sum()) - float(g.z[f"template/dist_S{S}_sum"])) < 1e-3
+        assert np.array_equal(torch.diagonal(d).numpy(), g.z[f"template/dist_S{S}_diag"])
+    xy = g.z["patch/xy"]
+    assert np.array_equal(O.crop_patches(dm, xy, 24, 40).numpy(), g.z["patch/dist"])
+    assert np.array_equal(O.crop_patches(gm, xy, 24, 40).numpy(), g.z["patch/gauss"])
+
+
+def test_known_answers():
+    """identity at init, one-hot soft-argmax, patch peak position, BCE(0,0) = ln2."""
+    cfg = O.sdd_short(train_net="mosa_2", position=["0", "1", "2", "3", "4"], enc=(8, 8, 16, 16, 16), dec=(16, 16, 16, 8, 8))
+    sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.0)
+    base = {k: v for k, v in sd.items() if "lora" not in k}
+    sc, mo = torch.rand(2, 6, 32, 32), torch.rand(2, 8, 32, 32)
+    for a, b in zip(O.encoder(sd, cfg, sc, mo), O.encoder(base, cfg, sc, mo)):
+        assert torch.equal(a, b)
+    x = torch.full((1, 1, 16, 24), -30.0)
+    x[0, 0, 9, 13] = 50.0
+    assert torch.allclose(O.softargmax2d(x)[0, 0], torch.tensor([13.0, 9.0]), atol=1e-4)
+    p = O.crop_patches(O.gaussian_template(210, 31, 4), np.array([[7.4, 11.6]], dtype=np.float32), 32, 32)[0]
+    assert divmod(int(p.argmax()), 32) == (12, 7)
+    assert abs(float(O.bce_logits_mean(torch.zeros(4, 4), torch.zeros(4, 4))) * 1000 - 1000 * np.log(2)) < 1e-3
+
+
+def test_fullsize_weight_checksums():
+    """The seeded full-size weights used by the GPU-side scalar goldens are reproducible here."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_scalars.npz"))
+    cfg = O.sdd_short(train_net="mosa_1", position=["0", "1", "2", "3", "4"])
+    sd = O.make_state_dict(cfg, seed=3, lora_b_std=0.05)
+    chk = sum(float(v.double().abs().sum()) for v in sd.values())
+    assert abs(chk - float(z["C2_sdd_short_mosa1/weight_checksum"])) <= 1e-9 * chk
+    assert sum(sd[n].numel() for n in O.trainable_names(cfg, sd)) == 8190
+    assert sum(v.numel() for k, v in sd.items() if "lora" not in k) == 1641381
