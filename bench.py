@@ -103,7 +103,21 @@ class ConvTimer:
 
 def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0):
     """CPU oracle (port of the reference's ATen-op path) on the host cores: bounded sample."""
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # torch's intra-op pool degrades badly when oversubscribed (256 threads on the GPU box's host ran
+    # 30x slower than 32): pick the fastest of a few thread counts on a quick conv probe.
+    import torch.nn.functional as F
+    probe_x, probe_w = torch.randn(4, 32, 128, 128), torch.randn(32, 32, 3, 3)
+    best, cores = None, 1
+    for t in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
+        torch.set_num_threads(t)
+        F.conv2d(probe_x, probe_w, padding=1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            F.conv2d(probe_x, probe_w, padding=1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, t
     torch.set_num_threads(cores)
     sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.05)
     scene = O.synthetic_scene(cfg, H, W, 0)
