@@ -29,7 +29,8 @@ struct ConvArgs {
     YDst dst[YNET_MAX_SRC];
     int ndst;
     int B, H, W, cout, cout_pad, relu;
-    int tiles_x, tiles_y, cgroups;
+    int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
+    int tiles_x, tiles_y, cgroups, ntiles, prio_mode, debug;   // debug: timing ablations only (tools/conv_bench.py)
 };
 
 template <int KS, int NCB, int R, int CC>
@@ -59,6 +60,15 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byt
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
+struct TileCoord {
+    int cg, x0, y0, b;
+};
+
+// Persistent workgroups: each walks tiles blockIdx.x, +gridDim.x, ... and runs ONE software pipeline
+// over the flattened (tile, channel-chunk) sequence:
+//     [barrier, regs -> LDS, barrier] [issue global loads of the NEXT chunk (maybe of the next tile)]
+//     [epilogue stores of the tile that just finished]  [MFMA loop of this chunk]
+// so neither a tile's first loads nor its output stores leave the matrix pipes idle.
 template <int KS, int NCB, int R, int CC, bool MASK>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<KS, NCB, R, CC>;
@@ -70,26 +80,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    int bid = blockIdx.x;
-    const int cg = bid % a.cgroups;
-    bid /= a.cgroups;
-    const int txi = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int tyi = bid % a.tiles_y;
-    const int b = bid / a.tiles_y;
-    const int x0 = txi * TW, y0 = tyi * TH;
     const int HW = __builtin_amdgcn_readfirstlane(a.H * a.W);   // keep plane arithmetic on the scalar unit
+    const unsigned plane_bytes = (unsigned)HW * 4u;
+    const int ntiles = a.ntiles, nchunks = (a.cin + CC - 1) / CC;
+    const int gstride = gridDim.x;
+
+    auto decode = [&](int t) {
+        TileCoord c;
+        c.cg = t % a.cgroups;
+        t /= a.cgroups;
+        c.x0 = (t % a.tiles_x) * TW;
+        t /= a.tiles_x;
+        c.y0 = (t % a.tiles_y) * TH;
+        c.b = t / a.tiles_y;
+        return c;
+    };
 
     f32x16 acc[NCB][R];
-#pragma unroll
-    for (int i = 0; i < NCB; ++i)
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][r][q] = 0.f;
-
-    // Register-staged software pipeline: the global loads of chunk ch+1 are issued before the MFMA
-    // loop of chunk ch and written to LDS after it, so their latency hides under ~10-18k MFMA cycles.
     constexpr int XI = C::XI;
     constexpr int ROW4 = CB / 4;
     constexpr int WI = (CC * KK * ROW4 + 255) / 256;       // filter float4 per thread
@@ -97,47 +104,49 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     float wr[WI][4];     // (a float4 array is not promoted to registers by hipcc here: scratch)
 
     // per-thread byte offsets of its XI tile elements inside an image plane (same for every channel
-    // and chunk); out-of-image elements get an offset past the buffer: the hardware range check of
-    // buffer_load returns 0 for them, so the staging loop has no branches.
+    // and chunk of a tile); out-of-image elements get an offset past the buffer: the hardware range
+    // check of buffer_load returns 0 for them, so the staging loop has no branches.
     unsigned goff[XI];
+    auto set_goff = [&](const TileCoord& t) {
 #pragma unroll
-    for (int k = 0; k < XI; ++k) {
-        const int i = tid + k * 256;
-        const int ty = i / TCOLS, tx = i - ty * TCOLS;
-        const int gy = y0 + ty - PAD, gx = x0 + tx - PAD;
-        const bool ok = i < PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0xFFFFFFF0u;
-    }
-    const unsigned plane_bytes = (unsigned)HW * 4u;
+        for (int k = 0; k < XI; ++k) {
+            const int i = tid + k * 256;
+            const int ty = i / TCOLS, tx = i - ty * TCOLS;
+            const int gy = t.y0 + ty - PAD, gx = t.x0 + tx - PAD;
+            const bool ok = i < PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0xFFFFFFF0u;
+        }
+    };
 
-    auto load_chunk = [&](int c0) {
+    // cumulative channel ends of the (virtual) concatenation; unused sources have c = 0
+    const int e0 = a.src[0].c, e1 = e0 + (a.nsrc > 1 ? a.src[1].c : 0), e2 = e1 + (a.nsrc > 2 ? a.src[2].c : 0);
+    auto load_chunk = [&](const TileCoord& t, int c0) {
+        // per-tile image bases of the sources (scalar registers)
+        const float* sb0 = a.src[0].p + (long long)t.b * a.src[0].bs;
+        const float* sb1 = a.nsrc > 1 ? a.src[1].p + (long long)t.b * a.src[1].bs : nullptr;
+        const float* sb2 = a.nsrc > 2 ? a.src[2].p + (long long)t.b * a.src[2].bs : nullptr;
+        const float* sb3 = a.nsrc > 3 ? a.src[3].p + (long long)t.b * a.src[3].bs : nullptr;
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
-            const float* base = nullptr;
             const int cc = c0 + c;
+            const float* base = nullptr;
             if (cc < a.cin) {
-                int rel = cc;
-#pragma unroll
-                for (int s = 0; s < YNET_MAX_SRC; ++s) {      // static indices only: keeps the args in SGPRs
-                    if (base == nullptr && s < a.nsrc) {
-                        if (rel < a.src[s].c || s == a.nsrc - 1)
-                            base = a.src[s].p + (long long)b * a.src[s].bs + (long long)rel * HW;
-                        else
-                            rel -= a.src[s].c;
-                    }
-                }
+                base = cc < e0 ? sb0 + (long long)cc * HW
+                     : cc < e1 ? sb1 + (long long)(cc - e0) * HW
+                     : cc < e2 ? sb2 + (long long)(cc - e1) * HW
+                               : sb3 + (long long)(cc - e2) * HW;
             }
             const __amdgpu_buffer_rsrc_t rx = plane_rsrc(base, plane_bytes);
 #pragma unroll
             for (int k = 0; k < XI; ++k) xr[c][k] = buf_load(rx, goff[k]);
             if (MASK) {
-                const float* mbase = cc < a.cin ? a.mask + (long long)b * a.mask_bs + (long long)cc * HW : nullptr;
+                const float* mbase = cc < a.cin ? a.mask + (long long)t.b * a.mask_bs + (long long)cc * HW : nullptr;
                 const __amdgpu_buffer_rsrc_t rm = plane_rsrc(mbase, plane_bytes);
 #pragma unroll
                 for (int k = 0; k < XI; ++k) mr[MASK ? c : 0][MASK ? k : 0] = buf_load(rm, goff[k]);
             }
         }
-        const float* wsrc = a.wp + (long long)c0 * KK * a.cout_pad + cg * CB;
+        const float* wsrc = a.wp + (long long)c0 * KK * a.cout_pad + t.cg * CB;
 #pragma unroll
         for (int k = 0; k < WI; ++k) {
             int i = tid + k * 256;
@@ -165,22 +174,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
     };
 
-    const int nchunks = (a.cin + CC - 1) / CC;
-    load_chunk(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * CC;
-        __syncthreads();            // every wave finished reading the previous chunk
-        store_chunk();
-        __syncthreads();
-        if (ch + 1 < nchunks) load_chunk(c0 + CC);
-        // ---- MFMA over (channel pair, tap)
+    // MFMA over (channel pair, tap) of the chunk in LDS.  Operands of tap t+1 are read from LDS while
+    // the MFMAs of tap t run (explicit two-stage register pipeline; sched_group_barrier pins "reads
+    // first, then MFMAs" so that no MFMA waits on an LDS read issued just before it).
+    auto mfma_chunk = [&](int c0) {
         const int rem = a.cin - c0;
         const int npairs = rem >= CC ? CC / 2 : (rem + 1) / 2;
         const float* xb = xs + half * CHS + (wave * R) * TCOLS + l31;
         const float* wb = ws + half * KK * CB + l31;
-        // Operands of tap t+1 are read from LDS while the MFMAs of tap t run (explicit two-stage
-        // register pipeline; sched_group_barrier pins "reads first, then MFMAs" so that no MFMA waits
-        // on an LDS read issued just before it).
         float a_cur[NCB], b_cur[R], a_nxt[NCB], b_nxt[R];
 #pragma unroll
         for (int i = 0; i < NCB; ++i) a_cur[i] = wb[i * 32];
@@ -215,56 +216,142 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 for (int r = 0; r < R; ++r) b_cur[r] = b_nxt[r];
             }
         }
-    }
+    };
 
-    // ---- epilogue: bias, ReLU, scatter to the (possibly split) destination.
-    // D = pixels x cout: lane (l31, half) owns output channel l31 of the block and, in registers
-    // 4g..4g+3, the four consecutive pixels x0 + 8g + 4*half .. +3  ->  one 16-byte store each.
-    const bool vec_ok = (a.W & 3) == 0;
+    // Epilogue: bias, ReLU, scatter to the (possibly split) destination.  D = pixels x cout: lane
+    // (l31, half) owns output channel l31 of the block and, in registers 4g..4g+3, the four consecutive
+    // pixels x0 + 8g + 4*half .. +3  ->  one 16-byte store each.
+    const int d0 = a.dst[0].c, d1 = d0 + (a.ndst > 1 ? a.dst[1].c : 0), d2 = d1 + (a.ndst > 2 ? a.dst[2].c : 0);
+    float bias_r[NCB];       // bias of the finished tile's channels, fetched when the tile completes
+    auto load_bias = [&](const TileCoord& t) {
 #pragma unroll
-    for (int i = 0; i < NCB; ++i) {
-        const int co = cg * CB + i * 32 + l31;
-        float* dp = nullptr;
-        if (co < a.cout) {
-            int rel = co;
-            bool found = false;
+        for (int i = 0; i < NCB; ++i) {
+            const int co = t.cg * CB + i * 32 + l31;
+            bias_r[i] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+        }
+    };
+    auto epilogue = [&](const TileCoord& t) {
+        // Touch the bias registers unconditionally first: the wait for their (long finished) load is
+        // then placed once here and not, as vmcnt(0), in front of every predicated store group below,
+        // where it would also wait for the stores already issued.
 #pragma unroll
-            for (int d = 0; d < YNET_MAX_SRC; ++d) {
-                if (!found && d < a.ndst) {
-                    if (rel < a.dst[d].c || d == a.ndst - 1) {
-                        found = true;
-                        if (a.dst[d].p != nullptr) dp = a.dst[d].p + (long long)b * a.dst[d].bs + (long long)rel * HW;
-                    } else {
-                        rel -= a.dst[d].c;
+        for (int i = 0; i < NCB; ++i) asm volatile("" : "+v"(bias_r[i]));
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) {
+            const int co = t.cg * CB + i * 32 + l31;
+            float* dp = nullptr;
+            if (co < a.cout) {
+                if (co < d0 || a.ndst == 1) {
+                    if (a.dst[0].p) dp = a.dst[0].p + (long long)t.b * a.dst[0].bs + (long long)co * HW;
+                } else if (co < d1 || a.ndst == 2) {
+                    if (a.dst[1].p) dp = a.dst[1].p + (long long)t.b * a.dst[1].bs + (long long)(co - d0) * HW;
+                } else if (co < d2 || a.ndst == 3) {
+                    if (a.dst[2].p) dp = a.dst[2].p + (long long)t.b * a.dst[2].bs + (long long)(co - d1) * HW;
+                } else {
+                    if (a.dst[3].p) dp = a.dst[3].p + (long long)t.b * a.dst[3].bs + (long long)(co - d2) * HW;
+                }
+            }
+            if (dp == nullptr) continue;
+            const float bsv = bias_r[i];
+            if (a.vec_store) {      // uniform: W % 4 == 0 and every destination plane is 16-byte aligned
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int gy = t.y0 + wave * R + r;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int gx = t.x0 + 8 * g + 4 * half;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float u = acc[i][r][4 * g + e] + bsv;
+                            if (a.relu) u = u < 0.f ? 0.f : u;
+                            v[e] = u;
+                        }
+                        if (gy < a.H && gx < a.W)
+                            *reinterpret_cast<f32x4*>(__builtin_assume_aligned(dp + (long long)gy * a.W + gx, 16)) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int gy = t.y0 + wave * R + r;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int gx = t.x0 + 8 * g + 4 * half;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float u = acc[i][r][4 * g + e] + bsv;
+                            if (a.relu) u = u < 0.f ? 0.f : u;
+                            if (gy < a.H && gx + e < a.W) dp[(long long)gy * a.W + gx + e] = u;
+                        }
                     }
                 }
             }
         }
-        if (dp == nullptr) continue;
-        const float bsv = a.bias ? a.bias[co] : 0.f;
-        const bool vec = vec_ok && ((reinterpret_cast<uintptr_t>(dp) & 15) == 0);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int gy = y0 + wave * R + r;
-            if (gy >= a.H) continue;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int gx = x0 + 8 * g + 4 * half;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[i][r][4 * g + e] + bsv;
-                    if (a.relu) v[e] = v[e] < 0.f ? 0.f : v[e];
-                }
-                float* o = dp + (long long)gy * a.W + gx;
-                if (vec && gx + 3 < a.W) {
-                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (gx + e < a.W) o[e] = v[e];
-                }
+    };
+
+    // ---- load cursor (lt, lch) runs one chunk ahead of the compute cursor (ct, cch)
+    int lt_idx = blockIdx.x, lch = 0;
+    if (lt_idx >= ntiles) return;
+    // Co-resident workgroups that share the matrix pipes round-robin fall into lockstep and then all
+    // stage / store at the same time; a fixed pecking order (one per residency "layer") staggers them.
+    {
+        const int layer = a.prio_mode == 1 ? (blockIdx.x >> 8) & 3 : (a.prio_mode == 2 ? blockIdx.x & 3 : 0);
+        if (layer == 1) __builtin_amdgcn_s_setprio(1);
+        else if (layer == 2) __builtin_amdgcn_s_setprio(2);
+        else if (layer == 3) __builtin_amdgcn_s_setprio(3);
+    }
+    TileCoord lt = decode(lt_idx);
+    set_goff(lt);
+    auto advance_load = [&]() {
+        if (++lch == nchunks) {
+            lch = 0;
+            lt_idx += gstride;
+            if (lt_idx < ntiles) {
+                lt = decode(lt_idx);
+                set_goff(lt);
             }
+        }
+    };
+    load_chunk(lt, 0);
+    advance_load();
+
+    int ct_idx = blockIdx.x, cch = 0;
+    TileCoord ct = decode(ct_idx), pt = ct;
+    bool pending = false;
+    for (;;) {
+        const bool have = ct_idx < ntiles;
+        const bool stage = have && !((a.debug & 1) && !(ct_idx == (int)blockIdx.x && cch == 0));
+        if (stage) {
+            __syncthreads();            // every wave finished reading the previous chunk
+            store_chunk();
+            __syncthreads();
+        }
+        if (pending) {                  // stores of the finished tile go out before the next prefetch is queued
+            if (!(a.debug & 2)) epilogue(pt);
+            pending = false;
+        }
+        if (stage && lt_idx < ntiles) {
+            load_chunk(lt, lch * CC);
+            advance_load();
+        }
+        if (!have) break;
+        if (cch == 0) {
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[i][r][q] = 0.f;
+        }
+        mfma_chunk(cch * CC);
+        if (++cch == nchunks) {
+            cch = 0;
+            pending = true;
+            pt = ct;
+            load_bias(pt);
+            ct_idx += gstride;
+            if (ct_idx < ntiles) ct = decode(ct_idx);
         }
     }
 }
@@ -275,14 +362,26 @@ static int launch_conv_m(ConvArgs& a, hipStream_t st) {
     a.tiles_x = ceil_div(a.W, C::TW);
     a.tiles_y = ceil_div(a.H, C::TH);
     a.cgroups = ceil_div(a.cout, C::CB);
-    const long long nblk = (long long)a.tiles_x * a.tiles_y * a.cgroups * a.B;
-    YNET_REQUIRE(nblk > 0 && nblk < (1ll << 31), "conv2d: grid of %lld blocks is out of range", nblk);
-    static bool attr_set = false;
-    if (!attr_set) {
+    const long long nt = (long long)a.tiles_x * a.tiles_y * a.cgroups * a.B;
+    YNET_REQUIRE(nt > 0 && nt < (1ll << 31), "conv2d: %lld tiles are out of range", nt);
+    a.ntiles = (int)nt;
+    static const int prio_mode = getenv("YNET_CONV_PRIO") ? atoi(getenv("YNET_CONV_PRIO")) : 0;
+    a.prio_mode = prio_mode;
+    static const int debug = getenv("YNET_CONV_DEBUG") ? atoi(getenv("YNET_CONV_DEBUG")) : 0;
+    a.debug = debug;
+    static int slots = 0;          // resident workgroups on the device for this instantiation
+    if (slots == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, NCB, R, CC, MASK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
+        int per_cu = 0, dev = 0, cus = 256;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_mfma_kernel<KS, NCB, R, CC, MASK>, 256, C::LDS_BYTES);
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (per_cu < 1) per_cu = 1;
+        if (cus < 1) cus = 256;
+        slots = per_cu * cus;
     }
+    const long long nblk = nt < slots ? nt : slots;
     hipLaunchKernelGGL((conv_mfma_kernel<KS, NCB, R, CC, MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
     return ynet_check_launch("conv2d");
 }
@@ -428,6 +527,9 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
     a.H = H;
     a.W = W;
     a.relu = relu;
+    a.vec_store = (W % 4 == 0) ? 1 : 0;
+    for (int i = 0; i < a.ndst; ++i)
+        if (a.dst[i].p && ((reinterpret_cast<uintptr_t>(a.dst[i].p) & 15) || (a.dst[i].bs & 3))) a.vec_store = 0;
     return conv_dispatch(a, K, (hipStream_t)stream);
 }
 
