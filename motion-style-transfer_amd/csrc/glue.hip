@@ -99,6 +99,90 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
     }
 }
 
+// 4 consecutive outputs per thread (one 16-byte store); needs W even
+__global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 long long N, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W, Wq = Wo >> 2;
+    const long long total = N * Ho * Wq;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Wq);
+        const int oy = (int)((i / Wq) % Ho);
+        const long long n = i / ((long long)Wq * Ho);
+        int h0, h1;
+        float hl0, hl1;
+        up2_src(oy, H, h0, h1, hl0, hl1);
+        const float* p0 = x + (n * H + h0) * W;
+        const float* p1 = x + (n * H + h1) * W;
+        // input columns 2j-1 .. 2j+2 (clamped) feed outputs 4j .. 4j+3
+        const int c0 = max(2 * j - 1, 0), c1 = 2 * j, c2 = 2 * j + 1, c3 = min(2 * j + 2, W - 1);
+        const float a0 = p0[c0], a1 = p0[c1], a2 = p0[c2], a3 = p0[c3];
+        const float b0 = p1[c0], b1 = p1[c1], b2 = p1[c2], b3 = p1[c3];
+        float4 o;
+        // same expression tree as the scalar kernel: hl0*(wl0*v00 + wl1*v01) + hl1*(wl0*v10 + wl1*v11)
+        const float w00 = j == 0 ? 1.f : 0.25f, w01 = j == 0 ? 0.f : 0.75f;     // output 4j: (c0|c1) -> at j==0 src clamps to 0
+        o.x = j == 0 ? hl0 * (1.f * a1 + 0.f * a2) + hl1 * (1.f * b1 + 0.f * b2)
+                     : hl0 * (w00 * a0 + w01 * a1) + hl1 * (w00 * b0 + w01 * b1);
+        o.y = hl0 * (0.75f * a1 + 0.25f * a2) + hl1 * (0.75f * b1 + 0.25f * b2);
+        o.z = hl0 * (0.25f * a1 + 0.75f * a2) + hl1 * (0.25f * b1 + 0.75f * b2);
+        o.w = hl0 * (0.75f * a2 + 0.25f * a3) + hl1 * (0.75f * b2 + 0.25f * b3);
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// 4 consecutive input-gradient pixels per thread; needs W % 4 == 0.  1-D weights of input i over outputs
+// 2i-1 .. 2i+2 are {.25,.75,.75,.25}, except that output 0 / 2W-1 put their whole weight on input 0 / W-1.
+__global__ __launch_bounds__(256) void upsample2x_bwd_vec_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 long long N, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W, Wq = W >> 2;
+    const long long total = N * H * Wq;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Wq);
+        const int iy = (int)((i / Wq) % H);
+        const long long n = i / ((long long)Wq * H);
+        const float* g = dy + n * Ho * Wo;
+        float wy[4];
+        wy[0] = iy > 0 ? 0.25f : 0.f;
+        wy[1] = iy > 0 ? 0.75f : 1.f;
+        wy[2] = iy < H - 1 ? 0.75f : 1.f;
+        wy[3] = iy < H - 1 ? 0.25f : 0.f;
+        // column sums: output columns 8j-1 .. 8j+8 are needed for inputs 4j .. 4j+3
+        float col[10];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) col[c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = 2 * iy - 1 + r;
+            if (wy[r] == 0.f) continue;
+            const float* row = g + (long long)oy * Wo + 8 * j;
+            const float4 m0 = *reinterpret_cast<const float4*>(row);
+            const float4 m1 = *reinterpret_cast<const float4*>(row + 4);
+            const float left = j > 0 ? row[-1] : 0.f;
+            const float right = j < Wq - 1 ? row[8] : 0.f;
+            col[0] += wy[r] * left;
+            col[1] += wy[r] * m0.x;
+            col[2] += wy[r] * m0.y;
+            col[3] += wy[r] * m0.z;
+            col[4] += wy[r] * m0.w;
+            col[5] += wy[r] * m1.x;
+            col[6] += wy[r] * m1.y;
+            col[7] += wy[r] * m1.z;
+            col[8] += wy[r] * m1.w;
+            col[9] += wy[r] * right;
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ix = 4 * j + e;
+            const float w0 = ix > 0 ? 0.25f : 0.f, w1 = ix > 0 ? 0.75f : 1.f;
+            const float w2 = ix < W - 1 ? 0.75f : 1.f, w3 = ix < W - 1 ? 0.25f : 0.f;
+            o[e] = (w0 * col[2 * e] + w1 * col[2 * e + 1]) + (w2 * col[2 * e + 2] + w3 * col[2 * e + 3]);
+        }
+        reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // dx[i][j] = sum over the (at most 4x4) output pixels whose stencil touches (i,j)
 __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long N, int H, int W) {
     const int Ho = 2 * H, Wo = 2 * W;
@@ -441,13 +525,19 @@ int ynet_maxpool2_bwd(const float* x, const float* dy, float* dx, long long N, i
 
 int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
     YNET_REQUIRE(x && y && N > 0 && H > 0 && W > 0, "upsample2x_fwd: bad arguments");
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(N * H * W * 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
+    if ((W & 1) == 0 && ((uintptr_t)y & 15) == 0)
+        hipLaunchKernelGGL(upsample2x_fwd_vec_kernel, dim3(grid_for(N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
+    else
+        hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(N * H * W * 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
     return ynet_check_launch("upsample2x_fwd");
 }
 
 int ynet_upsample2x_bwd(const float* dy, float* dx, long long N, int H, int W, void* stream) {
     YNET_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0, "upsample2x_bwd: bad arguments");
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+    if ((W & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
+        hipLaunchKernelGGL(upsample2x_bwd_vec_kernel, dim3(grid_for(N * H * (W / 4), 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+    else
+        hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
     return ynet_check_launch("upsample2x_bwd");
 }
 
