@@ -54,6 +54,9 @@ def make_cfg(O, name):
     if name == "C4":
         return O.ind_long(network="fusion", n_fusion=2, train_net="mosa_3", position=["scene"]), 512, 512, \
             "C4: inD longterm Y-Net-Mod, scene adapter only (LoRA r=3), 512x512, obs=5 pred=30"
+    if name == "C5":
+        return O.sdd_long(train_net="train"), 256, 256, \
+            "C5: SDD longterm eval sweep, K=20 goal samples, obs=5 pred=30 waypoints [14,29], 256x256"
     raise SystemExit(f"unknown config {name}")
 
 
@@ -153,7 +156,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU per step")
-    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4"])
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -187,7 +190,18 @@ def main():
     in_t, gt_t = O.dist_template(S).to(dev), O.gaussian_template(S, cfg.kernlen, cfg.nsig).to(dev)
     images = {"scene0": O.synthetic_scene(cfg, H, W, 0)[0].to(dev)}
 
+    ev = pkg("utils.evaluate")
+    soft_rec = []
+
+    def run_eval(n_steps, seed):
+        traj = O.synthetic_trajectories(cfg, B * N * n_steps, H, W, seed)
+        a, f, _, _ = ev.evaluate(model, loader_for(traj), images, dev, "sdd", None, in_t, list(cfg.waypoints), "test",
+                                 20, 1, cfg.obs_len, B * N, cfg.resize_factor, cfg.temperature, dp=dp)
+        return a, f, 0.0
+
     def run(n_steps, seed):
+        if args.config == "C5":
+            return run_eval(n_steps, seed)
         traj = O.synthetic_trajectories(cfg, B * N * n_steps, H, W, seed)
         return te.train_epoch(model, loader_for(traj), images, opt, crit, cfg.loss_scale, dev, "sdd", None, gt_t, in_t,
                               list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B * N, 10000, cfg.resize_factor,
@@ -213,7 +227,8 @@ def main():
     value = B * N * args.steps / elapsed
 
     out = {
-        "metric": "trajectories/sec fwd+bwd (Y-Net+LoRA, SDD shortterm)", "value": value, "unit": "trajectories/s",
+        "metric": ("trajectories/sec eval sweep K=20 (Y-Net, SDD longterm)" if args.config == "C5"
+                   else "trajectories/sec fwd+bwd (Y-Net+LoRA, SDD shortterm)"), "value": value, "unit": "trajectories/s",
         "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * N, "raster": f"{H}x{W}",
@@ -224,6 +239,22 @@ def main():
 
     if args.no_roofline:
         pass
+    elif args.config == "C5":
+        if rank == 0:      # the HBM-bound point: soft-argmax over [B, pred, H, W] planes, timed in isolation
+            x = torch.randn(B, cfg.pred_len, H, W, device=dev)
+            for _ in range(3):
+                ops.softargmax2d(x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.softargmax2d(x)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            gbs = x.numel() * 4 / us / 1e3
+            out["roofline"] = {"bound": "hbm", "kernel": "softargmax_kernel", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": us,
+                               "algorithmic_mb_per_launch": x.numel() * 4 / 1e6}
     elif rank == 0:
         with ConvTimer(ops) as ct:
             run(1, 3)
@@ -252,7 +283,7 @@ def main():
         run(1, 3)      # keep ranks in lock-step with rank 0's instrumented step (collectives inside)
     if world > 1:
         dist.barrier()
-    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+    if rank == 0 and N == 1 and not args.no_cpu_baseline and args.config != "C5":
         out["cpu_baseline"] = cpu_baseline(O, cfg, H, W, args.cpu_batch)
     if rank == 0:
         print(json.dumps(out))

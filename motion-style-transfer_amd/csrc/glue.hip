@@ -412,8 +412,7 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     if ((W & 3) == 0) {
         const int w4 = W >> 2, n4 = n >> 2;
         const float4* p4 = reinterpret_cast<const float4*>(p);
-        for (int i = tid; i < n4; i += 256) {
-            const float4 v = p4[i];
+        auto fold = [&](const float4 v, int i) {
             const int row = i / w4, col = (i - row * w4) << 2;
             // rescale at most once per 16-byte vector
             const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
@@ -429,7 +428,16 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
             a.s += es;
             a.sx += (e0 * (float)col + e1 * (float)(col + 1)) + (e2 * (float)(col + 2) + e3 * (float)(col + 3));
             a.sy += es * (float)row;
+        };
+        int i = tid;
+        for (; i + 3 * 256 < n4; i += 4 * 256) {     // four independent 16-byte loads in flight per thread
+            const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+            fold(v0, i);
+            fold(v1, i + 256);
+            fold(v2, i + 512);
+            fold(v3, i + 768);
         }
+        for (; i < n4; i += 256) fold(p4[i], i);
     } else {
         for (int i = tid; i < n; i += 256) {
             const int row = i / W, col = i - row * W;
