@@ -83,8 +83,10 @@ class ConvTimer:
             cout = sum(d[1] for d in dl)
             flops = 2.0 * B * H * W * cin * cout * K * K
             byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]))
-            rows = self.ops._lib().ynet_conv2d_plan_rows(B, H, W, cout, K)
-            name = f"conv_mfma_kernel<{K}, {2 if cout > 32 else 1}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}>"
+            plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
+            rows, tiles, m16 = plan & 255, (plan >> 8) & 255, plan >> 16
+            name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}, "
+                    f"{'true' if m16 else 'false'}>")
             self.rec.append((name, e0, e1, flops, byts, (B, H, W, cin, cout, K, bool(mask))))
         self.ops.conv2d_raw = timed
         return self

@@ -48,9 +48,9 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                 int B, int H, int W, int K, int relu, void* stream);
 
-/* Introspection for profiling: rows per wave (1, 2 or 4) the dispatcher uses for this problem, i.e. the
- * instantiation conv_mfma_kernel<K, cout > 32 ? 2 : 1, rows, ..> a rocprof trace will name. */
-int ynet_conv2d_plan_rows(int B, int H, int W, int cout, int K);
+/* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
+ * rows | tiles << 8 | m16 << 16  ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16> in a rocprof trace. */
+int ynet_conv2d_plan(int B, int H, int W, int cout, int K);
 
 /* convolution_backward -> grad_weight [Cout][Cin][K][K] and grad_bias [Cout] (db may be NULL).
  * x = concat(src...), dy = incoming gradient, mask = post-ReLU activation of this layer or NULL.

@@ -19,6 +19,10 @@
 #include "ynet_common.h"
 #include <stdlib.h>
 
+#ifndef YNET_CC_NARROW
+#define YNET_CC_NARROW 8      // input channels staged per chunk by the Cout <= 32 kernels
+#endif
+
 struct ConvArgs {
     YSrc src[YNET_MAX_SRC];
     int nsrc, cin;
@@ -33,14 +37,18 @@ struct ConvArgs {
     int tiles_x, tiles_y, cgroups, ntiles, prio_mode, debug;   // debug: timing ablations only (tools/conv_bench.py)
 };
 
-template <int KS, int NCB, int R, int CC>
+// M16 = false: v_mfma_f32_32x32x2_f32, NCB blocks of 32 output channels per workgroup.
+// M16 = true : v_mfma_f32_16x16x4_f32, NCB tiles of 16 output channels (Cout = 16 / 33..48 without padding
+//              the N dimension to 32 / 64); same FLOP/clk, pixels in two 16-wide halves.
+template <int KS, int NCB, int R, int CC, bool M16 = false>
 struct ConvCfg {
     static constexpr int PAD = KS / 2, KK = KS * KS;
     static constexpr int TH = 4 * R, TW = 32;
     static constexpr int TROWS = TH + KS - 1, TCOLS = TW + KS - 1, PLANE = TROWS * TCOLS;
-    static constexpr int CB = 32 * NCB;
+    static constexpr int CB = (M16 ? 16 : 32) * NCB;
     static constexpr int XI = (PLANE + 255) / 256;            // tile elements per thread per channel
-    static constexpr int CHS = XI * 256;                      // LDS channel stride (>= PLANE): unconditional staging stores
+    static constexpr int CHS = XI * 256 + (M16 ? 16 : 0);     // LDS channel stride (>= PLANE): unconditional staging stores;
+                                                              // = 16 mod 32 for M16 so the 4 channels of a K-step hit distinct banks
     static constexpr int XS_FLOATS = CC * CHS;
     static constexpr int WS_FLOATS = CC * KK * CB;
     static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
@@ -69,9 +77,9 @@ struct TileCoord {
 //     [barrier, regs -> LDS, barrier] [issue global loads of the NEXT chunk (maybe of the next tile)]
 //     [epilogue stores of the tile that just finished]  [MFMA loop of this chunk]
 // so neither a tile's first loads nor its output stores leave the matrix pipes idle.
-template <int KS, int NCB, int R, int CC, bool MASK>
+template <int KS, int NCB, int R, int CC, bool MASK, bool M16>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
-    using C = ConvCfg<KS, NCB, R, CC>;
+    using C = ConvCfg<KS, NCB, R, CC, M16>;
     constexpr int PAD = C::PAD, KK = C::KK, TH = C::TH, TW = C::TW;
     constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB, CHS = C::CHS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -96,7 +104,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         return c;
     };
 
-    f32x16 acc[NCB][R];
+    f32x16 acc[M16 ? 1 : NCB][M16 ? 1 : R];          // 32x32 accumulators (M16 = false)
+    f32x4 acc16[M16 ? NCB : 1][M16 ? R : 1][2];      // 16x16 accumulators: [cout tile][row][pixel half]
+    const int r16 = lane & 15, kq = lane >> 4;
     constexpr int XI = C::XI;
     constexpr int ROW4 = CB / 4;
     constexpr int WI = (CC * KK * ROW4 + 255) / 256;       // filter float4 per thread
@@ -179,6 +189,58 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // first, then MFMAs" so that no MFMA waits on an LDS read issued just before it).
     auto mfma_chunk = [&](int c0) {
         const int rem = a.cin - c0;
+        if constexpr (M16) {
+            // K = 4 input channels per instruction: lane (r16, kq) feeds pixel r16 (+16 for the second half)
+            // of channel kq as A and output channel r16 of channel kq as B.
+            const int ngroups = rem >= CC ? CC / 4 : (rem + 3) / 4;
+            const float* xb = xs + kq * CHS + (wave * R) * TCOLS + r16;
+            const float* wb = ws + kq * KK * CB + r16;
+            float a_cur[R][2], b_cur[NCB], a_nxt[R][2], b_nxt[NCB];
+#pragma unroll
+            for (int i = 0; i < NCB; ++i) b_cur[i] = wb[i * 16];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                a_cur[r][0] = xb[r * TCOLS];
+                a_cur[r][1] = xb[r * TCOLS + 16];
+            }
+#pragma unroll 1
+            for (int g = 0; g < ngroups; ++g) {
+                const float* xp = xb + 4 * g * CHS;
+                const float* wq = wb + 4 * g * KK * CB;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) {
+                    const int tn = (t + 1) % KK;
+                    const float* xn = t + 1 < KK ? xp : xp + 4 * CHS;
+                    const float* wn = t + 1 < KK ? wq : wq + 4 * KK * CB;
+                    const int kyn = tn / KS, kxn = tn % KS;
+                    if (t + 1 < KK || g + 1 < ngroups) {
+#pragma unroll
+                        for (int i = 0; i < NCB; ++i) b_nxt[i] = wn[tn * CB + i * 16];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            a_nxt[r][0] = xn[(r + kyn) * TCOLS + kxn];
+                            a_nxt[r][1] = xn[(r + kyn) * TCOLS + kxn + 16];
+                        }
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, NCB + 2 * R, 0);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int i = 0; i < NCB; ++i) {
+                            acc16[i][r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r][0], b_cur[i], acc16[i][r][0], 0, 0, 0);
+                            acc16[i][r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r][1], b_cur[i], acc16[i][r][1], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_group_barrier(0x8, 2 * NCB * R, 0);
+#pragma unroll
+                    for (int i = 0; i < NCB; ++i) b_cur[i] = b_nxt[i];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        a_cur[r][0] = a_nxt[r][0];
+                        a_cur[r][1] = a_nxt[r][1];
+                    }
+                }
+            }
+        } else {
         const int npairs = rem >= CC ? CC / 2 : (rem + 1) / 2;
         const float* xb = xs + half * CHS + (wave * R) * TCOLS + l31;
         const float* wb = ws + half * KK * CB + l31;
@@ -216,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 for (int r = 0; r < R; ++r) b_cur[r] = b_nxt[r];
             }
         }
+        }
     };
 
     // Epilogue: bias, ReLU, scatter to the (possibly split) destination.  D = pixels x cout: lane
@@ -226,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     auto load_bias = [&](const TileCoord& t) {
 #pragma unroll
         for (int i = 0; i < NCB; ++i) {
-            const int co = t.cg * CB + i * 32 + l31;
+            const int co = M16 ? t.cg * CB + i * 16 + r16 : t.cg * CB + i * 32 + l31;
             bias_r[i] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
         }
     };
@@ -238,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         for (int i = 0; i < NCB; ++i) asm volatile("" : "+v"(bias_r[i]));
 #pragma unroll
         for (int i = 0; i < NCB; ++i) {
-            const int co = t.cg * CB + i * 32 + l31;
+            const int co = M16 ? t.cg * CB + i * 16 + r16 : t.cg * CB + i * 32 + l31;
             float* dp = nullptr;
             if (co < a.cout) {
                 if (co < d0 || a.ndst == 1) {
@@ -253,17 +316,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             }
             if (dp == nullptr) continue;
             const float bsv = bias_r[i];
+            // register quad g of row r holds 4 consecutive pixels starting at px(g)
+            constexpr int NG = M16 ? 2 : 4;
             if (a.vec_store) {      // uniform: W % 4 == 0 and every destination plane is 16-byte aligned
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int gy = t.y0 + wave * R + r;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int gx = t.x0 + 8 * g + 4 * half;
+                    for (int g = 0; g < NG; ++g) {
+                        const int gx = M16 ? t.x0 + 16 * g + 4 * kq : t.x0 + 8 * g + 4 * half;
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float u = acc[i][r][4 * g + e] + bsv;
+                            float u = (M16 ? acc16[M16 ? i : 0][M16 ? r : 0][g & 1][e] : acc[M16 ? 0 : i][M16 ? 0 : r][(4 * g + e) & 15]) + bsv;
                             if (a.relu) u = u < 0.f ? 0.f : u;
                             v[e] = u;
                         }
@@ -276,11 +341,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 for (int r = 0; r < R; ++r) {
                     const int gy = t.y0 + wave * R + r;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int gx = t.x0 + 8 * g + 4 * half;
+                    for (int g = 0; g < NG; ++g) {
+                        const int gx = M16 ? t.x0 + 16 * g + 4 * kq : t.x0 + 8 * g + 4 * half;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float u = acc[i][r][4 * g + e] + bsv;
+                            float u = (M16 ? acc16[M16 ? i : 0][M16 ? r : 0][g & 1][e] : acc[M16 ? 0 : i][M16 ? 0 : r][(4 * g + e) & 15]) + bsv;
                             if (a.relu) u = u < 0.f ? 0.f : u;
                             if (gy < a.H && gx + e < a.W) dp[(long long)gy * a.W + gx + e] = u;
                         }
@@ -337,12 +402,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
         if (!have) break;
         if (cch == 0) {
+            if constexpr (M16) {
 #pragma unroll
-            for (int i = 0; i < NCB; ++i)
+                for (int i = 0; i < NCB; ++i)
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                    for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[i][r][q] = 0.f;
+                        for (int q = 0; q < 4; ++q) acc16[i][r][0][q] = acc16[i][r][1][q] = 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc[i][r][q] = 0.f;
+            }
         }
         mfma_chunk(cch * CC);
         if (++cch == nchunks) {
@@ -356,9 +430,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
 }
 
-template <int KS, int NCB, int R, int CC, bool MASK>
+template <int KS, int NCB, int R, int CC, bool MASK, bool M16>
 static int launch_conv_m(ConvArgs& a, hipStream_t st) {
-    using C = ConvCfg<KS, NCB, R, CC>;
+    using C = ConvCfg<KS, NCB, R, CC, M16>;
     a.tiles_x = ceil_div(a.W, C::TW);
     a.tiles_y = ceil_div(a.H, C::TH);
     a.cgroups = ceil_div(a.cout, C::CB);
@@ -371,10 +445,10 @@ static int launch_conv_m(ConvArgs& a, hipStream_t st) {
     a.debug = debug;
     static int slots = 0;          // resident workgroups on the device for this instantiation
     if (slots == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, NCB, R, CC, MASK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, NCB, R, CC, MASK, M16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         int per_cu = 0, dev = 0, cus = 256;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_mfma_kernel<KS, NCB, R, CC, MASK>, 256, C::LDS_BYTES);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_mfma_kernel<KS, NCB, R, CC, MASK, M16>, 256, C::LDS_BYTES);
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (per_cu < 1) per_cu = 1;
@@ -382,21 +456,21 @@ static int launch_conv_m(ConvArgs& a, hipStream_t st) {
         slots = per_cu * cus;
     }
     const long long nblk = nt < slots ? nt : slots;
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, NCB, R, CC, MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, NCB, R, CC, MASK, M16>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
     return ynet_check_launch("conv2d");
 }
 
-template <int KS, int NCB, int R, int CC>
+template <int KS, int NCB, int R, int CC, bool M16 = false>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
-    return a.mask ? launch_conv_m<KS, NCB, R, CC, true>(a, st) : launch_conv_m<KS, NCB, R, CC, false>(a, st);
+    return a.mask ? launch_conv_m<KS, NCB, R, CC, true, M16>(a, st) : launch_conv_m<KS, NCB, R, CC, false, M16>(a, st);
 }
 
 // Rows per wave (R): 4 gives the most operand reuse; small feature maps (8^2 .. 64^2) take R = 2 or 1
 // so that the launch still spreads over the 256 CUs (a workgroup's run time is its MFMA count).
-static int pick_rows(const ConvArgs& a, int ncb) {
+static int pick_rows(const ConvArgs& a, int cb) {
     static const int forced = getenv("YNET_CONV_R") ? atoi(getenv("YNET_CONV_R")) : 0;
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    const long long per_img_x = ceil_div(a.W, 32), cg = ceil_div(a.cout, 32 * ncb);
+    const long long per_img_x = ceil_div(a.W, 32), cg = ceil_div(a.cout, cb);
     for (int r = 4; r > 1; r >>= 1) {
         const long long nblk = per_img_x * ceil_div(a.H, 4 * r) * cg * a.B;
         if (nblk >= 1024) return r;
@@ -404,20 +478,37 @@ static int pick_rows(const ConvArgs& a, int ncb) {
     return 1;
 }
 
-template <int KS, int NCB, int CC>
+template <int KS, int NCB, int CC, bool M16 = false>
 static int launch_conv_r(ConvArgs& a, hipStream_t st) {
-    switch (pick_rows(a, NCB)) {
-        case 4: return launch_conv<KS, NCB, 4, CC>(a, st);
-        case 2: return launch_conv<KS, NCB, 2, CC>(a, st);
-        default: return launch_conv<KS, NCB, 1, CC>(a, st);
+    int rows = pick_rows(a, (M16 ? 16 : 32) * NCB);
+    if (M16 && NCB >= 3 && rows == 4) rows = 2;      // 3-4 tiles x 4 rows x 2 halves would spill (> 256 VGPRs)
+    switch (rows) {
+        case 4: if constexpr (!(M16 && NCB >= 3)) return launch_conv<KS, NCB, 4, CC, M16>(a, st);
+        case 2: return launch_conv<KS, NCB, 2, CC, M16>(a, st);
+        default: return launch_conv<KS, NCB, 1, CC, M16>(a, st);
     }
+}
+
+// 16-wide output-channel tiles pay off when padding Cout to 32 / 64 would waste a quarter or more
+static int m16_tiles(int K, int cout) {
+    static const int mode = getenv("YNET_CONV_M16") ? atoi(getenv("YNET_CONV_M16")) : 2;   // 0 off, 1 only where 32-wide tiles would pad, 2 always for 3x3 (2-6 % faster on MI355X)
+    if (mode == 0 || K != 3) return 0;
+    if (cout <= 16) return 1;
+    if (cout > 32 && cout <= 48) return 3;
+    if (mode == 2) return cout <= 32 ? 2 : 4;
+    return 0;
 }
 
 static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
     const bool wide = a.cout > 32;
+    const int nt16 = m16_tiles(K, a.cout);
+    if (nt16 == 1) return launch_conv_r<3, 1, 8, true>(a, st);
+    if (nt16 == 2) return launch_conv_r<3, 2, 8, true>(a, st);
+    if (nt16 == 3) return launch_conv_r<3, 3, 8, true>(a, st);
+    if (nt16 == 4) return launch_conv_r<3, 4, 8, true>(a, st);
     switch (K) {
         case 1: return wide ? launch_conv_r<1, 2, 16>(a, st) : launch_conv_r<1, 1, 16>(a, st);
-        case 3: return wide ? launch_conv_r<3, 2, 8>(a, st) : launch_conv_r<3, 1, 8>(a, st);
+        case 3: return wide ? launch_conv_r<3, 2, 8>(a, st) : launch_conv_r<3, 1, YNET_CC_NARROW>(a, st);
         case 5: return wide ? launch_conv<5, 2, 4, 4>(a, st) : launch_conv<5, 1, 4, 4>(a, st);
         default: ynet_set_error("conv2d: kernel size %d not supported (1, 3, 5)", K); return 1;
     }
@@ -451,16 +542,19 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 extern "C" {
 
-// rows per wave the dispatcher picks for this problem (1, 2 or 4): names the kernel instantiation
-// conv_mfma_kernel<K, cout>32 ? 2 : 1, rows, CC, mask> that a profile will show.
-int ynet_conv2d_plan_rows(int B, int H, int W, int cout, int K) {
-    if (K == 5) return 4;
+// The kernel instantiation the dispatcher picks for this problem, for naming it in profiles:
+// returns rows | tiles << 8 | m16 << 16  ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16>.
+int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     ConvArgs a{};
     a.B = B;
     a.H = H;
     a.W = W;
     a.cout = cout;
-    return pick_rows(a, cout > 32 ? 2 : 1);
+    const int nt16 = m16_tiles(K, cout);
+    const int tiles = nt16 ? nt16 : (cout > 32 ? 2 : 1);
+    int rows = K == 5 ? 4 : pick_rows(a, nt16 ? 16 * nt16 : 32 * tiles);
+    if (nt16 >= 3 && rows == 4) rows = 2;
+    return rows | (tiles << 8) | ((nt16 ? 1 : 0) << 16);
 }
 
 long long ynet_packed_weight_floats(int cout, int cin, int K, int mode) {
