@@ -42,11 +42,15 @@ int ynet_pack_weight(const float* w, float* wp, int cout, int cin, int K, int mo
  *   src[i]:   nsrc (1..4) sources, src_c[i] channels, batch stride src_bs[i] elements (0 = broadcast)
  *   dst[i]:   ndst (1..4) destinations, dst_c[i] channels, batch stride dst_bs[i]
  *   cin = sum(src_c), cout = sum(dst_c); wp packed for (cout, cin); bias [cout] or NULL
+ *   workspace: optional scratch of ynet_conv2d_workspace_floats(B, H, W, cout) floats (may be NULL / 0):
+ *   lets small-map launches (8^2 .. 32^2) split their input-channel loop over more workgroups.
  */
+long long ynet_conv2d_workspace_floats(int B, int H, int W, int cout);
 int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
                 const float* mask, long long mask_bs, const float* wp, const float* bias,
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
-                int B, int H, int W, int K, int relu, void* stream);
+                int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
+                void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16  ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16> in a rocprof trace. */

@@ -33,6 +33,9 @@ struct ConvArgs {
     YDst dst[YNET_MAX_SRC];
     int ndst;
     int B, H, W, cout, cout_pad, relu;
+    int ksplit, cps;        // split of the input-channel chunks over workgroups (small maps): chunks per split
+    float* partial;         // [ksplit][B][cout][H][W] raw partial sums when ksplit > 1 (NULL: never split)
+    long long partial_cap;  // floats available at `partial`
     int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
     int tiles_x, tiles_y, cgroups, ntiles, prio_mode, debug;   // debug: timing ablations only (tools/conv_bench.py)
 };
@@ -69,7 +72,7 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 
 struct TileCoord {
-    int cg, x0, y0, b;
+    int ks, cg, x0, y0, b;
 };
 
 // Persistent workgroups: each walks tiles blockIdx.x, +gridDim.x, ... and runs ONE software pipeline
@@ -91,10 +94,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int HW = __builtin_amdgcn_readfirstlane(a.H * a.W);   // keep plane arithmetic on the scalar unit
     const unsigned plane_bytes = (unsigned)HW * 4u;
     const int ntiles = a.ntiles, nchunks = (a.cin + CC - 1) / CC;
+    auto item_chunks = [&](const TileCoord& t) { return min(a.cps, nchunks - t.ks * a.cps); };
     const int gstride = gridDim.x;
 
     auto decode = [&](int t) {
         TileCoord c;
+        c.ks = t % a.ksplit;
+        t /= a.ksplit;
         c.cg = t % a.cgroups;
         t /= a.cgroups;
         c.x0 = (t % a.tiles_x) * TW;
@@ -303,7 +309,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         for (int i = 0; i < NCB; ++i) {
             const int co = M16 ? t.cg * CB + i * 16 + r16 : t.cg * CB + i * 32 + l31;
             float* dp = nullptr;
-            if (co < a.cout) {
+            if (a.ksplit > 1) {
+                if (co < a.cout) dp = a.partial + (((long long)t.ks * a.B + t.b) * a.cout + co) * HW;
+            } else if (co < a.cout) {
                 if (co < d0 || a.ndst == 1) {
                     if (a.dst[0].p) dp = a.dst[0].p + (long long)t.b * a.dst[0].bs + (long long)co * HW;
                 } else if (co < d1 || a.ndst == 2) {
@@ -315,7 +323,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 }
             }
             if (dp == nullptr) continue;
-            const float bsv = bias_r[i];
+            const float bsv = a.ksplit > 1 ? 0.f : bias_r[i];
+            const bool relu = a.relu && a.ksplit == 1;
             // register quad g of row r holds 4 consecutive pixels starting at px(g)
             constexpr int NG = M16 ? 2 : 4;
             if (a.vec_store) {      // uniform: W % 4 == 0 and every destination plane is 16-byte aligned
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float u = (M16 ? acc16[M16 ? i : 0][M16 ? r : 0][g & 1][e] : acc[M16 ? 0 : i][M16 ? 0 : r][(4 * g + e) & 15]) + bsv;
-                            if (a.relu) u = u < 0.f ? 0.f : u;
+                            if (relu) u = u < 0.f ? 0.f : u;
                             v[e] = u;
                         }
                         if (gy < a.H && gx < a.W)
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float u = (M16 ? acc16[M16 ? i : 0][M16 ? r : 0][g & 1][e] : acc[M16 ? 0 : i][M16 ? 0 : r][(4 * g + e) & 15]) + bsv;
-                            if (a.relu) u = u < 0.f ? 0.f : u;
+                            if (relu) u = u < 0.f ? 0.f : u;
                             if (gy < a.H && gx + e < a.W) dp[(long long)gy * a.W + gx + e] = u;
                         }
                     }
@@ -368,21 +377,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
     TileCoord lt = decode(lt_idx);
     set_goff(lt);
+    int lcnt = item_chunks(lt);
     auto advance_load = [&]() {
-        if (++lch == nchunks) {
+        if (++lch == lcnt) {
             lch = 0;
             lt_idx += gstride;
             if (lt_idx < ntiles) {
                 lt = decode(lt_idx);
+                lcnt = item_chunks(lt);
                 set_goff(lt);
             }
         }
     };
-    load_chunk(lt, 0);
+    load_chunk(lt, lt.ks * a.cps * CC);
     advance_load();
 
     int ct_idx = blockIdx.x, cch = 0;
     TileCoord ct = decode(ct_idx), pt = ct;
+    int ccnt = item_chunks(ct);
     bool pending = false;
     for (;;) {
         const bool have = ct_idx < ntiles;
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             pending = false;
         }
         if (stage && lt_idx < ntiles) {
-            load_chunk(lt, lch * CC);
+            load_chunk(lt, (lt.ks * a.cps + lch) * CC);
             advance_load();
         }
         if (!have) break;
@@ -418,14 +430,63 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                         for (int q = 0; q < 16; ++q) acc[i][r][q] = 0.f;
             }
         }
-        mfma_chunk(cch * CC);
-        if (++cch == nchunks) {
+        mfma_chunk((ct.ks * a.cps + cch) * CC);
+        if (++cch == ccnt) {
             cch = 0;
             pending = true;
             pt = ct;
             load_bias(pt);
             ct_idx += gstride;
-            if (ct_idx < ntiles) ct = decode(ct_idx);
+            if (ct_idx < ntiles) {
+                ct = decode(ct_idx);
+                ccnt = item_chunks(ct);
+            }
+        }
+    }
+}
+
+// Split of the input-channel loop over workgroups for launches with fewer work items than CUs.
+static int conv_ksplit(long long items, int nchunks) {
+    static const int off = getenv("YNET_CONV_NO_KSPLIT") ? 1 : 0;
+    if (off || items >= 256 || nchunks < 4) return 1;
+    long long k = (512 + items - 1) / items;
+    if (k > nchunks / 2) k = nchunks / 2;
+    if (k > 8) k = 8;
+    return k < 1 ? 1 : (int)k;
+}
+
+// y = [relu](sum_ks partial[ks] + bias), scattered to the (possibly split) destination
+struct SplitReduceArgs {
+    const float* partial;
+    const float* bias;
+    YDst dst[YNET_MAX_SRC];
+    int ndst, ksplit, B, cout, HW, relu;
+};
+
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const SplitReduceArgs a) {
+    const long long n4 = (long long)a.B * a.cout * (a.HW >> 2);
+    const int hw4 = a.HW >> 2;
+    const long long slab = (long long)a.B * a.cout * a.HW;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const int p4 = (int)(i % hw4);
+        const int co = (int)((i / hw4) % a.cout);
+        const int b = (int)(i / ((long long)hw4 * a.cout));
+        f32x4 s = *reinterpret_cast<const f32x4*>(a.partial + i * 4);
+        for (int k = 1; k < a.ksplit; ++k) s += *reinterpret_cast<const f32x4*>(a.partial + k * slab + i * 4);
+        const float bv = a.bias ? a.bias[co] : 0.f;
+        int rel = co, d = 0;
+        while (d < a.ndst - 1 && rel >= a.dst[d].c) {
+            rel -= a.dst[d].c;
+            ++d;
+        }
+        float* dp = a.dst[d].p;
+        if (dp == nullptr) continue;
+        dp += (long long)b * a.dst[d].bs + (long long)rel * a.HW + p4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u = s[e] + bv;
+            if (a.relu) u = u < 0.f ? 0.f : u;
+            dp[e] = u;
         }
     }
 }
@@ -436,7 +497,16 @@ static int launch_conv_m(ConvArgs& a, hipStream_t st) {
     a.tiles_x = ceil_div(a.W, C::TW);
     a.tiles_y = ceil_div(a.H, C::TH);
     a.cgroups = ceil_div(a.cout, C::CB);
-    const long long nt = (long long)a.tiles_x * a.tiles_y * a.cgroups * a.B;
+    long long nt = (long long)a.tiles_x * a.tiles_y * a.cgroups * a.B;
+    {   // small maps: split the channel chunks over several workgroups (partials summed by a second kernel)
+        const int nchunks = ceil_div(a.cin, CC);
+        a.ksplit = 1;
+        if (a.partial != nullptr) a.ksplit = conv_ksplit(nt, nchunks);
+        while (a.ksplit > 1 && (long long)a.ksplit * a.B * a.cout * a.H * a.W > a.partial_cap) --a.ksplit;
+        a.cps = ceil_div(nchunks, a.ksplit);
+        a.ksplit = ceil_div(nchunks, a.cps);          // no empty split
+        nt *= a.ksplit;
+    }
     YNET_REQUIRE(nt > 0 && nt < (1ll << 31), "conv2d: %lld tiles are out of range", nt);
     a.ntiles = (int)nt;
     static const int prio_mode = getenv("YNET_CONV_PRIO") ? atoi(getenv("YNET_CONV_PRIO")) : 0;
@@ -457,6 +527,22 @@ static int launch_conv_m(ConvArgs& a, hipStream_t st) {
     }
     const long long nblk = nt < slots ? nt : slots;
     hipLaunchKernelGGL((conv_mfma_kernel<KS, NCB, R, CC, MASK, M16>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    if (a.ksplit > 1) {
+        SplitReduceArgs r{};
+        r.partial = a.partial;
+        r.bias = a.bias;
+        for (int i = 0; i < a.ndst; ++i) r.dst[i] = a.dst[i];
+        r.ndst = a.ndst;
+        r.ksplit = a.ksplit;
+        r.B = a.B;
+        r.cout = a.cout;
+        r.HW = a.H * a.W;
+        r.relu = a.relu;
+        long long n4 = (long long)a.B * a.cout * (r.HW / 4);
+        int grid = (int)((n4 + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(conv_split_reduce_kernel, dim3(grid), dim3(256), 0, st, r);
+    }
     return ynet_check_launch("conv2d");
 }
 
@@ -579,10 +665,18 @@ int ynet_pack_weight(const float* w, float* wp, int cout, int cin, int K, int mo
 
 // y[dst...] = [relu](conv(cat(src...) [masked], wp) + bias); cin = sum of source channels,
 // cout = sum of destination channels.  See include/ynet_hip.h.
+// Workspace (floats) that lets ynet_conv2d split the input-channel loop of a small-map launch over
+// more workgroups; 0 when the problem is large enough not to need it.
+long long ynet_conv2d_workspace_floats(int B, int H, int W, int cout) {
+    if ((W & 3) != 0 || (long long)B * H * W > 64 * 1024) return 0;     // up to 32 x 32^2 or 64 x 16^2 ...
+    return 8ll * B * cout * H * W;
+}
+
 int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
                 const float* mask, long long mask_bs, const float* wp, const float* bias,
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
-                int B, int H, int W, int K, int relu, void* stream) {
+                int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
+                void* stream) {
     YNET_REQUIRE(nsrc >= 1 && nsrc <= YNET_MAX_SRC && ndst >= 1 && ndst <= YNET_MAX_SRC,
                  "conv2d: 1..%d sources/destinations supported (got %d/%d)", YNET_MAX_SRC, nsrc, ndst);
     YNET_REQUIRE(B > 0 && H > 0 && W > 0, "conv2d: empty problem B=%d H=%d W=%d", B, H, W);
@@ -621,6 +715,8 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
     a.H = H;
     a.W = W;
     a.relu = relu;
+    a.partial = ((W & 3) == 0 && workspace_floats > 0) ? workspace : nullptr;
+    a.partial_cap = workspace_floats;
     a.vec_store = (W % 4 == 0) ? 1 : 0;
     for (int i = 0; i < a.ndst; ++i)
         if (a.dst[i].p && ((reinterpret_cast<uintptr_t>(a.dst[i].p) & 15) || (a.dst[i].bs & 3))) a.vec_store = 0;

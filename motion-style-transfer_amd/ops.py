@@ -159,14 +159,25 @@ def lora_grad(dw, lora_a, lora_b, scale: float):
     return d_a, d_b
 
 
+_conv_ws = {}
+
+
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
     dp, dc, db = _arrays(dsts)
+    nws, ws = 0, None
+    if B * H * W <= 65536:                                       # small maps only (see ynet_conv2d_workspace_floats)
+        nws = lib.ynet_conv2d_workspace_floats(B, H, W, sum(d[1] for d in dsts))
+        if nws:
+            ws = _conv_ws.get(wp.device)                         # grow-only scratch; launches are stream-ordered
+            if ws is None or ws.numel() < nws:
+                ws = _conv_ws[wp.device] = torch.empty(nws, device=wp.device, dtype=torch.float32)
     L.check(lib.ynet_conv2d(sp, sc, sb, len(srcs), mask[0] if mask else None, mask[1] if mask else 0,
                             wp.data_ptr(), bias.data_ptr() if bias is not None else None,
-                            dp, dc, db, len(dsts), B, H, W, K, 1 if relu else 0, _stream()), lib)
+                            dp, dc, db, len(dsts), B, H, W, K, 1 if relu else 0,
+                            ws.data_ptr() if ws is not None else None, nws, _stream()), lib)
 
 
 def _weight_key(weight, lora_a, lora_b):
