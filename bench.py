@@ -271,7 +271,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get(name)
+                entry = json.load(f).get(name)
+            if entry:       # measured with rocprofv3 --pmc in separate passes, committed under profiles/
+                traffic = entry["hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                            "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
