@@ -25,7 +25,7 @@ int ynet_abi_version(void);
 const char* ynet_last_error(void);
 
 /* ---- convolution ----------------------------------------------------------------------------
- * Filters are consumed in a packed layout [cin_pad16][K*K][cout_pad64] built by ynet_pack_weight
+ * Filters are consumed in a packed layout [cin_pad16 + 16][K*K][cout_pad64] built by ynet_pack_weight
  * from the checkpoint layout [Cout][Cin][K][K] (models/ynet.py state-dict contract).
  *   mode 0: forward filter.   mode 1: data-gradient filter (taps flipped, cin/cout swapped).
  */

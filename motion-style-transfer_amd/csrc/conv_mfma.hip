@@ -93,9 +93,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int l31 = lane & 31, half = lane >> 5;
     const int HW = __builtin_amdgcn_readfirstlane(a.H * a.W);   // keep plane arithmetic on the scalar unit
     const unsigned plane_bytes = (unsigned)HW * 4u;
-    const int ntiles = a.ntiles, nchunks = (a.cin + CC - 1) / CC;
+    int nchunks = 0;
+#pragma unroll
+    for (int s = 0; s < YNET_MAX_SRC; ++s)
+        if (s < a.nsrc) nchunks += (a.src[s].c + CC - 1) / CC;
     auto item_chunks = [&](const TileCoord& t) { return min(a.cps, nchunks - t.ks * a.cps); };
-    const int gstride = gridDim.x;
+    // XCD-aware walk: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2), so each
+    // XCD gets its own contiguous eighth of the tile space and its 32 CUs sweep neighbouring tiles
+    // together: halo rows and filter slices are re-read from that XCD's L2 instead of HBM.
+    const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x && !(a.debug & 32);
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    const int gstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tile_first = xcd_walk ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tile_end = xcd_walk ? min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : a.ntiles;
+    const int ntiles = tile_end;      // exclusive end of this workgroup's tile walk
 
     auto decode = [&](int t) {
         TileCoord c;
@@ -130,38 +141,52 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int ty = i / TCOLS, tx = i - ty * TCOLS;
             const int gy = t.y0 + ty - PAD, gx = t.x0 + tx - PAD;
             const bool ok = i < PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0xFFFFFFF0u;
+            goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;    // + channel offsets stays past any buffer
         }
     };
 
-    // cumulative channel ends of the (virtual) concatenation; unused sources have c = 0
-    const int e0 = a.src[0].c, e1 = e0 + (a.nsrc > 1 ? a.src[1].c : 0), e2 = e1 + (a.nsrc > 2 ? a.src[2].c : 0);
-    auto load_chunk = [&](const TileCoord& t, int c0) {
-        // per-tile image bases of the sources (scalar registers)
-        const float* sb0 = a.src[0].p + (long long)t.b * a.src[0].bs;
-        const float* sb1 = a.nsrc > 1 ? a.src[1].p + (long long)t.b * a.src[1].bs : nullptr;
-        const float* sb2 = a.nsrc > 2 ? a.src[2].p + (long long)t.b * a.src[2].bs : nullptr;
-        const float* sb3 = a.nsrc > 3 ? a.src[3].p + (long long)t.b * a.src[3].bs : nullptr;
+    // Chunks are aligned to the sources of the (virtual) concatenation: chunk j covers up to CC
+    // consecutive channels of ONE source, so a chunk needs one buffer descriptor (built from scalars
+    // once) and per-channel plane offsets are a vector add; channels past the source's end fall outside
+    // the descriptor and read 0 (their filter rows then multiply zeros).
+    struct Chunk {
+        const float* base;   // plane of the chunk's first channel in image b
+        int cnt, cglob;      // valid channels; index of the first one in the concatenation (filter row)
+    };
+    auto locate = [&](int b, int j) {
+        Chunk c{nullptr, 0, 0};
+        int start = 0;
 #pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            const int cc = c0 + c;
-            const float* base = nullptr;
-            if (cc < a.cin) {
-                base = cc < e0 ? sb0 + (long long)cc * HW
-                     : cc < e1 ? sb1 + (long long)(cc - e0) * HW
-                     : cc < e2 ? sb2 + (long long)(cc - e1) * HW
-                               : sb3 + (long long)(cc - e2) * HW;
-            }
-            const __amdgpu_buffer_rsrc_t rx = plane_rsrc(base, plane_bytes);
-#pragma unroll
-            for (int k = 0; k < XI; ++k) xr[c][k] = buf_load(rx, goff[k]);
-            if (MASK) {
-                const float* mbase = cc < a.cin ? a.mask + (long long)t.b * a.mask_bs + (long long)cc * HW : nullptr;
-                const __amdgpu_buffer_rsrc_t rm = plane_rsrc(mbase, plane_bytes);
-#pragma unroll
-                for (int k = 0; k < XI; ++k) mr[MASK ? c : 0][MASK ? k : 0] = buf_load(rm, goff[k]);
+        for (int s = 0; s < YNET_MAX_SRC; ++s) {
+            if (c.base == nullptr && s < a.nsrc) {
+                const int n = (a.src[s].c + CC - 1) / CC;
+                if (j < n) {
+                    c.cnt = min(CC, a.src[s].c - j * CC);
+                    c.cglob = start + j * CC;
+                    c.base = a.src[s].p + (long long)b * a.src[s].bs + (long long)(j * CC) * HW;
+                } else {
+                    j -= n;
+                    start += a.src[s].c;
+                }
             }
         }
+        return c;
+    };
+    auto load_chunk = [&](const TileCoord& t, int j) {
+        const Chunk ck = locate(t.b, j);
+        const __amdgpu_buffer_rsrc_t rx = plane_rsrc(ck.base, (unsigned)ck.cnt * plane_bytes);
+        __amdgpu_buffer_rsrc_t rm = rx;
+        if (MASK) rm = plane_rsrc(a.mask + (long long)t.b * a.mask_bs + (long long)ck.cglob * HW, (unsigned)ck.cnt * plane_bytes);
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+#pragma unroll
+            for (int k = 0; k < XI; ++k) {
+                const unsigned off = goff[k] + (unsigned)c * plane_bytes;
+                xr[c][k] = buf_load(rx, off);
+                if (MASK) mr[MASK ? c : 0][MASK ? k : 0] = buf_load(rm, off);
+            }
+        }
+        const int c0 = ck.cglob;
         const float* wsrc = a.wp + (long long)c0 * KK * a.cout_pad + t.cg * CB;
 #pragma unroll
         for (int k = 0; k < WI; ++k) {
@@ -193,8 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // MFMA over (channel pair, tap) of the chunk in LDS.  Operands of tap t+1 are read from LDS while
     // the MFMAs of tap t run (explicit two-stage register pipeline; sched_group_barrier pins "reads
     // first, then MFMAs" so that no MFMA waits on an LDS read issued just before it).
-    auto mfma_chunk = [&](int c0) {
-        const int rem = a.cin - c0;
+    auto mfma_chunk = [&](int rem) {      // rem = valid channels of the chunk in LDS
         if constexpr (M16) {
             // K = 4 input channels per instruction: lane (r16, kq) feeds pixel r16 (+16 for the second half)
             // of channel kq as A and output channel r16 of channel kq as B.
@@ -365,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     };
 
     // ---- load cursor (lt, lch) runs one chunk ahead of the compute cursor (ct, cch)
-    int lt_idx = blockIdx.x, lch = 0;
+    int lt_idx = tile_first, lch = 0;
     if (lt_idx >= ntiles) return;
     // Co-resident workgroups that share the matrix pipes round-robin fall into lockstep and then all
     // stage / store at the same time; a fixed pecking order (one per residency "layer") staggers them.
@@ -389,27 +413,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             }
         }
     };
-    load_chunk(lt, lt.ks * a.cps * CC);
+    load_chunk(lt, lt.ks * a.cps);
     advance_load();
 
-    int ct_idx = blockIdx.x, cch = 0;
+    int ct_idx = tile_first, cch = 0;
     TileCoord ct = decode(ct_idx), pt = ct;
     int ccnt = item_chunks(ct);
     bool pending = false;
     for (;;) {
         const bool have = ct_idx < ntiles;
-        const bool stage = have && !((a.debug & 1) && !(ct_idx == (int)blockIdx.x && cch == 0));
+        const bool stage = have && !((a.debug & 1) && !(ct_idx == tile_first && cch == 0));
         if (stage) {
-            __syncthreads();            // every wave finished reading the previous chunk
-            store_chunk();
-            __syncthreads();
+            if (!(a.debug & 4)) __syncthreads();            // every wave finished reading the previous chunk
+            if (!(a.debug & 8)) store_chunk();
+            if (!(a.debug & 4)) __syncthreads();
         }
         if (pending) {                  // stores of the finished tile go out before the next prefetch is queued
             if (!(a.debug & 2)) epilogue(pt);
             pending = false;
         }
         if (stage && lt_idx < ntiles) {
-            load_chunk(lt, (lt.ks * a.cps + lch) * CC);
+            if (!(a.debug & 16)) load_chunk(lt, lt.ks * a.cps + lch);
             advance_load();
         }
         if (!have) break;
@@ -430,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                         for (int q = 0; q < 16; ++q) acc[i][r][q] = 0.f;
             }
         }
-        mfma_chunk((ct.ks * a.cps + cch) * CC);
+        mfma_chunk(locate(ct.b, ct.ks * a.cps + cch).cnt);
         if (++cch == ccnt) {
             cch = 0;
             pending = true;
@@ -499,7 +523,8 @@ static int launch_conv_m(ConvArgs& a, hipStream_t st) {
     a.cgroups = ceil_div(a.cout, C::CB);
     long long nt = (long long)a.tiles_x * a.tiles_y * a.cgroups * a.B;
     {   // small maps: split the channel chunks over several workgroups (partials summed by a second kernel)
-        const int nchunks = ceil_div(a.cin, CC);
+        int nchunks = 0;
+        for (int i = 0; i < a.nsrc; ++i) nchunks += ceil_div(a.src[i].c, CC);
         a.ksplit = 1;
         if (a.partial != nullptr) a.ksplit = conv_ksplit(nt, nchunks);
         while (a.ksplit > 1 && (long long)a.ksplit * a.B * a.cout * a.H * a.W > a.partial_cap) --a.ksplit;
@@ -645,7 +670,7 @@ int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
 
 long long ynet_packed_weight_floats(int cout, int cin, int K, int mode) {
     const int rows = mode == 0 ? cin : cout, cols = mode == 0 ? cout : cin;
-    const long long rp = (long long)ceil_div(rows, YNET_CIN_PAD) * YNET_CIN_PAD;
+    const long long rp = (long long)ceil_div(rows, YNET_CIN_PAD) * YNET_CIN_PAD + YNET_CIN_PAD;   // + one chunk of slack rows
     const long long cp = (long long)ceil_div(cols, YNET_COUT_PAD) * YNET_COUT_PAD;
     return rp * K * K * cp;
 }
@@ -655,7 +680,7 @@ int ynet_pack_weight(const float* w, float* wp, int cout, int cin, int K, int mo
     YNET_REQUIRE(mode == 0 || mode == 1, "pack_weight: mode must be 0 (forward) or 1 (dgrad)");
     YNET_REQUIRE(cout > 0 && cin > 0 && (K == 1 || K == 3 || K == 5), "pack_weight: bad shape %d %d %d", cout, cin, K);
     const int rows = mode == 0 ? cin : cout, cols = mode == 0 ? cout : cin;
-    const int rp = ceil_div(rows, YNET_CIN_PAD) * YNET_CIN_PAD, cp = ceil_div(cols, YNET_COUT_PAD) * YNET_COUT_PAD;
+    const int rp = ceil_div(rows, YNET_CIN_PAD) * YNET_CIN_PAD + YNET_CIN_PAD, cp = ceil_div(cols, YNET_COUT_PAD) * YNET_COUT_PAD;
     const long long n = (long long)rp * K * K * cp;
     const int grid = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp, cout, cin, K * K,

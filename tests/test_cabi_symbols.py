@@ -18,8 +18,8 @@ def test_load_binds_and_reports_errors():
     L = pkg("_lib")
     lib = L.load()
     assert lib.ynet_abi_version() == 1
-    assert lib.ynet_packed_weight_floats(32, 14, 3, 0) == 16 * 9 * 64
-    assert lib.ynet_packed_weight_floats(32, 14, 3, 1) == 32 * 9 * 64
+    assert lib.ynet_packed_weight_floats(32, 14, 3, 0) == (16 + 16) * 9 * 64      # rows: cin -> 16, + one chunk of slack
+    assert lib.ynet_packed_weight_floats(32, 14, 3, 1) == (32 + 16) * 9 * 64
     # argument validation happens before any launch, so it is testable without a GPU
     rc = lib.ynet_pack_weight(None, None, 4, 4, 3, 0, None)
     assert rc != 0 and b"null" in lib.ynet_last_error()
