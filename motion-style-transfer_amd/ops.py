@@ -160,6 +160,16 @@ def lora_grad(dw, lora_a, lora_b, scale: float):
 
 
 _conv_ws = {}
+_side_streams = {}
+
+
+def side_streams(device):
+    """Two persistent side streams per device (goal / trajectory decoder overlap)."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _side_streams[key]
 
 
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
@@ -171,9 +181,10 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
     if B * H * W <= 65536:                                       # small maps only (see ynet_conv2d_workspace_floats)
         nws = lib.ynet_conv2d_workspace_floats(B, H, W, sum(d[1] for d in dsts))
         if nws:
-            ws = _conv_ws.get(wp.device)                         # grow-only scratch; launches are stream-ordered
+            key = (wp.device, torch.cuda.current_stream().cuda_stream)   # grow-only scratch per stream (stream-ordered reuse)
+            ws = _conv_ws.get(key)
             if ws is None or ws.numel() < nws:
-                ws = _conv_ws[wp.device] = torch.empty(nws, device=wp.device, dtype=torch.float32)
+                ws = _conv_ws[key] = torch.empty(nws, device=wp.device, dtype=torch.float32)
     L.check(lib.ynet_conv2d(sp, sc, sb, len(srcs), mask[0] if mask else None, mask[1] if mask else 0,
                             wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                             dp, dc, db, len(dsts), B, H, W, K, 1 if relu else 0,

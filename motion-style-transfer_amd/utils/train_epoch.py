@@ -57,13 +57,32 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
 
                 semantic_map = semantic_img.expand(n_local, -1, -1, -1)
                 features = model.pred_features(semantic_map, observed_map)
-                pred_goal_map = model.pred_goal(features)
-                goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
-
-                pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
-                traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]   # concat fused into the convs
-                pred_traj_map = model.pred_traj(traj_input)
-                traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
+                # The goal and the trajectory decoder are independent given the features: run them on two
+                # HIP streams so the launch-latency-bound small maps (8^2 .. 32^2) of one overlap the other
+                # (autograd replays each backward op on the stream of its forward op).
+                main = torch.cuda.current_stream(device)
+                s_goal, s_traj = ops.side_streams(device)
+                for f in features:
+                    for t in ops._parts(f):
+                        t.record_stream(s_goal)
+                        t.record_stream(s_traj)
+                gt_future_map.record_stream(s_goal)
+                gt_future_map.record_stream(s_traj)
+                gt_waypoint_map.record_stream(s_traj)
+                s_goal.wait_stream(main)
+                s_traj.wait_stream(main)
+                with torch.cuda.stream(s_goal):
+                    pred_goal_map = model.pred_goal(features)
+                    goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
+                with torch.cuda.stream(s_traj):
+                    pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
+                    traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]   # concat fused into the convs
+                    pred_traj_map = model.pred_traj(traj_input)
+                    traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
+                main.wait_stream(s_goal)
+                main.wait_stream(s_traj)
+                for t in (pred_goal_map, goal_loss, pred_traj_map, traj_loss):
+                    t.record_stream(main)
 
                 loss = goal_loss + traj_loss
                 if dp is not None:
