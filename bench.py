@@ -258,8 +258,10 @@ def main():
                                "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": us,
                                "algorithmic_mb_per_launch": x.numel() * 4 / 1e6}
     elif rank == 0:
+        ops.overlap_decoders = False      # kernels are timed in isolation: the two decoder streams run back to back
         with ConvTimer(ops) as ct:
             run(1, 3)
+        ops.overlap_decoders = True
         agg = ct.summary()
         if args.layers:
             for name, e0, e1, fl, by, shape in ct.rec:
@@ -278,7 +280,10 @@ def main():
                            "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                            "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-                           "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9}
+                           "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
+                           "note": "per-kernel HIP-event timing of one instrumented step with the goal/trajectory decoder "
+                                   "streams serialized (YNET_SERIAL_DECODERS=1 reproduces it under rocprofv3); in the timed "
+                                   "region the two streams overlap"}
         out["conv_kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}
         total_conv_ms = sum(v["ms"] for v in agg.values())

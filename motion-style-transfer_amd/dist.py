@@ -5,7 +5,7 @@ One process per GPU (torchrun); backend "nccl" = RCCL over xGMI on ROCm, "gloo" 
 Every batch of trajectories is split into contiguous row shards; the semantic map, templates and
 weights are replicated.  BCE is a mean over B*pred*H*W (models/trainer.py:206), so a rank scales its
 local loss by B_local / B_global and ONE all-reduce(SUM) of the flat trainable-gradient buffer per
-step (32 KB for mosa_1 ... 6.6 MB full model) reproduces the single-GPU gradient; every rank then
+step (32 KB for mosa_1 ... 6.6 MB full model; the loss rides in its last slot) reproduces the single-GPU gradient; every rank then
 applies the identical Adam update.  The flat buffer is persistent and ``p.grad`` are views into it,
 so the collective runs in place on the compute stream with no packing copies.
 """
@@ -26,7 +26,9 @@ class DataParallel:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        # one extra slot carries the shard-weighted loss, so a step needs exactly ONE collective
+        self.n_grad = n
+        self.flat = torch.zeros(n + 1, device=dev, dtype=torch.float32)
         self._views = []
         off = 0
         for p in self.params:
@@ -50,15 +52,19 @@ class DataParallel:
         self.flat.zero_()
         self.bind()
 
-    def allreduce_grads(self):
+    def allreduce_grads(self, loss: torch.Tensor = None) -> torch.Tensor:
+        """SUM all-reduce of the flat gradient buffer (+ the loss in its last slot); returns the global loss."""
         for p, v in zip(self.params, self._views):      # a rank with an empty shard never ran backward
             if p.grad is None:
                 p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
+        if loss is not None:
+            self.flat[-1:].copy_(loss.detach().reshape(1))
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        return self.flat[-1].clone()
 
     def sum_scalar(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:

@@ -159,13 +159,21 @@ def lora_grad(dw, lora_a, lora_b, scale: float):
     return d_a, d_b
 
 
+import os as _os
+
 _conv_ws = {}
 _side_streams = {}
+# goal / trajectory decoders on two streams (utils/train_epoch.py); YNET_SERIAL_DECODERS=1 or setting this
+# to False runs them back to back on the current stream (used when timing kernels in isolation)
+overlap_decoders = _os.environ.get("YNET_SERIAL_DECODERS", "0") != "1"
 
 
 def side_streams(device):
     """Two persistent side streams per device (goal / trajectory decoder overlap)."""
     dev = torch.device(device)
+    if not overlap_decoders:
+        cur = torch.cuda.current_stream(dev)
+        return cur, cur
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _side_streams:
         _side_streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))

@@ -91,8 +91,7 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
             else:
                 loss = torch.zeros((), device=device)
             if dp is not None:
-                dp.allreduce_grads()
-                loss = dp.sum_scalar(loss.detach())
+                loss = dp.allreduce_grads(loss)          # ONE collective per step: gradients + loss
             optimizer.step()
 
             with torch.no_grad():
@@ -104,13 +103,17 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                     fde = ((((gt_future[:, -1:] - pred_goal[:, -1:]) / resize_factor) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
                 else:
                     ade = fde = torch.zeros(0, device=device)
-                if dp is not None:
-                    sizes = dp.shard_sizes(n_global)
-                    ade, fde = dp.gather_rows(ade, sizes), dp.gather_rows(fde, sizes)
                 train_ADE.append(ade)
                 train_FDE.append(fde)
 
-    train_ADE = torch.cat(train_ADE).mean()
-    train_FDE = torch.cat(train_FDE).mean()
+    train_ADE, train_FDE = torch.cat(train_ADE), torch.cat(train_FDE)
+    if dp is not None and dp.world > 1:
+        # per-trajectory errors stay local during the epoch; one (sum, sum, count) reduction at its end
+        stats = torch.stack([train_ADE.sum(), train_FDE.sum(),
+                             torch.tensor(float(train_ADE.numel()), device=train_ADE.device)])
+        stats = dp.sum_scalar(stats)
+        train_ADE, train_FDE = stats[0] / stats[2], stats[1] / stats[2]
+    else:
+        train_ADE, train_FDE = train_ADE.mean(), train_FDE.mean()
     ops.check_patch_status()
     return train_ADE.item(), train_FDE.item(), train_loss.item()

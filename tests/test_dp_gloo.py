@@ -48,8 +48,7 @@ def _worker(rank, world, port, n_rows, out):
             p.grad.copy_(res["grads"][n])            # what autograd's AccumulateGrad does into the bound views
         loss = res["loss"] * ((hi - lo) / n_rows)
         ade = res["ade"]
-    dp.allreduce_grads()
-    loss = dp.sum_scalar(loss)
+    loss = dp.allreduce_grads(loss)
     ade = dp.gather_rows(ade, dp.shard_sizes(n_rows))
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in params], "loss": loss, "ade": ade, "flat": dp.flat.numel()}, out)
@@ -69,7 +68,7 @@ def test_two_rank_gradient_equals_single_process(tmp_path, n_rows):
     S = cfg.template_size
     ref = O.train_step(sd, cfg, O.synthetic_scene(cfg, 32, 32, 0), O.synthetic_trajectories(cfg, n_rows, 32, 32, 0),
                        O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig), names)
-    assert got["flat"] == sum(sd[n].numel() for n in names)
+    assert got["flat"] == sum(sd[n].numel() for n in names) + 1        # + the loss slot
     for g, n in zip(got["grads"], names):
         w = ref["grads"][n]
         assert float((g - w).abs().max()) <= 1e-5 * float(w.abs().max()) + 1e-7, n
