@@ -80,8 +80,15 @@ struct TileCoord {
 //     [barrier, regs -> LDS, barrier] [issue global loads of the NEXT chunk (maybe of the next tile)]
 //     [epilogue stores of the tile that just finished]  [MFMA loop of this chunk]
 // so neither a tile's first loads nor its output stores leave the matrix pipes idle.
+// accumulator registers per lane: 16 per 32x32 tile, 8 per (16x16 tile x 2 pixel halves)
+constexpr int conv_acc_regs(int ncb, int r, bool m16) { return m16 ? 8 * ncb * r : 16 * ncb * r; }
+#ifndef YNET_CONV_WAVES_SMALL
+#define YNET_CONV_WAVES_SMALL 2     // 3 makes the 64-accumulator variants spill (measured slower)
+#endif
+
 template <int KS, int NCB, int R, int CC, bool MASK, bool M16>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (conv_acc_regs(NCB, R, M16) <= 64 ? YNET_CONV_WAVES_SMALL : 2))
+void conv_mfma_kernel(const ConvArgs a) {
     using C = ConvCfg<KS, NCB, R, CC, M16>;
     constexpr int PAD = C::PAD, KK = C::KK, TH = C::TH, TW = C::TW;
     constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB, CHS = C::CHS;
