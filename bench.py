@@ -84,9 +84,13 @@ class ConvTimer:
             flops = 2.0 * B * H * W * cin * cout * K * K
             byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]))
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
-            rows, tiles, m16 = plan & 255, (plan >> 8) & 255, plan >> 16
-            name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}, "
-                    f"{'true' if m16 else 'false'}>")
+            rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
+            if dma:
+                cc = 4
+                name = f"conv_dma_kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}>"
+            else:
+                name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}, "
+                        f"{'true' if m16 else 'false'}>")
             self.rec.append((name, e0, e1, flops, byts, (B, H, W, cin, cout, K, bool(mask))))
         self.ops.conv2d_raw = timed
         return self
