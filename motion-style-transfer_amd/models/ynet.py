@@ -322,8 +322,7 @@ class YNet(nn.Module):
         return self.softargmax_(output)
 
     def sigmoid(self, output):
-        c = output.shape[1]
-        return ops.sigmoid_temp(output, list(range(c)), 1.0) if c <= 8 else torch.sigmoid(output)
+        return ops.sigmoid(output)
 
     def softargmax_on_softmax_map(self, x):
         pos_y, pos_x = create_meshgrid(x, normalized_coordinates=False)

@@ -426,6 +426,13 @@ def softargmax2d(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def sigmoid(x: torch.Tensor) -> torch.Tensor:
+    """Elementwise sigmoid of any tensor (models/ynet.py:585-586) on the same kernel."""
+    _need_gpu(x, "sigmoid")
+    flat = x.detach().contiguous().view(1, 1, 1, -1)
+    return sigmoid_temp(flat, [0], 1.0).view(x.shape)
+
+
 def sigmoid_temp(x: torch.Tensor, channels: Sequence[int], temperature: float) -> torch.Tensor:
     """sigmoid(x[:, channels] / temperature) (utils/evaluate.py:128-131) in one pass."""
     _need_gpu(x, "sigmoid_temp")

@@ -37,3 +37,37 @@ def test_ops_refuse_host_tensors():
         ops.conv2d(torch.zeros(1, 2, 8, 8), torch.zeros(3, 2, 3, 3), None, True, {})
     with pytest.raises(ValueError):
         ops.softargmax2d(torch.zeros(4, 4))
+
+
+def test_argument_validation_without_gpu():
+    """Every entry point validates its arguments before touching the device (status != 0 + message)."""
+    import ctypes
+    L = pkg("_lib")
+    lib = L.load()
+    vp = ctypes.c_void_p
+    one = (vp * 1)(vp(16))
+    ci = (ctypes.c_int * 1)(4)
+    cl = (ctypes.c_longlong * 1)(64)
+    pp = ctypes.cast(one, L.PP)
+    # 5 sources: too many
+    assert lib.ynet_conv2d(pp, ci, cl, 5, None, 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 3, 0, None, 0, None) != 0
+    assert b"sources" in lib.ynet_last_error()
+    # kernel size 7 is not supported
+    assert lib.ynet_conv2d(pp, ci, cl, 1, None, 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 7, 0, None, 0, None) != 0
+    assert b"kernel size" in lib.ynet_last_error()
+    # a ReLU mask needs a single source
+    two_p = ctypes.cast((vp * 2)(vp(16), vp(32)), L.PP)
+    two_c, two_b = (ctypes.c_int * 2)(2, 2), (ctypes.c_longlong * 2)(128, 128)
+    assert lib.ynet_conv2d(two_p, two_c, two_b, 2, vp(16), 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 3, 0, None, 0, None) != 0
+    assert lib.ynet_avgpool_pyramid(vp(16), pp, 1, 1, 48, 64, None) != 0 and b"multiples of 32" in lib.ynet_last_error()
+    assert lib.ynet_avgpool_pyramid(vp(16), pp, 6, 1, 64, 64, None) != 0
+    assert lib.ynet_sigmoid_temp(vp(16), vp(16), 1, 4, 64, (ctypes.c_int * 1)(9), 1, 1.0, None) != 0
+    assert b"out of range" in lib.ynet_last_error()
+    assert lib.ynet_sigmoid_temp(vp(16), vp(16), 1, 4, 64, (ctypes.c_int * 1)(0), 1, 0.0, None) != 0
+    assert lib.ynet_gather_patch(vp(16), 16, 16, vp(16), vp(16), 1, 32, 32, vp(16), None) != 0
+    assert lib.ynet_bce_logits_fwd(vp(4), vp(16), 8, vp(16), vp(16), None) != 0 and b"aligned" in lib.ynet_last_error()
+    assert lib.ynet_conv2d_wgrad_workspace_floats(2, 16, 32, 8, 4, 3) > 0
+    assert lib.ynet_conv2d_workspace_floats(32, 8, 8, 128) == 8 * 32 * 128 * 64
+    assert lib.ynet_conv2d_workspace_floats(32, 256, 256, 32) == 0
+    plan = lib.ynet_conv2d_plan(32, 256, 256, 32, 3)
+    assert plan & 255 == 4 and (plan >> 8) & 255 == 2 and (plan >> 16) & 1 == 1      # 4 rows, two 16-wide tiles
