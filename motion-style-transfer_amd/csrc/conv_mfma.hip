@@ -896,7 +896,7 @@ static int pick_rows(const ConvArgs& a, int cb) {
     const long long per_img_x = ceil_div(a.W, 32), cg = ceil_div(a.cout, cb);
     for (int r = 4; r > 1; r >>= 1) {
         const long long nblk = per_img_x * ceil_div(a.H, 4 * r) * cg * a.B;
-        if (nblk >= 1024) return r;
+        if (nblk >= (r == 4 ? 1024 : 512)) return r;
     }
     return 1;
 }
