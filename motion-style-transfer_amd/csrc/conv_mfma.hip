@@ -710,10 +710,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
                         if (relu) u = u < 0.f ? 0.f : u;
                         v[e] = u;
                     }
-                    if (gy < a.H && gx < a.W) {
-                        f32x4* q = reinterpret_cast<f32x4*>(__builtin_assume_aligned(dp + (long long)gy * a.W + gx, 16));
-                        *q = v;
-                    }
+                    if (gy < a.H && gx < a.W)
+                        *reinterpret_cast<f32x4*>(__builtin_assume_aligned(dp + (long long)gy * a.W + gx, 16)) = v;
                 }
             }
         }
