@@ -39,14 +39,17 @@ int ynet_pack_weight(const float* w, float* wp, int cout, int cin, int K, int mo
  * (convolution_backward -> grad_input) when handed a mode-1 filter, the incoming gradient as the
  * source, `mask` = the post-ReLU activation of the layer (gradient kept where mask > 0) and one
  * destination per concatenated input (NULL = not wanted).
- *   src[i]:   nsrc (1..4) sources, src_c[i] channels, batch stride src_bs[i] elements (0 = broadcast)
+ *   src[i]:   nsrc (1..4) sources, src_c[i] channels, batch stride src_bs[i] elements (0 = broadcast);
+ *             src_bmod (may be NULL): src_bmod[i] > 0 means source i holds that many images which repeat along
+ *             the batch (image b % src_bmod[i]) — the K goal samples of utils/evaluate.py:248-266 share the
+ *             encoder features of their trajectory without replicating them
  *   dst[i]:   ndst (1..4) destinations, dst_c[i] channels, batch stride dst_bs[i]
  *   cin = sum(src_c), cout = sum(dst_c); wp packed for (cout, cin); bias [cout] or NULL
  *   workspace: optional scratch of ynet_conv2d_workspace_floats(B, H, W, cout) floats (may be NULL / 0):
  *   lets small-map launches (8^2 .. 32^2) split their input-channel loop over more workgroups.
  */
 long long ynet_conv2d_workspace_floats(int B, int H, int W, int cout);
-int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
+int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, const int* src_bmod, int nsrc,
                 const float* mask, long long mask_bs, const float* wp, const float* bias,
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                 int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,

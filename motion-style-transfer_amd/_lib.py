@@ -26,7 +26,7 @@ SIGNATURES = {
     "ynet_packed_weight_floats": (c_ll, [c_i, c_i, c_i, c_i]),
     "ynet_pack_weight": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_workspace_floats": (c_ll, [c_i, c_i, c_i, c_i]),
-    "ynet_conv2d": (c_i, [PP, PI, PLL, c_i, c_fp, c_ll, c_fp, c_fp, PP, PI, PLL, c_i,
+    "ynet_conv2d": (c_i, [PP, PI, PLL, PI, c_i, c_fp, c_ll, c_fp, c_fp, PP, PI, PLL, c_i,
                           c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_fp]),
     "ynet_conv2d_plan": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_wgrad_workspace_floats": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i]),

@@ -170,7 +170,7 @@ void conv_mfma_kernel(const ConvArgs a) {
                 if (j < n) {
                     c.cnt = min(CC, a.src[s].c - j * CC);
                     c.cglob = start + j * CC;
-                    c.base = a.src[s].p + (long long)b * a.src[s].bs + (long long)(j * CC) * HW;
+                    c.base = a.src[s].p + (long long)(a.src[s].bmod > 0 ? b % a.src[s].bmod : b) * a.src[s].bs + (long long)(j * CC) * HW;
                 } else {
                     j -= n;
                     start += a.src[s].c;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
                 if (j < n) {
                     c.cnt = min(CC, a.src[s].c - j * CC);
                     c.cglob = start + j * CC;
-                    c.base = a.src[s].p + (long long)b * a.src[s].bs + (long long)(j * CC) * HW;
+                    c.base = a.src[s].p + (long long)(a.src[s].bmod > 0 ? b % a.src[s].bmod : b) * a.src[s].bs + (long long)(j * CC) * HW;
                 } else {
                     j -= n;
                     start += a.src[s].c;
@@ -1095,7 +1095,7 @@ long long ynet_conv2d_workspace_floats(int B, int H, int W, int cout) {
     return 8ll * B * cout * H * W;
 }
 
-int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
+int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, const int* src_bmod, int nsrc,
                 const float* mask, long long mask_bs, const float* wp, const float* bias,
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                 int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
@@ -1110,7 +1110,8 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
     a.cin = 0;
     for (int i = 0; i < nsrc; ++i) {
         YNET_REQUIRE(src[i] != nullptr && src_c[i] > 0, "conv2d: source %d is null/empty", i);
-        a.src[i] = YSrc{src[i], src_c[i], src_bs[i]};
+        a.src[i] = YSrc{src[i], src_c[i], src_bs[i], src_bmod ? src_bmod[i] : 0};
+        YNET_REQUIRE(a.src[i].bmod >= 0, "conv2d: negative batch modulus");
         a.cin += src_c[i];
     }
     a.ndst = ndst;

@@ -317,7 +317,7 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
     a.cin = 0;
     for (int i = 0; i < nsrc; ++i) {
         YNET_REQUIRE(src[i] != nullptr && src_c[i] > 0, "conv2d_wgrad: source %d is null/empty", i);
-        a.src[i] = YSrc{src[i], src_c[i], src_bs[i]};
+        a.src[i] = YSrc{src[i], src_c[i], src_bs[i], 0};
         a.cin += src_c[i];
     }
     a.dy = dy;

@@ -11,6 +11,7 @@ struct YSrc {
     const float* p;
     int c;
     long long bs;
+    int bmod;   // > 0: the source holds bmod images that repeat along the batch (image = b % bmod)
 };
 struct YDst {
     float* p;   // may be NULL: channels are computed but not stored (no gradient wanted)

@@ -46,7 +46,7 @@ class LazyCat:
         flat: List[torch.Tensor] = []
         for p in parts:
             flat.extend(p.parts if isinstance(p, LazyCat) else [p])
-        b, _, h, w = flat[0].shape
+        b, _, h, w = flat[0].shape     # parts are tensors or BatchRepeat views
         for p in flat:
             if p.dim() != 4 or p.shape[0] != b or p.shape[2:] != (h, w):
                 raise ValueError(f"lazy_cat: incompatible shapes {[tuple(q.shape) for q in flat]}")
@@ -72,7 +72,8 @@ class LazyCat:
         return self.parts[0].dtype
 
     def materialize(self) -> torch.Tensor:
-        return torch.cat([p.contiguous() for p in self.parts], dim=1)
+        return torch.cat([(p.tensor.repeat(p.times, 1, 1, 1) if isinstance(p, BatchRepeat) else p).contiguous()
+                          for p in self.parts], dim=1)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -90,6 +91,42 @@ class LazyCat:
                 return type(o)(mat(i) for i in o)
             return o
         return func(*mat(args), **{k: mat(v) for k, v in kwargs.items()})
+
+
+class BatchRepeat:
+    """``tensor.repeat(times, 1, 1, 1)`` that is never materialised: a conv source whose images repeat along the
+    batch (kernel reads image b % B).  Used by utils/evaluate.py to share the encoder features of a trajectory
+    among its K goal samples.  Inference only (no gradient flows into it)."""
+
+    def __init__(self, tensor: torch.Tensor, times: int):
+        if tensor.dim() != 4 or times < 1:
+            raise ValueError("BatchRepeat: expected a BxCxHxW tensor and times >= 1")
+        self.tensor, self.times = tensor.detach(), int(times)
+
+    @property
+    def shape(self):
+        t = self.tensor
+        return torch.Size((t.shape[0] * self.times, t.shape[1], t.shape[2], t.shape[3]))
+
+    def dim(self):
+        return 4
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @property
+    def dtype(self):
+        return self.tensor.dtype
+
+
+def batch_repeat(x, times: int):
+    """Repeat a tensor / LazyCat along the batch without materialising it (conv sources only)."""
+    if times == 1:
+        return x
+    if isinstance(x, LazyCat):
+        return LazyCat([BatchRepeat(p, times) for p in x.parts])
+    return BatchRepeat(x, times)
 
 
 def lazy_cat(parts: Sequence[torch.Tensor]):
@@ -120,6 +157,13 @@ def _arrays(descs):
     cs = (ctypes.c_int * n)(*[d[1] for d in descs])
     bss = (ctypes.c_longlong * n)(*[d[2] for d in descs])
     return ctypes.cast(ptrs, L.PP), cs, bss
+
+
+def _bmods(descs):
+    """Optional 4th field of a source descriptor: batch modulus (0 = none)."""
+    if not any(len(d) > 3 and d[3] for d in descs):
+        return None
+    return (ctypes.c_int * len(descs))(*[(d[3] if len(d) > 3 else 0) for d in descs])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -193,7 +237,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
             ws = _conv_ws.get(key)
             if ws is None or ws.numel() < nws:
                 ws = _conv_ws[key] = torch.empty(nws, device=wp.device, dtype=torch.float32)
-    L.check(lib.ynet_conv2d(sp, sc, sb, len(srcs), mask[0] if mask else None, mask[1] if mask else 0,
+    L.check(lib.ynet_conv2d(sp, sc, sb, _bmods(srcs), len(srcs), mask[0] if mask else None, mask[1] if mask else 0,
                             wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                             dp, dc, db, len(dsts), B, H, W, K, 1 if relu else 0,
                             ws.data_ptr() if ws is not None else None, nws, _stream()), lib)
@@ -231,15 +275,25 @@ class _Conv2dFn(torch.autograd.Function):
         _need_gpu(weight, "conv2d weight")
         cout, cin, k, _ = weight.shape
         descs, keep = [], []
+        reps = meta.get("repeat") or [1] * len(srcs)
         for i, s in enumerate(srcs):
             t, c, bs = _plane_desc(s, f"conv2d input {i}")
             keep.append(t)
-            descs.append((t.data_ptr(), c, bs))
+            if reps[i] > 1:
+                if ctx.needs_input_grad[5 + i]:
+                    raise NotImplementedError("conv2d: a batch-repeated input cannot receive a gradient")
+                descs.append((t.data_ptr(), c, c * t.shape[2] * t.shape[3] if t.shape[0] == 1 else t.stride(0), t.shape[0]))
+            else:
+                descs.append((t.data_ptr(), c, bs))
         if len(descs) > MAX_SRC:
             raise ValueError(f"conv2d: at most {MAX_SRC} concatenated inputs (got {len(descs)})")
         if sum(d[1] for d in descs) != cin:
             raise ValueError(f"conv2d: inputs carry {sum(d[1] for d in descs)} channels, weight expects {cin}")
         B, _, H, W = keep[0].shape
+        B = max(t.shape[0] * r for t, r in zip(keep, reps))
+        for t, r in zip(keep, reps):
+            if t.shape[0] * r != B and not (t.shape[0] > 1 and t.stride(0) == 0):
+                raise ValueError(f"conv2d: inputs disagree on the batch size ({[tuple(q.shape) for q in keep]}, repeat {reps})")
         wp = _cached(cache, weight, lora_a, lora_b, scale, "fwd")
         y = torch.empty((B, cout, H, W), device=weight.device, dtype=torch.float32)
         b = bias.detach() if bias is not None else None
@@ -303,8 +357,14 @@ class _Conv2dFn(torch.autograd.Function):
 
 def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0):
     """[ReLU](conv(cat(x), W_eff) + bias); x is a tensor or a LazyCat."""
+    parts = _parts(x)
     meta = {"relu": bool(relu), "scale": float(scale), "cache": cache}
-    return _Conv2dFn.apply(meta, weight, bias, lora_a, lora_b, *_parts(x))
+    if any(isinstance(p, BatchRepeat) for p in parts):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (weight, bias, lora_a, lora_b) if t is not None):
+            raise NotImplementedError("conv2d: batch-repeated inputs are for inference (torch.no_grad) only")
+        meta["repeat"] = [p.times if isinstance(p, BatchRepeat) else 1 for p in parts]
+        parts = [p.tensor if isinstance(p, BatchRepeat) else p for p in parts]
+    return _Conv2dFn.apply(meta, weight, bias, lora_a, lora_b, *parts)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -2,8 +2,8 @@
 off in every shipped config): encoder + goal decoder once per batch, sigmoid(x/T) and multinomial
 goal/waypoint sampling, then K = n_goal*n_traj passes of {gather_patch, waypoint pyramid, trajectory
 decoder, soft-argmax}; best-of-K ADE/FDE.  Same signature and return value as the reference;
-``forced_samples`` (not in the reference) teacher-forces the sampled way-points for parity tests and
-``dp`` shards every batch over ranks.
+``forced_samples`` (not in the reference) teacher-forces the sampled way-points for parity tests,
+``dp`` shards every batch over ranks, ``max_effective_batch`` bounds the K-folding of the decoder passes.
 """
 import numpy as np
 import pandas as pd
@@ -16,7 +16,7 @@ from .image_utils import gather_patches, image2world, sampling, swap_pavement_te
 def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, input_template, waypoints, mode,
              n_goal, n_traj, obs_len, batch_size, resize_factor=0.25, temperature=1, use_TTST=False, use_CWS=False,
              rel_thresh=0.002, CWS_params=None, return_preds=False, return_samples=False, network=None,
-             swap_semantic=False, forced_samples=None, dp=None):
+             swap_semantic=False, forced_samples=None, dp=None, max_effective_batch=256):
     if use_TTST or use_CWS:
         raise NotImplementedError("TTST / CWS are outside the MI355X hot path (disabled in every shipped config)")
     if network == "embed":
@@ -78,14 +78,21 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
                         trajs_dict["goal_sigmoid_map"].append(model.sigmoid(pred_goal_map / temperature).cpu().numpy())
                         trajs_dict["waypoint_sample"].append(waypoint_samples.permute(1, 2, 0, 3).cpu().numpy())
 
+                    # The K = n_goal * n_traj decoder passes of the reference loop are folded into the batch:
+                    # G samples at a time run as ONE pass over G * n_local virtual batch items whose encoder
+                    # features repeat along the batch (read in place by the conv kernels, never replicated).
+                    K = waypoint_samples.shape[0]
+                    G = max(1, min(K, max_effective_batch // max(n_local, 1)))
                     trajs_samples = []
-                    for waypoint in waypoint_samples:        # K = n_goal * n_traj decoder passes
-                        waypoint_map = gather_patches(input_template, waypoint.reshape(-1, 2), H, W).view(-1, n_wp, H, W)
+                    for k0 in range(0, K, G):
+                        g = min(G, K - k0)
+                        coords = waypoint_samples[k0:k0 + g].reshape(-1, 2)            # [g * n_local * n_wp, 2]
+                        waypoint_map = gather_patches(input_template, coords, H, W).view(g * n_local, n_wp, H, W)
                         pyramid = ops.avgpool_pyramid(waypoint_map, len(features))
-                        traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]
-                        pred_traj = model.softargmax(model.pred_traj(traj_input))
-                        trajs_samples.append(pred_traj)
-                    trajs_samples = torch.stack(trajs_samples)
+                        traj_input = [ops.lazy_cat([ops.batch_repeat(f, g), p]) for f, p in zip(features, pyramid)]
+                        pred_traj = model.softargmax(model.pred_traj(traj_input))       # [g * n_local, pred, 2]
+                        trajs_samples.append(pred_traj.view(g, n_local, -1, 2))
+                    trajs_samples = torch.cat(trajs_samples)
                     gt_goal = gt_future[:, -1:]
                     if dataset_name == "eth":
                         waypoint_samples = image2world(waypoint_samples, scene_id, homo_mat, resize_factor)

@@ -50,15 +50,15 @@ def test_argument_validation_without_gpu():
     cl = (ctypes.c_longlong * 1)(64)
     pp = ctypes.cast(one, L.PP)
     # 5 sources: too many
-    assert lib.ynet_conv2d(pp, ci, cl, 5, None, 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 3, 0, None, 0, None) != 0
+    assert lib.ynet_conv2d(pp, ci, cl, None, 5, None, 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 3, 0, None, 0, None) != 0
     assert b"sources" in lib.ynet_last_error()
     # kernel size 7 is not supported
-    assert lib.ynet_conv2d(pp, ci, cl, 1, None, 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 7, 0, None, 0, None) != 0
+    assert lib.ynet_conv2d(pp, ci, cl, None, 1, None, 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 7, 0, None, 0, None) != 0
     assert b"kernel size" in lib.ynet_last_error()
     # a ReLU mask needs a single source
     two_p = ctypes.cast((vp * 2)(vp(16), vp(32)), L.PP)
     two_c, two_b = (ctypes.c_int * 2)(2, 2), (ctypes.c_longlong * 2)(128, 128)
-    assert lib.ynet_conv2d(two_p, two_c, two_b, 2, vp(16), 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 3, 0, None, 0, None) != 0
+    assert lib.ynet_conv2d(two_p, two_c, two_b, None, 2, vp(16), 0, vp(16), None, pp, ci, cl, 1, 1, 8, 8, 3, 0, None, 0, None) != 0
     assert lib.ynet_avgpool_pyramid(vp(16), pp, 1, 1, 48, 64, None) != 0 and b"multiples of 32" in lib.ynet_last_error()
     assert lib.ynet_avgpool_pyramid(vp(16), pp, 6, 1, 64, 64, None) != 0
     assert lib.ynet_sigmoid_temp(vp(16), vp(16), 1, 4, 64, (ctypes.c_int * 1)(9), 1, 1.0, None) != 0
