@@ -37,6 +37,7 @@ struct ConvArgs {
     float* partial;         // [ksplit][B][cout][H][W] raw partial sums when ksplit > 1 (NULL: never split)
     long long partial_cap;  // floats available at `partial`
     int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
+    int vec_load;           // 16-byte LDS-DMA of the input tile is legal (W % 4 == 0, aligned sources / mask)
     int tiles_x, tiles_y, cgroups, ntiles, prio_mode, debug;   // debug: timing ablations only (tools/conv_bench.py)
 };
 
@@ -487,23 +488,36 @@ void conv_mfma_kernel(const ConvArgs a) {
 // ================================================================================================
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int NCB, int R, int CC, bool MASK>
+// 16 bytes per lane, global -> LDS (lane i lands at lds + 16 i).  Kept in a __device__ helper: used directly
+// inside `if constexpr` in the kernel template, hipcc's host pass silently drops the kernel's stub.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, const float* lds, unsigned byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, byte_off, 0, 0, 0);
+}
+
+// X4 = true: the input tile is fetched as aligned 16-byte quads, 10 per row ([x0-4, x0+36): W % 4 == 0 makes
+// every quad lie wholly inside or wholly outside the image), a quarter of the DMA instructions of the
+// dword form for 18 % more bytes; tile column 0 (gx = x0-1) then sits at LDS column 3.
+template <int NCB, int R, int CC, bool MASK, bool X4>
 struct DmaCfg {
     static constexpr int KS = 3, PAD = 1, KK = 9;
     static constexpr int TH = 4 * R, TW = 32;
-    static constexpr int TROWS = TH + 2, TCOLS = TW + 2, PLANE = TROWS * TCOLS;
+    static constexpr int TROWS = TH + 2, TCOLS = X4 ? TW + 8 : TW + 2, PLANE = TROWS * TCOLS;
+    static constexpr int XOFF = X4 ? 3 : 0;
     static constexpr int CB = 16 * NCB;
-    static constexpr int XI = (PLANE + 255) / 256;
-    static constexpr int CHS = XI * 256 + 16;                 // = 16 mod 32: the 4 channels of a K-step on distinct banks
+    static constexpr int XN = X4 ? PLANE / 4 : PLANE;         // DMA lanes per channel
+    static constexpr int XI = (XN + 255) / 256;
+    // channel stride = 16 mod 32: the 4 channels of a K-step on distinct banks (40 * (4R + 2) is 16 mod 32)
+    static constexpr int CHS = X4 ? PLANE : XI * 256 + 16;
     static constexpr int XS_FLOATS = CC * CHS;                // one buffer of the input (or mask) tile
     static constexpr int WS_FLOATS = CC * KK * CB;            // one buffer of the filter slice
     static constexpr int BUF_FLOATS = XS_FLOATS * (MASK ? 2 : 1) + WS_FLOATS;
     static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+    static_assert(!X4 || (CHS % 32 == 16 && XI == 1), "X4 tile geometry");
 };
 
-template <int NCB, int R, int CC, bool MASK>
+template <int NCB, int R, int CC, bool MASK, bool X4>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
-    using C = DmaCfg<NCB, R, CC, MASK>;
+    using C = DmaCfg<NCB, R, CC, MASK, X4>;
     constexpr int KS = 3, PAD = 1, KK = 9, TH = C::TH, TW = C::TW;
     constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB, CHS = C::CHS, XI = C::XI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -547,10 +561,17 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < XI; ++k) {
             const int i = tid + k * 256;
-            const int ty = i / TCOLS, tx = i - ty * TCOLS;
-            const int gy = t.y0 + ty - PAD, gx = t.x0 + tx - PAD;
-            const bool ok = i < PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
+            if constexpr (X4) {
+                const int ty = i / (TCOLS / 4), q = i - ty * (TCOLS / 4);
+                const int gy = t.y0 + ty - PAD, gx = t.x0 - 4 + 4 * q;
+                const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
+            } else {
+                const int ty = i / TCOLS, tx = i - ty * TCOLS;
+                const int gy = t.y0 + ty - PAD, gx = t.x0 + tx - PAD;
+                const bool ok = i < PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
+            }
         }
     };
     struct Chunk {
@@ -585,22 +606,38 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
         const Chunk ck = locate(t.b, j);
         const __amdgpu_buffer_rsrc_t rx = plane_rsrc(ck.base, (unsigned)ck.cnt * plane_bytes);
         float* xs = xs_of(buf);
+        if constexpr (X4) {
+            if (tid < C::XN) {
 #pragma unroll
-        for (int c = 0; c < CC; ++c)
-#pragma unroll
-            for (int k = 0; k < XI; ++k)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs + c * CHS + k * 256 + wave * 64), 4,
-                                                         goff[k] + (unsigned)c * plane_bytes, 0, 0, 0);
-        if (MASK) {
-            const __amdgpu_buffer_rsrc_t rm =
-                plane_rsrc(a.mask + (long long)t.b * a.mask_bs + (long long)ck.cglob * HW, (unsigned)ck.cnt * plane_bytes);
-            float* ms = ms_of(buf);
+                for (int c = 0; c < CC; ++c)
+                    dma16(rx, xs + c * CHS + wave * 256, goff[0] + (unsigned)c * plane_bytes);
+            }
+        } else {
 #pragma unroll
             for (int c = 0; c < CC; ++c)
 #pragma unroll
                 for (int k = 0; k < XI; ++k)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_ptr_t)(ms + c * CHS + k * 256 + wave * 64), 4,
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs + c * CHS + k * 256 + wave * 64), 4,
                                                              goff[k] + (unsigned)c * plane_bytes, 0, 0, 0);
+        }
+        if (MASK) {
+            const __amdgpu_buffer_rsrc_t rm =
+                plane_rsrc(a.mask + (long long)t.b * a.mask_bs + (long long)ck.cglob * HW, (unsigned)ck.cnt * plane_bytes);
+            float* ms = ms_of(buf);
+            if constexpr (X4) {
+                if (tid < C::XN) {
+#pragma unroll
+                    for (int c = 0; c < CC; ++c)
+                        dma16(rm, ms + c * CHS + wave * 256, goff[0] + (unsigned)c * plane_bytes);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+#pragma unroll
+                    for (int k = 0; k < XI; ++k)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_ptr_t)(ms + c * CHS + k * 256 + wave * 64), 4,
+                                                                 goff[k] + (unsigned)c * plane_bytes, 0, 0, 0);
+            }
         }
         // filter rows cglob .. cglob+CC-1, columns cg*CB .. +CB-1: 16 bytes per lane
         const float* wsrc = a.wp + (long long)ck.cglob * KK * a.cout_pad + t.cg * CB;
@@ -618,8 +655,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
 
     auto mfma_chunk = [&](int cnt, int buf) {
         const int ngroups = (cnt + 3) / 4;
-        const float* xb = xs_of(buf) + kq * CHS + (wave * R) * TCOLS + r16;
-        const float* mb = ms_of(buf) + kq * CHS + (wave * R) * TCOLS + r16;
+        const float* xb = xs_of(buf) + kq * CHS + (wave * R) * TCOLS + r16 + C::XOFF;
+        const float* mb = ms_of(buf) + kq * CHS + (wave * R) * TCOLS + r16 + C::XOFF;
         const float* wb = ws_of(buf) + kq * KK * CB + r16;
         auto rd = [&](const float* xp, const float* mp, int off) {
             const float v = xp[off];
@@ -899,9 +936,9 @@ static int pick_rows(const ConvArgs& a, int cb) {
     return 1;
 }
 
-template <int NCB, int R, int CC, bool MASK>
+template <int NCB, int R, int CC, bool MASK, bool X4>
 static int launch_dma_m(ConvArgs& a, hipStream_t st) {
-    using C = DmaCfg<NCB, R, CC, MASK>;
+    using C = DmaCfg<NCB, R, CC, MASK, X4>;
     a.tiles_x = ceil_div(a.W, C::TW);
     a.tiles_y = ceil_div(a.H, C::TH);
     a.cgroups = ceil_div(a.cout, C::CB);
@@ -923,10 +960,10 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     a.prio_mode = 0;
     static int slots = 0;
     if (slots == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<NCB, R, CC, MASK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<NCB, R, CC, MASK, X4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         int per_cu = 0, dev = 0, cus = 256;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<NCB, R, CC, MASK>, 256, C::LDS_BYTES);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<NCB, R, CC, MASK, X4>, 256, C::LDS_BYTES);
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (per_cu < 1) per_cu = 1;
@@ -934,7 +971,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         slots = per_cu * cus;
     }
     const long long nblk = nt < slots ? nt : slots;
-    hipLaunchKernelGGL((conv_dma_kernel<NCB, R, CC, MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_dma_kernel<NCB, R, CC, MASK, X4>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
     if (a.ksplit > 1) {
         SplitReduceArgs r{};
         r.partial = a.partial;
@@ -958,7 +995,9 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
 // 3-4 workgroups stay resident per CU (measured 5-10 % faster than CC = 8 with 2 resident workgroups).
 template <int NCB, int R>
 static int launch_dma(ConvArgs& a, hipStream_t st) {
-    return a.mask ? launch_dma_m<NCB, R, 4, true>(a, st) : launch_dma_m<NCB, R, 4, false>(a, st);
+    static const int x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
+    if (x4 && a.vec_load) return a.mask ? launch_dma_m<NCB, R, 4, true, true>(a, st) : launch_dma_m<NCB, R, 4, false, true>(a, st);
+    return a.mask ? launch_dma_m<NCB, R, 4, true, false>(a, st) : launch_dma_m<NCB, R, 4, false, false>(a, st);
 }
 
 // The DMA generation wins on the large maps (rows >= 2: 2-8 % faster, 60 fewer VGPRs); the latency-bound
@@ -1144,6 +1183,10 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
     a.vec_store = (W % 4 == 0) ? 1 : 0;
     for (int i = 0; i < a.ndst; ++i)
         if (a.dst[i].p && ((reinterpret_cast<uintptr_t>(a.dst[i].p) & 15) || (a.dst[i].bs & 3))) a.vec_store = 0;
+    a.vec_load = (W % 4 == 0) ? 1 : 0;
+    for (int i = 0; i < a.nsrc; ++i)
+        if ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) || (a.src[i].bs & 3)) a.vec_load = 0;
+    if (mask && ((reinterpret_cast<uintptr_t>(mask) & 15) || (mask_bs & 3))) a.vec_load = 0;
     return conv_dispatch(a, K, (hipStream_t)stream);
 }
 
