@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libynet_hip.so")
+LIB_PATH = os.environ.get("YNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libynet_hip.so")   # override: A/B builds (tools/)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ynet_hip.h")
 
 c_fp = ctypes.c_void_p       # device pointers travel as plain addresses

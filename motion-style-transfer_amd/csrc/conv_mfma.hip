@@ -19,6 +19,9 @@
 #include "ynet_common.h"
 #include <stdlib.h>
 
+#ifndef YNET_DMA_SCHED
+#define YNET_DMA_SCHED 0      // pinned "reads, then MFMAs" groups: measured 0-5 % slower than hipcc's own schedule here
+#endif
 #ifndef YNET_CC_NARROW
 #define YNET_CC_NARROW 8      // input channels staged per chunk by the Cout <= 32 kernels
 #endif
@@ -692,6 +695,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
                         a_nxt[r][1] = rd(xn, mn, (r + kyn) * TCOLS + kxn + 16);
                     }
                 }
+#if YNET_DMA_SCHED
+                // pin "LDS reads of tap t+1 first, then the MFMAs of tap t": left alone the scheduler sinks
+                // reads to just before their first use and the wave then waits out the LDS latency
+                __builtin_amdgcn_sched_group_barrier(0x100, NCB + 2 * R * (MASK ? 2 : 1), 0);
+#endif
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -699,6 +707,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
                         acc[i][r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r][0], b_cur[i], acc[i][r][0], 0, 0, 0);
                         acc[i][r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r][1], b_cur[i], acc[i][r][1], 0, 0, 0);
                     }
+#if YNET_DMA_SCHED
+                __builtin_amdgcn_sched_group_barrier(0x8, 2 * NCB * R, 0);
+#endif
 #pragma unroll
                 for (int i = 0; i < NCB; ++i) b_cur[i] = b_nxt[i];
 #pragma unroll
@@ -732,7 +743,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
             if (dp == nullptr) continue;
             // the bias is read here, AFTER the barrier that already drained this wave's memory counter and
             // BEFORE the next DMAs are queued, so its wait costs one L2 round trip per tile and nothing else
-            const float bsv = (a.ksplit > 1 || a.bias == nullptr) ? 0.f : a.bias[co];
+            float bsv = (a.ksplit > 1 || a.bias == nullptr) ? 0.f : a.bias[co];
+            // consume the loaded value once, here: otherwise hipcc cannot prove the load finished at the
+            // control-flow merges below and puts s_waitcnt vmcnt(0) in front of EVERY predicated store, which
+            // also waits for the previous store's acknowledgement (16 serialized round trips per tile)
+            asm volatile("" : "+v"(bsv));
             const bool relu = a.relu && a.ksplit == 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {

@@ -17,6 +17,8 @@
 // Pixels are split over the 4 waves (summed through LDS in wave order) and over `nsplit` workgroups
 // (partials reduced by a second kernel in fixed order): bitwise reproducible, no float atomics.
 #include "ynet_common.h"
+#include <stdlib.h>
+#include <stdio.h>
 
 struct WgradArgs {
     YSrc src[YNET_MAX_SRC];   // x = virtual concat of the sources
@@ -238,21 +240,299 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
     }
 }
 
-// out[i] = sum_s partial[s][i], fixed order
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, long long n,
-                                       int nsplit) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int s = 0;
-        for (; s + 4 <= nsplit; s += 4) {
-            s0 += partial[(long long)s * n + i];
-            s1 += partial[(long long)(s + 1) * n + i];
-            s2 += partial[(long long)(s + 2) * n + i];
-            s3 += partial[(long long)(s + 3) * n + i];
+
+// ================================================================================================
+// LDS-DMA generation of the 3x3 filter gradient (v_mfma_f32_16x16x4_f32).
+//   * tiles of 2 x 32 pixels; x (with halo, as aligned 16-byte quads: rows of 40 floats), dy and the
+//     ReLU mask go global -> LDS by `buffer_load_dwordx4 ... lds` into the OTHER half of a double
+//     buffer while the MFMA loop reads this half: one barrier per tile, no staging registers;
+//   * the four waves split the OUTPUT (16 co x 16 ci x 9 taps = 36 accumulator registers each), not the
+//     pixels, so nothing is summed across waves when the block is a full 32 x 32; a partial block
+//     (Cin = 14, Cout = 12 ...) hands its spare waves every 2nd / 4th K-step instead and those are
+//     summed through LDS in fixed order;
+//   * K = 4 consecutive pixels per instruction: lane (r16, kq) reads channel r16, pixel 4s + kq; channel
+//     strides are 4 mod 32 floats, so the 64 lanes of an operand read cover every bank exactly twice;
+//   * the mask is applied to the one A operand per K-step (second LDS read + v_cndmask); db is a VALU
+//     sum of that same operand.
+// Needs W % 4 == 0 and 16-byte aligned planes; everything else stays on wgrad_mfma_kernel.
+// ================================================================================================
+typedef __attribute__((address_space(3))) void* wg_lds_ptr_t;
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t r, const float* lds, unsigned byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (wg_lds_ptr_t)lds, 16, byte_off, 0, 0, 0);
+}
+
+template <bool MASK>
+struct WgDmaCfg {
+    static constexpr int TH = 2, TW = 32, TROWS = TH + 2, TCOLS = TW + 8;
+    static constexpr int XQ = TROWS * TCOLS / 4 + 1;     // quads per x channel (+1 pad quad): 41
+    static constexpr int XCH = XQ * 4;                   // 164 = 4 mod 32
+    static constexpr int DQ = TH * TW / 4 + 1;           // quads per dy channel (+1 pad quad): 17
+    static constexpr int DCH = DQ * 4;                   // 68 = 4 mod 32
+    static constexpr int XS = 32 * XCH, DS = 32 * DCH;
+    static constexpr int BUF = XS + DS * (MASK ? 2 : 1);
+    static constexpr int LDS_BYTES = 2 * BUF * 4;
+    static constexpr int XI = (32 * XQ + 255) / 256;     // x DMA instructions per thread per tile (6)
+    static constexpr int DI = (32 * DQ + 255) / 256;     // dy (and mask) DMA instructions per thread per tile (3)
+    static constexpr int KSTEPS = TH * TW / 4;
+    static_assert(XCH % 32 == 4 && DCH % 32 == 4, "bank-conflict-free channel strides");
+    static_assert(3 * 37 * 64 <= 2 * BUF, "cross-wave reduction scratch fits");
+};
+
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
+    using C = WgDmaCfg<MASK>;
+    constexpr int TH = C::TH, TW = C::TW, TCOLS = C::TCOLS, XQ = C::XQ, XCH = C::XCH, DQ = C::DQ, DCH = C::DCH;
+    constexpr int XI = C::XI, DI = C::DI, KK = 9;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto xs_of = [&](int b) { return smem + b * C::BUF; };
+    auto ds_of = [&](int b) { return smem + b * C::BUF + C::XS; };
+    auto ms_of = [&](int b) { return smem + b * C::BUF + C::XS + C::DS; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    int bid = blockIdx.x;
+    const int cib = bid % a.ci_blks;
+    bid /= a.ci_blks;
+    const int cob = bid % a.co_blks;
+    const int split = bid / a.co_blks;
+    const int HW = __builtin_amdgcn_readfirstlane(a.H * a.W);
+    const unsigned plane_bytes = (unsigned)HW * 4u;
+    const int ci0 = cib * 32, co0 = cob * 32;
+    const int ncib = min(32, a.cin - ci0), nco = min(32, a.cout - co0);
+    const bool want_bias = (a.partial_b != nullptr) && cib == 0;
+    // wave roles: (16-wide co block, 16-wide ci block, K-step residue)
+    const int cbN = nco > 16 ? 2 : 1, ibN = ncib > 16 ? 2 : 1, rpN = 4 / (cbN * ibN);
+    const int cb = wave % cbN, ib = (wave / cbN) % ibN, rp = wave / (cbN * ibN);
+
+    // ---- tile-independent part of the DMA addressing
+    // x: LDS image = 32 channels x XQ quads, linear in the quad index q = tid + 256 k
+    int xsrc[XI];            // source of the quad's channel (-1: nothing to fetch)
+    unsigned xcoff[XI];      // byte offset of the channel's plane inside that source's image
+    int xrow[XI], xcol[XI];  // tile row (0 .. TH+1) and first column (-4, 0, 4 ...) of the quad
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const int q = tid + k * 256;
+        const int ch = q / XQ, within = q - ch * XQ;
+        xrow[k] = within / (TCOLS / 4);
+        xcol[k] = (within - xrow[k] * (TCOLS / 4)) * 4 - 4;
+        int c = ci0 + ch, sid = -1;
+        unsigned off = 0;
+        if (q < 32 * XQ && within < XQ - 1 && ch < ncib) {
+#pragma unroll
+            for (int s = 0; s < YNET_MAX_SRC; ++s) {
+                if (sid < 0 && s < a.nsrc) {
+                    if (c < a.src[s].c) {
+                        sid = s;
+                        off = (unsigned)c * plane_bytes;
+                    } else {
+                        c -= a.src[s].c;
+                    }
+                }
+            }
         }
-        for (; s < nsplit; ++s) s0 += partial[(long long)s * n + i];
-        out[i] = (s0 + s1) + (s2 + s3);
+        xsrc[k] = sid;
+        xcoff[k] = off;
+    }
+    unsigned dcoff[DI];
+    int drow[DI], dcol[DI];  // drow < 0: pad quad / past the image
+#pragma unroll
+    for (int k = 0; k < DI; ++k) {
+        const int q = tid + k * 256;
+        const int ch = q / DQ, within = q - ch * DQ;
+        const bool ok = q < 32 * DQ && within < DQ - 1;
+        drow[k] = ok ? within / (TW / 4) : -1;
+        dcol[k] = (within % (TW / 4)) * 4;
+        dcoff[k] = (unsigned)ch * plane_bytes;       // channels >= nco fall outside the descriptor: zero
+    }
+
+    auto decode = [&](int t) {
+        WgTile c;
+        c.x0 = (t % a.tiles_x) * TW;
+        t /= a.tiles_x;
+        c.y0 = (t % a.tiles_y) * TH;
+        c.b = t / a.tiles_y;
+        return c;
+    };
+    auto issue = [&](const WgTile& t, int buf) {
+        float* xs = xs_of(buf);
+        unsigned xo[XI];
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            const int gy = t.y0 + xrow[k] - 1, gx = t.x0 + xcol[k];
+            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            xo[k] = ok ? xcoff[k] + (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
+        }
+#pragma unroll
+        for (int s = 0; s < YNET_MAX_SRC; ++s) {
+            if (s < a.nsrc) {
+                const __amdgpu_buffer_rsrc_t r = wg_rsrc(a.src[s].p + (long long)t.b * a.src[s].bs, (unsigned)a.src[s].c * plane_bytes);
+#pragma unroll
+                for (int k = 0; k < XI; ++k)
+                    if (xsrc[k] == s) wg_dma16(r, xs + (k * 256 + wave * 64) * 4, xo[k]);
+            }
+        }
+        unsigned dofs[DI];
+#pragma unroll
+        for (int k = 0; k < DI; ++k) {
+            const int gy = t.y0 + drow[k], gx = t.x0 + dcol[k];
+            const bool ok = drow[k] >= 0 && gy < a.H && gx < a.W;
+            dofs[k] = ok ? dcoff[k] + (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
+        }
+        {
+            const __amdgpu_buffer_rsrc_t r = wg_rsrc(a.dy + (long long)t.b * a.dy_bs + (long long)co0 * HW, (unsigned)nco * plane_bytes);
+            float* ds = ds_of(buf);
+#pragma unroll
+            for (int k = 0; k < DI; ++k)
+                if (tid + k * 256 < 32 * DQ) wg_dma16(r, ds + (k * 256 + wave * 64) * 4, dofs[k]);
+        }
+        if (MASK) {
+            const __amdgpu_buffer_rsrc_t r = wg_rsrc(a.mask + (long long)t.b * a.mask_bs + (long long)co0 * HW, (unsigned)nco * plane_bytes);
+            float* ms = ms_of(buf);
+#pragma unroll
+            for (int k = 0; k < DI; ++k)
+                if (tid + k * 256 < 32 * DQ) wg_dma16(r, ms + (k * 256 + wave * 64) * 4, dofs[k]);
+        }
+    };
+
+    f32x4 acc[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const int xoff = (ib * 16 + r16) * XCH + 3 + kq;     // tile column 0 (gx = x0-1) sits at LDS column 3
+    const int doff = (cb * 16 + r16) * DCH + kq;
+    auto compute = [&](int buf) {
+        const float* xb = xs_of(buf) + xoff;
+        const float* ab = ds_of(buf) + doff;
+        const float* mb = ms_of(buf) + doff;
+        auto rd_a = [&](int s) {
+            const float v = ab[4 * s];          // rows are 32 pixels = 8 K-steps: 4 s is the pixel offset in the tile
+            if (MASK) return mb[4 * s] > 0.f ? v : 0.f;
+            return v;
+        };
+        auto rd_b = [&](int s, float* b) {
+            const float* p = xb + (s >> 3) * TCOLS + (s & 7) * 4;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) b[ky * 3 + kx] = p[ky * TCOLS + kx];
+        };
+        float a_cur, b_cur[KK], a_nxt, b_nxt[KK];
+        int s = rp;
+        a_cur = rd_a(s);
+        rd_b(s, b_cur);
+        // consume the first operands here: with reads still pending at the loop header hipcc waits for ALL LDS
+        // reads (also the prefetch of the next K-step) in front of the second MFMA of every iteration
+        asm volatile("" : "+v"(a_cur));
+#pragma unroll
+        for (int t = 0; t < KK; ++t) asm volatile("" : "+v"(b_cur[t]));
+        // one K-step: queue the LDS reads of the following step into (a_n, b_n), then the 9 MFMAs of (a_c, b_c)
+        auto step = [&](int sn, float a_c, const float* b_c, float& a_n, float* b_n) {
+            const float v = ab[4 * sn];
+            float m = 1.f;
+            if (MASK) m = mb[4 * sn];
+            rd_b(sn, b_n);
+            __builtin_amdgcn_sched_barrier(0);      // nothing moves across: reads of the next step, THEN the MFMAs of this one
+#pragma unroll
+            for (int t = 0; t < KK; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_n = m > 0.f ? v : 0.f;        // VALU work on the fresh reads goes behind the MFMAs (their data has landed by then)
+            bsum += a_c;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // a wave runs KSTEPS / rpN = 16, 8 or 4 steps: two per iteration, the register sets swapping roles
+        // (the last step re-reads itself: no branch in the loop body)
+#pragma unroll 1
+        for (; s < C::KSTEPS; s += 2 * rpN) {
+            step(s + rpN, a_cur, b_cur, a_nxt, b_nxt);
+            step(s + 2 * rpN < C::KSTEPS ? s + 2 * rpN : s + rpN, a_nxt, b_nxt, a_cur, b_cur);
+        }
+    };
+
+    int tile = split, buf = 0;
+    if (tile < a.ntiles) issue(decode(tile), 0);
+    for (; tile < a.ntiles; tile += a.nsplit) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + a.nsplit < a.ntiles) issue(decode(tile + a.nsplit), buf ^ 1);
+        compute(buf);
+        buf ^= 1;
+    }
+
+    // ---- K-step residues of a partial block: waves rp = 1.. hand their sums to wave rp = 0 (fixed order)
+    if (rpN > 1) {
+        float* red = smem;
+        __syncthreads();
+        if (rp > 0) {
+            float* w = red + (wave - cbN * ibN) * 37 * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < KK; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[(t * 4 + e) * 64] = acc[t][e];
+            w[36 * 64] = bsum;
+        }
+        __syncthreads();
+        if (rp == 0) {
+            for (int q = 1; q < rpN; ++q) {
+                const float* w = red + (cb + cbN * (ib + ibN * q) - cbN * ibN) * 37 * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < KK; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][e] += w[(t * 4 + e) * 64];
+                bsum += w[36 * 64];
+            }
+        }
+    }
+    if (rp == 0) {
+        float* pw = a.partial_w + (long long)split * a.cout * a.cin * KK;
+        const int ci = ib * 16 + r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = cb * 16 + 4 * kq + e;
+            if (co < nco && ci < ncib) {
+#pragma unroll
+                for (int t = 0; t < KK; ++t) pw[((long long)(co0 + co) * a.cin + ci0 + ci) * KK + t] = acc[t][e];
+            }
+        }
+        if (want_bias && ib == 0) {          // lane (r16, kq) summed pixels = kq mod 4 of channel cb*16 + r16
+            float v = bsum;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int co = cb * 16 + r16;
+            if (kq == 0 && co < nco) a.partial_b[(long long)split * a.cout + co0 + co] = v;
+        }
+    }
+}
+
+// out[i] = sum_s partial[s][i] in a fixed order: thread (o, g) of a block sums the splits s = g mod 8 of output
+// base + o (four independent chains, 128-byte coalesced rows), the eight g are then added in order through LDS.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              long long n, int nsplit) {
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (long long base = blockIdx.x * 32ll; base < n; base += (long long)gridDim.x * 32) {
+        const long long i = base + o;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (i < n) {
+            int s = g;
+            for (; s + 24 < nsplit; s += 32) {
+                s0 += partial[(long long)s * n + i];
+                s1 += partial[(long long)(s + 8) * n + i];
+                s2 += partial[(long long)(s + 16) * n + i];
+                s3 += partial[(long long)(s + 24) * n + i];
+            }
+            for (; s < nsplit; s += 8) s0 += partial[(long long)s * n + i];
+        }
+        red[g][o] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (g == 0 && i < n) {
+            float t = red[0][o];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += red[q][o];
+            out[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -270,8 +550,50 @@ static int launch_wgrad_m(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     int rc = ynet_check_launch("conv2d_wgrad");
     if (rc) return rc;
     const long long nw = (long long)a.cout * a.cin * C::KK;
-    int grid = (int)((nw + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    int grid = (int)((nw + 31) / 32);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, a.partial_w, dw, nw, a.nsplit);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.partial_b, db, (long long)a.cout, a.nsplit);
+    return ynet_check_launch("conv2d_wgrad(reduce)");
+}
+
+template <bool MASK>
+static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) {
+    using C = WgDmaCfg<MASK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<MASK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+        if (getenv("YNET_DEBUG_OCC")) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_dma_kernel<MASK>, 256, C::LDS_BYTES);
+            fprintf(stderr, "wgrad_dma_kernel<%d>: %d bytes of LDS, %d workgroups per CU\n", (int)MASK, C::LDS_BYTES, per_cu);
+        }
+    }
+    const long long nblk = (long long)a.nsplit * a.co_blks * a.ci_blks;
+    static const bool timing = getenv("YNET_WGRAD_TIME") != nullptr;     // development aid: per-launch time of the main kernel
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, st);
+    }
+    hipLaunchKernelGGL((wgrad_dma_kernel<MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    if (timing) {
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "wgrad_dma_kernel<%d> nsplit %d tiles %d blocks %lld: %.1f us\n", (int)MASK, a.nsplit, a.ntiles, nblk, ms * 1e3f);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    int rc = ynet_check_launch("conv2d_wgrad");
+    if (rc) return rc;
+    const long long nw = (long long)a.cout * a.cin * 9;
+    int grid = (int)((nw + 31) / 32);
+    if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, a.partial_w, dw, nw, a.nsplit);
     if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.partial_b, db, (long long)a.cout, a.nsplit);
     return ynet_check_launch("conv2d_wgrad(reduce)");
@@ -285,8 +607,14 @@ static int launch_wgrad(WgradArgs& a, float* dw, float* db, hipStream_t st) {
 
 static int wgrad_cib(int K) { return K == 5 ? 6 : 32; }
 
-static int wgrad_plan(int B, int H, int W, int cout, int cin, int K, int* nsplit_out) {
-    const int tiles = B * ceil_div(H, 4) * ceil_div(W, 32);
+// the 3x3 DMA path (2-row tiles) needs W % 4 == 0; alignment of the planes is checked per call
+static bool wgrad_dma_shape(int W, int K) {
+    static const int on = getenv("YNET_WGRAD_DMA") ? atoi(getenv("YNET_WGRAD_DMA")) : 1;
+    return on && K == 3 && (W % 4) == 0;
+}
+
+static int wgrad_plan(int B, int H, int W, int cout, int cin, int K, int th, int* nsplit_out) {
+    const int tiles = B * ceil_div(H, th) * ceil_div(W, 32);
     const int blocks_per_split = ceil_div(cout, 32) * ceil_div(cin, wgrad_cib(K));
     int nsplit = 512 / blocks_per_split;       // ~2 resident workgroups per CU
     if (nsplit < 1) nsplit = 1;
@@ -300,9 +628,10 @@ extern "C" {
 
 // floats of workspace ynet_conv2d_wgrad needs for this problem
 long long ynet_conv2d_wgrad_workspace_floats(int B, int H, int W, int cout, int cin, int K) {
-    int nsplit;
-    wgrad_plan(B, H, W, cout, cin, K, &nsplit);
-    return (long long)nsplit * ((long long)cout * cin * K * K + cout);
+    int n2 = 0, n4 = 0;     // either tile height may be chosen at call time (alignment): size for the larger split
+    wgrad_plan(B, H, W, cout, cin, K, 2, &n2);
+    wgrad_plan(B, H, W, cout, cin, K, 4, &n4);
+    return (long long)(n2 > n4 ? n2 : n4) * ((long long)cout * cin * K * K + cout);
 }
 
 int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
@@ -328,13 +657,24 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
     a.H = H;
     a.W = W;
     a.cout = cout;
+    bool dma = wgrad_dma_shape(W, K);
+    {
+        auto misaligned = [](const void* p, long long bs) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0 || (bs & 3) != 0; };
+        for (int i = 0; i < nsrc; ++i) dma = dma && !misaligned(src[i], src_bs[i]);
+        dma = dma && !misaligned(dy, dy_bs) && (mask == nullptr || !misaligned(mask, mask_bs));
+    }
+    const int th = dma ? 2 : 4;
     a.tiles_x = ceil_div(W, 32);
-    a.tiles_y = ceil_div(H, 4);
-    a.ntiles = wgrad_plan(B, H, W, cout, a.cin, K, &a.nsplit);
+    a.tiles_y = ceil_div(H, th);
+    a.ntiles = wgrad_plan(B, H, W, cout, a.cin, K, th, &a.nsplit);
     a.co_blks = ceil_div(cout, 32);
     a.partial_w = workspace;
     a.partial_b = db ? workspace + (long long)a.nsplit * cout * a.cin * K * K : nullptr;
     hipStream_t st = (hipStream_t)stream;
+    if (dma) {
+        a.ci_blks = ceil_div(a.cin, 32);
+        return mask ? launch_wgrad_dma<true>(a, dw, db, st) : launch_wgrad_dma<false>(a, dw, db, st);
+    }
     switch (K) {
         case 1: return launch_wgrad<1>(a, dw, db, st);
         case 3: return launch_wgrad<3>(a, dw, db, st);
