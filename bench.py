@@ -87,7 +87,8 @@ class ConvTimer:
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             if dma:
                 cc = 4
-                name = f"conv_dma_kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}>"
+                x4 = (plan >> 18) & 1
+                name = f"conv_dma_kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, {'true' if x4 else 'false'}>"
             else:
                 name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}, "
                         f"{'true' if m16 else 'false'}>")

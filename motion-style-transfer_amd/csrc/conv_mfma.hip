@@ -18,6 +18,7 @@
 // workgroups per CU overlap one group's staging with another's MFMAs.
 #include "ynet_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #ifndef YNET_DMA_SCHED
 #define YNET_DMA_SCHED 0      // pinned "reads, then MFMAs" groups: measured 0-5 % slower than hipcc's own schedule here
@@ -518,8 +519,31 @@ struct DmaCfg {
     static_assert(!X4 || (CHS % 32 == 16 && XI == 1), "X4 tile geometry");
 };
 
+// Kernel arguments re-read through an opaque pointer to the kernarg segment: the loads are issued (s_load) where
+// they are written instead of being hoisted to the kernel entry and kept in SGPRs for its whole life.  With
+// every ConvArgs field live the kernel needs > 102 SGPRs and hipcc spills them to VGPR lanes (v_readlane /
+// v_writelane); a vector-ALU instruction of a wave whose SIMD neighbours stream MFMAs waits for ~1 MFMA slot
+// per neighbour (tools/valu_under_mfma.hip: 38 / 70 / 100 cycles per VALU op with 1 / 2 / 3 MFMA waves on the
+// SIMD, 0.8 cycles per SALU op regardless), so the control code of this kernel is written to stay scalar.
+typedef const __attribute__((address_space(4))) ConvArgs* conv_kargs_t;
+__device__ __forceinline__ conv_kargs_t conv_kargs() {
+    conv_kargs_t p = (conv_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, unsigned lds_byte, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(uintptr_t)lds_byte, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void dma4s(__amdgpu_buffer_rsrc_t r, unsigned lds_byte, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(uintptr_t)lds_byte, 4, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sgpr_rsrc(const void* p, unsigned bytes) {     // p, bytes: scalar values
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0u, 0x00020000);
+}
+
 template <int NCB, int R, int CC, bool MASK, bool X4>
-__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
     using C = DmaCfg<NCB, R, CC, MASK, X4>;
     constexpr int KS = 3, PAD = 1, KK = 9, TH = C::TH, TW = C::TW;
     constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB, CHS = C::CHS, XI = C::XI;
@@ -528,37 +552,44 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     auto xs_of = [&](int b) { return smem + b * C::BUF_FLOATS; };
     auto ms_of = [&](int b) { return smem + b * C::BUF_FLOATS + C::XS_FLOATS; };
     auto ws_of = [&](int b) { return smem + b * C::BUF_FLOATS + C::XS_FLOATS * (MASK ? 2 : 1); };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);     // byte address of the LDS image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
-    const int HW = __builtin_amdgcn_readfirstlane(a.H * a.W);
+    const conv_kargs_t ka = conv_kargs();
+    const int H = ka->H, W = ka->W;
+    const int HW = H * W;
     const unsigned plane_bytes = (unsigned)HW * 4u;
+    const int ksplit = ka->ksplit, cps = ka->cps, cgroups = ka->cgroups, tiles_x = ka->tiles_x, tiles_y = ka->tiles_y;
+    const int nsrc = ka->nsrc;
+    const unsigned wrow_bytes = (unsigned)ka->cout_pad * 4u;
 
-    const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
-    const int per_xcd = (a.ntiles + 7) >> 3;
+    const bool xcd_walk = (gridDim.x & 7) == 0 && ka->ntiles >= (int)gridDim.x;
+    const int per_xcd = (ka->ntiles + 7) >> 3;
     const int gstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
     const int tile_first = xcd_walk ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int ntiles = xcd_walk ? min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : a.ntiles;
+    const int ntiles = xcd_walk ? min(ka->ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : ka->ntiles;
     int nchunks = 0;
 #pragma unroll
     for (int s = 0; s < YNET_MAX_SRC; ++s)
-        if (s < a.nsrc) nchunks += (a.src[s].c + CC - 1) / CC;
-    auto item_chunks = [&](const TileCoord& t) { return min(a.cps, nchunks - t.ks * a.cps); };
+        if (s < nsrc) nchunks += (ka->src[s].c + CC - 1) / CC;
+    auto item_chunks = [&](const TileCoord& t) { return min(cps, nchunks - t.ks * cps); };
     auto decode = [&](int t) {
         TileCoord c;
-        c.ks = t % a.ksplit;
-        t /= a.ksplit;
-        c.cg = t % a.cgroups;
-        t /= a.cgroups;
-        c.x0 = (t % a.tiles_x) * TW;
-        t /= a.tiles_x;
-        c.y0 = (t % a.tiles_y) * TH;
-        c.b = t / a.tiles_y;
+        c.ks = t % ksplit;
+        t /= ksplit;
+        c.cg = t % cgroups;
+        t /= cgroups;
+        c.x0 = (t % tiles_x) * TW;
+        t /= tiles_x;
+        c.y0 = (t % tiles_y) * TH;
+        c.b = t / tiles_y;
         return c;
     };
 
     f32x4 acc[NCB][R][2];
+    float bias_r[NCB];           // bias of the tile whose first chunk was queued last (0 without a bias / under ksplit)
     unsigned goff[XI];
     auto set_goff = [&](const TileCoord& t) {
 #pragma unroll
@@ -567,92 +598,109 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
             if constexpr (X4) {
                 const int ty = i / (TCOLS / 4), q = i - ty * (TCOLS / 4);
                 const int gy = t.y0 + ty - PAD, gx = t.x0 - 4 + 4 * q;
-                const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                goff[k] = ok ? (unsigned)(gy * W + gx) * 4u : 0x80000000u;
             } else {
                 const int ty = i / TCOLS, tx = i - ty * TCOLS;
                 const int gy = t.y0 + ty - PAD, gx = t.x0 + tx - PAD;
-                const bool ok = i < PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                goff[k] = ok ? (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
+                const bool ok = i < PLANE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                goff[k] = ok ? (unsigned)(gy * W + gx) * 4u : 0x80000000u;
             }
         }
     };
-    struct Chunk {
-        const float* base;
-        int cnt, cglob;
-    };
-    auto locate = [&](int b, int j) {
-        Chunk c{nullptr, 0, 0};
-        int start = 0;
-#pragma unroll
-        for (int s = 0; s < YNET_MAX_SRC; ++s) {
-            if (c.base == nullptr && s < a.nsrc) {
-                const int n = (a.src[s].c + CC - 1) / CC;
-                if (j < n) {
-                    c.cnt = min(CC, a.src[s].c - j * CC);
-                    c.cglob = start + j * CC;
-                    c.base = a.src[s].p + (long long)(a.src[s].bmod > 0 ? b % a.src[s].bmod : b) * a.src[s].bs + (long long)(j * CC) * HW;
-                } else {
-                    j -= n;
-                    start += a.src[s].c;
-                }
-            }
-        }
-        return c;
-    };
+    // per-lane byte offsets of the filter quads inside a chunk's filter slice (the same for every chunk)
     constexpr int ROW4 = CB / 4;
     constexpr int WN = CC * KK * ROW4;                 // filter float4 per chunk
     constexpr int WI = (WN + 255) / 256;
-    const unsigned wrow_bytes = (unsigned)a.cout_pad * 4u;
-    // issue the DMA of chunk j of tile t into buffer `buf`
-    auto dma_chunk = [&](const TileCoord& t, int j, int buf) {
-        const Chunk ck = locate(t.b, j);
-        const __amdgpu_buffer_rsrc_t rx = plane_rsrc(ck.base, (unsigned)ck.cnt * plane_bytes);
-        float* xs = xs_of(buf);
+    unsigned woff[WI];
+#pragma unroll
+    for (int k = 0; k < WI; ++k) {
+        const int i = tid + k * 256;
+        const int row = i / ROW4, j4 = i - row * ROW4;
+        woff[k] = i < WN ? (unsigned)row * wrow_bytes + (unsigned)j4 * 16u : 0x80000000u;
+    }
+    const unsigned oob = 0x80000000u + (unsigned)(lane & 0);      // a VGPR holding the out-of-range marker
+
+    // valid channels of chunk j of the (virtual) concatenation; scalar code only
+    auto chunk_cnt = [&](int j) {
+        const conv_kargs_t kb = conv_kargs();
+        int s = 0, cs = kb->src[0].c;
+        while (s + 1 < nsrc && j >= (cs + CC - 1) / CC) {
+            j -= (cs + CC - 1) / CC;
+            ++s;
+            cs = kb->src[s].c;
+        }
+        return min(CC, cs - j * CC);
+    };
+    // issue the DMA of chunk j of tile t into buffer `buf` (and, with the tile's first chunk, the load of its bias)
+    auto dma_chunk = [&](const TileCoord& t, int j, int buf, bool first) {
+        const conv_kargs_t kb = conv_kargs();
+        int s = 0, cs = kb->src[0].c, start = 0;
+        while (s + 1 < nsrc && j >= (cs + CC - 1) / CC) {
+            j -= (cs + CC - 1) / CC;
+            start += cs;
+            ++s;
+            cs = kb->src[s].c;
+        }
+        const int cnt = min(CC, cs - j * CC), cglob = start + j * CC;
+        const int bmod = kb->src[s].bmod;
+        const float* base = kb->src[s].p + (long long)(bmod > 0 ? t.b % bmod : t.b) * kb->src[s].bs + (long long)(j * CC) * HW;
+        const __amdgpu_buffer_rsrc_t rx = sgpr_rsrc(base, (unsigned)cnt * plane_bytes);
+        const unsigned xdst = lds0 + (unsigned)(buf * C::BUF_FLOATS) * 4u;
+        // channels past the source's end (cnt < CC) are zero-filled through the marker offset
         if constexpr (X4) {
             if (tid < C::XN) {
 #pragma unroll
-                for (int c = 0; c < CC; ++c)
-                    dma16(rx, xs + c * CHS + wave * 256, goff[0] + (unsigned)c * plane_bytes);
+                for (int c = 0; c < CC; ++c) {
+                    if (c < cnt) dma16s(rx, xdst + (unsigned)(c * CHS + wave * 256) * 4u, goff[0], (unsigned)c * plane_bytes);
+                    else dma16s(rx, xdst + (unsigned)(c * CHS + wave * 256) * 4u, oob, 0u);
+                }
             }
         } else {
 #pragma unroll
             for (int c = 0; c < CC; ++c)
 #pragma unroll
-                for (int k = 0; k < XI; ++k)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xs + c * CHS + k * 256 + wave * 64), 4,
-                                                             goff[k] + (unsigned)c * plane_bytes, 0, 0, 0);
+                for (int k = 0; k < XI; ++k) {
+                    if (c < cnt) dma4s(rx, xdst + (unsigned)(c * CHS + k * 256 + wave * 64) * 4u, goff[k], (unsigned)c * plane_bytes);
+                    else dma4s(rx, xdst + (unsigned)(c * CHS + k * 256 + wave * 64) * 4u, oob, 0u);
+                }
         }
         if (MASK) {
             const __amdgpu_buffer_rsrc_t rm =
-                plane_rsrc(a.mask + (long long)t.b * a.mask_bs + (long long)ck.cglob * HW, (unsigned)ck.cnt * plane_bytes);
-            float* ms = ms_of(buf);
+                sgpr_rsrc(kb->mask + (long long)t.b * kb->mask_bs + (long long)cglob * HW, (unsigned)cnt * plane_bytes);
+            const unsigned mdst = xdst + (unsigned)C::XS_FLOATS * 4u;
             if constexpr (X4) {
                 if (tid < C::XN) {
 #pragma unroll
-                    for (int c = 0; c < CC; ++c)
-                        dma16(rm, ms + c * CHS + wave * 256, goff[0] + (unsigned)c * plane_bytes);
+                    for (int c = 0; c < CC; ++c) {
+                        if (c < cnt) dma16s(rm, mdst + (unsigned)(c * CHS + wave * 256) * 4u, goff[0], (unsigned)c * plane_bytes);
+                        else dma16s(rm, mdst + (unsigned)(c * CHS + wave * 256) * 4u, oob, 0u);
+                    }
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < CC; ++c)
 #pragma unroll
-                    for (int k = 0; k < XI; ++k)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_ptr_t)(ms + c * CHS + k * 256 + wave * 64), 4,
-                                                                 goff[k] + (unsigned)c * plane_bytes, 0, 0, 0);
+                    for (int k = 0; k < XI; ++k) {
+                        if (c < cnt) dma4s(rm, mdst + (unsigned)(c * CHS + k * 256 + wave * 64) * 4u, goff[k], (unsigned)c * plane_bytes);
+                        else dma4s(rm, mdst + (unsigned)(c * CHS + k * 256 + wave * 64) * 4u, oob, 0u);
+                    }
             }
         }
         // filter rows cglob .. cglob+CC-1, columns cg*CB .. +CB-1: 16 bytes per lane
-        const float* wsrc = a.wp + (long long)ck.cglob * KK * a.cout_pad + t.cg * CB;
-        const __amdgpu_buffer_rsrc_t rw = plane_rsrc(wsrc, (unsigned)(CC * KK) * wrow_bytes);
-        float* ws = ws_of(buf);
+        const float* wsrc = kb->wp + (long long)cglob * KK * (long long)(wrow_bytes / 4u) + t.cg * CB;
+        const __amdgpu_buffer_rsrc_t rw = sgpr_rsrc(wsrc, (unsigned)(CC * KK) * wrow_bytes);
+        const unsigned wdst = xdst + (unsigned)(C::XS_FLOATS * (MASK ? 2 : 1)) * 4u;
 #pragma unroll
-        for (int k = 0; k < WI; ++k) {
-            const int i = tid + k * 256;
-            const int row = i / ROW4, j4 = i - row * ROW4;
-            if (i < WN)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws + (k * 256 + wave * 64) * 4), 16,
-                                                         (unsigned)row * wrow_bytes + (unsigned)j4 * 16u, 0, 0, 0);
+        for (int k = 0; k < WI; ++k)
+            if (tid + k * 256 < WN) dma16s(rw, wdst + (unsigned)(k * 256 + wave * 64) * 16u, woff[k], 0u);
+        if (first) {
+            // range check: channels >= cout read 0; no bias (dgrad) or a split channel loop: a zero-size buffer
+            const float* bp = ksplit > 1 ? nullptr : kb->bias;
+            const __amdgpu_buffer_rsrc_t rb = sgpr_rsrc(bp, (unsigned)kb->cout * 4u);
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+                bias_r[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(i * 16 + r16) * 4u, (unsigned)(t.cg * CB) * 4u, 0));
         }
     };
 
@@ -695,11 +743,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
                         a_nxt[r][1] = rd(xn, mn, (r + kyn) * TCOLS + kxn + 16);
                     }
                 }
-#if YNET_DMA_SCHED
-                // pin "LDS reads of tap t+1 first, then the MFMAs of tap t": left alone the scheduler sinks
-                // reads to just before their first use and the wave then waits out the LDS latency
-                __builtin_amdgcn_sched_group_barrier(0x100, NCB + 2 * R * (MASK ? 2 : 1), 0);
-#endif
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -707,9 +750,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
                         acc[i][r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r][0], b_cur[i], acc[i][r][0], 0, 0, 0);
                         acc[i][r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r][1], b_cur[i], acc[i][r][1], 0, 0, 0);
                     }
-#if YNET_DMA_SCHED
-                __builtin_amdgcn_sched_group_barrier(0x8, 2 * NCB * R, 0);
-#endif
 #pragma unroll
                 for (int i = 0; i < NCB; ++i) b_cur[i] = b_nxt[i];
 #pragma unroll
@@ -721,50 +761,63 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
         }
     };
 
-    const int d0 = a.dst[0].c, d1 = d0 + (a.ndst > 1 ? a.dst[1].c : 0), d2 = d1 + (a.ndst > 2 ? a.dst[2].c : 0);
+    // Epilogue.  D = pixels x cout: lane (r16, kq) owns output channel cg*CB + 16 i + r16 and, in acc[i][r][g],
+    // the four consecutive pixels x0 + 16 g + 4 kq .. +3 of row y0 + wave*R + r -> one 16-byte buffer store each.
+    // The bias is already in the accumulators.  Per destination the descriptor covers exactly its channels of
+    // image b, the per-lane offset carries (channel - first channel of the destination) and the column (lanes of
+    // another destination, of channels >= cout, or of columns >= W fall outside the descriptor and are dropped by
+    // the range check), the row goes into the scalar offset: ~10 vector-ALU instructions per destination.
     auto epilogue = [&](const TileCoord& t) {
+        const conv_kargs_t ke = conv_kargs();
+        if (ke->relu && ksplit == 1) {
 #pragma unroll
-        for (int i = 0; i < NCB; ++i) {
-            const int co = t.cg * CB + i * 16 + r16;
-            float* dp = nullptr;
-            if (a.ksplit > 1) {
-                if (co < a.cout) dp = a.partial + (((long long)t.ks * a.B + t.b) * a.cout + co) * HW;
-            } else if (co < a.cout) {
-                if (co < d0 || a.ndst == 1) {
-                    if (a.dst[0].p) dp = a.dst[0].p + (long long)t.b * a.dst[0].bs + (long long)co * HW;
-                } else if (co < d1 || a.ndst == 2) {
-                    if (a.dst[1].p) dp = a.dst[1].p + (long long)t.b * a.dst[1].bs + (long long)(co - d0) * HW;
-                } else if (co < d2 || a.ndst == 3) {
-                    if (a.dst[2].p) dp = a.dst[2].p + (long long)t.b * a.dst[2].bs + (long long)(co - d1) * HW;
-                } else {
-                    if (a.dst[3].p) dp = a.dst[3].p + (long long)t.b * a.dst[3].bs + (long long)(co - d2) * HW;
-                }
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][r][g][e] = acc[i][r][g][e] < 0.f ? 0.f : acc[i][r][g][e];
+        }
+        unsigned lo[NCB][2];       // ((16 i + r16) * HW + x) * 4 for the two pixel groups, marker when x >= W
+#pragma unroll
+        for (int i = 0; i < NCB; ++i)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int gx = t.x0 + 16 * g + 4 * kq;
+                lo[i][g] = gx < W ? (unsigned)((i * 16 + r16) * HW + gx) * 4u : 0x80000000u;
             }
-            if (dp == nullptr) continue;
-            // the bias is read here, AFTER the barrier that already drained this wave's memory counter and
-            // BEFORE the next DMAs are queued, so its wait costs one L2 round trip per tile and nothing else
-            float bsv = (a.ksplit > 1 || a.bias == nullptr) ? 0.f : a.bias[co];
-            // consume the loaded value once, here: otherwise hipcc cannot prove the load finished at the
-            // control-flow merges below and puts s_waitcnt vmcnt(0) in front of EVERY predicated store, which
-            // also waits for the previous store's acknowledgement (16 serialized round trips per tile)
-            asm volatile("" : "+v"(bsv));
-            const bool relu = a.relu && a.ksplit == 1;
+        const int ybase = t.y0 + wave * R;
+        const int c_lo = t.cg * CB;        // first output channel of this tile
+        auto store_all = [&](__amdgpu_buffer_rsrc_t rd, unsigned ubase) {
+            // ubase = ((c_lo - first channel of the destination) * HW + ybase * W) * 4, modulo 2^32
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int gy = t.y0 + wave * R + r;
+            for (int i = 0; i < NCB; ++i)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    const int gx = t.x0 + 16 * g + 4 * kq;
-                    f32x4 v;
+                    const unsigned vo = lo[i][g] + ubase;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float u = acc[i][r][g][e] + bsv;
-                        if (relu) u = u < 0.f ? 0.f : u;
-                        v[e] = u;
-                    }
-                    if (gy < a.H && gx < a.W)
-                        *reinterpret_cast<f32x4*>(__builtin_assume_aligned(dp + (long long)gy * a.W + gx, 16)) = v;
+                    for (int r = 0; r < R; ++r)
+                        if (ybase + r < H)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][r][g]), rd, vo, (unsigned)(r * W) * 4u, 0);
                 }
+        };
+        if (ksplit > 1) {
+            const int cout = ke->cout;
+            float* pp = ke->partial + ((long long)t.ks * ke->B + t.b) * cout * (long long)HW;
+            store_all(sgpr_rsrc(pp, (unsigned)cout * plane_bytes), (unsigned)(c_lo * HW + ybase * W) * 4u);
+        } else {
+            const int ndst = ke->ndst;
+            int d_lo = 0;
+#pragma unroll 1
+            for (int d = 0; d < ndst; ++d) {
+                const int dc = ke->dst[d].c;
+                float* dp = ke->dst[d].p;
+                // destinations this tile's channels do not touch (and unwanted ones) are skipped outright
+                if (dp != nullptr && d_lo < c_lo + CB && d_lo + dc > c_lo)
+                    store_all(sgpr_rsrc(dp + (long long)t.b * ke->dst[d].bs, (unsigned)dc * plane_bytes),
+                              (unsigned)((c_lo - d_lo) * HW + ybase * W) * 4u);
+                d_lo += dc;
             }
         }
     };
@@ -786,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
             }
         }
     };
-    dma_chunk(lt, lt.ks * a.cps, 0);
+    dma_chunk(lt, lt.ks * cps, 0, true);
     advance_load();
 
     int ct_idx = tile_first, cch = 0, buf = 0;
@@ -800,23 +853,27 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (pending) {
-            if (!(a.debug & 2)) epilogue(pt);
+            epilogue(pt);
             pending = false;
         }
         if (!have) break;
-        if (lt_idx < ntiles) {
-            if (!(a.debug & 16)) dma_chunk(lt, lt.ks * a.cps + lch, buf ^ 1);
-            advance_load();
-        }
         if (cch == 0) {
+            // (the bias load was queued with this tile's first DMA, a chunk ago: consume it here so that hipcc
+            // places its wait before the next DMAs are queued, where the counter is already 0)
+#pragma unroll
+            for (int i = 0; i < NCB; ++i) asm volatile("" : "+v"(bias_r[i]));
 #pragma unroll
             for (int i = 0; i < NCB; ++i)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[i][r][0][q] = acc[i][r][1][q] = 0.f;
+                    for (int q = 0; q < 4; ++q) acc[i][r][0][q] = acc[i][r][1][q] = bias_r[i];
         }
-        mfma_chunk(locate(ct.b, ct.ks * a.cps + cch).cnt, buf);
+        if (lt_idx < ntiles) {
+            dma_chunk(lt, lt.ks * cps + lch, buf ^ 1, lch == 0);
+            advance_load();
+        }
+        mfma_chunk(chunk_cnt(ct.ks * cps + cch), buf);
         buf ^= 1;
         if (++cch == ccnt) {
             cch = 0;
@@ -1103,8 +1160,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 extern "C" {
 
 // The kernel instantiation the dispatcher picks for this problem, for naming it in profiles:
-// returns rows | tiles << 8 | m16 << 16 | dma << 17  ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16>
-// or, with dma, conv_dma_kernel<tiles, rows, CC, mask>.
+// returns rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18  ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16>
+// or, with dma, conv_dma_kernel<tiles, rows, CC, mask, x4>.
 int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     ConvArgs a{};
     a.B = B;
@@ -1117,7 +1174,8 @@ int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     if (nt16 >= 3 && rows == 4) rows = 2;
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     const int dma = (nt16 && use_dma && rows >= 2 && (W % 4) == 0) ? 1 : 0;
-    return rows | (tiles << 8) | ((nt16 ? 1 : 0) << 16) | (dma << 17);
+    static const int x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;      // 16-byte input DMA (aligned planes assumed)
+    return rows | (tiles << 8) | ((nt16 ? 1 : 0) << 16) | (dma << 17) | ((dma && x4 ? 1 : 0) << 18);
 }
 
 long long ynet_packed_weight_floats(int cout, int cin, int K, int mode) {
