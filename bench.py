@@ -88,7 +88,8 @@ class ConvTimer:
             if dma:
                 cc = 4
                 x4 = (plan >> 18) & 1
-                name = f"conv_dma_kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, {'true' if x4 else 'false'}>"
+                fold = 1 << ((plan >> 19) & 3)
+                name = f"conv_dma_kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, {'true' if x4 else 'false'}, {fold}>"
             else:
                 name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}, "
                         f"{'true' if m16 else 'false'}>")

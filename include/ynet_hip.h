@@ -56,8 +56,9 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
                 void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
- * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18  ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16>, or
- * with dma the LDS-DMA generation conv_dma_kernel<tiles, rows, CC, mask, x4>, in a rocprof trace. */
+ * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19  ->  conv_mfma_kernel<K, tiles, rows,
+ * CC, mask, m16>, or with dma the LDS-DMA generation conv_dma_kernel<tiles, rows, CC, mask, x4, fold>, in a
+ * rocprof trace. */
 int ynet_conv2d_plan(int B, int H, int W, int cout, int K);
 
 /* convolution_backward -> grad_weight [Cout][Cin][K][K] and grad_bias [Cout] (db may be NULL).

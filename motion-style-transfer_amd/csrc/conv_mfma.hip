@@ -501,22 +501,27 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, const float* lds
 // X4 = true: the input tile is fetched as aligned 16-byte quads, 10 per row ([x0-4, x0+36): W % 4 == 0 makes
 // every quad lie wholly inside or wholly outside the image), a quarter of the DMA instructions of the
 // dword form for 18 % more bytes; tile column 0 (gx = x0-1) then sits at LDS column 3.
-template <int NCB, int R, int CC, bool MASK, bool X4>
+// FOLD = 2 / 4 (feature maps no wider than 16 / 8): the 32 pixels of an MFMA row unit are FOLD rows of
+// 32 / FOLD columns instead of one row of 32 (which would compute 50 / 75 % padding); needs H % FOLD == 0.
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD = 1>
 struct DmaCfg {
     static constexpr int KS = 3, PAD = 1, KK = 9;
-    static constexpr int TH = 4 * R, TW = 32;
+    static constexpr int TW = 32 / FOLD, TH = 4 * R * FOLD;
     static constexpr int TROWS = TH + 2, TCOLS = X4 ? TW + 8 : TW + 2, PLANE = TROWS * TCOLS;
     static constexpr int XOFF = X4 ? 3 : 0;
+    static constexpr int GOFF = FOLD == 1 ? 16 : (16 / TW) * TCOLS;     // LDS distance of the second 16-pixel group
     static constexpr int CB = 16 * NCB;
     static constexpr int XN = X4 ? PLANE / 4 : PLANE;         // DMA lanes per channel
     static constexpr int XI = (XN + 255) / 256;
-    // channel stride = 16 mod 32: the 4 channels of a K-step on distinct banks (40 * (4R + 2) is 16 mod 32)
-    static constexpr int CHS = X4 ? PLANE : XI * 256 + 16;
+    // channel stride: the 4 channels of a K-step on distinct banks for the 32 lanes of a ds_read_b32 group
+    // (= 16 mod 32 when the 16 pixel lanes are consecutive floats; = 8 mod 32 for FOLD 4: two rows of 8, 16 apart)
+    static constexpr int CHS = X4 ? PLANE + (FOLD == 4 ? ((8 - PLANE % 32) + 32) % 32 : 0) : XI * 256 + 16;
     static constexpr int XS_FLOATS = CC * CHS;                // one buffer of the input (or mask) tile
     static constexpr int WS_FLOATS = CC * KK * CB;            // one buffer of the filter slice
     static constexpr int BUF_FLOATS = XS_FLOATS * (MASK ? 2 : 1) + WS_FLOATS;
     static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
-    static_assert(!X4 || (CHS % 32 == 16 && XI == 1), "X4 tile geometry");
+    static_assert(FOLD == 1 || X4, "folded tiles use the quad layout");
+    static_assert(!X4 || (CHS % 32 == (FOLD == 4 ? 8 : 16) && CHS % 4 == 0 && XI == 1), "X4 tile geometry");
 };
 
 // Kernel arguments re-read through an opaque pointer to the kernarg segment: the loads are issued (s_load) where
@@ -542,9 +547,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sgpr_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0u, 0x00020000);
 }
 
-template <int NCB, int R, int CC, bool MASK, bool X4>
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
-    using C = DmaCfg<NCB, R, CC, MASK, X4>;
+    using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
     constexpr int KS = 3, PAD = 1, KK = 9, TH = C::TH, TW = C::TW;
     constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB, CHS = C::CHS, XI = C::XI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -706,8 +711,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
 
     auto mfma_chunk = [&](int cnt, int buf) {
         const int ngroups = (cnt + 3) / 4;
-        const float* xb = xs_of(buf) + kq * CHS + (wave * R) * TCOLS + r16 + C::XOFF;
-        const float* mb = ms_of(buf) + kq * CHS + (wave * R) * TCOLS + r16 + C::XOFF;
+        // pixel lane r16 of a 16-pixel group: row r16 / TW, column r16 % TW of the (folded) row unit
+        const float* xb = xs_of(buf) + kq * CHS + (wave * R * FOLD + r16 / TW) * TCOLS + (r16 % TW) + C::XOFF;
+        const float* mb = xb;
         const float* wb = ws_of(buf) + kq * KK * CB + r16;
         auto rd = [&](const float* xp, const float*, int off) { return xp[off]; };      // (a dgrad's tile was masked in place)
         float a_cur[R][2], b_cur[NCB], a_nxt[R][2], b_nxt[NCB];
@@ -715,8 +721,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
         for (int i = 0; i < NCB; ++i) b_cur[i] = wb[i * 16];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            a_cur[r][0] = rd(xb, mb, r * TCOLS);
-            a_cur[r][1] = rd(xb, mb, r * TCOLS + 16);
+            a_cur[r][0] = rd(xb, mb, r * FOLD * TCOLS);
+            a_cur[r][1] = rd(xb, mb, r * FOLD * TCOLS + C::GOFF);
         }
 #pragma unroll 1
         for (int g = 0; g < ngroups; ++g) {
@@ -735,8 +741,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
                     for (int i = 0; i < NCB; ++i) b_nxt[i] = wn[tn * CB + i * 16];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        a_nxt[r][0] = rd(xn, mn, (r + kyn) * TCOLS + kxn);
-                        a_nxt[r][1] = rd(xn, mn, (r + kyn) * TCOLS + kxn + 16);
+                        a_nxt[r][0] = rd(xn, mn, (r * FOLD + kyn) * TCOLS + kxn);
+                        a_nxt[r][1] = rd(xn, mn, (r * FOLD + kyn) * TCOLS + kxn + C::GOFF);
                     }
                 }
 #pragma unroll
@@ -805,15 +811,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[i][r][g][e] = acc[i][r][g][e] < 0.f ? 0.f : acc[i][r][g][e];
         }
-        unsigned lo[NCB][2];       // ((16 i + r16) * HW + x) * 4 for the two pixel groups, marker when x >= W
+        unsigned lo[NCB][2];       // ((16 i + r16) * HW + row-in-unit * W + x) * 4 for the two pixel groups, marker when x >= W
 #pragma unroll
         for (int i = 0; i < NCB; ++i)
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const int gx = t.x0 + 16 * g + 4 * kq;
-                lo[i][g] = gx < W ? (unsigned)((i * 16 + r16) * HW + gx) * 4u : 0x80000000u;
+                const int q0 = 16 * g + 4 * kq;                     // first of this lane's 4 pixels in the 32-pixel row unit
+                const int gx = t.x0 + q0 % TW;
+                lo[i][g] = gx < W ? (unsigned)((i * 16 + r16) * HW + (q0 / TW) * W + gx) * 4u : 0x80000000u;
             }
-        const int ybase = t.y0 + wave * R;
+        const int ybase = t.y0 + wave * R * FOLD;    // (H % FOLD == 0: a row unit lies wholly inside or outside the image)
         const int c_lo = t.cg * CB;        // first output channel of this tile
         auto store_all = [&](__amdgpu_buffer_rsrc_t rd, unsigned ubase) {
             // ubase = ((c_lo - first channel of the destination) * HW + ybase * W) * 4, modulo 2^32
@@ -824,8 +831,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
                     const unsigned vo = lo[i][g] + ubase;
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        if (ybase + r < H)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][r][g]), rd, vo, (unsigned)(r * W) * 4u, 0);
+                        if (ybase + r * FOLD < H)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][r][g]), rd, vo, (unsigned)(r * FOLD * W) * 4u, 0);
                 }
         };
         if (ksplit > 1) {
@@ -1035,9 +1042,9 @@ static int pick_rows(const ConvArgs& a, int cb) {
     return 1;
 }
 
-template <int NCB, int R, int CC, bool MASK, bool X4>
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
 static int launch_dma_m(ConvArgs& a, hipStream_t st) {
-    using C = DmaCfg<NCB, R, CC, MASK, X4>;
+    using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
     a.tiles_x = ceil_div(a.W, C::TW);
     a.tiles_y = ceil_div(a.H, C::TH);
     a.cgroups = ceil_div(a.cout, C::CB);
@@ -1059,10 +1066,10 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     a.prio_mode = 0;
     static int slots = 0;
     if (slots == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<NCB, R, CC, MASK, X4>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         int per_cu = 0, dev = 0, cus = 256;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<NCB, R, CC, MASK, X4>, 256, C::LDS_BYTES);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>, 256, C::LDS_BYTES);
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (per_cu < 1) per_cu = 1;
@@ -1070,7 +1077,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         slots = per_cu * cus;
     }
     const long long nblk = nt < slots ? nt : slots;
-    hipLaunchKernelGGL((conv_dma_kernel<NCB, R, CC, MASK, X4>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
     if (a.ksplit > 1) {
         SplitReduceArgs r{};
         r.partial = a.partial;
@@ -1092,21 +1099,26 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
 
 // CC = 4 input channels (one K-step of the 16x16x4 MFMA) per chunk: 34-60 KB of LDS for both buffers, so
 // 3-4 workgroups stay resident per CU (measured 5-10 % faster than CC = 8 with 2 resident workgroups).
-template <int NCB, int R>
+// Only the quad-DMA form is instantiated (callers check a.vec_load).
+template <int NCB, int R, int FOLD = 1>
 static int launch_dma(ConvArgs& a, hipStream_t st) {
-    static const int x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
-    if (x4 && a.vec_load) return a.mask ? launch_dma_m<NCB, R, 4, true, true>(a, st) : launch_dma_m<NCB, R, 4, false, true>(a, st);
-    return a.mask ? launch_dma_m<NCB, R, 4, true, false>(a, st) : launch_dma_m<NCB, R, 4, false, false>(a, st);
+    return a.mask ? launch_dma_m<NCB, R, 4, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, 4, false, true, FOLD>(a, st);
 }
 
-// The DMA generation wins on the large maps (rows >= 2: 2-8 % faster, 60 fewer VGPRs); the latency-bound
-// one-row launches of the small maps stay on the register-staged kernel (3-9 % faster there).
+// Large maps: rows >= 2 per wave (R = 4 only up to 32 output channels per workgroup: registers).
 template <int NCB>
 static int launch_dma_r(ConvArgs& a, hipStream_t st, int rows) {
     if (rows == 4) {
         if constexpr (NCB < 3) return launch_dma<NCB, 4>(a, st);
     }
-    return launch_dma<NCB, 2>(a, st);
+    if (rows >= 2) return launch_dma<NCB, 2>(a, st);
+    return launch_dma<NCB, 1>(a, st);
+}
+
+// Maps no wider than 16 / 8 pixels: folded row units, one per wave
+template <int NCB>
+static int launch_dma_fold(ConvArgs& a, hipStream_t st, int fold) {
+    return fold == 4 ? launch_dma<NCB, 1, 4>(a, st) : launch_dma<NCB, 1, 2>(a, st);
 }
 
 template <int KS, int NCB, int CC, bool M16 = false>
@@ -1130,14 +1142,33 @@ static int m16_tiles(int K, int cout) {
     return 0;
 }
 
+static int conv_fold(int H, int W) {
+    static const int on = getenv("YNET_CONV_FOLD") ? atoi(getenv("YNET_CONV_FOLD")) : 1;
+    if (!on) return 1;
+    if (W <= 8 && (H & 3) == 0) return 4;
+    if (W <= 16 && (H & 1) == 0) return 2;
+    return 1;
+}
+
 static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
     const bool wide = a.cout > 32;
     const int nt16 = m16_tiles(K, a.cout);
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
-    if (nt16 && use_dma && a.vec_store) {
+    static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
+    static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 0;
+    if (nt16 && use_dma && use_x4 && a.vec_store && a.vec_load) {
+        const int fold = conv_fold(a.H, a.W);
+        if (fold > 1) {
+            switch (nt16) {
+                case 1: return launch_dma_fold<1>(a, st, fold);
+                case 2: return launch_dma_fold<2>(a, st, fold);
+                case 3: return launch_dma_fold<3>(a, st, fold);
+                default: return launch_dma_fold<4>(a, st, fold);
+            }
+        }
         int rows = pick_rows(a, 16 * nt16);
         if (nt16 >= 3 && rows == 4) rows = 2;
-        if (rows >= 2) {
+        if (rows >= 2 || dma_r1) {
             switch (nt16) {
                 case 1: return launch_dma_r<1>(a, st, rows);
                 case 2: return launch_dma_r<2>(a, st, rows);
@@ -1187,8 +1218,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 extern "C" {
 
 // The kernel instantiation the dispatcher picks for this problem, for naming it in profiles:
-// returns rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18  ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16>
-// or, with dma, conv_dma_kernel<tiles, rows, CC, mask, x4>.
+// returns rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19
+//   ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16> or, with dma, conv_dma_kernel<tiles, rows, CC, mask, x4, fold>.
 int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     ConvArgs a{};
     a.B = B;
@@ -1200,9 +1231,14 @@ int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     int rows = K == 5 ? 4 : pick_rows(a, nt16 ? 16 * nt16 : 32 * tiles);
     if (nt16 >= 3 && rows == 4) rows = 2;
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
-    const int dma = (nt16 && use_dma && rows >= 2 && (W % 4) == 0) ? 1 : 0;
-    static const int x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;      // 16-byte input DMA (aligned planes assumed)
-    return rows | (tiles << 8) | ((nt16 ? 1 : 0) << 16) | (dma << 17) | ((dma && x4 ? 1 : 0) << 18);
+    static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;      // 16-byte input DMA (aligned planes assumed)
+    static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 0;
+    const bool can = nt16 && use_dma && use_x4 && (W % 4) == 0;
+    const int fold = can ? conv_fold(H, W) : 1;
+    if (fold > 1) rows = 1;
+    const int dma = (can && (fold > 1 || rows >= 2 || dma_r1)) ? 1 : 0;
+    const int flog = fold == 4 ? 2 : (fold == 2 ? 1 : 0);
+    return rows | (tiles << 8) | ((nt16 ? 1 : 0) << 16) | (dma << 17) | (dma << 18) | (flog << 19);
 }
 
 long long ynet_packed_weight_floats(int cout, int cin, int K, int mode) {

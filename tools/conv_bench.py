@@ -66,7 +66,7 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     fl = 2.0 * B * H * W * cin * cout * K * K
     plan = lib.ynet_conv2d_plan(B, H, W, cout, K)
-    rows = f"{plan & 255} tiles {(plan >> 8) & 255} m16 {(plan >> 16) & 1} dma {(plan >> 17) & 1} x4 {(plan >> 18) & 1}"
+    rows = f"{plan & 255} tiles {(plan >> 8) & 255} m16 {(plan >> 16) & 1} dma {(plan >> 17) & 1} x4 {(plan >> 18) & 1} fold {1 << ((plan >> 19) & 3)}"
     print(f"shape {a.shape} mask {a.mask} rows {rows}: {us:9.1f} us  {fl / us / 1e6:7.2f} TFLOP/s")
 
 
