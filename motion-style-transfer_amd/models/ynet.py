@@ -10,8 +10,11 @@ The arithmetic runs in the hand-written gfx950 kernels behind ``..ops``:
   * torch.cat of skip / waypoint   -> never materialised; the conv reads its parts (ops.LazyCat)
   * MaxPool2d, bilinear x2, soft-argmax, sigmoid -> dedicated HBM-bound kernels
 
-Reference: models/ynet.py:134-151 (get_conv2d), 170-234 (YNetEncoder/L), 286-395
-(YNetEncoderFusion), 398-471 (YNetDecoder), 474-600 (YNet).
+  * serial / parallel adapters (AdapterBlock, AdapterLayer), Embedding -> the same conv kernels (1x1, 3x3, 5x5,
+    no bias) around torch's BatchNorm2d / add / ReLU (variants outside the BASELINE configs)
+
+Reference: models/ynet.py:15-131 (Adapter, AdapterBlock, AdapterLayer), 134-151 (get_conv2d), 154-167
+(Embedding), 170-283 (YNetEncoder/L/B), 286-395 (YNetEncoderFusion), 398-471 (YNetDecoder), 474-600 (YNet).
 """
 import math
 
@@ -84,6 +87,86 @@ class HipMaxPool2d(nn.MaxPool2d):
         return ops.max_pool2(x)
 
 
+def _plain_conv(in_channels, out_channels=None, kernel_size=1, stride=1, padding=None, is_bias=False):
+    """models/ynet.py:8-12."""
+    if out_channels is None:
+        out_channels = in_channels
+    return HipConv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding, bias=is_bias)
+
+
+class _AdapterMixin:
+    """Construction / zero initialisation shared by AdapterBlock and AdapterLayer (models/ynet.py:15-56, 72-115):
+    'serial...'            -> serial_layer = [BatchNorm2d, 1x1 conv]      (applied to the conv / stage output)
+    'parallel..._KxK'      -> parallel_layer = KxK conv (no bias) of the input
+    'parallel..._KxK_LxL'  -> parallel_layer = ModuleList of such convs, summed."""
+
+    def _build_adapter(self, adapter_name, in_channels, out_channels, stride, is_bias, serial_channels):
+        self.is_bias = is_bias
+        self.adapter_name = adapter_name
+        self.adapter_size = adapter_name.split("_")[1:]
+        self.is_multiple = len(self.adapter_size) >= 2
+        if "serial" in adapter_name:
+            self.serial_layer = nn.Sequential(nn.BatchNorm2d(serial_channels), _plain_conv(serial_channels, is_bias=is_bias))
+        elif "parallel" in adapter_name and not self.is_multiple:
+            k = int(self.adapter_size[0].split("x")[0]) if self.adapter_size else 1
+            self.parallel_layer = _plain_conv(in_channels, out_channels, k, stride, is_bias=is_bias)
+        elif "parallel" in adapter_name:
+            self.parallel_layer = nn.ModuleList(
+                _plain_conv(in_channels, out_channels, int(z.split("x")[0]), stride, is_bias=is_bias)
+                for z in self.adapter_size)
+        else:
+            raise ValueError(f"Invalid adapter={adapter_name}")
+        self.initialize()
+
+    def initialize(self):
+        if "serial" in self.adapter_name:
+            nn.init.zeros_(self.serial_layer[1].weight)
+            if self.is_bias:
+                nn.init.zeros_(self.serial_layer[1].bias)
+        elif "parallel" in self.adapter_name:
+            for p in self.parallel_layer.parameters():
+                nn.init.zeros_(p)
+
+    def _branch(self, x_in, x_out):
+        """The adapter branch without the residual."""
+        if "serial" in self.adapter_name:
+            return self.serial_layer[1](self.serial_layer[0](x_out))
+        if self.is_multiple:
+            y = None
+            for layer in self.parallel_layer:
+                z = layer(x_in)
+                y = z if y is None else y + z
+            return y
+        return self.parallel_layer(x_in)
+
+
+class AdapterBlock(nn.Module, _AdapterMixin):
+    """models/ynet.py:15-69: adapter between encoder stages (YNetEncoderB)."""
+
+    def __init__(self, adapter_name, in_channels, out_channels=None, stride=1, is_bias=False):
+        nn.Module.__init__(self)
+        self._build_adapter(adapter_name, in_channels, out_channels, stride, is_bias, serial_channels=in_channels)
+
+    def forward(self, x):
+        if "serial" in self.adapter_name:
+            return self._branch(None, x) + x
+        return self._branch(x, None)
+
+
+class AdapterLayer(HipConv2d, _AdapterMixin):
+    """models/ynet.py:72-131: the conv plus a serial / parallel adapter on the same input, ReLU afterwards."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, adapter_name, adapter_dropout=0.0, stride=1,
+                 is_bias=False, **kwargs):
+        HipConv2d.__init__(self, in_channels, out_channels, kernel_size, stride=kwargs.pop("stride_", stride), **kwargs)
+        self._build_adapter(adapter_name, in_channels, out_channels, stride, is_bias, serial_channels=out_channels)
+
+    def forward(self, x, relu=False):
+        out = ops.conv2d(x, self.weight, self.bias, False, self._packed)
+        y = self._branch(x, out) + out
+        return torch.relu(y) if relu else y
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential with the reference's child indices, executing Conv2d+ReLU pairs as one launch."""
 
@@ -117,7 +200,8 @@ def get_conv2d(train_net, l, position, kernel_size, in_channels, out_channels=No
         assert rank != 0 and rank is not None
         return LoRAConv2d(in_channels, out_channels, kernel_size=kernel_size, r=rank, stride=stride, padding=padding)
     if "Layer" in train_net and l in position:
-        raise NotImplementedError(f"adapter layers ({train_net}) are not on the MI355X hot path yet")
+        return AdapterLayer(adapter_name=train_net, in_channels=in_channels, out_channels=out_channels,
+                            kernel_size=kernel_size, stride=stride, padding=padding)
     return HipConv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding)
 
 
@@ -160,13 +244,58 @@ class YNetEncoderL(YNetEncoder):
     pass
 
 
+class Embedding(nn.Module):
+    """models/ynet.py:154-167 (network='embed'): three 3x3 conv + ReLU on the scene / the motion maps."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = FusedSequential(
+            HipConv2d(channels, channels, kernel_size=3, stride=1, padding=1), nn.ReLU(inplace=False),
+            HipConv2d(channels, channels, kernel_size=3, stride=1, padding=1), nn.ReLU(inplace=False),
+            HipConv2d(channels, channels, kernel_size=3, stride=1, padding=1), nn.ReLU(inplace=False))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
 class YNetEncoderB(YNetEncoder):
-    """Reference models/ynet.py:237-283.  Without serial/parallel adapters it is the plain encoder."""
+    """Reference models/ynet.py:237-283: the plain encoder, optionally with AdapterBlocks at ``position``."""
 
     def __init__(self, in_channels, channels=(64, 128, 256, 512, 512), train_net=None, position=[]):
-        if "serial" in train_net or "parallel" in train_net:
-            raise NotImplementedError(f"adapter blocks ({train_net}) are not on the MI355X hot path yet")
-        super().__init__(in_channels, channels, train_net, [int(i) for i in position])
+        self.position = [int(i) for i in position]
+        super().__init__(in_channels, channels, train_net, self.position)
+        par_channels_in = [in_channels] + list(channels[:-1])
+        if "serial" in self.train_net:
+            self.adapters = nn.ModuleList([AdapterBlock(train_net, channels[i]) for i in self.position])
+        elif "parallel" in self.train_net:
+            self.adapters = nn.ModuleList([AdapterBlock(train_net, par_channels_in[i], channels[i]) for i in self.position])
+
+    def forward(self, x):
+        features = []
+        j = 0
+        for i, stage in enumerate(self.stages):
+            if "serial" in self.train_net:
+                x = stage(x)
+                if i in self.position:
+                    x = self.adapters[j](x)
+                    j += 1
+            elif "parallel" in self.train_net:
+                if isinstance(stage[0], nn.MaxPool2d):
+                    y = stage[0](x)
+                    x = stage(x)
+                    if i in self.position:
+                        x = x + self.adapters[j](y)
+                        j += 1
+                else:
+                    y = stage(x)
+                    if i in self.position:
+                        y = y + self.adapters[j](x)
+                        j += 1
+                    x = y
+            else:
+                x = stage(x)
+            features.append(x)
+        return features
 
 
 class YNetEncoderFusion(nn.Module):
@@ -283,12 +412,13 @@ class YNet(nn.Module):
             assert n_fusion is not None
             self.encoder = YNetEncoderFusion(n_semantic_classes, obs_len, encoder_channels, train_net=train_net,
                                              position=position, n_fusion=n_fusion)
-        elif network == "original":
+        elif network == "original" or network == "embed":
+            if network == "embed":
+                self.scene_embedding = Embedding(n_semantic_classes)
+                self.motion_embedding = Embedding(obs_len)
             cls = YNetEncoderL if ("mosa" in train_net or "Layer" in train_net) else YNetEncoderB
             self.encoder = cls(in_channels=self.feature_channels, channels=encoder_channels, train_net=train_net,
                                position=position)
-        elif network == "embed":
-            raise NotImplementedError("network='embed' is not on the MI355X hot path")
         else:
             raise ValueError("No network parameter is provided")
         self.goal_decoder = YNetDecoder(encoder_channels, decoder_channels, output_len=pred_len)

@@ -326,8 +326,8 @@ class _Conv2dFn(torch.autograd.Function):
             for i, s in enumerate(srcs):
                 c = s.shape[1]
                 if need_src[i]:
-                    if s.stride(0) == 0 and s.shape[0] > 1:
-                        raise NotImplementedError("conv2d backward: gradient of a batch-broadcast input")
+                    # (a batch-broadcast input -- stride 0 -- gets the full per-image gradient; the expand's own
+                    # backward sums it over the batch, as in the reference's semantic_img.expand(...))
                     d_srcs[i] = torch.empty((B, c, H, W), device=dy.device, dtype=torch.float32)
                     dsts.append((d_srcs[i].data_ptr(), c, c * H * W))
                 else:

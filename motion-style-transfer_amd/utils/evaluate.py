@@ -19,8 +19,6 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
              swap_semantic=False, forced_samples=None, dp=None, max_effective_batch=256):
     if use_TTST or use_CWS:
         raise NotImplementedError("TTST / CWS are outside the MI355X hot path (disabled in every shipped config)")
-    if network == "embed":
-        raise NotImplementedError("network='embed' is not on the MI355X hot path")
     model.eval()
     waypoints = list(waypoints)
     n_wp = len(waypoints)
@@ -40,6 +38,8 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
             n_data = trajectory.shape[0]
             if swap_semantic:
                 scene_image = swap_pavement_terrain(scene_image)
+            if network == "embed":          # utils/evaluate.py:98-100
+                scene_image = model.scene_embedding(scene_image)
             if dataset_name == "eth":
                 print(counter)
                 counter += batch_size
@@ -58,6 +58,8 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
                 if n_local > 0:
                     observed_map = gather_patches(input_template, batch[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
                     gt_future = batch[:, obs_len:].to(device)
+                    if network == "embed":      # utils/evaluate.py:119-121
+                        observed_map = model.motion_embedding(observed_map)
                     features = model.pred_features(scene_image.expand(n_local, -1, -1, -1), observed_map)
                     pred_goal_map = model.pred_goal(features)
                     # sigmoid(pred_goal_map[:, waypoints] / T): channel gather + scale + sigmoid in one pass

@@ -52,10 +52,12 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                 gt_future_map = gather_patches(gt_template, batch[:, obs_len:].reshape(-1, 2), H, W).view(-1, pred_len, H, W)
                 gt_waypoints = batch[:, obs_len:][:, waypoints]
                 gt_waypoint_map = gather_patches(input_template, gt_waypoints.reshape(-1, 2), H, W).view(-1, len(waypoints), H, W)
-                if network == "embed":
-                    raise NotImplementedError("network='embed' is not on the MI355X hot path")
+                sem1 = semantic_img
+                if network == "embed":      # utils/train_epoch.py:80-83 (before the expand)
+                    sem1 = model.scene_embedding(semantic_img)
+                    observed_map = model.motion_embedding(observed_map)
 
-                semantic_map = semantic_img.expand(n_local, -1, -1, -1)
+                semantic_map = sem1.expand(n_local, -1, -1, -1)
                 features = model.pred_features(semantic_map, observed_map)
                 # The goal and the trajectory decoder are independent given the features: run them on two
                 # HIP streams so the launch-latency-bound small maps (8^2 .. 32^2) of one overlap the other

@@ -103,17 +103,19 @@ class Capture:
             h.remove()
 
 
-def make_case(tag, cfg, H, W, B, seed, lora_b_std=0.05, lr=1e-3, n_goal=20, do_epoch=True, do_eval=True):
+def make_case(tag, cfg, H, W, B, seed, lora_b_std=0.05, lr=1e-3, n_goal=20, do_epoch=True, do_eval=True, adapter_std=0.05):
+    if ONLY and not any(o in tag for o in ONLY):
+        return
     print(f"[{tag}] network={cfg.network} train_net={cfg.train_net} position={list(cfg.position)} {H}x{W} B={B}")
     store = {}
-    sd0 = O.make_state_dict(cfg, seed=seed, lora_b_std=lora_b_std)
+    sd0 = O.make_state_dict(cfg, seed=seed, lora_b_std=lora_b_std, adapter_std=adapter_std)
     scene = O.synthetic_scene(cfg, H, W, seed)
     traj = O.synthetic_trajectories(cfg, B, H, W, seed)
     S = cfg.template_size
     meta = dict(obs_len=cfg.obs_len, pred_len=cfg.pred_len, waypoints=list(cfg.waypoints), enc=list(cfg.enc),
                 dec=list(cfg.dec), network=cfg.network, n_fusion=cfg.n_fusion or 0, train_net=cfg.train_net,
                 position=list(cfg.position), resize_factor=cfg.resize_factor, temperature=cfg.temperature,
-                loss_scale=cfg.loss_scale, H=H, W=W, B=B, seed=seed, lr=lr, n_goal=n_goal,
+                loss_scale=cfg.loss_scale, H=H, W=W, B=B, seed=seed, lr=lr, n_goal=n_goal, adapter_std=adapter_std,
                 lora_source="oracle/_stubs/loralib (restated 0.1.1, PARITY UNPINNED)")
     store["meta"] = np.array(repr(meta))
     for k, v in sd0.items():
@@ -172,6 +174,10 @@ def make_case(tag, cfg, H, W, B, seed, lora_b_std=0.05, lr=1e-3, n_goal=20, do_e
         # _train reloads nothing when best_epoch == 0, so the model holds the post-step weights
         check("adam " + n, p1, named[n].detach(), rtol=1e-5, atol=1e-7)
         store["step/after/" + n] = named[n].detach().numpy()
+    for n, b in model.named_buffers():       # BatchNorm statistics of serial adapters after the step
+        if n in sd0:
+            check("buffer " + n, st["buffers"][n], b, rtol=1e-5, atol=1e-6)
+            store["step/buffers/" + n] = b.detach().numpy()
     store["step/trainable"] = np.array(tr_names)
     store["step/n_trainable"] = np.array(n_trainable)
     store["step/ckpt_keys"] = np.array(ck_keys)
@@ -353,12 +359,16 @@ def fullsize_scalars():
     print("  wrote fullsize_scalars.npz")
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]      # optional substrings of the case tags to (re)generate
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     tiny = dict(enc=(8, 8, 16, 16, 16), dec=(16, 16, 16, 8, 8))
     pos5 = ["0", "1", "2", "3", "4"]
-    kernel_vectors()
+    if not ONLY or "kernels" in ONLY:
+        kernel_vectors()
     make_case("tiny_short_train", O.sdd_short(train_net="train", **tiny), 32, 64, 2, seed=1)
     make_case("tiny_short_mosa1", O.sdd_short(train_net="mosa_1", position=pos5, **tiny), 32, 64, 2, seed=2)
     make_case("tiny_short_mosa4_partial", O.sdd_short(train_net="mosa_4", position=["0", "2", "4"], **tiny), 64, 32, 3, seed=3, do_eval=False)
@@ -367,7 +377,16 @@ def main():
     make_case("tiny_short_encoder_pos", O.sdd_short(train_net="encoder", position=["1", "3"], **tiny), 32, 32, 2, seed=6, do_eval=False)
     make_case("tiny_fusion_scene_only", O.sdd_short(network="fusion", n_fusion=2, train_net="scene", **tiny), 32, 32, 2, seed=7, do_eval=False, do_epoch=False)
     make_case("tiny_short_bias", O.sdd_short(train_net="bias", **tiny), 32, 32, 2, seed=8, do_eval=False, do_epoch=False)
-    fullsize_scalars()
+    # adapters (models/ynet.py:15-131, 237-283) and the embedding network (154-167); SURVEY 8(f)-2
+    make_case("tiny_short_serial_blocks", O.sdd_short(train_net="serial", position=["1", "3"], **tiny), 32, 32, 3, seed=9, do_epoch=False)
+    make_case("tiny_short_parallel3_blocks", O.sdd_short(train_net="parallel_3x3", position=["0", "2"], **tiny), 32, 32, 2, seed=10, do_eval=False)
+    make_case("tiny_short_parallel5_blocks", O.sdd_short(train_net="parallel_5x5", position=["1"], **tiny), 32, 32, 2, seed=11, do_eval=False, do_epoch=False)
+    make_case("tiny_short_parallelLayer3", O.sdd_short(train_net="parallelLayer_3x3", position=pos5, **tiny), 32, 32, 2, seed=12, do_epoch=False)
+    make_case("tiny_short_parallelLayer_multi", O.sdd_short(train_net="parallelLayer_1x1_3x3", position=["1", "2"], **tiny), 32, 32, 2, seed=13, do_eval=False, do_epoch=False)
+    make_case("tiny_short_serialLayer", O.sdd_short(train_net="serialLayer", position=["0", "4"], **tiny), 32, 32, 3, seed=14, do_eval=False)
+    make_case("tiny_short_embed_train", O.sdd_short(network="embed", train_net="train", **tiny), 32, 32, 2, seed=15, do_epoch=False)
+    if not ONLY or "fullsize" in ONLY:
+        fullsize_scalars()
 
 
 if __name__ == "__main__":

@@ -10,6 +10,9 @@ CPU — the very ATen ops the reference dispatches) of these reference symbols:
   * models/ynet.py:134-151      get_conv2d / loralib.Conv2d      -> :func:`effective_weight`, :func:`conv`
   * models/ynet.py:170-234      YNetEncoder / YNetEncoderL       -> :func:`encoder`
   * models/ynet.py:286-395      YNetEncoderFusion (Y-Net-Mod)    -> :func:`encoder`
+  * models/ynet.py:15-131       Adapter / AdapterBlock / AdapterLayer (serial, parallel) -> :func:`conv`, :func:`encoder`
+  * models/ynet.py:154-167      Embedding (network='embed')      -> :func:`embedding`
+  * models/ynet.py:237-283      YNetEncoderB                     -> :func:`encoder`
   * models/ynet.py:398-471      YNetDecoder                      -> :func:`decoder`
   * utils/softargmax.py:55-81   SoftArgmax2D.forward             -> :func:`softargmax2d`
   * utils/image_utils.py:7-63   gkern / templates / get_patch    -> :func:`gaussian_template`,
@@ -70,6 +73,35 @@ class Cfg:
             return None
         parts = self.train_net.split("_")
         return int(parts[1]) if len(parts) > 1 else 1
+
+    # ---- adapters (models/ynet.py:15-131, 237-283)
+    @property
+    def adapter_kind(self) -> Optional[str]:
+        """'serial' | 'parallel' | None (mosa / plain training modes)."""
+        if "mosa" in self.train_net:
+            return None
+        if "serial" in self.train_net:
+            return "serial"
+        if "parallel" in self.train_net:
+            return "parallel"
+        return None
+
+    @property
+    def adapter_in_layer(self) -> bool:
+        # 'Layer' in train_net: the adapter lives inside the conv (AdapterLayer, YNetEncoderL);
+        # otherwise AdapterBlocks sit between the stages (YNetEncoderB)
+        return "Layer" in self.train_net
+
+    @property
+    def adapter_kernels(self) -> List[int]:
+        """Kernel sizes of the parallel adapter convs: 'parallel_3x3' -> [3], 'parallelLayer_1x1_3x3' -> [1, 3],
+        no size -> [1] (models/ynet.py:29,36)."""
+        sizes = self.train_net.split("_")[1:]
+        return [int(z.split("x")[0]) for z in sizes] if sizes else [1]
+
+    @property
+    def adapter_multiple(self) -> bool:
+        return len(self.train_net.split("_")[1:]) >= 2
 
     @property
     def template_size(self) -> int:
@@ -140,7 +172,8 @@ def decoder_specs(cfg: Cfg, which: str) -> List[ConvSpec]:
 
 
 def all_specs(cfg: Cfg) -> List[ConvSpec]:
-    return encoder_specs(cfg) + decoder_specs(cfg, "goal_decoder") + decoder_specs(cfg, "traj_decoder")
+    return (embedding_specs(cfg) + encoder_specs(cfg) + decoder_specs(cfg, "goal_decoder")
+            + decoder_specs(cfg, "traj_decoder"))
 
 
 def is_adapted(cfg: Cfg, spec: ConvSpec) -> bool:
@@ -148,27 +181,87 @@ def is_adapted(cfg: Cfg, spec: ConvSpec) -> bool:
     return cfg.rank is not None and spec.layer != "" and spec.layer in [str(p) for p in cfg.position]
 
 
-def make_state_dict(cfg: Cfg, seed: int = 0, lora_b_std: float = 0.0) -> Dict[str, Tensor]:
+BUFFER_SUFFIXES = (".running_mean", ".running_var", ".num_batches_tracked")
+
+
+def is_buffer(name: str) -> bool:
+    return name.endswith(BUFFER_SUFFIXES)
+
+
+def has_layer_adapter(cfg: Cfg, spec: ConvSpec) -> bool:
+    # models/ynet.py:145-148: AdapterLayer iff 'Layer' in train_net and str(l) in position
+    return (cfg.adapter_kind is not None and cfg.adapter_in_layer and spec.layer != ""
+            and spec.layer in [str(p) for p in cfg.position])
+
+
+def embedding_specs(cfg: Cfg) -> List[ConvSpec]:
+    out: List[ConvSpec] = []
+    if cfg.network == "embed":      # models/ynet.py:154-167, 528-531
+        for which, c in (("scene_embedding", cfg.n_classes), ("motion_embedding", cfg.obs_len)):
+            out += [ConvSpec(f"{which}.conv.{j}", c, c, 3, "") for j in (0, 2, 4)]
+    return out
+
+
+def _adapter_entries(g, prefix: str, kind: str, cin: int, cout: int, kernels: Sequence[int], multiple: bool,
+                     std: float) -> Dict[str, Tensor]:
+    """Parameters (and BatchNorm buffers) of one Adapter (models/ynet.py:15-56 / 72-115).  The reference
+    zero-initialises the adapter convs; ``std`` > 0 draws them from N(0, std) so that tests exercise them."""
+    e: Dict[str, Tensor] = {}
+    if kind == "serial":
+        c = cout
+        e[prefix + ".serial_layer.0.weight"] = 1.0 + 0.1 * torch.randn(c, generator=g) if std > 0 else torch.ones(c)
+        e[prefix + ".serial_layer.0.bias"] = 0.1 * torch.randn(c, generator=g) if std > 0 else torch.zeros(c)
+        e[prefix + ".serial_layer.0.running_mean"] = torch.zeros(c)
+        e[prefix + ".serial_layer.0.running_var"] = torch.ones(c)
+        e[prefix + ".serial_layer.0.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+        e[prefix + ".serial_layer.1.weight"] = torch.randn(c, c, 1, 1, generator=g) * std
+    else:
+        for j, k in enumerate(kernels):
+            name = f"{prefix}.parallel_layer.{j}.weight" if multiple else f"{prefix}.parallel_layer.weight"
+            e[name] = torch.randn(cout, cin, k, k, generator=g) * std
+    return e
+
+
+def make_state_dict(cfg: Cfg, seed: int = 0, lora_b_std: float = 0.0, adapter_std: float = 0.0) -> Dict[str, Tensor]:
     """Deterministic random-init weights (CPU generator): conv weight/bias ~ U(+-1/sqrt(fan_in)) like
-    nn.Conv2d's default, lora_A ~ U(+-1/sqrt(fan_in)), lora_B ~ N(0, lora_b_std) (0 => identity)."""
+    nn.Conv2d's default, lora_A ~ U(+-1/sqrt(fan_in)), lora_B ~ N(0, lora_b_std) (0 => identity), adapter
+    convs ~ N(0, adapter_std) (0 => the reference's zero init).  Key order = the reference's registration order."""
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, Tensor] = {}
-    for s in all_specs(cfg):
+
+    def plain(s: ConvSpec):
         bound = 1.0 / math.sqrt(s.cin * s.k * s.k)
         sd[s.name + ".weight"] = (torch.rand(s.cout, s.cin, s.k, s.k, generator=g) * 2 - 1) * bound
         sd[s.name + ".bias"] = (torch.rand(s.cout, generator=g) * 2 - 1) * bound
+
+    for s in embedding_specs(cfg):
+        plain(s)
+    for s in encoder_specs(cfg):
+        plain(s)
         if is_adapted(cfg, s):
             r = cfg.rank
             ba = 1.0 / math.sqrt(s.cin * s.k)
             sd[s.name + ".lora_A"] = (torch.rand(r * s.k, s.cin * s.k, generator=g) * 2 - 1) * ba
             sd[s.name + ".lora_B"] = torch.randn(s.cout * s.k, r * s.k, generator=g) * lora_b_std
+        if has_layer_adapter(cfg, s):
+            sd.update(_adapter_entries(g, s.name, cfg.adapter_kind, s.cin, s.cout, cfg.adapter_kernels,
+                                       cfg.adapter_multiple, adapter_std))
+    if cfg.adapter_kind is not None and not cfg.adapter_in_layer and cfg.network != "fusion":
+        # YNetEncoderB: one AdapterBlock per position, after the stages (models/ynet.py:249-256)
+        ch = list(cfg.enc)
+        par_in = [cfg.n_classes + cfg.obs_len] + ch[:-1]
+        for j, i in enumerate(int(p) for p in cfg.position):
+            sd.update(_adapter_entries(g, f"encoder.adapters.{j}", cfg.adapter_kind, par_in[i], ch[i],
+                                       cfg.adapter_kernels, cfg.adapter_multiple, adapter_std))
+    for s in decoder_specs(cfg, "goal_decoder") + decoder_specs(cfg, "traj_decoder"):
+        plain(s)
     return sd
 
 
 def trainable_names(cfg: Cfg, sd: Dict[str, Tensor], ynet_bias: bool = False) -> List[str]:
     """Freeze policy of models/trainer.py:116-195 restricted to the Y-Net parameters."""
     tn, pos = cfg.train_net, [str(p) for p in cfg.position]
-    names = list(sd.keys())
+    names = [n for n in sd.keys() if not is_buffer(n)]
     enc = [n for n in names if n.startswith("encoder.")]
     if tn in ("all", "train"):
         out = names
@@ -176,6 +269,10 @@ def trainable_names(cfg: Cfg, sd: Dict[str, Tensor], ynet_bias: bool = False) ->
         out = enc
     elif tn == "encoder":
         out = [n for n in enc if n[len("encoder."):].split(".")[1] in pos]
+    elif "serial" in tn:        # trainer.py:128-131 (checked before 'mosa')
+        out = [n for n in enc if "serial" in n]
+    elif "parallel" in tn:      # trainer.py:132-135
+        out = [n for n in enc if "parallel" in n]
     elif "mosa" in tn:
         # loralib freezes the adapted conv's weight; trainer.py:137-139 enables names containing 'lora'
         out = [n for n in enc if "lora" in n]
@@ -214,21 +311,62 @@ def effective_weight(sd: Dict[str, Tensor], name: str) -> Tensor:
     return w + (b @ a).view(w.shape) * (1.0 / r)
 
 
-def conv(sd, name: str, x: Tensor, relu: bool) -> Tensor:
+def _batch_norm(sd, prefix: str, x: Tensor, training: bool) -> Tensor:
+    """nn.BatchNorm2d defaults (momentum 0.1, eps 1e-5); in training mode the running statistics held in
+    ``sd`` are updated in place, exactly like the module's buffers."""
+    nb = sd.get(prefix + ".num_batches_tracked")
+    if training and nb is not None:
+        nb += 1
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                        sd[prefix + ".bias"], training, 0.1, 1e-5)
+
+
+def _adapter(sd, prefix: str, x_in: Tensor, x_out: Optional[Tensor], training: bool) -> Tensor:
+    """Adapter branch WITHOUT the residual.  serial: conv1x1(BN(x_out)) (models/ynet.py:24-26,64-66); parallel:
+    sum of KxK convs of x_in, no bias (27-39, 57-63)."""
+    if prefix + ".serial_layer.1.weight" in sd:
+        z = _batch_norm(sd, prefix + ".serial_layer.0", x_out, training)
+        return F.conv2d(z, sd[prefix + ".serial_layer.1.weight"], None)
+    if prefix + ".parallel_layer.weight" in sd:
+        w = sd[prefix + ".parallel_layer.weight"]
+        return F.conv2d(x_in, w, None, padding=w.shape[-1] // 2)
+    y, j = 0, 0
+    while f"{prefix}.parallel_layer.{j}.weight" in sd:
+        w = sd[f"{prefix}.parallel_layer.{j}.weight"]
+        y = y + F.conv2d(x_in, w, None, padding=w.shape[-1] // 2)
+        j += 1
+    return y
+
+
+def _has_adapter(sd, prefix: str) -> bool:
+    return any(k in sd for k in (prefix + ".serial_layer.1.weight", prefix + ".parallel_layer.weight",
+                                 prefix + ".parallel_layer.0.weight"))
+
+
+def conv(sd, name: str, x: Tensor, relu: bool, training: bool = True) -> Tensor:
     w = effective_weight(sd, name)
     y = F.conv2d(x, w, sd[name + ".bias"], stride=1, padding=w.shape[-1] // 2)
+    if _has_adapter(sd, name):      # AdapterLayer.forward (models/ynet.py:117-131): branch + conv output, ReLU after
+        y = _adapter(sd, name, x, y, training) + y
     return F.relu(y) if relu else y
 
 
-def _stage(sd, prefix: str, x: Tensor, first: bool) -> Tensor:
+def _stage(sd, prefix: str, x: Tensor, first: bool, training: bool = True) -> Tensor:
     if first:
-        return conv(sd, prefix + ".0", x, True)
+        return conv(sd, prefix + ".0", x, True, training)
     x = F.max_pool2d(x, 2, 2)
-    x = conv(sd, prefix + ".1", x, True)
-    return conv(sd, prefix + ".3", x, True)
+    x = conv(sd, prefix + ".1", x, True, training)
+    return conv(sd, prefix + ".3", x, True, training)
 
 
-def encoder(sd, cfg: Cfg, scene: Tensor, motion: Tensor) -> List[Tensor]:
+def embedding(sd, which: str, x: Tensor) -> Tensor:
+    """models/ynet.py:154-167: three 3x3 conv + ReLU."""
+    for j in (0, 2, 4):
+        x = conv(sd, f"{which}.conv.{j}", x, True)
+    return x
+
+
+def encoder(sd, cfg: Cfg, scene: Tensor, motion: Tensor, training: bool = True) -> List[Tensor]:
     ch = list(cfg.enc)
     feats: List[Tensor] = []
     if cfg.network == "fusion":
@@ -237,19 +375,34 @@ def encoder(sd, cfg: Cfg, scene: Tensor, motion: Tensor) -> List[Tensor]:
         for br, x in (("scene", scene), ("motion", motion)):
             fs = []
             for i in range(nsep + 1):
-                x = _stage(sd, f"encoder.{br}_stages.{i}", x, i == 0)
+                x = _stage(sd, f"encoder.{br}_stages.{i}", x, i == 0, training)
                 fs.append(x)
             branches.append(fs)
         feats = [torch.cat([s, m], dim=1) for s, m in zip(*branches)]
         x = feats[-1]
         for j in range(cfg.n_fusion):
-            x = _stage(sd, f"encoder.fusion_stages.{j}", x, False)
+            x = _stage(sd, f"encoder.fusion_stages.{j}", x, False, training)
             feats.append(x)
         feats.append(F.max_pool2d(x, 2, 2))
     else:
         x = torch.cat([scene, motion], dim=1)
+        blocks = cfg.adapter_kind if (cfg.adapter_kind is not None and not cfg.adapter_in_layer) else None
+        pos = [int(p) for p in cfg.position] if blocks else []
+        j = 0
         for i in range(len(ch)):
-            x = _stage(sd, f"encoder.stages.{i}", x, i == 0)
+            # YNetEncoderB.forward (models/ynet.py:258-283): serial blocks transform the stage output; parallel
+            # blocks see the stage's (pooled) input and are added after the stage's last ReLU
+            if blocks == "parallel":
+                src = x if i == 0 else F.max_pool2d(x, 2, 2)
+                x = _stage(sd, f"encoder.stages.{i}", x, i == 0, training)
+                if i in pos:
+                    x = x + _adapter(sd, f"encoder.adapters.{j}", src, None, training)
+                    j += 1
+            else:
+                x = _stage(sd, f"encoder.stages.{i}", x, i == 0, training)
+                if blocks == "serial" and i in pos:
+                    x = _adapter(sd, f"encoder.adapters.{j}", None, x, training) + x
+                    j += 1
             feats.append(x)
         feats.append(F.max_pool2d(x, 2, 2))
     return feats
@@ -377,10 +530,15 @@ def train_step(sd: Dict[str, Tensor], cfg: Cfg, scene: Tensor, traj: Tensor, in_
     ``loss_weight`` scales the loss (B_local/B_global in data-parallel runs)."""
     H, W = scene.shape[-2:]
     b = traj.shape[0]
-    params = {k: v.detach().clone().requires_grad_(k in set(trainable)) for k, v in sd.items()}
+    params = {k: (v.detach().clone().requires_grad_(k in set(trainable)) if v.is_floating_point() else v.clone())
+              for k, v in sd.items()}
     observed, gt_map, wp_map = build_maps(cfg, traj, H, W, in_tmpl, gt_tmpl)
-    sem = scene.expand(b, -1, -1, -1)
-    feats = encoder(params, cfg, sem, observed)
+    sem1 = scene
+    if cfg.network == "embed":      # utils/train_epoch.py:80-83 (before the expand)
+        sem1 = embedding(params, "scene_embedding", scene)
+        observed = embedding(params, "motion_embedding", observed)
+    sem = sem1.expand(b, -1, -1, -1)
+    feats = encoder(params, cfg, sem, observed, training=True)
     goal_map = decoder(params, cfg, "goal_decoder", feats)
     goal_loss = bce_logits_mean(goal_map, gt_map) * cfg.loss_scale
     traj_map = decoder(params, cfg, "traj_decoder", traj_inputs(feats, wp_map))
@@ -397,6 +555,7 @@ def train_step(sd: Dict[str, Tensor], cfg: Cfg, scene: Tensor, traj: Tensor, in_
     out = {"loss": loss.detach(), "goal_loss": goal_loss.detach(), "traj_loss": traj_loss.detach(),
            "grads": {n: (g if g is not None else torch.zeros_like(sd[n])) for n, g in zip(names, grads)},
            "ade": ade, "fde": fde, "pred_traj": pred_traj, "pred_goal": pred_goal}
+    out["buffers"] = {k: v.detach() for k, v in params.items() if is_buffer(k)}     # BatchNorm statistics after the step
     if keep_maps:
         out.update(features=[f.detach() for f in feats], goal_map=goal_map.detach(),
                    traj_map=traj_map.detach(), observed=observed, gt_map=gt_map, wp_map=wp_map)
@@ -424,7 +583,11 @@ def eval_batch(sd, cfg: Cfg, scene: Tensor, traj: Tensor, in_tmpl: Tensor, n_goa
     b = traj.shape[0]
     observed, _, _ = build_maps(cfg, traj, H, W, in_tmpl, None)
     fut = traj[:, cfg.obs_len:]
-    feats = encoder(sd, cfg, scene.expand(b, -1, -1, -1), observed)
+    sem1 = scene
+    if cfg.network == "embed":      # utils/evaluate.py:98-100, 119-121
+        sem1 = embedding(sd, "scene_embedding", scene)
+        observed = embedding(sd, "motion_embedding", observed)
+    feats = encoder(sd, cfg, sem1.expand(b, -1, -1, -1), observed, training=False)
     goal_map = decoder(sd, cfg, "goal_decoder", feats)
     wp_logits = goal_map[:, list(cfg.waypoints)]
     wp_sig = torch.sigmoid(wp_logits / cfg.temperature)

@@ -66,7 +66,11 @@ class Golden:
 
 
 TINY_CASES = ["tiny_short_train", "tiny_short_mosa1", "tiny_short_mosa4_partial", "tiny_long_fusion_mosa3_scene",
-              "tiny_long_train", "tiny_short_encoder_pos", "tiny_fusion_scene_only", "tiny_short_bias"]
+              "tiny_long_train", "tiny_short_encoder_pos", "tiny_fusion_scene_only", "tiny_short_bias",
+              # adapters / embedding network
+              "tiny_short_serial_blocks", "tiny_short_parallel3_blocks", "tiny_short_parallel5_blocks",
+              "tiny_short_parallelLayer3", "tiny_short_parallelLayer_multi", "tiny_short_serialLayer",
+              "tiny_short_embed_train"]
 
 
 def build_model(cfg, sd=None, device="cpu"):

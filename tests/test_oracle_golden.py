@@ -35,6 +35,8 @@ def test_train_step(case):
         z = torch.zeros_like(sd[n])
         p1, _, _ = O.adam_update(sd[n], st["grads"][n], z, z.clone(), 1, m["lr"])
         g.compare("step/after/" + n, p1, rtol=1e-5, atol=1e-7)
+    for n in g.keys("step/buffers/"):       # BatchNorm running statistics of serial adapters after the step
+        g.compare("step/buffers/" + n, st["buffers"][n], rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("case", [c for c in TINY_CASES if "epoch/ade" in Golden(c).z.files])
