@@ -119,6 +119,17 @@ int ynet_sigmoid_temp(const float* x, float* y, long long B, int C, long long HW
 int ynet_gather_patch(const float* tmpl, int SH, int SW, const float* xy, float* out, int N, int H, int W,
                       int* status, void* stream);
 
+/* ---- test-time sampling trick ------------------------------------------------------------------ */
+/* kmeans (utils/kmeans.py:22-108) as evaluate() calls it for TTST (utils/evaluate.py:146-152): Lloyd's algorithm on
+ * P independent sets of N 2-D points with integer-valued coordinates (sampled pixels), K clusters each.
+ * points [P][N][2] fp32, init_idx [P][K] = indices of the initial centres (the host draws them with
+ * np.random.choice, keeping the reference's RNG stream), centers [P][K][2] out.  Stops when (sum of centre
+ * shifts)^2 < tol or after iter_limit iterations (0 = no limit).  status[p] = (iterations << 8) | empty, where
+ * empty = 1 means a cluster lost all its points (the reference then re-seeds it with torch.randint): the centres of
+ * that set are undefined and the caller must redo it on the host path.  N <= 18000, K <= 32. */
+int ynet_kmeans2d(const float* points, const int* init_idx, float* centers, int* status, int P, int N, int K, float tol,
+                  int iter_limit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

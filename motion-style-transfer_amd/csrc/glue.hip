@@ -515,6 +515,91 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// TTST (utils/evaluate.py:134-161, utils/kmeans.py:22-108): Lloyd's k-means of the N = 10000 goal samples of one
+// person, one workgroup per person, the whole iteration on chip.  Points are pixel coordinates (integer valued), so
+// cluster sums are exact in int32 whatever the summation order and the result does not depend on the thread count:
+//   assign:  d_j = fl(fl(dx*dx) + fl(dy*dy)), first minimum wins          (pairwise_distance + argmin)
+//   update:  c_j = sum_j / n_j (one fp32 division per coordinate)          (selected.mean(dim=0))
+//   stop:    (sum_j sqrt(fl(ddx^2 + ddy^2)))^2 < tol, or iter_limit         (center_shift ** 2 < tol)
+// An empty cluster needs the reference's torch.randint re-seed: the kernel reports it (status 1) and the host
+// runs that person on its slow path.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void kmeans2d_kernel(const float* __restrict__ points, const int* __restrict__ init_idx,
+                                                        float* __restrict__ centers, int* __restrict__ status, int N, int K,
+                                                        float tol, int iter_limit) {
+    extern __shared__ int klds[];
+    int* px = klds;                 // [N]
+    int* py = klds + N;             // [N]
+    float* cx = reinterpret_cast<float*>(klds + 2 * N);      // [32]
+    float* cy = cx + 32;                                     // [32]
+    int* sums = reinterpret_cast<int*>(cy + 32);             // [32][3]: sum x, sum y, count
+    int* flag = sums + 96;                                   // [2]: 0 running, 1 converged / limit, 2 empty cluster
+    const int person = blockIdx.x, tid = threadIdx.x;
+    const float* P = points + (long long)person * N * 2;
+    for (int i = tid; i < N; i += blockDim.x) {
+        px[i] = (int)rintf(P[2 * i]);
+        py[i] = (int)rintf(P[2 * i + 1]);
+    }
+    __syncthreads();
+    if (tid < K) {
+        const int j = init_idx[person * K + tid];
+        cx[tid] = (float)px[j];
+        cy[tid] = (float)py[j];
+    }
+    if (tid == 0) flag[0] = 0;
+    int it = 0;
+    for (;;) {
+        if (tid < 3 * K) sums[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += blockDim.x) {
+            const float x = (float)px[i], y = (float)py[i];
+            int best = 0;
+            float bd = __fadd_rn(__fmul_rn(__fsub_rn(x, cx[0]), __fsub_rn(x, cx[0])), __fmul_rn(__fsub_rn(y, cy[0]), __fsub_rn(y, cy[0])));
+            for (int j = 1; j < K; ++j) {
+                const float dx = __fsub_rn(x, cx[j]), dy = __fsub_rn(y, cy[j]);
+                const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                if (d < bd) {
+                    bd = d;
+                    best = j;
+                }
+            }
+            atomicAdd(&sums[3 * best], px[i]);
+            atomicAdd(&sums[3 * best + 1], py[i]);
+            atomicAdd(&sums[3 * best + 2], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float shift = 0.f;
+            int state = 0;
+            for (int j = 0; j < K; ++j) {
+                const int n = sums[3 * j + 2];
+                if (n == 0) {
+                    state = 2;
+                    break;
+                }
+                const float nx = (float)sums[3 * j] / (float)n, ny = (float)sums[3 * j + 1] / (float)n;
+                const float ddx = __fsub_rn(nx, cx[j]), ddy = __fsub_rn(ny, cy[j]);
+                shift = __fadd_rn(shift, sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy))));
+                cx[j] = nx;
+                cy[j] = ny;
+            }
+            ++it;
+            if (state == 0 && (__fmul_rn(shift, shift) < tol || (iter_limit != 0 && it >= iter_limit))) state = 1;
+            flag[0] = state;
+            flag[1] = it;
+        }
+        __syncthreads();
+        if (flag[0] != 0) break;
+    }
+    if (tid < K) {
+        centers[((long long)person * K + tid) * 2] = cx[tid];
+        centers[((long long)person * K + tid) * 2 + 1] = cy[tid];
+    }
+    if (tid == 0) status[person] = (flag[0] == 2 ? 1 : 0) | (flag[1] << 8);
+}
+
 extern "C" {
 
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
@@ -629,6 +714,20 @@ int ynet_gather_patch(const float* tmpl, int SH, int SW, const float* xy, float*
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(gather_patch_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, tmpl, SH, SW, xy, out, H, W, status);
     return ynet_check_launch("gather_patch");
+}
+
+int ynet_kmeans2d(const float* points, const int* init_idx, float* centers, int* status, int P, int N, int K, float tol,
+                  int iter_limit, void* stream) {
+    YNET_REQUIRE(points && init_idx && centers && status, "kmeans2d: null pointer");
+    YNET_REQUIRE(P > 0 && N > 0 && N <= 18000 && K >= 1 && K <= 32 && K <= N, "kmeans2d: bad shape P=%d N=%d K=%d (N <= 18000, K <= 32)", P, N, K);
+    const int lds = (2 * N + 64 + 96 + 2) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kmeans2d_kernel, dim3(P), dim3(1024), lds, (hipStream_t)stream, points, init_idx, centers, status, N, K, tol, iter_limit);
+    return ynet_check_launch("kmeans2d");
 }
 
 }  // extern "C"

@@ -537,6 +537,23 @@ def gather_patches(template: torch.Tensor, xy, H: int, W: int) -> torch.Tensor:
     return out
 
 
+def kmeans2d(points: torch.Tensor, init_idx: torch.Tensor, tol: float = 1e-3, iter_limit: int = 1000):
+    """Lloyd's k-means of P independent point sets on the device (one workgroup per set; TTST).
+    points [P,N,2] fp32 with integer-valued coordinates, init_idx [P,K] int32 -> (centers [P,K,2], status [P] int32:
+    bit 0 = a cluster went empty (centres undefined, redo on the host path), bits 8.. = iterations)."""
+    _need_gpu(points, "kmeans2d points")
+    P, N, _ = points.shape
+    K = init_idx.shape[1]
+    pts = points.contiguous().float()
+    idx = init_idx.to(device=points.device, dtype=torch.int32).contiguous()
+    centers = torch.empty((P, K, 2), device=points.device, dtype=torch.float32)
+    status = torch.empty(P, device=points.device, dtype=torch.int32)
+    lib = _lib()
+    L.check(lib.ynet_kmeans2d(pts.data_ptr(), idx.data_ptr(), centers.data_ptr(), status.data_ptr(), P, N, K,
+                              float(tol), int(iter_limit), _stream()), lib)
+    return centers, status
+
+
 def check_patch_status():
     """Raise if a device-side coordinate ever left the template (checked at sync points)."""
     for dev, st in _patch_status.items():

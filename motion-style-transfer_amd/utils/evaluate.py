@@ -1,6 +1,6 @@
-"""Evaluation sweep (mirror of utils/evaluate.py:37-315 without the TTST / CWS branches, which are
-off in every shipped config): encoder + goal decoder once per batch, sigmoid(x/T) and multinomial
-goal/waypoint sampling, then K = n_goal*n_traj passes of {gather_patch, waypoint pyramid, trajectory
+"""Evaluation sweep (mirror of utils/evaluate.py:37-315): encoder + goal decoder once per batch, sigmoid(x/T) and
+multinomial goal/waypoint sampling (optionally TTST: k-means of 10000 goal samples on the device, and CWS: Gaussian
+prior on the intermediate waypoints), then K = n_goal*n_traj passes of {gather_patch, waypoint pyramid, trajectory
 decoder, soft-argmax}; best-of-K ADE/FDE.  Same signature and return value as the reference;
 ``forced_samples`` (not in the reference) teacher-forces the sampled way-points for parity tests,
 ``dp`` shards every batch over ranks, ``max_effective_batch`` bounds the K-folding of the decoder passes.
@@ -16,9 +16,11 @@ from .image_utils import gather_patches, image2world, sampling, swap_pavement_te
 def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, input_template, waypoints, mode,
              n_goal, n_traj, obs_len, batch_size, resize_factor=0.25, temperature=1, use_TTST=False, use_CWS=False,
              rel_thresh=0.002, CWS_params=None, return_preds=False, return_samples=False, network=None,
-             swap_semantic=False, forced_samples=None, dp=None, max_effective_batch=256):
-    if use_TTST or use_CWS:
-        raise NotImplementedError("TTST / CWS are outside the MI355X hot path (disabled in every shipped config)")
+             swap_semantic=False, forced_samples=None, dp=None, max_effective_batch=256, forced_goals=None,
+             forced_ttst_samples=None):
+    """utils/evaluate.py:37-315.  Extra keyword arguments (tests / data-parallel runs): ``forced_samples`` [K,B,nwp,2]
+    per batch replaces every random draw, ``forced_goals`` [n_goal,B,1,2] per batch only the goal draw,
+    ``forced_ttst_samples`` [10000,B,1,2] per batch the TTST draw; ``dp`` shards each batch over ranks."""
     model.eval()
     waypoints = list(waypoints)
     n_wp = len(waypoints)
@@ -68,8 +70,19 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
                     if forced_samples is not None:
                         waypoint_samples = forced_samples[b][:, lo:lo + n_local].to(device)
                     else:
-                        goal_samples = sampling(wp_sigmoid[:, -1:], num_samples=n_goal).permute(2, 0, 1, 3)
-                        if n_wp > 1:
+                        if forced_goals is not None:
+                            goal_samples = forced_goals[b][:, lo:lo + n_local].to(device)
+                        elif use_TTST:
+                            draw = None if forced_ttst_samples is None else forced_ttst_samples[b][:, lo:lo + n_local].to(device)
+                            goal_samples = ttst_goals(model, wp_sigmoid[:, -1:], pred_goal_map[:, waypoints[-1:]], n_goal,
+                                                      rel_thresh, draw)
+                        else:
+                            goal_samples = sampling(wp_sigmoid[:, -1:], num_samples=n_goal).permute(2, 0, 1, 3)
+                        if use_CWS and n_wp > 1:
+                            last_observed = batch[:, obs_len - 1].to(device)
+                            waypoint_samples = cws_waypoints(model, wp_sigmoid, goal_samples, last_observed, n_goal, n_traj,
+                                                             CWS_params["sigma_factor"], CWS_params["ratio"], CWS_params["rot"])
+                        elif n_wp > 1:
                             waypoint_samples = sampling(wp_sigmoid[:, :-1], num_samples=n_goal * n_traj).permute(2, 0, 1, 3)
                             waypoint_samples = torch.cat([waypoint_samples, goal_samples.repeat(n_traj, 1, 1, 1)], dim=2)
                         else:
@@ -129,3 +142,90 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
         trajs_dict["metaId"] = df_out["metaId"].to_numpy()
         trajs_dict["sceneId"] = list(df_out["sceneId"])
     return val_ade_arr.mean(), val_fde_arr.mean(), df_out, trajs_dict
+
+
+def _kmeans_host_path(X, k, init_idx, tol=1e-3, iter_limit=1000):
+    """The reference's Lloyd iteration with device tensors (utils/kmeans.py:22-108), used only for a point set in
+    which a cluster went empty (it then needs the reference's torch.randint re-seed)."""
+    X = X.float()
+    c = X[init_idx.to(X.device).long()].clone()
+    it = 0
+    while True:
+        d = ((X.unsqueeze(1) - c.unsqueeze(0)) ** 2.0).sum(dim=-1)
+        assign = torch.argmin(d, dim=1)
+        prev = c.clone()
+        for j in range(k):
+            sel = X[assign == j]
+            if sel.shape[0] == 0:
+                sel = X[torch.randint(len(X), (1,))]
+            c[j] = sel.mean(dim=0)
+        shift = torch.sum(torch.sqrt(torch.sum((c - prev) ** 2, dim=1)))
+        it += 1
+        if float(shift) ** 2 < tol or (iter_limit != 0 and it >= iter_limit):
+            return c
+
+
+def ttst_goals(model, wp_sigmoid_last, wp_logits_last, n_goal, rel_thresh, draw=None):
+    """Test-time sampling trick (utils/evaluate.py:134-161): 10000 thresholded goal samples per person (with
+    replacement) clustered into n_goal - 1 centres by ``ynet_kmeans2d`` (one workgroup per person; the reference
+    loops over persons in Python); the first goal is the soft-argmax of the logits.  The initial centres are drawn
+    with np.random.choice per person, in order, like the reference.  -> [n_goal, B, 1, 2]."""
+    if draw is None:
+        draw = sampling(wp_sigmoid_last, num_samples=10000, replacement=True, rel_threshold=rel_thresh).permute(2, 0, 1, 3)
+    first = model.softargmax(wp_logits_last)                     # [B,1,2]
+    n_people, k = draw.shape[1], n_goal - 1
+    points = draw[:, :, 0].permute(1, 0, 2).contiguous()         # [B, 10000, 2]
+    init = torch.from_numpy(np.stack([np.random.choice(points.shape[1], k, replace=False) for _ in range(n_people)]).astype(np.int32))
+    centers, status = ops.kmeans2d(points, init, tol=0.001, iter_limit=1000)
+    for person in torch.nonzero(status.cpu() & 1).flatten().tolist():
+        centers[person] = _kmeans_host_path(points[person], k, init[person])
+    goals = centers.permute(1, 0, 2).unsqueeze(2)                # [k, B, 1, 2]
+    return torch.cat([first.unsqueeze(0), goals], dim=0)
+
+
+def cws_gaussians(mean_xy, H, W, dist, sigma_factor, ratio, rot):
+    """torch_multivariate_gaussian_heatmap (utils/evaluate.py:9-34) for all N persons at once: anisotropic Gaussians
+    centred at mean_xy [N,2], long axis along dist [N,2], std (|dist| + 5) / sigma_factor along it and that / ratio
+    across, on linspace(0, H, H) x linspace(0, W, W), each normalised to sum 1.  -> [N,H,W]."""
+    dev = mean_xy.device
+    ax = torch.linspace(0, H, H, device=dev).view(1, H) - mean_xy[:, 1:2]         # [N,H]
+    ay = torch.linspace(0, W, W, device=dev).view(1, W) - mean_xy[:, 0:1]         # [N,W]
+    mesh = torch.stack([ay.unsqueeze(1).expand(-1, H, -1), ax.unsqueeze(2).expand(-1, -1, W)], dim=-1)   # [N,H,W,2] = (x, y) offsets
+    rad = torch.atan2(dist[:, 0], dist[:, 1])
+    c, s = torch.cos(rad), torch.sin(rad)
+    R = torch.stack([torch.stack([c, s], dim=-1), torch.stack([-s, c], dim=-1)], dim=-2)                  # [N,2,2]
+    if rot:
+        R = torch.matmul(torch.tensor([[0.0, -1.0], [1.0, 0.0]], device=dev), R)
+    norm = dist.square().sum(-1).sqrt() + 5
+    cov = torch.zeros(len(norm), 2, 2, device=dev)
+    cov[:, 0, 0] = (norm / sigma_factor / ratio) ** 2
+    cov[:, 1, 1] = (norm / sigma_factor) ** 2
+    T = torch.matmul(torch.matmul(R, cov), R.transpose(1, 2))
+    Tinv = torch.inverse(T)
+    k = torch.exp(-0.5 * (torch.einsum("nhwi,nij->nhwj", mesh, Tinv) * mesh).sum(-1))
+    return k / k.sum(dim=(1, 2), keepdim=True)
+
+
+def cws_waypoints(model, wp_sigmoid, goal_samples, last_observed, n_goal, n_traj, sigma_factor, ratio, rot):
+    """Conditioned waypoint sampling (utils/evaluate.py:172-224), batched over the persons of a batch: waypoints are
+    drawn backwards from the goal; the sigmoid map of waypoint w is multiplied by a Gaussian centred at
+    goal + (last_observed - goal) / (w + 2) and renormalised; the first n_goal trajectories take its expectation,
+    later ones one thresholded sample.  -> [n_goal * n_traj, B, n_waypoints, 2]."""
+    _, nwp, H, W = wp_sigmoid.shape
+    goals = goal_samples.repeat(n_traj, 1, 1, 1)
+    out = []
+    for g_num, wp in enumerate(goals.squeeze(2)):
+        chain = [wp]
+        traj_idx = g_num // n_goal
+        for w in reversed(range(nwp - 1)):
+            distance = last_observed - wp
+            maps = cws_gaussians(wp + distance * (1 / (w + 2)), H, W, distance, sigma_factor - traj_idx, ratio, rot)
+            m = wp_sigmoid[:, w] * maps
+            m = (m.flatten(1) / m.flatten(1).sum(-1, keepdim=True)).view_as(m)
+            if traj_idx == 0:
+                wp = model.softargmax_on_softmax_map(m.unsqueeze(0)).squeeze(0)
+            else:
+                wp = sampling(m.unsqueeze(1), num_samples=1, rel_threshold=0.05).permute(2, 0, 1, 3).squeeze(2).squeeze(0)
+            chain.append(wp)
+        out.append(torch.stack(chain[::-1]).permute(1, 0, 2))
+    return torch.stack(out)

@@ -257,6 +257,65 @@ def make_case(tag, cfg, H, W, B, seed, lora_b_std=0.05, lr=1e-3, n_goal=20, do_e
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def ttst_cws_case(tag, cfg, H, W, B, seed, n_goal, n_traj, use_ttst, use_cws, cws_params, rel_thresh=0.002):
+    """Evaluation sweep with the test-time sampling trick and / or conditioned waypoint sampling
+    (utils/evaluate.py:134-161, 172-224), RNG streams shared between the reference and the oracle."""
+    if ONLY and not any(o in tag for o in ONLY):
+        return
+    print(f"[{tag}] ttst={use_ttst} cws={use_cws} n_goal={n_goal} n_traj={n_traj} {H}x{W} B={B}")
+    store = {}
+    sd0 = O.make_state_dict(cfg, seed=seed)
+    scene = O.synthetic_scene(cfg, H, W, seed)
+    traj = O.synthetic_trajectories(cfg, B, H, W, seed)
+    S = cfg.template_size
+    meta = dict(obs_len=cfg.obs_len, pred_len=cfg.pred_len, waypoints=list(cfg.waypoints), enc=list(cfg.enc),
+                dec=list(cfg.dec), network=cfg.network, n_fusion=cfg.n_fusion or 0, train_net=cfg.train_net,
+                position=list(cfg.position), resize_factor=cfg.resize_factor, temperature=cfg.temperature,
+                loss_scale=cfg.loss_scale, H=H, W=W, B=B, seed=seed, lr=1e-3, n_goal=n_goal, n_traj=n_traj,
+                use_ttst=use_ttst, use_cws=use_cws, cws_params=cws_params or {}, rel_thresh=rel_thresh)
+    store["meta"] = np.array(repr(meta))
+    for k, v in sd0.items():
+        store["sd/" + k] = v.numpy()
+    store["scene"], store["traj"] = scene.numpy(), traj.numpy()
+    in_t = O.dist_template(S)
+    model = fresh_reference(cfg, sd0, B, 1e-3, O.trainable_names(cfg, sd0))
+    images = {"scene0": scene[0].clone()}
+    cap = Capture(model)
+    torch.manual_seed(seed + 3)
+    np.random.seed(seed + 3)
+    ade, fde, df, td = ref_evaluate(
+        model, loader_for(traj), images, torch.device("cpu"), "sdd", None, in_t, list(cfg.waypoints), "test",
+        n_goal, n_traj, cfg.obs_len, B, cfg.resize_factor, cfg.temperature, use_ttst, use_cws, rel_thresh, cws_params,
+        return_preds=True, return_samples=True, network=cfg.network)
+    cap.close()
+    wps = torch.from_numpy(td["waypoint_sample"]).permute(2, 0, 1, 3).contiguous()       # [K,B,nwp,2]
+    n_first = 1 if use_ttst else 0          # TTST calls the soft-argmax once more, before the trajectory passes
+    ref_trajs = torch.stack(cap.soft[n_first:])
+    torch.manual_seed(seed + 3)
+    np.random.seed(seed + 3)
+    ev = O.eval_batch(sd0, cfg, scene, traj, in_t, n_goal=n_goal, n_traj=n_traj, use_ttst=use_ttst, use_cws=use_cws,
+                      cws_params=cws_params, rel_thresh=rel_thresh)
+    check("waypoint samples", ev["waypoint_samples"], wps, rtol=1e-5, atol=1e-4)
+    check("eval trajs", ev["trajs"], ref_trajs, rtol=1e-5, atol=1e-4)
+    check("eval ade/traj", ev["ade"], df["ade"].to_numpy(), rtol=1e-5, atol=1e-4)
+    check("eval fde/traj", ev["fde"], df["fde"].to_numpy(), rtol=1e-5, atol=1e-4)
+    if use_ttst:
+        # the 10000-sample draw itself, so that device runs can be fed the very same points
+        torch.manual_seed(seed + 3)
+        goal_map = torch.from_numpy(td["goal_map"])
+        sig = torch.sigmoid(goal_map[:, list(cfg.waypoints)] / cfg.temperature)
+        draw = O.sample_coords(sig[:, -1:], 10000, rel_threshold=rel_thresh, replacement=True).permute(2, 0, 1, 3)
+        store["eval/ttst_samples"] = draw.numpy().astype(np.int16)
+    store["eval/waypoint_samples"] = wps.numpy()
+    store["eval/trajs"] = ref_trajs.numpy()
+    store["eval/ade_per_traj"], store["eval/fde_per_traj"] = df["ade"].to_numpy(), df["fde"].to_numpy()
+    store["eval/ade"], store["eval/fde"] = np.array(ade), np.array(fde)
+    store["eval/seed"] = np.array(seed + 3)
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def fresh_reference(cfg, sd0, B, lr, trainable):
     with contextlib.redirect_stdout(io.StringIO()):
         t = YNetTrainer(ref_params(cfg, B, lr), device=torch.device("cpu"))
@@ -385,6 +444,14 @@ def main():
     make_case("tiny_short_parallelLayer_multi", O.sdd_short(train_net="parallelLayer_1x1_3x3", position=["1", "2"], **tiny), 32, 32, 2, seed=13, do_eval=False, do_epoch=False)
     make_case("tiny_short_serialLayer", O.sdd_short(train_net="serialLayer", position=["0", "4"], **tiny), 32, 32, 3, seed=14, do_eval=False)
     make_case("tiny_short_embed_train", O.sdd_short(network="embed", train_net="train", **tiny), 32, 32, 2, seed=15, do_epoch=False)
+    # TTST (k-means of 10000 goal samples) and CWS (Gaussian prior on intermediate waypoints); SURVEY 8(f)-1
+    make_eval = ttst_cws_case
+    make_eval("tiny_short_ttst", O.sdd_short(train_net="train", **tiny), 32, 32, 3, seed=21, n_goal=5, n_traj=1,
+              use_ttst=True, use_cws=False, cws_params=None)
+    make_eval("tiny_long_cws", O.sdd_long(train_net="train", **tiny), 32, 32, 2, seed=22, n_goal=4, n_traj=1,
+              use_ttst=False, use_cws=True, cws_params={"sigma_factor": 6.0, "ratio": 2.0, "rot": True})
+    make_eval("tiny_long_ttst_cws_ntraj2", O.sdd_long(train_net="train", **tiny), 32, 32, 2, seed=23, n_goal=3, n_traj=2,
+              use_ttst=True, use_cws=True, cws_params={"sigma_factor": 6.0, "ratio": 2.0, "rot": False})
     if not ONLY or "fullsize" in ONLY:
         fullsize_scalars()
 

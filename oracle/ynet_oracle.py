@@ -19,7 +19,9 @@ CPU — the very ATen ops the reference dispatches) of these reference symbols:
                                                                     :func:`dist_template`, :func:`crop_patches`
   * utils/image_utils.py:110-135 sampling                        -> :func:`sample_coords`
   * utils/train_epoch.py:44-126 one training step                -> :func:`train_step`
-  * utils/evaluate.py:109-291   one evaluation batch (no TTST/CWS) -> :func:`eval_batch`
+  * utils/evaluate.py:109-291   one evaluation batch              -> :func:`eval_batch`
+  * utils/evaluate.py:134-161 + utils/kmeans.py:9-108  TTST (k-means of 10000 goal samples) -> :func:`ttst_goals`, :func:`kmeans_lloyd`
+  * utils/evaluate.py:9-34, 172-224  CWS (Gaussian prior on the intermediate waypoints) -> :func:`cws_waypoints`, :func:`cws_gaussian`
   * models/trainer.py:116-195   freeze policy                    -> :func:`trainable_names`
   * torch.optim.Adam (trainer.py:197)                            -> :func:`adam_update`
 
@@ -495,12 +497,115 @@ def crop_patches(template: Tensor, xy, H: int, W: int) -> Tensor:
     return out
 
 
-def sample_coords(prob: Tensor, num_samples: int, generator=None) -> Tensor:
-    """[B,C,H,W] -> [B,C,K,2] float (x,y): multinomial without replacement on the flat plane."""
+def sample_coords(prob: Tensor, num_samples: int, generator=None, rel_threshold: Optional[float] = None,
+                  replacement: bool = False) -> Tensor:
+    """[B,C,H,W] -> [B,C,K,2] float (x,y): multinomial on the flat plane (utils/image_utils.py:110-135).
+    ``rel_threshold`` zeroes entries below that fraction of the plane's maximum; the renormalisation divides by
+    the sum over ALL planes (as the reference does: multinomial only needs per-row proportions)."""
     b, c, h, w = prob.shape
-    idx = torch.multinomial(prob.reshape(b * c, -1), num_samples, replacement=False, generator=generator)
+    pm = prob.reshape(b * c, -1)
+    if rel_threshold is not None:
+        mask = pm < pm.max(dim=1)[0].unsqueeze(1) * rel_threshold
+        pm = pm * (~mask).int()
+        pm = pm / pm.sum()
+    idx = torch.multinomial(pm, num_samples, replacement=replacement, generator=generator)
     idx = idx.view(b, c, num_samples).float()
     return torch.stack([idx % w, torch.floor(idx / w)], dim=-1)
+
+
+def kmeans_lloyd(X: Tensor, k: int, tol: float = 1e-3, iter_limit: int = 1000) -> Tensor:
+    """Lloyd's algorithm as utils/kmeans.py:22-108 runs it for TTST: centres initialised with k distinct points
+    drawn by ``np.random.choice`` (global NumPy RNG), squared-Euclidean assignment (first minimum wins), an empty
+    cluster re-seeded with one point drawn by ``torch.randint`` (global torch RNG), stop when
+    (sum_k ||c_k - c_k_prev||)^2 < tol or after ``iter_limit`` iterations.  Returns the [k, 2] centres."""
+    X = X.float()
+    c = X[np.random.choice(len(X), k, replace=False)]
+    it = 0
+    while True:
+        d = ((X.unsqueeze(1) - c.unsqueeze(0)) ** 2.0).sum(dim=-1).squeeze()
+        assign = torch.argmin(d, dim=1)
+        prev = c.clone()
+        for j in range(k):
+            sel = X[assign == j]
+            if sel.shape[0] == 0:
+                sel = X[torch.randint(len(X), (1,))]
+            c[j] = sel.mean(dim=0)
+        shift = torch.sum(torch.sqrt(torch.sum((c - prev) ** 2, dim=1)))
+        it += 1
+        if shift ** 2 < tol:
+            break
+        if iter_limit != 0 and it >= iter_limit:
+            break
+    return c
+
+
+def ttst_goals(wp_sig_last: Tensor, wp_logits_last: Tensor, n_goal: int, rel_thresh: float, generator=None,
+               samples: Optional[Tensor] = None) -> Tensor:
+    """Test-time sampling trick (utils/evaluate.py:134-161): 10000 thresholded goal samples per person (with
+    replacement), clustered into n_goal - 1 centres; the first goal is the soft-argmax of the logits.
+    [B,1,H,W] x2 -> [n_goal, B, 1, 2].  ``samples`` [10000, B, 1, 2] overrides the draw (tests)."""
+    if samples is None:
+        samples = sample_coords(wp_sig_last, 10000, generator, rel_threshold=rel_thresh, replacement=True).permute(2, 0, 1, 3)
+    first = softargmax2d(wp_logits_last)                       # [B,1,2]
+    centres = [kmeans_lloyd(samples[:, person, 0], n_goal - 1) for person in range(samples.shape[1])]
+    goals = torch.stack(centres).permute(1, 0, 2).unsqueeze(2)
+    return torch.cat([first.unsqueeze(0), goals], dim=0)
+
+
+def cws_gaussian(mean_xy: Tensor, H: int, W: int, dist: Tensor, sigma_factor: float, ratio: float, rot: bool = False) -> Tensor:
+    """utils/evaluate.py:9-34: anisotropic Gaussian centred at ``mean_xy``, long axis along ``dist`` (the vector from
+    the goal to the last observed position), std = (|dist| + 5) / sigma_factor along it and that / ratio across;
+    sampled on linspace(0, H, H) x linspace(0, W, W) and normalised to sum 1."""
+    ax = torch.linspace(0, H, H) - mean_xy[1]
+    ay = torch.linspace(0, W, W) - mean_xy[0]
+    xx, yy = torch.meshgrid([ax, ay], indexing="ij")
+    mesh = torch.stack([yy, xx], dim=-1)
+    rad = torch.atan2(dist[0], dist[1])
+    c, sn = torch.cos(rad), torch.sin(rad)
+    R = torch.Tensor([[c, sn], [-sn, c]])
+    if rot:
+        R = torch.matmul(torch.Tensor([[0, -1], [1, 0]]), R)
+    norm = dist.square().sum(-1).sqrt() + 5
+    cov = torch.square(torch.Tensor([[norm / sigma_factor / ratio, 0], [0, norm / sigma_factor]]))
+    T = torch.matmul(torch.matmul(R, cov), R.T)
+    k = torch.exp(-0.5 * (torch.matmul(mesh, torch.inverse(T)) * mesh).sum(-1))
+    return k / k.sum()
+
+
+def softargmax_on_map(p: Tensor) -> Tensor:
+    """models/ynet.py:588-600: expectation of (x, y) under maps that already sum to 1.  [B,C,H,W] -> [B,C,2]."""
+    b, c, h, w = p.shape
+    ys = torch.arange(h, dtype=p.dtype).view(h, 1).expand(h, w).reshape(-1)
+    xs = torch.arange(w, dtype=p.dtype).view(1, w).expand(h, w).reshape(-1)
+    flat = p.flatten(2)
+    return torch.cat([(xs * flat).sum(-1, keepdim=True), (ys * flat).sum(-1, keepdim=True)], dim=-1)
+
+
+def cws_waypoints(wp_sig: Tensor, goals: Tensor, last_obs: Tensor, n_goal: int, n_traj: int, sigma_factor: float,
+                  ratio: float, rot: bool, generator=None) -> Tensor:
+    """Conditioned waypoint sampling (utils/evaluate.py:172-224).  wp_sig [B,nwp,H,W] (sigmoid maps), goals
+    [n_goal,B,1,2], last_obs [B,2] -> [n_goal*n_traj, B, nwp, 2].  Waypoints are drawn backwards from the goal: the
+    map of waypoint w is multiplied by a Gaussian centred at goal + (last_obs - goal) / (w + 2); the first n_goal
+    trajectories take its expectation, the others one thresholded sample."""
+    b, nwp, H, W = wp_sig.shape
+    goals = goals.repeat(n_traj, 1, 1, 1)
+    out = []
+    for g_num, wp in enumerate(goals.squeeze(2)):
+        chain = [wp]
+        for w in reversed(range(nwp - 1)):
+            distance = last_obs - wp
+            traj_idx = g_num // n_goal
+            maps = torch.stack([cws_gaussian(coord + d * (1 / (w + 2)), H, W, d, sigma_factor - traj_idx, ratio, rot)
+                                for d, coord in zip(distance, wp)])
+            m = wp_sig[:, w] * maps
+            m = (m.flatten(1) / m.flatten(1).sum(-1, keepdim=True)).view_as(m)
+            if traj_idx == 0:
+                wp = softargmax_on_map(m.unsqueeze(0)).squeeze(0)
+            else:
+                wp = sample_coords(m.unsqueeze(1), 1, generator, rel_threshold=0.05).permute(2, 0, 1, 3).squeeze(2).squeeze(0)
+            chain.append(wp)
+        out.append(torch.stack(chain[::-1]).permute(1, 0, 2))
+    return torch.stack(out)
 
 
 def displacement_error(gt: Tensor, pred: Tensor, resize: float) -> Tensor:
@@ -575,10 +680,11 @@ def adam_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float
 
 @torch.no_grad()
 def eval_batch(sd, cfg: Cfg, scene: Tensor, traj: Tensor, in_tmpl: Tensor, n_goal: int = 20,
-               n_traj: int = 1, waypoint_samples: Optional[Tensor] = None,
-               generator=None) -> Dict[str, Tensor]:
-    """utils/evaluate.py:109-291 (use_TTST=False, use_CWS=False) for ONE batch.
-    ``waypoint_samples`` [K,B,nwp,2] teacher-forces the sampled goals/waypoints."""
+               n_traj: int = 1, waypoint_samples: Optional[Tensor] = None, generator=None, use_ttst: bool = False,
+               use_cws: bool = False, cws_params: Optional[dict] = None, rel_thresh: float = 0.002,
+               ttst_samples: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """utils/evaluate.py:109-291 for ONE batch.  ``waypoint_samples`` [K,B,nwp,2] teacher-forces the sampled
+    goals/waypoints; ``ttst_samples`` [10000,B,1,2] the TTST draw."""
     H, W = scene.shape[-2:]
     b = traj.shape[0]
     observed, _, _ = build_maps(cfg, traj, H, W, in_tmpl, None)
@@ -592,8 +698,14 @@ def eval_batch(sd, cfg: Cfg, scene: Tensor, traj: Tensor, in_tmpl: Tensor, n_goa
     wp_logits = goal_map[:, list(cfg.waypoints)]
     wp_sig = torch.sigmoid(wp_logits / cfg.temperature)
     if waypoint_samples is None:
-        goals = sample_coords(wp_sig[:, -1:], n_goal, generator).permute(2, 0, 1, 3)
-        if cfg.n_wp > 1:
+        if use_ttst:
+            goals = ttst_goals(wp_sig[:, -1:], wp_logits[:, -1:], n_goal, rel_thresh, generator, ttst_samples)
+        else:
+            goals = sample_coords(wp_sig[:, -1:], n_goal, generator).permute(2, 0, 1, 3)
+        if use_cws and cfg.n_wp > 1:
+            waypoint_samples = cws_waypoints(wp_sig, goals, traj[:, cfg.obs_len - 1], n_goal, n_traj,
+                                             cws_params["sigma_factor"], cws_params["ratio"], cws_params["rot"], generator)
+        elif cfg.n_wp > 1:
             wps = sample_coords(wp_sig[:, :-1], n_goal * n_traj, generator).permute(2, 0, 1, 3)
             waypoint_samples = torch.cat([wps, goals.repeat(n_traj, 1, 1, 1)], dim=2)
         else:

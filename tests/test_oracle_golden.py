@@ -81,6 +81,26 @@ def test_eval_sweep(case):
     assert torch.equal(ev2["waypoint_samples"], g.t("eval/waypoint_samples"))
 
 
+TTST_CWS_CASES = ["tiny_short_ttst", "tiny_long_cws", "tiny_long_ttst_cws_ntraj2"]
+
+
+@pytest.mark.parametrize("case", TTST_CWS_CASES)
+def test_eval_sweep_ttst_cws(case):
+    """TTST (k-means of 10000 goal samples) / CWS (Gaussian waypoint prior): same RNG streams -> the reference's numbers."""
+    g = Golden(case)
+    cfg, m = g.cfg(), g.meta
+    in_t = O.dist_template(cfg.template_size)
+    torch.manual_seed(int(g.z["eval/seed"]))
+    np.random.seed(int(g.z["eval/seed"]))
+    ev = O.eval_batch(g.state_dict(), cfg, g.t("scene"), g.t("traj"), in_t, n_goal=m["n_goal"], n_traj=m["n_traj"],
+                      use_ttst=m["use_ttst"], use_cws=m["use_cws"], cws_params=m["cws_params"] or None,
+                      rel_thresh=m["rel_thresh"])
+    np.testing.assert_allclose(ev["waypoint_samples"].numpy(), g.z["eval/waypoint_samples"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(ev["trajs"].numpy(), g.z["eval/trajs"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(ev["ade"].numpy(), g.z["eval/ade_per_traj"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(ev["fde"].numpy(), g.z["eval/fde_per_traj"], rtol=1e-5, atol=1e-4)
+
+
 def test_leaf_vectors():
     g = Golden("kernels")
     np.testing.assert_allclose(O.softargmax2d(g.t("softargmax/x")).numpy(), g.z["softargmax/out"], rtol=1e-6, atol=1e-6)
