@@ -20,6 +20,10 @@
 #include <stdlib.h>
 #include <stdio.h>
 
+#ifndef YNET_WG_DEFER
+#define YNET_WG_DEFER 0
+#endif
+
 struct WgradArgs {
     YSrc src[YNET_MAX_SRC];   // x = virtual concat of the sources
     int nsrc, cin;
@@ -31,6 +35,9 @@ struct WgradArgs {
     float* partial_b;         // [nsplit][cout] or NULL
     int B, H, W, cout;
     int tiles_x, tiles_y, ntiles, nsplit, co_blks, ci_blks;
+#ifdef YNET_WG_PROFILE
+    unsigned long long* prof;      // development build: per-phase cycle sums
+#endif
 };
 
 template <int KS>
@@ -261,6 +268,10 @@ __device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t r, const float* 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (wg_lds_ptr_t)lds, 16, byte_off, 0, 0, 0);
 }
 
+__device__ __forceinline__ void wg_dma16s(__amdgpu_buffer_rsrc_t r, const float* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (wg_lds_ptr_t)lds, 16, voff, soff, 0, 0);
+}
+
 template <bool MASK>
 struct WgDmaCfg {
     static constexpr int TH = 2, TW = 32, TROWS = TH + 2, TCOLS = TW + 8;
@@ -268,7 +279,10 @@ struct WgDmaCfg {
     static constexpr int XCH = XQ * 4;                   // 164 = 4 mod 32
     static constexpr int DQ = TH * TW / 4 + 1;           // quads per dy channel (+1 pad quad): 17
     static constexpr int DCH = DQ * 4;                   // 68 = 4 mod 32
-    static constexpr int XS = 32 * XCH, DS = 32 * DCH;
+    // + 128 floats of slack each: the last, partial DMA instruction of a tile image is issued by a whole wave
+    // (no per-lane predicate = no vector-ALU compare); its surplus lanes carry the out-of-range marker and write
+    // zeros into the slack
+    static constexpr int XS = 32 * XCH + 128, DS = 32 * DCH + 128;
     static constexpr int BUF = XS + DS * (MASK ? 2 : 1);
     static constexpr int LDS_BYTES = 2 * BUF * 4;
     static constexpr int XI = (32 * XQ + 255) / 256;     // x DMA instructions per thread per tile (6)
@@ -354,45 +368,169 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         c.b = t / a.tiles_y;
         return c;
     };
-    auto issue = [&](const WgTile& t, int buf) {
+    // ---- fast path of the addressing (tiles whose halo rows lie inside the image, W % 32 == 0): the per-lane
+    // offsets are STATIC (relative to the tile's top-left halo element / first pixel) and the tile position goes
+    // into the scalar offset of the DMA, so a tile costs no vector-ALU instruction at all; tiles of the first /
+    // last column use a second / third static set whose outer halo quads carry the out-of-range marker.  (A VALU
+    // instruction issues once per ~MFMA slot of the other wave on the SIMD: the ~100 of the generic path below
+    // took about as long as the tile's 144 MFMAs.)
+    // static offsets for a tile of an interior column / the first column (left halo quads zeroed) / the last / both
+    unsigned xs_in[XI], xs_l[XI], xs_r[XI], xs_lr[XI], dstat[DI];     // (separate arrays: a 2-D one selected by value goes to scratch)
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const bool ok = xsrc[k] >= 0;
+        const unsigned in = ok ? xcoff[k] + (unsigned)(xrow[k] * a.W + xcol[k] + 4) * 4u : 0x80000000u;
+        const bool lh = xcol[k] < 0, rh = xcol[k] >= TW;
+        xs_in[k] = in;
+        xs_l[k] = lh ? 0x80000000u : in;
+        xs_r[k] = rh ? 0x80000000u : in;
+        xs_lr[k] = (lh || rh) ? 0x80000000u : in;
+    }
+#pragma unroll
+    for (int k = 0; k < DI; ++k) dstat[k] = drow[k] >= 0 ? dcoff[k] + (unsigned)(drow[k] * a.W + dcol[k]) * 4u : 0x80000000u;
+    const int H = a.H, W = a.W;
+    const bool regular = (W % TW) == 0 && (H % TH) == 0;
+
+    // queue the DMAs of one tile given its per-lane offsets (+ scalar offsets xso / dso).  The arguments are re-read
+    // through the kernarg segment (s_load) so that they do not occupy SGPRs across the MFMA loop (spills to VGPR
+    // lanes are reloaded by v_readlane, a vector-ALU instruction).
+    typedef const __attribute__((address_space(4))) WgradArgs* wg_kargs_t;
+    auto queue = [&](const WgTile& t, int buf, const unsigned* xo, unsigned xso, const unsigned* dofs, unsigned dso) {
+        wg_kargs_t ka = (wg_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
         float* xs = xs_of(buf);
-        unsigned xo[XI];
+        const int nsrc = ka->nsrc;
+        constexpr int XFULL = 32 * XQ / 256, DFULL = 32 * DQ / 256;      // instructions issued by all four waves
+        static_assert(32 * XQ - XFULL * 256 <= 64 && 32 * DQ - DFULL * 256 <= 64, "the partial instruction fits one wave");
+        if (nsrc == 1) {        // lanes without data carry the marker: no predicate at all
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(ka->src[0].p + (long long)t.b * ka->src[0].bs), 0, (unsigned)ka->src[0].c * plane_bytes, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < XI; ++k) {
-            const int gy = t.y0 + xrow[k] - 1, gx = t.x0 + xcol[k];
-            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            xo[k] = ok ? xcoff[k] + (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
-        }
-#pragma unroll
-        for (int s = 0; s < YNET_MAX_SRC; ++s) {
-            if (s < a.nsrc) {
-                const __amdgpu_buffer_rsrc_t r = wg_rsrc(a.src[s].p + (long long)t.b * a.src[s].bs, (unsigned)a.src[s].c * plane_bytes);
+            for (int k = 0; k < XFULL; ++k) wg_dma16s(r, xs + (k * 256 + wave * 64) * 4, xo[k], xso);
+            if (XI > XFULL && wave == 0) wg_dma16s(r, xs + (XFULL * 256) * 4, xo[XI - 1], xso);
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < nsrc; ++s) {
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(ka->src[s].p + (long long)t.b * ka->src[s].bs), 0, (unsigned)ka->src[s].c * plane_bytes, 0x00020000);
 #pragma unroll
                 for (int k = 0; k < XI; ++k)
-                    if (xsrc[k] == s) wg_dma16(r, xs + (k * 256 + wave * 64) * 4, xo[k]);
+                    if (xsrc[k] == s) wg_dma16s(r, xs + (k * 256 + wave * 64) * 4, xo[k], xso);
             }
         }
-        unsigned dofs[DI];
-#pragma unroll
-        for (int k = 0; k < DI; ++k) {
-            const int gy = t.y0 + drow[k], gx = t.x0 + dcol[k];
-            const bool ok = drow[k] >= 0 && gy < a.H && gx < a.W;
-            dofs[k] = ok ? dcoff[k] + (unsigned)(gy * a.W + gx) * 4u : 0x80000000u;
-        }
         {
-            const __amdgpu_buffer_rsrc_t r = wg_rsrc(a.dy + (long long)t.b * a.dy_bs + (long long)co0 * HW, (unsigned)nco * plane_bytes);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(ka->dy + (long long)t.b * ka->dy_bs + (long long)co0 * HW), 0, (unsigned)nco * plane_bytes, 0x00020000);
             float* ds = ds_of(buf);
 #pragma unroll
-            for (int k = 0; k < DI; ++k)
-                if (tid + k * 256 < 32 * DQ) wg_dma16(r, ds + (k * 256 + wave * 64) * 4, dofs[k]);
+            for (int k = 0; k < DFULL; ++k) wg_dma16s(r, ds + (k * 256 + wave * 64) * 4, dofs[k], dso);
+            if (DI > DFULL && wave == 0) wg_dma16s(r, ds + (DFULL * 256) * 4, dofs[DI - 1], dso);
         }
         if (MASK) {
-            const __amdgpu_buffer_rsrc_t r = wg_rsrc(a.mask + (long long)t.b * a.mask_bs + (long long)co0 * HW, (unsigned)nco * plane_bytes);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(ka->mask + (long long)t.b * ka->mask_bs + (long long)co0 * HW), 0, (unsigned)nco * plane_bytes, 0x00020000);
             float* ms = ms_of(buf);
 #pragma unroll
-            for (int k = 0; k < DI; ++k)
-                if (tid + k * 256 < 32 * DQ) wg_dma16(r, ms + (k * 256 + wave * 64) * 4, dofs[k]);
+            for (int k = 0; k < DFULL; ++k) wg_dma16s(r, ms + (k * 256 + wave * 64) * 4, dofs[k], dso);
+            if (DI > DFULL && wave == 0) wg_dma16s(r, ms + (DFULL * 256) * 4, dofs[DI - 1], dso);
         }
+    };
+
+    // ---- DMAs interleaved with the MFMA stream.  For the common case (one source, fast addressing) the 12 DMA
+    // instructions of the NEXT tile are not queued in one go after the barrier (measured: 25-30 % of every wave's
+    // time, during which its MFMA slot idles when the co-resident workgroup is in the same phase) but handed out a
+    // few per K-step pair inside the MFMA loop, where they issue beside the MFMAs.
+    constexpr int XFULL_ = 32 * XQ / 256, DFULL_ = 32 * DQ / 256;
+    constexpr int NSLOT = XI + DI * (MASK ? 2 : 1);
+    struct Pending {
+        bool inloop;
+        int buf, variant;            // variant: 0 interior column, 1 first, 2 last, 3 both
+        __amdgpu_buffer_rsrc_t rx, rd, rm;
+        unsigned xso, dso;
+    } pend;
+    pend.inloop = false;
+    pend.buf = 0;
+    pend.variant = 0;
+    pend.xso = pend.dso = 0;
+    pend.rx = pend.rd = pend.rm = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+    // slot j of the pending tile: x quads k = 0..XI-1, then dy, then mask (static register names: unrolled switch)
+    auto dma_slot = [&](int j) {
+        float* xs = xs_of(pend.buf);
+        float* ds = ds_of(pend.buf);
+        float* ms = ms_of(pend.buf);
+#pragma unroll
+        for (int k = 0; k < XI; ++k) {
+            if (j == k) {
+                const bool part = k >= XFULL_;
+                if (!part || wave == 0) {
+                    float* dst = xs + (part ? k * 256 : k * 256 + wave * 64) * 4;
+                    if (pend.variant == 0) wg_dma16s(pend.rx, dst, xs_in[k], pend.xso);
+                    else if (pend.variant == 1) wg_dma16s(pend.rx, dst, xs_l[k], pend.xso);
+                    else if (pend.variant == 2) wg_dma16s(pend.rx, dst, xs_r[k], pend.xso);
+                    else wg_dma16s(pend.rx, dst, xs_lr[k], pend.xso);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DI; ++k) {
+            const bool part = k >= DFULL_;
+            if (j == XI + k && (!part || wave == 0))
+                wg_dma16s(pend.rd, ds + (part ? k * 256 : k * 256 + wave * 64) * 4, dstat[k], pend.dso);
+            if (MASK && j == XI + DI + k && (!part || wave == 0))
+                wg_dma16s(pend.rm, ms + (part ? k * 256 : k * 256 + wave * 64) * 4, dstat[k], pend.dso);
+        }
+    };
+    // Set up the next tile: either leaves its DMAs pending for the MFMA loop (returns true) or queues them all now.
+    auto issue = [&](const WgTile& t, int buf, bool may_defer) {
+        const bool fast = regular && t.y0 >= 1 && t.y0 + TH + 1 <= H;
+        wg_kargs_t ka = (wg_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        if (fast && ka->nsrc == 1) {
+            pend.buf = buf;
+            pend.xso = (unsigned)((t.y0 - 1) * W + t.x0 - 4) * 4u;
+            pend.dso = (unsigned)(t.y0 * W + t.x0) * 4u;
+            pend.variant = (t.x0 == 0 ? 1 : 0) | (t.x0 + TW >= W ? 2 : 0);
+            pend.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ka->src[0].p + (long long)t.b * ka->src[0].bs), 0,
+                                                        (unsigned)ka->src[0].c * plane_bytes, 0x00020000);
+            pend.rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ka->dy + (long long)t.b * ka->dy_bs + (long long)co0 * HW), 0,
+                                                        (unsigned)nco * plane_bytes, 0x00020000);
+            if (MASK)
+                pend.rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ka->mask + (long long)t.b * ka->mask_bs + (long long)co0 * HW), 0,
+                                                            (unsigned)nco * plane_bytes, 0x00020000);
+            if (may_defer) return true;
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) dma_slot(q);
+            return false;
+        }
+        if (fast) {
+            const unsigned xso = (unsigned)((t.y0 - 1) * W + t.x0 - 4) * 4u;
+            const unsigned dso = (unsigned)(t.y0 * W + t.x0) * 4u;
+            const bool at_left = t.x0 == 0, at_right = t.x0 + TW >= W;
+            unsigned xo[XI];
+#pragma unroll
+            for (int k = 0; k < XI; ++k) {
+                const unsigned l = at_right ? xs_lr[k] : xs_l[k];
+                const unsigned m = at_right ? xs_r[k] : xs_in[k];
+                xo[k] = at_left ? l : m;
+            }
+            queue(t, buf, xo, xso, dstat, dso);
+        } else {
+            unsigned xo[XI], dofs[DI];
+#pragma unroll
+            for (int k = 0; k < XI; ++k) {
+                const int gy = t.y0 + xrow[k] - 1, gx = t.x0 + xcol[k];
+                const bool ok = xsrc[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                xo[k] = ok ? xcoff[k] + (unsigned)(gy * W + gx) * 4u : 0x80000000u;
+            }
+#pragma unroll
+            for (int k = 0; k < DI; ++k) {
+                const int gy = t.y0 + drow[k], gx = t.x0 + dcol[k];
+                const bool ok = drow[k] >= 0 && gy < H && gx < W;
+                dofs[k] = ok ? dcoff[k] + (unsigned)(gy * W + gx) * 4u : 0x80000000u;
+            }
+            queue(t, buf, xo, 0u, dofs, 0u);
+        }
+        return false;
     };
 
     f32x4 acc[KK];
@@ -402,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
 
     const int xoff = (ib * 16 + r16) * XCH + 3 + kq;     // tile column 0 (gx = x0-1) sits at LDS column 3
     const int doff = (cb * 16 + r16) * DCH + kq;
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, bool deferred) {
         const float* xb = xs_of(buf) + xoff;
         const float* ab = ds_of(buf) + doff;
         const float* mb = ms_of(buf) + doff;
@@ -416,7 +554,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) b[ky * 3 + kx] = p[ky * TCOLS + kx];
+                for (int kx = 0; kx < 3; ++kx) {
+#ifdef YNET_WG_EXPERIMENT_FEWER_READS      // timing experiment only (wrong results): a third of the B reads
+                    b[ky * 3 + kx] = kx == 0 ? p[ky * TCOLS] : b[ky * 3];
+#else
+                    b[ky * 3 + kx] = p[ky * TCOLS + kx];
+#endif
+                }
         };
         float a_cur, b_cur[KK], a_nxt, b_nxt[KK];
         int s = rp;
@@ -443,20 +587,49 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         };
         // a wave runs KSTEPS / rpN = 16, 8 or 4 steps: two per iteration, the register sets swapping roles
         // (the last step re-reads itself: no branch in the loop body)
+        // pending DMAs of the next tile: NSLOT instructions spread over the first half of this wave's K-step pairs
+        const int per_iter = deferred ? (2 * NSLOT * 2 * rpN + C::KSTEPS - 1) / C::KSTEPS : 0;
+        int slot = 0;
 #pragma unroll 1
         for (; s < C::KSTEPS; s += 2 * rpN) {
             step(s + rpN, a_cur, b_cur, a_nxt, b_nxt);
+            for (int q = 0; q < per_iter && slot < NSLOT; ++q, ++slot) dma_slot(slot);
             step(s + 2 * rpN < C::KSTEPS ? s + 2 * rpN : s + rpN, a_nxt, b_nxt, a_cur, b_cur);
         }
+        for (; deferred && slot < NSLOT; ++slot) dma_slot(slot);
     };
 
+    // The load cursor walks tiles split, split + nsplit, ...: its (x, y, image) coordinates advance by a fixed
+    // mixed-radix step with carries -- scalar adds and compares; a division per tile is ~20 vector-ALU
+    // instructions each (v_rcp based), which the MFMA stream of the other wave stretches to ~1 slot apiece.
+    const int step_x = a.nsplit % a.tiles_x, step_q = a.nsplit / a.tiles_x;
+    const int step_y = step_q % a.tiles_y, step_b = step_q / a.tiles_y;
+    WgTile nt = decode(split);          // tile coordinates in tile units until handed to issue()
+    nt.x0 /= TW;
+    nt.y0 /= TH;
+    auto next_tile = [&]() {
+        WgTile t = nt;
+        t.x0 *= TW;
+        t.y0 *= TH;
+        nt.x0 += step_x;
+        const int cx = nt.x0 >= a.tiles_x ? 1 : 0;
+        nt.x0 -= cx * a.tiles_x;
+        nt.y0 += step_y + cx;
+        const int cy = nt.y0 >= a.tiles_y ? 1 : 0;
+        nt.y0 -= cy * a.tiles_y;
+        nt.b += step_b + cy;
+        return t;
+    };
     int tile = split, buf = 0;
-    if (tile < a.ntiles) issue(decode(tile), 0);
+    if (tile < a.ntiles) issue(next_tile(), 0, false);
     for (; tile < a.ntiles; tile += a.nsplit) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tile + a.nsplit < a.ntiles) issue(decode(tile + a.nsplit), buf ^ 1);
-        compute(buf);
+        bool deferred = false;
+        // (deferring the DMAs into the MFMA loop was measured 6-15 % SLOWER: a buffer_load ... lds holds the wave's
+        // instruction stream for hundreds of cycles wherever it is placed -- tools/dma_issue.hip)
+        if (tile + a.nsplit < a.ntiles) deferred = issue(next_tile(), buf ^ 1, YNET_WG_DEFER != 0);
+        compute(buf, deferred);
         buf ^= 1;
     }
 
@@ -579,7 +752,24 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
         (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, st);
     }
+#ifdef YNET_WG_PROFILE
+    static unsigned long long* prof_dev = nullptr;
+    if (!prof_dev) (void)hipMalloc(&prof_dev, 64);
+    (void)hipMemsetAsync(prof_dev, 0, 64, st);
+    a.prof = prof_dev;
+#endif
     hipLaunchKernelGGL((wgrad_dma_kernel<MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+#ifdef YNET_WG_PROFILE
+    {
+        unsigned long long h[8];
+        (void)hipMemcpyAsync(h, prof_dev, 64, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        const double tot = (double)h[0];
+        fprintf(stderr, "wgrad_dma<%d> waves %llu avg cycles %.0f: vmcnt-wait %.1f%% barrier %.1f%% issue %.1f%% compute %.1f%% rest %.1f%%\n", (int)MASK,
+                h[5], tot / (double)h[5], 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot,
+                100.0 * (tot - h[1] - h[2] - h[3] - h[4]) / tot);
+    }
+#endif
     if (timing) {
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);

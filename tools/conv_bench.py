@@ -42,13 +42,14 @@ def main():
         dw = torch.empty(cout, cin, K, K, device=dev)
         dbias = torch.empty(cout, device=dev)
         ws = torch.empty(lib.ynet_conv2d_wgrad_workspace_floats(B, H, W, cout, cin, K), device=dev)
-        sp, sc, sb = ops._arrays([(x.data_ptr(), cin, cin * H * W)])
+        sp, sc, sb = ops._arrays([(x.data_ptr(), cin, 0 if a.srcbs0 else cin * H * W)])
         ym = torch.randn(B, cout, H, W, device=dev) if a.mask else None
 
     def run():
         if a.wgrad:
-            ops.L.check(lib.ynet_conv2d_wgrad(sp, sc, sb, 1, dy.data_ptr(), cout * H * W,
-                                              ym.data_ptr() if a.mask else None, cout * H * W if a.mask else 0,
+            dbs = 0 if a.dstbs0 else cout * H * W
+            ops.L.check(lib.ynet_conv2d_wgrad(sp, sc, sb, 1, dy.data_ptr(), dbs,
+                                              ym.data_ptr() if a.mask else None, dbs if a.mask else 0,
                                               dw.data_ptr(), dbias.data_ptr(), ws.data_ptr(), B, H, W, cout, K,
                                               ops._stream()), lib)
             return
