@@ -593,6 +593,40 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
         return c;
     };
 
+    // A workgroup's tiles are gstride apart: their (split, channel group, x, y, image) coordinates advance by a
+    // fixed mixed-radix step with carries (scalar adds / compares).  decode() divides -- ~20 vector-ALU
+    // instructions per division -- and is only used for the first tile.
+    int st_ks, st_cg, st_x, st_y, st_b;
+    {
+        int q = gstride;
+        st_ks = q % ksplit;
+        q /= ksplit;
+        st_cg = q % cgroups;
+        q /= cgroups;
+        st_x = q % tiles_x;
+        q /= tiles_x;
+        st_y = q % tiles_y;
+        st_b = q / tiles_y;
+    }
+    auto advance_tile = [&](TileCoord& c) {
+        int carry;
+        c.ks += st_ks;
+        carry = c.ks >= ksplit ? 1 : 0;
+        c.ks -= carry * ksplit;
+        c.cg += st_cg + carry;
+        carry = c.cg >= cgroups ? 1 : 0;
+        c.cg -= carry * cgroups;
+        int tx = c.x0 / TW + st_x + carry;          // (TW, TH: powers of two -> shifts)
+        carry = tx >= tiles_x ? 1 : 0;
+        tx -= carry * tiles_x;
+        c.x0 = tx * TW;
+        int ty = c.y0 / TH + st_y + carry;
+        carry = ty >= tiles_y ? 1 : 0;
+        ty -= carry * tiles_y;
+        c.y0 = ty * TH;
+        c.b += st_b + carry;
+    };
+
     f32x4 acc[NCB][R][2];
     float bias_r[NCB];           // bias of the tile whose first chunk was queued last (0 without a bias / under ksplit)
     unsigned goff[XI];
@@ -866,7 +900,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
             lch = 0;
             lt_idx += gstride;
             if (lt_idx < ntiles) {
-                lt = decode(lt_idx);
+                advance_tile(lt);
                 lcnt = item_chunks(lt);
                 set_goff(lt);
             }
@@ -915,7 +949,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
             pt = ct;
             ct_idx += gstride;
             if (ct_idx < ntiles) {
-                ct = decode(ct_idx);
+                advance_tile(ct);
                 ccnt = item_chunks(ct);
             }
         }
