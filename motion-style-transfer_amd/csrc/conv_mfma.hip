@@ -1166,6 +1166,91 @@ static int launch_conv_r(ConvArgs& a, hipStream_t st) {
     }
 }
 
+
+// ================================================================================================
+// 1x1 convolution with few output channels (the predictors: 32 -> pred_len, and their dgrad pred_len -> 32): 4.4-12
+// FLOP per byte, HBM-bound.  One thread owns 4 consecutive pixels (16-byte loads / stores, a wave reads 1 KB
+// contiguous per input channel) and all CT output channels; the filter row of each input channel arrives through
+// scalar loads (uniform address) and feeds v_fmac from SGPRs.  fp32 FMA chain over the input channels in order.
+// ================================================================================================
+struct Conv1x1Args {
+    const float* x;
+    long long x_bs;
+    const float* wp;        // packed [cin_pad][cout_pad]
+    const float* bias;
+    float* y;
+    long long y_bs;
+    int cin, cout, cout_pad, relu, B;
+    long long hw4;          // H * W / 4
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) float* const_f32_ptr;      // uniform reads -> scalar loads
+
+// PX pixels per thread (4: 16-byte accesses, CT <= 16; 2: 8-byte accesses, CT = 32 -> 64 accumulator registers)
+template <int CT, int PX>
+__global__ __launch_bounds__(256) void conv1x1_stream_kernel(const Conv1x1Args a) {
+    typedef float vec_t __attribute__((ext_vector_type(PX)));
+    const long long hwv = a.hw4 * (4 / PX);
+    const long long total = (long long)a.B * hwv;
+    const const_f32_ptr w = (const_f32_ptr)a.wp, bias = (const_f32_ptr)a.bias;
+    for (long long q = blockIdx.x * 256ll + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const int b = (int)(q / hwv);
+        const long long p = q - (long long)b * hwv;
+        const vec_t* xp = reinterpret_cast<const vec_t*>(a.x + (long long)b * a.x_bs) + p;
+        vec_t acc[CT];
+#pragma unroll
+        for (int co = 0; co < CT; ++co) {
+            const float bv = (a.bias != nullptr && co < a.cout) ? bias[co] : 0.f;
+#pragma unroll
+            for (int e = 0; e < PX; ++e) acc[co][e] = bv;
+        }
+#pragma unroll 2
+        for (int ci = 0; ci < a.cin; ++ci) {
+            const vec_t v = xp[(long long)ci * hwv];
+#pragma unroll
+            for (int co = 0; co < CT; ++co) {
+                const float wv = w[ci * a.cout_pad + co];
+#pragma unroll
+                for (int e = 0; e < PX; ++e) acc[co][e] = __builtin_fmaf(v[e], wv, acc[co][e]);
+            }
+        }
+        vec_t* yp = reinterpret_cast<vec_t*>(a.y + (long long)b * a.y_bs) + p;
+#pragma unroll
+        for (int co = 0; co < CT; ++co) {
+            if (co < a.cout) {
+                vec_t o = acc[co];
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < PX; ++e) o[e] = o[e] < 0.f ? 0.f : o[e];
+                }
+                yp[(long long)co * hwv] = o;
+            }
+        }
+    }
+}
+
+template <int CT, int PX>
+static int launch_conv1x1_stream(const ConvArgs& a, hipStream_t st) {
+    Conv1x1Args k{};
+    k.x = a.src[0].p;
+    k.x_bs = a.src[0].bs;
+    k.wp = a.wp;
+    k.bias = a.bias;
+    k.y = a.dst[0].p;
+    k.y_bs = a.dst[0].bs;
+    k.cin = a.src[0].c;
+    k.cout = a.cout;
+    k.cout_pad = a.cout_pad;
+    k.relu = a.relu;
+    k.B = a.B;
+    k.hw4 = (long long)a.H * a.W / 4;
+    long long blocks = ((long long)a.B * k.hw4 * (4 / PX) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((conv1x1_stream_kernel<CT, PX>), dim3((unsigned)blocks), dim3(256), 0, st, k);
+    return ynet_check_launch("conv2d(1x1)");
+}
+
 // 16-wide output-channel tiles pay off when padding Cout to 32 / 64 would waste a quarter or more
 static int m16_tiles(int K, int cout) {
     static const int mode = getenv("YNET_CONV_M16") ? atoi(getenv("YNET_CONV_M16")) : 2;   // 0 off, 1 only where 32-wide tiles would pad, 2 always for 3x3 (2-6 % faster on MI355X)
@@ -1211,6 +1296,10 @@ static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
             }
         }
     }
+    static const int stream1 = getenv("YNET_CONV_1X1_STREAM") ? atoi(getenv("YNET_CONV_1X1_STREAM")) : 1;
+    if (K == 1 && stream1 && a.nsrc == 1 && a.ndst == 1 && a.dst[0].p != nullptr && a.mask == nullptr && a.cout <= 32 &&
+        a.src[0].bmod == 0 && a.vec_store && a.vec_load && ((long long)a.H * a.W) % 4 == 0)
+        return a.cout <= 16 ? launch_conv1x1_stream<16, 4>(a, st) : launch_conv1x1_stream<32, 2>(a, st);
     if (nt16 == 1) return launch_conv_r<3, 1, 8, true>(a, st);
     if (nt16 == 2) return launch_conv_r<3, 2, 8, true>(a, st);
     if (nt16 == 3) return launch_conv_r<3, 3, 8, true>(a, st);
