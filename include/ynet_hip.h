@@ -81,6 +81,13 @@ int ynet_lora_compose(const float* w, const float* lora_a, const float* lora_b, 
 int ynet_lora_grad(const float* dw, const float* lora_a, const float* lora_b, float scale, float* d_a, float* d_b,
                    int cout, int cin, int K, int r, void* stream);
 
+/* lora_compose followed by ynet_pack_weight in mode 0 AND mode 1, in one launch: W_eff is never materialised, its
+ * elements go straight into the two packed layouts.  wp_fwd / wp_dgrad: ynet_packed_weight_floats(cout, cin, K, 0 / 1)
+ * floats each, ZERO-FILLED by the caller before the first use (the padding is not written; the buffers can be
+ * reused for the same layer every step). */
+int ynet_lora_compose_pack(const float* w, const float* lora_a, const float* lora_b, float scale, float* wp_fwd,
+                           float* wp_dgrad, int cout, int cin, int K, int r, void* stream);
+
 /* ---- pooling / resampling ------------------------------------------------------------------- */
 /* nn.MaxPool2d(2,2) (models/ynet.py:202,215,326,340,354,367); N = B*C planes of H x W. */
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream);

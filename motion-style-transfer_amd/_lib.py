@@ -34,6 +34,7 @@ SIGNATURES = {
                                 c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_compose": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_grad": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_lora_compose_pack": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_maxpool2_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_maxpool2_bwd": (c_i, [c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_upsample2x_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),

@@ -44,6 +44,72 @@ __global__ __launch_bounds__(64) void small_gemm_mfma_kernel(const GemmArgs g) {
     }
 }
 
+// Two independent small GEMMs in one launch (blocks [0, tiles0) -> g0, the rest -> g1): dA and dB of one layer.
+__global__ __launch_bounds__(64) void small_gemm2_mfma_kernel(const GemmArgs g0, const GemmArgs g1, int tiles0) {
+    const bool first = (int)blockIdx.x < tiles0;
+    const GemmArgs& g = first ? g0 : g1;
+    const int blk = first ? (int)blockIdx.x : (int)blockIdx.x - tiles0;
+    const int lane = threadIdx.x;
+    const int tiles_n = (g.N + 15) / 16;
+    const int m0 = (blk / tiles_n) * 16, n0 = (blk % tiles_n) * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int am = m0 + r, bn = n0 + r;
+    for (int k0 = 0; k0 < g.K; k0 += 4) {
+        const int k = k0 + kq;
+        const float a = (am < g.M && k < g.K) ? g.A[am * g.sam + k * g.sak] : 0.f;
+        const float b = (bn < g.N && k < g.K) ? g.B[k * g.sbk + bn * g.sbn] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + kq * 4 + q, n = n0 + r;
+        if (m < g.M && n < g.N) g.C[(long long)m * g.N + n] = g.alpha * acc[q];
+    }
+}
+
+// W_eff = W + s * (B @ A) computed tile by tile and written straight into BOTH packed filter layouts of the conv
+// kernels (forward [ci][tap][co] and dgrad [co][flipped tap][ci], see conv_mfma.hip: pack_weight_kernel); the zero
+// padding of the packed buffers is the caller's (they are allocated zeroed once per layer and reused).
+struct ComposePackArgs {
+    const float* w;
+    const float* lora_a;
+    const float* lora_b;
+    float* wp_fwd;
+    float* wp_dgrad;
+    int cout, cin, KK, K, r;
+    int fwd_cols, dgrad_cols;      // padded column counts of the two packed layouts
+    float scale;
+};
+
+__global__ __launch_bounds__(64) void lora_compose_pack_kernel(const ComposePackArgs g) {
+    const int M = g.cout * g.K, N = g.cin * g.K, Kd = g.r * g.K;
+    const int lane = threadIdx.x;
+    const int tiles_n = (N + 15) / 16;
+    const int m0 = ((int)blockIdx.x / tiles_n) * 16, n0 = ((int)blockIdx.x % tiles_n) * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int am = m0 + r, bn = n0 + r;
+    for (int k0 = 0; k0 < Kd; k0 += 4) {
+        const int k = k0 + kq;
+        const float a = (am < M && k < Kd) ? g.lora_b[am * Kd + k] : 0.f;
+        const float b = (bn < N && k < Kd) ? g.lora_a[k * N + bn] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + kq * 4 + q, n = n0 + r;
+        if (m < M && n < N) {
+            const int flat = m * N + n;                       // index into the flat [Cout][Cin][K][K] weight
+            const float v = g.scale * acc[q] + g.w[flat];
+            const int co = flat / (g.cin * g.KK), rem = flat - co * g.cin * g.KK;
+            const int ci = rem / g.KK, t = rem - ci * g.KK;
+            g.wp_fwd[((long long)ci * g.KK + t) * g.fwd_cols + co] = v;
+            g.wp_dgrad[((long long)co * g.KK + (g.KK - 1 - t)) * g.dgrad_cols + ci] = v;
+        }
+    }
+}
+
 static int run_gemm(const GemmArgs& g, hipStream_t st, const char* what) {
     const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
     hipLaunchKernelGGL(small_gemm_mfma_kernel, dim3(tiles), dim3(64), 0, st, g);
@@ -89,8 +155,6 @@ int ynet_lora_grad(const float* dw, const float* lora_a, const float* lora_b, fl
     ga.sbn = 1;
     ga.C = d_a;
     ga.alpha = scale;
-    int rc = run_gemm(ga, (hipStream_t)stream, "lora_grad(dA)");
-    if (rc) return rc;
     GemmArgs gb{};   // dB[M][Kd] = s * dWm[M][N] @ A^T[N][Kd]
     gb.M = M;
     gb.N = Kd;
@@ -103,7 +167,32 @@ int ynet_lora_grad(const float* dw, const float* lora_a, const float* lora_b, fl
     gb.sbn = N;
     gb.C = d_b;
     gb.alpha = scale;
-    return run_gemm(gb, (hipStream_t)stream, "lora_grad(dB)");
+    const int tiles_a = ((ga.M + 15) / 16) * ((ga.N + 15) / 16), tiles_b = ((gb.M + 15) / 16) * ((gb.N + 15) / 16);
+    hipLaunchKernelGGL(small_gemm2_mfma_kernel, dim3(tiles_a + tiles_b), dim3(64), 0, (hipStream_t)stream, ga, gb, tiles_a);
+    return ynet_check_launch("lora_grad");
+}
+
+int ynet_lora_compose_pack(const float* w, const float* lora_a, const float* lora_b, float scale, float* wp_fwd,
+                           float* wp_dgrad, int cout, int cin, int K, int r, void* stream) {
+    YNET_REQUIRE(w && lora_a && lora_b && wp_fwd && wp_dgrad, "lora_compose_pack: null pointer");
+    YNET_REQUIRE(cout > 0 && cin > 0 && (K == 1 || K == 3 || K == 5) && r > 0, "lora_compose_pack: bad shape");
+    ComposePackArgs g{};
+    g.w = w;
+    g.lora_a = lora_a;
+    g.lora_b = lora_b;
+    g.wp_fwd = wp_fwd;
+    g.wp_dgrad = wp_dgrad;
+    g.cout = cout;
+    g.cin = cin;
+    g.K = K;
+    g.KK = K * K;
+    g.r = r;
+    g.fwd_cols = (cout + 63) / 64 * 64;        // YNET_COUT_PAD of conv_mfma.hip
+    g.dgrad_cols = (cin + 63) / 64 * 64;
+    g.scale = scale;
+    const int tiles = ((cout * K + 15) / 16) * ((cin * K + 15) / 16);
+    hipLaunchKernelGGL(lora_compose_pack_kernel, dim3(tiles), dim3(64), 0, (hipStream_t)stream, g);
+    return ynet_check_launch("lora_compose_pack");
 }
 
 }  // extern "C"

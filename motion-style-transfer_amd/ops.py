@@ -193,6 +193,26 @@ def lora_compose(w, lora_a, lora_b, scale: float) -> torch.Tensor:
     return out
 
 
+def lora_compose_pack(w, lora_a, lora_b, scale: float, bufs=None):
+    """Both packed filters (forward, dgrad) of W + s * (lora_B @ lora_A).view(W.shape) in one launch; ``bufs`` = the
+    pair returned by an earlier call for the same layer (their zero padding is kept)."""
+    for t, n in ((w, "weight"), (lora_a, "lora_A"), (lora_b, "lora_B")):
+        _need_gpu(t, "lora_compose_pack " + n)
+    cout, cin, k, _ = w.shape
+    r = lora_a.shape[0] // k
+    if tuple(lora_a.shape) != (r * k, cin * k) or tuple(lora_b.shape) != (cout * k, r * k):
+        raise ValueError(f"lora_compose: lora_A {tuple(lora_a.shape)} / lora_B {tuple(lora_b.shape)} do not fit "
+                         f"weight {tuple(w.shape)}")
+    lib = _lib()
+    if bufs is None:
+        bufs = tuple(torch.zeros(lib.ynet_packed_weight_floats(cout, cin, k, mode), device=w.device, dtype=torch.float32)
+                     for mode in (0, 1))
+    L.check(lib.ynet_lora_compose_pack(w.contiguous().data_ptr(), lora_a.contiguous().data_ptr(),
+                                       lora_b.contiguous().data_ptr(), scale, bufs[0].data_ptr(), bufs[1].data_ptr(),
+                                       cout, cin, k, r, _stream()), lib)
+    return bufs
+
+
 def lora_grad(dw, lora_a, lora_b, scale: float):
     cout, cin, k, _ = dw.shape
     r = lora_a.shape[0] // k
@@ -251,20 +271,29 @@ def _weight_key(weight, lora_a, lora_b):
 
 
 def _cached(cache: dict, weight, lora_a, lora_b, scale, what: str):
-    """Per-layer cache of w_eff and the two packed filters, invalidated when a parameter changes."""
+    """Per-layer cache of the two packed filters ('fwd' / 'dgrad'), invalidated when a parameter changes.  A LoRA
+    layer composes W + BA*s and writes both layouts in one launch, into buffers it keeps across steps."""
     key = _weight_key(weight, lora_a, lora_b)
     if cache.get("key") != key:
+        bufs = cache.get("lora_bufs")
         cache.clear()
         cache["key"] = key
-    if "w_eff" not in cache:
+        if bufs is not None:
+            cache["lora_bufs"] = bufs
+    if what not in cache:
         with torch.no_grad():
             w = weight.detach()
-            cache["w_eff"] = lora_compose(w, lora_a.detach(), lora_b.detach(), scale) if lora_a is not None \
-                else (w if w.is_contiguous() else w.contiguous())
-    if what == "w_eff":
-        return cache["w_eff"]
-    if what not in cache:
-        cache[what] = pack_weight(cache["w_eff"], 0 if what == "fwd" else 1)
+            if lora_a is not None:
+                bufs = cache.get("lora_bufs")
+                if bufs is not None and (bufs[0].device != w.device or cache.get("lora_shape") != tuple(w.shape)):
+                    bufs = None
+                # (the conv launches of this step that still read the buffers are ordered before this launch on the
+                # stream; backward of an earlier forward with the old weights is rejected by the version check)
+                cache["lora_bufs"] = bufs = lora_compose_pack(w, lora_a.detach(), lora_b.detach(), scale, bufs)
+                cache["lora_shape"] = tuple(w.shape)
+                cache["fwd"], cache["dgrad"] = bufs
+            else:
+                cache[what] = pack_weight(w if w.is_contiguous() else w.contiguous(), 0 if what == "fwd" else 1)
     return cache[what]
 
 
