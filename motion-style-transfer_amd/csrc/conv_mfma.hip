@@ -518,7 +518,7 @@ struct DmaCfg {
     static constexpr int CHS = X4 ? PLANE + (FOLD == 4 ? ((8 - PLANE % 32) + 32) % 32 : 0) : XI * 256 + 16;
     static constexpr int XS_FLOATS = CC * CHS;                // one buffer of the input (or mask) tile
     static constexpr int WS_FLOATS = CC * KK * CB;            // one buffer of the filter slice
-    static constexpr int BUF_FLOATS = XS_FLOATS * (MASK ? 2 : 1) + WS_FLOATS;
+    static constexpr int BUF_FLOATS = XS_FLOATS * ((MASK && !X4) ? 2 : 1) + WS_FLOATS;     // (X4: the mask quads stay in registers)
     static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
     static_assert(FOLD == 1 || X4, "folded tiles use the quad layout");
     static_assert(!X4 || (CHS % 32 == (FOLD == 4 ? 8 : 16) && CHS % 4 == 0 && XI == 1), "X4 tile geometry");
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
     // buffer b: [xs | ms (MASK) | ws]
     auto xs_of = [&](int b) { return smem + b * C::BUF_FLOATS; };
     auto ms_of = [&](int b) { return smem + b * C::BUF_FLOATS + C::XS_FLOATS; };
-    auto ws_of = [&](int b) { return smem + b * C::BUF_FLOATS + C::XS_FLOATS * (MASK ? 2 : 1); };
+    auto ws_of = [&](int b) { return smem + b * C::BUF_FLOATS + C::XS_FLOATS * ((MASK && !X4) ? 2 : 1); };
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);     // byte address of the LDS image
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -628,6 +628,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
     };
 
     f32x4 acc[NCB][R][2];
+    u32x4 mreg[(MASK && X4) ? CC : 1];      // ReLU-mask quads of the chunk in flight (this lane's part of the tile)
     float bias_r[NCB];           // bias of the tile whose first chunk was queued last (0 without a bias / under ksplit)
     unsigned goff[XI];
     auto set_goff = [&](const TileCoord& t) {
@@ -707,16 +708,17 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
         if (MASK) {
             const __amdgpu_buffer_rsrc_t rm =
                 sgpr_rsrc(kb->mask + (long long)t.b * kb->mask_bs + (long long)cglob * HW, (unsigned)cnt * plane_bytes);
-            const unsigned mdst = xdst + (unsigned)C::XS_FLOATS * 4u;
             if constexpr (X4) {
+                // the mask quads go to registers (not through LDS): no second tile image -> 32 KB instead of
+                // 55 KB of LDS per workgroup, and no LDS traffic for them; consumed by mask_in_place after the
+                // wait that precedes the next barrier
                 if (tid < C::XN) {
 #pragma unroll
-                    for (int c = 0; c < CC; ++c) {
-                        if (c < cnt) dma16s(rm, mdst + (unsigned)(c * CHS + wave * 256) * 4u, goff[0], (unsigned)c * plane_bytes);
-                        else dma16s(rm, mdst + (unsigned)(c * CHS + wave * 256) * 4u, oob, 0u);
-                    }
+                    for (int c = 0; c < CC; ++c)
+                        if (c < cnt) mreg[c] = __builtin_amdgcn_raw_buffer_load_b128(rm, goff[0], (unsigned)c * plane_bytes, 0);
                 }
             } else {
+                const unsigned mdst = xdst + (unsigned)C::XS_FLOATS * 4u;
 #pragma unroll
                 for (int c = 0; c < CC; ++c)
 #pragma unroll
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
         // filter rows cglob .. cglob+CC-1, columns cg*CB .. +CB-1: 16 bytes per lane
         const float* wsrc = kb->wp + (long long)cglob * KK * (long long)(wrow_bytes / 4u) + t.cg * CB;
         const __amdgpu_buffer_rsrc_t rw = sgpr_rsrc(wsrc, (unsigned)(CC * KK) * wrow_bytes);
-        const unsigned wdst = xdst + (unsigned)(C::XS_FLOATS * (MASK ? 2 : 1)) * 4u;
+        const unsigned wdst = xdst + (unsigned)(C::XS_FLOATS * ((MASK && !X4) ? 2 : 1)) * 4u;
 #pragma unroll
         for (int k = 0; k < WI; ++k)
             if (tid + k * 256 < WN) dma16s(rw, wdst + (unsigned)(k * 256 + wave * 64) * 16u, woff[k], 0u);
@@ -801,22 +803,24 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
     // LDS, exactly the elements its own DMA instructions delivered (complete after this wave's vmcnt(0)), so no
     // extra barrier is needed, and the MFMA loop reads plain operands: 32 vector-ALU instructions per chunk and
     // lane instead of 144 selects inside the MFMA stream.
-    auto mask_in_place = [&](int buf) {
+    auto mask_in_place = [&](int buf, int cnt) {
         float* xs = xs_of(buf);
-        const float* ms = ms_of(buf);
         if constexpr (X4) {
             if (tid < C::XN) {
 #pragma unroll
                 for (int c = 0; c < CC; ++c) {
-                    f32x4* xp = reinterpret_cast<f32x4*>(xs + c * CHS) + tid;
-                    const f32x4 m = *(reinterpret_cast<const f32x4*>(ms + c * CHS) + tid);
-                    f32x4 v = *xp;
+                    if (c < cnt) {          // (channels past the source's end are zeros already)
+                        f32x4* xp = reinterpret_cast<f32x4*>(xs + c * CHS) + tid;
+                        const f32x4 m = __builtin_bit_cast(f32x4, mreg[c]);
+                        f32x4 v = *xp;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
-                    *xp = v;
+                        for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+                        *xp = v;
+                    }
                 }
             }
         } else {
+            const float* ms = ms_of(buf);
 #pragma unroll
             for (int c = 0; c < CC; ++c)
 #pragma unroll
@@ -918,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
         // this wave's DMAs of the chunk about to be consumed have landed; after the barrier every wave's
         // have, and every wave is done reading the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (MASK && have) mask_in_place(buf);
+        if (MASK && have) mask_in_place(buf, chunk_cnt(ct.ks * cps + cch));
         __syncthreads();
         if (pending) {
             epilogue(pt);
