@@ -554,13 +554,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-#ifdef YNET_WG_EXPERIMENT_FEWER_READS      // timing experiment only (wrong results): a third of the B reads
-                    b[ky * 3 + kx] = kx == 0 ? p[ky * TCOLS] : b[ky * 3];
-#else
-                    b[ky * 3 + kx] = p[ky * TCOLS + kx];
-#endif
-                }
+                for (int kx = 0; kx < 3; ++kx) b[ky * 3 + kx] = p[ky * TCOLS + kx];
         };
         float a_cur, b_cur[KK], a_nxt, b_nxt[KK];
         int s = rp;
