@@ -7,15 +7,23 @@
 // because dgrad of a stride-1 "same" convolution is a convolution with the flipped, transposed filter;
 // the two differ only in the packed filter handed in (see ynet_pack_weight).
 //
-// Mapping (v_mfma_f32_32x32x2_f32, exact fp32 = an fmaf chain, 64 FLOP/clk/SIMD):
-//   M = 32 consecutive x     -> A operand = input tile row (LDS, x fastest)
-//   N = 32 output channels   -> B operand = packed filter  [cin][tap][cout]   (LDS, cout fastest)
-//   K = 2 input channels at one filter tap per instruction (lanes 0-31: channel c, 32-63: c+1)
-//   D: a lane owns one output channel and 4 consecutive pixels per register quad -> 16-byte NCHW stores
-// A workgroup = 4 waves computes a 32(x) x 4R(y) pixel tile for 32*NCB output channels; each wave
-// owns R rows, so one A fragment feeds R MFMAs and one B fragment NCB MFMAs.  The input tile
-// (with halo) and the filter slice for CC input channels are staged in LDS per chunk; 2-4 resident
-// workgroups per CU overlap one group's staging with another's MFMAs.
+// Kernels in this file (fp32 MFMA = an exact fmaf chain at the vector-ALU peak, 64 FLOP/clk/SIMD):
+//   conv_dma_kernel<NT,R,CC,MASK,X4,FOLD>   3x3, aligned planes: v_mfma_f32_16x16x4_f32, M = 16 pixels, N = 16 output
+//       channels (NT tiles per workgroup), K = 4 input channels at one tap; input / filter tiles go global -> LDS
+//       by `buffer_load ... lds` (LDS-DMA) into a double buffer, scalar-only control code, buffer stores.
+//       The default for every 3x3 launch with >= 2 rows per wave or a folded (W <= 16) map.
+//   conv_mfma_kernel<K,NCB,R,CC,MASK,M16>   register-staged generation (global -> VGPR -> LDS): one-row launches
+//       of the 32^2..64^2 maps, 5x5, unaligned planes; M16 = false keeps the 32x32x2 tile form
+//       (M = 32 pixels, N = 32 channels, K = 2 channels).
+//   conv1x1_stream_kernel<CT,PX>            the HBM-bound 1x1 predictors (few channels) on the vector ALU.
+//   conv_split_reduce_kernel                sums the partials of a channel-split small-map launch (+bias, ReLU).
+//   pack_weight_kernel                      checkpoint layout -> packed [cin][tap][cout] (mode 1: flipped/transposed).
+// In all of them a lane ends up owning one output channel and 4 consecutive pixels per accumulator quad
+// -> 16-byte NCHW stores.  A workgroup = 4 waves computes a 32(x) x 4R(y) pixel tile (folded: 16 x 8R, 8 x 16R)
+// for 16*NT (32*NCB) output channels; each wave owns R rows, so one A fragment feeds NT MFMAs and one B
+// fragment 2R.  Persistent workgroups walk tiles in an XCD-aware order; 2-4 are resident per CU and overlap
+// one group's staging / epilogue with another's MFMAs.  DESIGN.md section 4.1 has the measurements behind
+// each choice.
 #include "ynet_common.h"
 #include <stdlib.h>
 #include <stdio.h>

@@ -7,15 +7,17 @@
 //   dW[co][ci][ky][kx] = sum_{b,y,x} dy[b,co,y,x] * [yact[b,co,y,x] > 0] * x[b,ci,y+ky-P,x+kx-P]
 //   db[co]             = sum_{b,y,x} dy[b,co,y,x] * [yact > 0]
 //
-// GEMM view (v_mfma_f32_32x32x2_f32): M = 32 output channels (A = masked dy tile, LDS [co][pixel], odd
-// stride), N = 32 columns of the flattened (ci, kx) index (B = x tile with halo, LDS [ci][row][col], odd
-// channel stride; flattening kx into N means Cin = 14 costs 2 column tiles instead of 3 padded taps),
-// K = pixels, two per instruction; one accumulator tile per (column tile, ky).  db comes from one more
-// MFMA per K-step against a B operand of ones.
-// Pipeline: persistent workgroups walk 4x32-pixel tiles; the buffer_loads (hardware range check =
-// zero padding) of tile t+1 are issued before the MFMA loop of tile t and written to LDS after it.
-// Pixels are split over the 4 waves (summed through LDS in wave order) and over `nsplit` workgroups
-// (partials reduced by a second kernel in fixed order): bitwise reproducible, no float atomics.
+// wgrad_dma_kernel<MASK> (3x3, aligned planes; described at its definition): v_mfma_f32_16x16x4_f32 with K = 4
+// consecutive pixels, LDS-DMA double buffer, waves split the 32 co x 32 ci x 9 output block.
+// wgrad_mfma_kernel<K,MASK> (1x1, 5x5, unaligned planes): v_mfma_f32_32x32x2_f32, M = 32 output channels (A = masked
+// dy tile, LDS [co][pixel], odd stride), N = 32 columns of the flattened (ci, kx) index (B = x tile with halo, LDS
+// [ci][row][col], odd channel stride; flattening kx into N means Cin = 14 costs 2 column tiles instead of 3 padded
+// taps), K = pixels, two per instruction; one accumulator tile per (column tile, ky); db from one more MFMA per K-step
+// against a B operand of ones; persistent workgroups walk 4x32-pixel tiles, the buffer_loads (hardware range check =
+// zero padding) of tile t+1 are issued before the MFMA loop of tile t and written to LDS after it; pixels are split
+// over the 4 waves (summed through LDS in wave order).
+// Both split the pixels over `nsplit` workgroups and reduce the partials with reduce_partials_kernel in a fixed
+// order: bitwise reproducible, no float atomics.
 #include "ynet_common.h"
 #include <stdlib.h>
 #include <stdio.h>
