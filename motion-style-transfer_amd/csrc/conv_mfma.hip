@@ -971,8 +971,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
 // Split of the input-channel loop over workgroups for launches with fewer work items than CUs.
 static int conv_ksplit(long long items, int nchunks) {
     static const int off = getenv("YNET_CONV_NO_KSPLIT") ? 1 : 0;
-    if (off || items >= 256 || nchunks < 4) return 1;
-    long long k = (512 + items - 1) / items;
+    static const int min_items = getenv("YNET_KSPLIT_ITEMS") ? atoi(getenv("YNET_KSPLIT_ITEMS")) : 256;
+    static const int target = getenv("YNET_KSPLIT_TARGET") ? atoi(getenv("YNET_KSPLIT_TARGET")) : 512;
+    if (off || items >= min_items || nchunks < 4) return 1;
+    long long k = (target + items - 1) / items;
     if (k > nchunks / 2) k = nchunks / 2;
     if (k > 8) k = 8;
     return k < 1 ? 1 : (int)k;
