@@ -92,6 +92,10 @@ int ynet_lora_compose_pack(const float* w, const float* lora_a, const float* lor
 /* nn.MaxPool2d(2,2) (models/ynet.py:202,215,326,340,354,367); N = B*C planes of H x W. */
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream);
 int ynet_maxpool2_bwd(const float* x, const float* dy, float* dx, long long N, int H, int W, void* stream);
+/* dx = maxpool2_bwd(x, dy) + add0 + add1 (addends may be NULL; even H, W): folds the skip-connection gradients of the
+ * two decoders into the pool's backward instead of two autograd adds (utils/train_epoch.py:110 loss.backward()). */
+int ynet_maxpool2_bwd_add(const float* x, const float* dy, const float* add0, const float* add1, float* dx, long long N,
+                          int H, int W, void* stream);
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (models/ynet.py:463);
  * H, W are the LOW-resolution sizes in both directions. */
 int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream);

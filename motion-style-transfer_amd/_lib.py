@@ -37,6 +37,7 @@ SIGNATURES = {
     "ynet_lora_compose_pack": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_maxpool2_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_maxpool2_bwd": (c_i, [c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
+    "ynet_maxpool2_bwd_add": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_upsample2x_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_upsample2x_bwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_avgpool_pyramid": (c_i, [c_fp, PP, c_i, c_ll, c_i, c_i, c_fp]),

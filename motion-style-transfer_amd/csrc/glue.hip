@@ -35,6 +35,42 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
+// dx = route(dy) + add0 + add1 (either addend may be NULL): the max-pool backward also folds in the gradients the two
+// decoders produced for the same feature map (skip connections), replacing two full-size elementwise adds of the
+// autograd engine.  Even H and W, 8-byte aligned rows.
+__global__ void maxpool2_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                        const float* __restrict__ add0, const float* __restrict__ add1,
+                                        float* __restrict__ dx, long long N, int H, int W) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long long total = N * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo);
+        const int yo = (int)((i / Wo) % Ho);
+        const long long n = i / ((long long)Wo * Ho);
+        const long long base = (n * H + 2 * yo) * W + 2 * xo;
+        const f2 t = *reinterpret_cast<const f2*>(x + base), b = *reinterpret_cast<const f2*>(x + base + W);
+        float m = t[0];
+        int arg = 0;
+        if (t[1] > m || t[1] != t[1]) { m = t[1]; arg = 1; }
+        if (b[0] > m || b[0] != b[0]) { m = b[0]; arg = 2; }
+        if (b[1] > m || b[1] != b[1]) { m = b[1]; arg = 3; }
+        const float g = dy[i];
+        f2 o0 = {arg == 0 ? g : 0.f, arg == 1 ? g : 0.f}, o1 = {arg == 2 ? g : 0.f, arg == 3 ? g : 0.f};
+        if (add0) {
+            o0 += *reinterpret_cast<const f2*>(add0 + base);
+            o1 += *reinterpret_cast<const f2*>(add0 + base + W);
+        }
+        if (add1) {
+            o0 += *reinterpret_cast<const f2*>(add1 + base);
+            o1 += *reinterpret_cast<const f2*>(add1 + base + W);
+        }
+        *reinterpret_cast<f2*>(dx + base) = o0;
+        *reinterpret_cast<f2*>(dx + base + W) = o1;
+    }
+}
+
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                     float* __restrict__ dx, long long N, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1;
@@ -614,6 +650,16 @@ int ynet_maxpool2_bwd(const float* x, const float* dy, float* dx, long long N, i
     const long long total = N * ((H + 1) / 2) * ((W + 1) / 2);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W);
     return ynet_check_launch("maxpool2_bwd");
+}
+
+int ynet_maxpool2_bwd_add(const float* x, const float* dy, const float* add0, const float* add1, float* dx, long long N,
+                          int H, int W, void* stream) {
+    YNET_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2, "maxpool2_bwd_add: bad arguments");
+    YNET_REQUIRE((H & 1) == 0 && (W & 1) == 0, "maxpool2_bwd_add: H and W must be even (got %dx%d)", H, W);
+    YNET_REQUIRE((((uintptr_t)x | (uintptr_t)dx | (uintptr_t)add0 | (uintptr_t)add1) & 7) == 0, "maxpool2_bwd_add: 8-byte aligned planes required");
+    const long long total = N * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(maxpool2_bwd_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, add0, add1, dx, N, H, W);
+    return ynet_check_launch("maxpool2_bwd_add");
 }
 
 int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {

@@ -224,6 +224,7 @@ def lora_grad(dw, lora_a, lora_b, scale: float):
 
 
 import os as _os
+import weakref
 
 _conv_ws = {}
 _side_streams = {}
@@ -297,6 +298,42 @@ def _cached(cache: dict, weight, lora_a, lora_b, scale, what: str):
     return cache[what]
 
 
+# ------------------------------------------------------------------------------------------------
+# Skip-connection gradients folded into the max-pool backward
+# ------------------------------------------------------------------------------------------------
+# An encoder feature map feeds the next stage's max-pool AND the two decoders (torch.cat skips).  Left to the
+# autograd engine its gradient is summed by two full-size elementwise adds (6 passes over the largest tensors of
+# the step).  Instead: the pool's forward registers its input; a conv backward that produces a gradient for a
+# registered tensor hands it over here (and returns None to autograd); the pool's backward adds the handed-over
+# gradients while it writes its own (ynet_maxpool2_bwd_add).  Always correct: a gradient is only handed over while
+# the pool's backward has not run yet, and only for the very tensor (weak reference, address, shape) the pool saw.
+class _SkipEntry:
+    __slots__ = ("ref", "shape", "stash", "consumed")
+
+
+_skip_registry = {}
+skip_fold = _os.environ.get("YNET_SKIP_FOLD", "1") != "0"
+
+
+def _skip_register(x: torch.Tensor):
+    if len(_skip_registry) > 64:
+        for k in [k for k, e in _skip_registry.items() if e.ref() is None]:
+            del _skip_registry[k]
+    e = _SkipEntry()
+    e.ref, e.shape, e.stash, e.consumed = weakref.ref(x), tuple(x.shape), [], False
+    _skip_registry[x.data_ptr()] = e
+
+
+def _skip_entry(t: torch.Tensor):
+    e = _skip_registry.get(t.data_ptr())
+    if e is None:
+        return None
+    if e.ref() is None or e.shape != tuple(t.shape):
+        del _skip_registry[t.data_ptr()]
+        return None
+    return e
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, weight, bias, lora_a, lora_b, *srcs):
@@ -362,6 +399,16 @@ class _Conv2dFn(torch.autograd.Function):
                 else:
                     dsts.append((None, c, 0))
             conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False)
+            if skip_fold:
+                for i, s in enumerate(srcs):
+                    if d_srcs[i] is None:
+                        continue
+                    e = _skip_entry(s)
+                    if e is not None and not e.consumed and len(e.stash) < 2:
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(dy.device))
+                        e.stash.append((d_srcs[i], ev))
+                        d_srcs[i] = None        # the pool's backward adds it in (see _MaxPool2Fn.backward)
         d_w = d_b = d_a = d_bm = None
         want_w = need[1] or (ctx.has_lora and (need[3] or need[4]))
         want_b = ctx.has_bias and need[2]
@@ -409,6 +456,9 @@ class _MaxPool2Fn(torch.autograd.Function):
         lib = _lib()
         L.check(lib.ynet_maxpool2_fwd(x.data_ptr(), y.data_ptr(), B * C, H, W, _stream()), lib)
         ctx.save_for_backward(x)
+        ctx.folds = bool(skip_fold and ctx.needs_input_grad[0] and H % 2 == 0 and W % 2 == 0)
+        if ctx.folds:
+            _skip_register(x)
         return y
 
     @staticmethod
@@ -417,7 +467,23 @@ class _MaxPool2Fn(torch.autograd.Function):
         B, C, H, W = x.shape
         dx = torch.empty_like(x)
         lib = _lib()
-        L.check(lib.ynet_maxpool2_bwd(x.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), B * C, H, W, _stream()), lib)
+        adds = []
+        if ctx.folds:
+            e = _skip_entry(x)
+            if e is not None:
+                adds, e.stash, e.consumed = e.stash, [], True
+        if adds:
+            cur = torch.cuda.current_stream(dy.device)
+            for t, ev in adds:          # produced on the decoders' streams
+                cur.wait_event(ev)
+                t.record_stream(cur)
+            a0 = adds[0][0]
+            a1 = adds[1][0] if len(adds) > 1 else None
+            L.check(lib.ynet_maxpool2_bwd_add(x.data_ptr(), dy.contiguous().data_ptr(), a0.data_ptr(),
+                                              a1.data_ptr() if a1 is not None else None, dx.data_ptr(), B * C, H, W,
+                                              _stream()), lib)
+        else:
+            L.check(lib.ynet_maxpool2_bwd(x.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), B * C, H, W, _stream()), lib)
         return dx
 
 
