@@ -7,7 +7,7 @@
 //   dW[co][ci][ky][kx] = sum_{b,y,x} dy[b,co,y,x] * [yact[b,co,y,x] > 0] * x[b,ci,y+ky-P,x+kx-P]
 //   db[co]             = sum_{b,y,x} dy[b,co,y,x] * [yact > 0]
 //
-// wgrad_dma_kernel<MASK> (3x3, aligned planes; described at its definition): v_mfma_f32_16x16x4_f32 with K = 4
+// wgrad_dma_kernel<MASK, TH_> (3x3, aligned planes; described at its definition): v_mfma_f32_16x16x4_f32 with K = 4
 // consecutive pixels, LDS-DMA double buffer, waves split the 32 co x 32 ci x 9 output block.
 // wgrad_mfma_kernel<K,MASK> (1x1, 5x5, unaligned planes): v_mfma_f32_32x32x2_f32, M = 32 output channels (A = masked
 // dy tile, LDS [co][pixel], odd stride), N = 32 columns of the flattened (ci, kx) index (B = x tile with halo, LDS
@@ -37,6 +37,7 @@ struct WgradArgs {
     float* partial_b;         // [nsplit][cout] or NULL
     int B, H, W, cout;
     int tiles_x, tiles_y, ntiles, nsplit, co_blks, ci_blks;
+    int stagger;            // start delay (x 64 cycles) of the workgroup in the odd wave slot of a CU (0: off)
 #ifdef YNET_WG_PROFILE
     unsigned long long* prof;      // development build: per-phase cycle sums
 #endif
@@ -274,35 +275,37 @@ __device__ __forceinline__ void wg_dma16s(__amdgpu_buffer_rsrc_t r, const float*
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (wg_lds_ptr_t)lds, 16, voff, soff, 0, 0);
 }
 
-template <bool MASK>
+template <bool MASK, int TH_>
 struct WgDmaCfg {
-    static constexpr int TH = 2, TW = 32, TROWS = TH + 2, TCOLS = TW + 8;
-    static constexpr int XQ = TROWS * TCOLS / 4 + 1;     // quads per x channel (+1 pad quad): 41
-    static constexpr int XCH = XQ * 4;                   // 164 = 4 mod 32
-    static constexpr int DQ = TH * TW / 4 + 1;           // quads per dy channel (+1 pad quad): 17
-    static constexpr int DCH = DQ * 4;                   // 68 = 4 mod 32
+    static constexpr int TH = TH_, TW = 32, TROWS = TH + 2, TCOLS = TW + 8;
+    // quads per x / dy channel incl. pad quads, = 1 mod 8 so that the channel stride in floats is 4 mod 32
+    static constexpr int XDATA = TROWS * TCOLS / 4, DDATA = TH * TW / 4;
+    static constexpr int XQ = (XDATA + 1 + 6) / 8 * 8 + 1;
+    static constexpr int XCH = XQ * 4;
+    static constexpr int DQ = (DDATA + 1 + 6) / 8 * 8 + 1;
+    static constexpr int DCH = DQ * 4;
     // + 128 floats of slack each: the last, partial DMA instruction of a tile image is issued by a whole wave
     // (no per-lane predicate = no vector-ALU compare); its surplus lanes carry the out-of-range marker and write
     // zeros into the slack
     static constexpr int XS = 32 * XCH + 128, DS = 32 * DCH + 128;
-    static constexpr int BUF = XS + DS * (MASK ? 2 : 1);
+    static constexpr int BUF = XS + DS;                  // (the ReLU-mask quads stay in registers)
     static constexpr int LDS_BYTES = 2 * BUF * 4;
-    static constexpr int XI = (32 * XQ + 255) / 256;     // x DMA instructions per thread per tile (6)
-    static constexpr int DI = (32 * DQ + 255) / 256;     // dy (and mask) DMA instructions per thread per tile (3)
+    static constexpr int XI = (32 * XQ + 255) / 256;     // x DMA instructions per thread per tile
+    static constexpr int DI = (32 * DQ + 255) / 256;     // dy DMA instructions (and mask loads) per thread per tile
     static constexpr int KSTEPS = TH * TW / 4;
     static_assert(XCH % 32 == 4 && DCH % 32 == 4, "bank-conflict-free channel strides");
     static_assert(3 * 37 * 64 <= 2 * BUF, "cross-wave reduction scratch fits");
+    static_assert(KSTEPS % 8 == 0, "a wave runs KSTEPS / rpN K-steps in pairs (rpN <= 4)");
 };
 
-template <bool MASK>
+template <bool MASK, int TH_>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
-    using C = WgDmaCfg<MASK>;
+    using C = WgDmaCfg<MASK, TH_>;
     constexpr int TH = C::TH, TW = C::TW, TCOLS = C::TCOLS, XQ = C::XQ, XCH = C::XCH, DQ = C::DQ, DCH = C::DCH;
     constexpr int XI = C::XI, DI = C::DI, KK = 9;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     auto xs_of = [&](int b) { return smem + b * C::BUF; };
     auto ds_of = [&](int b) { return smem + b * C::BUF + C::XS; };
-    auto ms_of = [&](int b) { return smem + b * C::BUF + C::XS + C::DS; };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         xcol[k] = (within - xrow[k] * (TCOLS / 4)) * 4 - 4;
         int c = ci0 + ch, sid = -1;
         unsigned off = 0;
-        if (q < 32 * XQ && within < XQ - 1 && ch < ncib) {
+        if (q < 32 * XQ && within < C::XDATA && ch < ncib) {
 #pragma unroll
             for (int s = 0; s < YNET_MAX_SRC; ++s) {
                 if (sid < 0 && s < a.nsrc) {
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     for (int k = 0; k < DI; ++k) {
         const int q = tid + k * 256;
         const int ch = q / DQ, within = q - ch * DQ;
-        const bool ok = q < 32 * DQ && within < DQ - 1;
+        const bool ok = q < 32 * DQ && within < C::DDATA;
         drow[k] = ok ? within / (TW / 4) : -1;
         dcol[k] = (within % (TW / 4)) * 4;
         dcoff[k] = (unsigned)ch * plane_bytes;       // channels >= nco fall outside the descriptor: zero
@@ -377,6 +380,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     // instruction issues once per ~MFMA slot of the other wave on the SIMD: the ~100 of the generic path below
     // took about as long as the tile's 144 MFMAs.)
     // static offsets for a tile of an interior column / the first column (left halo quads zeroed) / the last / both
+    typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+    wg_u32x4 mq[MASK ? DI : 1];      // ReLU-mask quads of the tile in flight
     unsigned xs_in[XI], xs_l[XI], xs_r[XI], xs_lr[XI], dstat[DI];     // (separate arrays: a 2-D one selected by value goes to scratch)
 #pragma unroll
     for (int k = 0; k < XI; ++k) {
@@ -429,93 +434,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
             if (DI > DFULL && wave == 0) wg_dma16s(r, ds + (DFULL * 256) * 4, dofs[DI - 1], dso);
         }
         if (MASK) {
+            // the mask quads that correspond to this lane's dy DMA lanes go to registers; mask_in_place applies them
+            // to the dy tile in LDS after the wait that precedes the next barrier (no mask image in LDS)
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(ka->mask + (long long)t.b * ka->mask_bs + (long long)co0 * HW), 0, (unsigned)nco * plane_bytes, 0x00020000);
-            float* ms = ms_of(buf);
 #pragma unroll
-            for (int k = 0; k < DFULL; ++k) wg_dma16s(r, ms + (k * 256 + wave * 64) * 4, dofs[k], dso);
-            if (DI > DFULL && wave == 0) wg_dma16s(r, ms + (DFULL * 256) * 4, dofs[DI - 1], dso);
+            for (int k = 0; k < DFULL; ++k) mq[k] = __builtin_amdgcn_raw_buffer_load_b128(r, dofs[k], dso, 0);
+            if (DI > DFULL && wave == 0) mq[DI - 1] = __builtin_amdgcn_raw_buffer_load_b128(r, dofs[DI - 1], dso, 0);
+        }
+    };
+    auto mask_in_place = [&](int buf) {
+        float* ds = ds_of(buf);
+#pragma unroll
+        for (int k = 0; k < DI; ++k) {
+            const bool part = k >= 32 * DQ / 256;
+            if (!part || wave == 0) {
+                f32x4* p = reinterpret_cast<f32x4*>(ds) + (part ? k * 256 + lane : k * 256 + tid);
+                const f32x4 m = __builtin_bit_cast(f32x4, mq[k]);
+                f32x4 v = *p;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+                *p = v;
+            }
         }
     };
 
-    // ---- DMAs interleaved with the MFMA stream.  For the common case (one source, fast addressing) the 12 DMA
-    // instructions of the NEXT tile are not queued in one go after the barrier (measured: 25-30 % of every wave's
-    // time, during which its MFMA slot idles when the co-resident workgroup is in the same phase) but handed out a
-    // few per K-step pair inside the MFMA loop, where they issue beside the MFMAs.
-    constexpr int XFULL_ = 32 * XQ / 256, DFULL_ = 32 * DQ / 256;
-    constexpr int NSLOT = XI + DI * (MASK ? 2 : 1);
-    struct Pending {
-        bool inloop;
-        int buf, variant;            // variant: 0 interior column, 1 first, 2 last, 3 both
-        __amdgpu_buffer_rsrc_t rx, rd, rm;
-        unsigned xso, dso;
-    } pend;
-    pend.inloop = false;
-    pend.buf = 0;
-    pend.variant = 0;
-    pend.xso = pend.dso = 0;
-    pend.rx = pend.rd = pend.rm = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
-    // slot j of the pending tile: x quads k = 0..XI-1, then dy, then mask (static register names: unrolled switch)
-    auto dma_slot = [&](int j) {
-        float* xs = xs_of(pend.buf);
-        float* ds = ds_of(pend.buf);
-        float* ms = ms_of(pend.buf);
-#pragma unroll
-        for (int k = 0; k < XI; ++k) {
-            if (j == k) {
-                const bool part = k >= XFULL_;
-                if (!part || wave == 0) {
-                    float* dst = xs + (part ? k * 256 : k * 256 + wave * 64) * 4;
-                    if (pend.variant == 0) wg_dma16s(pend.rx, dst, xs_in[k], pend.xso);
-                    else if (pend.variant == 1) wg_dma16s(pend.rx, dst, xs_l[k], pend.xso);
-                    else if (pend.variant == 2) wg_dma16s(pend.rx, dst, xs_r[k], pend.xso);
-                    else wg_dma16s(pend.rx, dst, xs_lr[k], pend.xso);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < DI; ++k) {
-            const bool part = k >= DFULL_;
-            if (j == XI + k && (!part || wave == 0))
-                wg_dma16s(pend.rd, ds + (part ? k * 256 : k * 256 + wave * 64) * 4, dstat[k], pend.dso);
-            if (MASK && j == XI + DI + k && (!part || wave == 0))
-                wg_dma16s(pend.rm, ms + (part ? k * 256 : k * 256 + wave * 64) * 4, dstat[k], pend.dso);
-        }
-    };
-    // Set up the next tile: either leaves its DMAs pending for the MFMA loop (returns true) or queues them all now.
-    auto issue = [&](const WgTile& t, int buf, bool may_defer) {
-        const bool fast = regular && t.y0 >= 1 && t.y0 + TH + 1 <= H;
-        wg_kargs_t ka = (wg_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        if (fast && ka->nsrc == 1) {
-            pend.buf = buf;
-            pend.xso = (unsigned)((t.y0 - 1) * W + t.x0 - 4) * 4u;
-            pend.dso = (unsigned)(t.y0 * W + t.x0) * 4u;
-            pend.variant = (t.x0 == 0 ? 1 : 0) | (t.x0 + TW >= W ? 2 : 0);
-            pend.rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ka->src[0].p + (long long)t.b * ka->src[0].bs), 0,
-                                                        (unsigned)ka->src[0].c * plane_bytes, 0x00020000);
-            pend.rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ka->dy + (long long)t.b * ka->dy_bs + (long long)co0 * HW), 0,
-                                                        (unsigned)nco * plane_bytes, 0x00020000);
-            if (MASK)
-                pend.rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ka->mask + (long long)t.b * ka->mask_bs + (long long)co0 * HW), 0,
-                                                            (unsigned)nco * plane_bytes, 0x00020000);
-            if (may_defer) return true;
-#pragma unroll
-            for (int q = 0; q < NSLOT; ++q) dma_slot(q);
-            return false;
-        }
+    // Queue the DMAs of a tile.  (Handing them out inside the MFMA loop instead was measured 6-15 % slower: a
+    // buffer_load ... lds holds the wave's instruction stream for ~50-60 cycles wherever it is placed.)
+    auto issue = [&](const WgTile& t, int buf) {
+        // (the scalar offset of the x tile must not be negative: row y0-1 = 0 of the first tile column is left to the
+        // generic path)
+        const bool fast = regular && t.y0 >= 1 && t.y0 + TH + 1 <= H && (t.y0 - 1) * W + t.x0 - 4 >= 0;
         if (fast) {
             const unsigned xso = (unsigned)((t.y0 - 1) * W + t.x0 - 4) * 4u;
             const unsigned dso = (unsigned)(t.y0 * W + t.x0) * 4u;
             const bool at_left = t.x0 == 0, at_right = t.x0 + TW >= W;
-            unsigned xo[XI];
+            if (!at_left && !at_right) {
+                queue(t, buf, xs_in, xso, dstat, dso);              // interior: no vector-ALU instruction
+            } else {
+                unsigned xo[XI];                                    // first / last column: one or two selects per quad
 #pragma unroll
-            for (int k = 0; k < XI; ++k) {
-                const unsigned l = at_right ? xs_lr[k] : xs_l[k];
-                const unsigned m = at_right ? xs_r[k] : xs_in[k];
-                xo[k] = at_left ? l : m;
+                for (int k = 0; k < XI; ++k) {
+                    const unsigned l = at_right ? xs_lr[k] : xs_l[k];
+                    xo[k] = at_left ? l : xs_r[k];
+                }
+                queue(t, buf, xo, xso, dstat, dso);
             }
-            queue(t, buf, xo, xso, dstat, dso);
         } else {
             unsigned xo[XI], dofs[DI];
 #pragma unroll
@@ -532,7 +496,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
             }
             queue(t, buf, xo, 0u, dofs, 0u);
         }
-        return false;
     };
 
     f32x4 acc[KK];
@@ -542,15 +505,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
 
     const int xoff = (ib * 16 + r16) * XCH + 3 + kq;     // tile column 0 (gx = x0-1) sits at LDS column 3
     const int doff = (cb * 16 + r16) * DCH + kq;
-    auto compute = [&](int buf, bool deferred) {
+    auto compute = [&](int buf) {
         const float* xb = xs_of(buf) + xoff;
         const float* ab = ds_of(buf) + doff;
-        const float* mb = ms_of(buf) + doff;
-        auto rd_a = [&](int s) {
-            const float v = ab[4 * s];          // rows are 32 pixels = 8 K-steps: 4 s is the pixel offset in the tile
-            if (MASK) return mb[4 * s] > 0.f ? v : 0.f;
-            return v;
-        };
+        auto rd_a = [&](int s) { return ab[4 * s]; };     // rows are 32 pixels = 8 K-steps: 4 s is the pixel offset in the tile
         auto rd_b = [&](int s, float* b) {
             const float* p = xb + (s >> 3) * TCOLS + (s & 7) * 4;
 #pragma unroll
@@ -569,30 +527,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         for (int t = 0; t < KK; ++t) asm volatile("" : "+v"(b_cur[t]));
         // one K-step: queue the LDS reads of the following step into (a_n, b_n), then the 9 MFMAs of (a_c, b_c)
         auto step = [&](int sn, float a_c, const float* b_c, float& a_n, float* b_n) {
-            const float v = ab[4 * sn];
-            float m = 1.f;
-            if (MASK) m = mb[4 * sn];
+            a_n = ab[4 * sn];
             rd_b(sn, b_n);
             __builtin_amdgcn_sched_barrier(0);      // nothing moves across: reads of the next step, THEN the MFMAs of this one
 #pragma unroll
             for (int t = 0; t < KK; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[t], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            a_n = m > 0.f ? v : 0.f;        // VALU work on the fresh reads goes behind the MFMAs (their data has landed by then)
             bsum += a_c;
             __builtin_amdgcn_sched_barrier(0);
         };
-        // a wave runs KSTEPS / rpN = 16, 8 or 4 steps: two per iteration, the register sets swapping roles
+        // a wave runs KSTEPS / rpN steps (an even number): two per iteration, the register sets swapping roles
         // (the last step re-reads itself: no branch in the loop body)
-        // pending DMAs of the next tile: NSLOT instructions spread over the first half of this wave's K-step pairs
-        const int per_iter = deferred ? (2 * NSLOT * 2 * rpN + C::KSTEPS - 1) / C::KSTEPS : 0;
-        int slot = 0;
 #pragma unroll 1
         for (; s < C::KSTEPS; s += 2 * rpN) {
             step(s + rpN, a_cur, b_cur, a_nxt, b_nxt);
-            for (int q = 0; q < per_iter && slot < NSLOT; ++q, ++slot) dma_slot(slot);
             step(s + 2 * rpN < C::KSTEPS ? s + 2 * rpN : s + rpN, a_nxt, b_nxt, a_cur, b_cur);
         }
-        for (; deferred && slot < NSLOT; ++slot) dma_slot(slot);
     };
 
     // The load cursor walks tiles split, split + nsplit, ...: its (x, y, image) coordinates advance by a fixed
@@ -616,16 +566,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         nt.b += step_b + cy;
         return t;
     };
+    // Two workgroups share a CU.  Started together they stay in lockstep -- both queue DMAs, then both stream MFMAs at
+    // half rate -- so the one in the odd wave slot starts half a tile period late and they alternate instead.
+    if (a.stagger > 0) {
+        if (tid == 0) smem[0] = __builtin_bit_cast(float, (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4));   // HW_ID.wave_id
+        __syncthreads();
+        const int slot = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, smem[0]));
+        __syncthreads();
+        if (slot & 1)
+            for (int q = 0; q < a.stagger; ++q) __builtin_amdgcn_s_sleep(1);
+    }
     int tile = split, buf = 0;
-    if (tile < a.ntiles) issue(next_tile(), 0, false);
+    if (tile < a.ntiles) issue(next_tile(), 0);
     for (; tile < a.ntiles; tile += a.nsplit) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MASK) mask_in_place(buf);           // each lane rewrites what its own DMA lanes delivered
         __syncthreads();
-        bool deferred = false;
-        // (deferring the DMAs into the MFMA loop was measured 6-15 % SLOWER: a buffer_load ... lds holds the wave's
-        // instruction stream for hundreds of cycles wherever it is placed -- tools/dma_issue.hip)
-        if (tile + a.nsplit < a.ntiles) deferred = issue(next_tile(), buf ^ 1, YNET_WG_DEFER != 0);
-        compute(buf, deferred);
+        if (tile + a.nsplit < a.ntiles) issue(next_tile(), buf ^ 1);
+        compute(buf);
         buf ^= 1;
     }
 
@@ -726,18 +684,18 @@ static int launch_wgrad_m(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     return ynet_check_launch("conv2d_wgrad(reduce)");
 }
 
-template <bool MASK>
+template <bool MASK, int TH_>
 static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) {
-    using C = WgDmaCfg<MASK>;
+    using C = WgDmaCfg<MASK, TH_>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<MASK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<MASK, TH_>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
         if (getenv("YNET_DEBUG_OCC")) {
             int per_cu = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_dma_kernel<MASK>, 256, C::LDS_BYTES);
-            fprintf(stderr, "wgrad_dma_kernel<%d>: %d bytes of LDS, %d workgroups per CU\n", (int)MASK, C::LDS_BYTES, per_cu);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_dma_kernel<MASK, TH_>, 256, C::LDS_BYTES);
+            fprintf(stderr, "wgrad_dma_kernel<%d,%d>: %d bytes of LDS, %d workgroups per CU\n", (int)MASK, TH_, C::LDS_BYTES, per_cu);
         }
     }
     const long long nblk = (long long)a.nsplit * a.co_blks * a.ci_blks;
@@ -754,7 +712,8 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
     (void)hipMemsetAsync(prof_dev, 0, 64, st);
     a.prof = prof_dev;
 #endif
-    hipLaunchKernelGGL((wgrad_dma_kernel<MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    static const int lds_pad = getenv("YNET_WG_LDS_PAD") ? atoi(getenv("YNET_WG_LDS_PAD")) : 0;     // occupancy experiments
+    hipLaunchKernelGGL((wgrad_dma_kernel<MASK, TH_>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES + lds_pad, st, a);
 #ifdef YNET_WG_PROFILE
     {
         unsigned long long h[8];
@@ -802,10 +761,11 @@ static bool wgrad_dma_shape(int W, int K) {
 static int wgrad_plan(int B, int H, int W, int cout, int cin, int K, int th, int* nsplit_out) {
     const int tiles = B * ceil_div(H, th) * ceil_div(W, 32);
     const int blocks_per_split = ceil_div(cout, 32) * ceil_div(cin, wgrad_cib(K));
-    int nsplit = 512 / blocks_per_split;       // ~2 resident workgroups per CU
+    const int resident = th == 1 ? 768 : 512;  // 3 (one-row tiles: 45 KB of LDS) or 2 resident workgroups per CU
+    int nsplit = resident / blocks_per_split;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > tiles) nsplit = tiles;
-    if (nsplit > 512) nsplit = 512;
+    if (nsplit > resident) nsplit = resident;
     *nsplit_out = nsplit;
     return tiles;
 }
@@ -814,10 +774,12 @@ extern "C" {
 
 // floats of workspace ynet_conv2d_wgrad needs for this problem
 long long ynet_conv2d_wgrad_workspace_floats(int B, int H, int W, int cout, int cin, int K) {
-    int n2 = 0, n4 = 0;     // either tile height may be chosen at call time (alignment): size for the larger split
+    int n1 = 0, n2 = 0, n4 = 0;     // any tile height may be chosen at call time (alignment, env): size for the largest split
+    wgrad_plan(B, H, W, cout, cin, K, 1, &n1);
     wgrad_plan(B, H, W, cout, cin, K, 2, &n2);
     wgrad_plan(B, H, W, cout, cin, K, 4, &n4);
-    return (long long)(n2 > n4 ? n2 : n4) * ((long long)cout * cin * K * K + cout);
+    const int n = n1 > n2 ? (n1 > n4 ? n1 : n4) : (n2 > n4 ? n2 : n4);
+    return (long long)n * ((long long)cout * cin * K * K + cout);
 }
 
 int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
@@ -849,7 +811,8 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
         for (int i = 0; i < nsrc; ++i) dma = dma && !misaligned(src[i], src_bs[i]);
         dma = dma && !misaligned(dy, dy_bs) && (mask == nullptr || !misaligned(mask, mask_bs));
     }
-    const int th = dma ? 2 : 4;
+    static const int dma_th = getenv("YNET_WGRAD_TH") ? atoi(getenv("YNET_WGRAD_TH")) : 2;      // rows per tile of the DMA kernel (2: 2 workgroups per CU; 1: 3, more halo traffic -- measured equal)
+    const int th = dma ? (dma_th == 2 ? 2 : 1) : 4;
     a.tiles_x = ceil_div(W, 32);
     a.tiles_y = ceil_div(H, th);
     a.ntiles = wgrad_plan(B, H, W, cout, a.cin, K, th, &a.nsplit);
@@ -859,7 +822,8 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
     hipStream_t st = (hipStream_t)stream;
     if (dma) {
         a.ci_blks = ceil_div(a.cin, 32);
-        return mask ? launch_wgrad_dma<true>(a, dw, db, st) : launch_wgrad_dma<false>(a, dw, db, st);
+        if (th == 2) return mask ? launch_wgrad_dma<true, 2>(a, dw, db, st) : launch_wgrad_dma<false, 2>(a, dw, db, st);
+        return mask ? launch_wgrad_dma<true, 1>(a, dw, db, st) : launch_wgrad_dma<false, 1>(a, dw, db, st);
     }
     switch (K) {
         case 1: return launch_wgrad<1>(a, dw, db, st);
