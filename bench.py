@@ -163,7 +163,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="trajectories per GPU per step (default: BASELINE.json's per-GPU batch: 32; C4 16; C5 128)")
     ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,6 +184,8 @@ def main():
 
     ynet, trainer, te, ops = pkg("models.ynet"), pkg("models.trainer"), pkg("utils.train_epoch"), pkg("ops")
     cfg, H, W, workload = make_cfg(O, args.config)
+    if args.batch is None:
+        args.batch = {"C4": 16, "C5": 128}.get(args.config, 32)
     B, N = args.batch, world
     sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.05)
     model = ynet.YNet(cfg.obs_len, cfg.pred_len, None, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
