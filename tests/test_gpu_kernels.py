@@ -155,6 +155,56 @@ def test_maxpool(dev, shape):
     assert torch.equal(xd.grad.cpu(), xc.grad)
 
 
+def test_skip_gradients_fold_into_maxpool_backward(dev):
+    """A feature map consumed by a max-pool AND by two convolutions (the decoders' skip connections): the conv
+    backwards hand their gradients to the pool's backward (ynet_maxpool2_bwd_add) instead of autograd adding them;
+    the total must equal stock autograd, with folding on and off, and the pool-first order must fall back."""
+    ops = pkg("ops")
+    x = rnd(2, 6, 16, 32, seed=1)
+    w0, w1, w2 = rnd(8, 6, 3, 3, seed=2, scale=0.2), rnd(4, 8, 3, 3, seed=3, scale=0.2), rnd(5, 10, 3, 3, seed=4, scale=0.2)
+    extra = rnd(2, 2, 16, 32, seed=5)
+    # stock torch
+    xc = x.clone().requires_grad_(True)
+    f = F.relu(F.conv2d(xc, w0, padding=1))
+    loss = F.max_pool2d(f, 2, 2).square().sum() + F.conv2d(f, w1, padding=1).sum() * 0.5 \
+        + F.conv2d(torch.cat([f, extra], 1), w2, padding=1).square().sum()
+    loss.backward()
+    for fold in (True, False):
+        ops.skip_fold = fold
+        try:
+            xd = x.to(dev).requires_grad_(True)
+            fd = ops.conv2d(xd, w0.to(dev), None, True, {})
+            ld = ops.max_pool2(fd).square().sum() + ops.conv2d(fd, w1.to(dev), None, False, {}).sum() * 0.5 \
+                + ops.conv2d(ops.lazy_cat([fd, extra.to(dev)]), w2.to(dev), None, False, {}).square().sum()
+            ld.backward()
+        finally:
+            ops.skip_fold = True
+        close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx (fold={fold})")
+    # odd spatial size: never registered, plain path
+    xo = rnd(1, 3, 7, 9, seed=6)
+    xoc = xo.clone().requires_grad_(True)
+    (F.max_pool2d(F.relu(F.conv2d(xoc, w0[:, :3], padding=1)), 2, 2).sum()).backward()
+    xod = xo.to(dev).requires_grad_(True)
+    ops.max_pool2(ops.conv2d(xod, w0[:, :3].to(dev).contiguous(), None, True, {})).sum().backward()
+    close(xod.grad, xoc.grad, rtol=1e-4, scale_rel=2e-6, msg="odd size")
+
+
+@pytest.mark.parametrize("cin,cout,relu", [(32, 12, False), (12, 32, False), (32, 30, True), (7, 16, True), (32, 33, False)])
+def test_conv1x1_predictor_kernels(dev, cin, cout, relu):
+    """The streaming 1x1 kernel (Cout <= 32: 16 x 4-pixel and 32 x 2-pixel variants) and the MFMA path beyond it."""
+    ops = pkg("ops")
+    B, H, W = 3, 16, 24
+    x, w, b = rnd(B, cin, H, W, seed=1), rnd(cout, cin, 1, 1, seed=2, scale=0.3), rnd(cout, seed=3, scale=0.1)
+    y = F.conv2d(x, w, b)
+    y = F.relu(y) if relu else y
+    yd = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), relu, {})
+    close(yd, y, msg="1x1")
+    # batch-broadcast input (stride 0)
+    y1 = F.conv2d(x[:1].expand(B, -1, -1, -1), w, b)
+    y1 = F.relu(y1) if relu else y1
+    close(ops.conv2d(x[:1].to(dev).expand(B, -1, -1, -1), w.to(dev), b.to(dev), relu, {}), y1, msg="1x1 broadcast")
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 8, 16), (1, 2, 1, 1), (1, 4, 5, 3), (2, 16, 32, 32)])
 def test_upsample2x(dev, shape):
     ops = pkg("ops")
