@@ -179,6 +179,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    if os.environ.get("YNET_BENCH_SINGLE_DEVICE") == "1":      # development: every rank on cuda:0 (with YNET_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
