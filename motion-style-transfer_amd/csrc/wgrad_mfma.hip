@@ -402,11 +402,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     // through the kernarg segment (s_load) so that they do not occupy SGPRs across the MFMA loop (spills to VGPR
     // lanes are reloaded by v_readlane, a vector-ALU instruction).
     typedef const __attribute__((address_space(4))) WgradArgs* wg_kargs_t;
+#ifdef YNET_WG_PROFILE
+    unsigned long long prof_dma = 0;
+#endif
     auto queue = [&](const WgTile& t, int buf, const unsigned* xo, unsigned xso, const unsigned* dofs, unsigned dso) {
         wg_kargs_t ka = (wg_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         float* xs = xs_of(buf);
         const int nsrc = ka->nsrc;
+#ifdef YNET_WG_PROFILE
+        const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#endif
         constexpr int XFULL = 32 * XQ / 256, DFULL = 32 * DQ / 256;      // instructions issued by all four waves
         static_assert(32 * XQ - XFULL * 256 <= 64 && 32 * DQ - DFULL * 256 <= 64, "the partial instruction fits one wave");
         if (nsrc == 1) {        // lanes without data carry the marker: no predicate at all
@@ -442,6 +448,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
             for (int k = 0; k < DFULL; ++k) mq[k] = __builtin_amdgcn_raw_buffer_load_b128(r, dofs[k], dso, 0);
             if (DI > DFULL && wave == 0) mq[DI - 1] = __builtin_amdgcn_raw_buffer_load_b128(r, dofs[DI - 1], dso, 0);
         }
+#ifdef YNET_WG_PROFILE
+        prof_dma += __builtin_amdgcn_s_memtime() - q0;
+#endif
     };
     auto mask_in_place = [&](int buf) {
         float* ds = ds_of(buf);
@@ -578,14 +587,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     }
     int tile = split, buf = 0;
     if (tile < a.ntiles) issue(next_tile(), 0);
+#ifdef YNET_WG_PROFILE
+    unsigned long long pw = 0, pb = 0, pi = 0, pc = 0;
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
     for (; tile < a.ntiles; tile += a.nsplit) {
+#ifdef YNET_WG_PROFILE
+        const unsigned long long p0 = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef YNET_WG_PROFILE
+        const unsigned long long p1 = __builtin_amdgcn_s_memtime();
+#endif
         if (MASK) mask_in_place(buf);           // each lane rewrites what its own DMA lanes delivered
         __syncthreads();
+#ifdef YNET_WG_PROFILE
+        const unsigned long long p2 = __builtin_amdgcn_s_memtime();
+#endif
         if (tile + a.nsplit < a.ntiles) issue(next_tile(), buf ^ 1);
+#ifdef YNET_WG_PROFILE
+        const unsigned long long p3 = __builtin_amdgcn_s_memtime();
+#endif
         compute(buf);
+#ifdef YNET_WG_PROFILE
+        const unsigned long long p4 = __builtin_amdgcn_s_memtime();
+        pw += p1 - p0; pb += p2 - p1; pi += p3 - p2; pc += p4 - p3;
+#endif
         buf ^= 1;
     }
+#ifdef YNET_WG_PROFILE
+    if (lane == 0) {
+        unsigned long long* pr = a.prof;
+        atomicAdd(pr + 0, __builtin_amdgcn_s_memtime() - pt0);
+        atomicAdd(pr + 1, pw); atomicAdd(pr + 2, pb); atomicAdd(pr + 3, pi); atomicAdd(pr + 4, pc); atomicAdd(pr + 5, 1ull);
+        atomicAdd(pr + 6, prof_dma);
+    }
+#endif
 
     // ---- K-step residues of a partial block: waves rp = 1.. hand their sums to wave rp = 0 (fixed order)
     if (rpN > 1) {
@@ -720,8 +757,8 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
         (void)hipMemcpyAsync(h, prof_dev, 64, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         const double tot = (double)h[0];
-        fprintf(stderr, "wgrad_dma<%d> waves %llu avg cycles %.0f: vmcnt-wait %.1f%% barrier %.1f%% issue %.1f%% compute %.1f%% rest %.1f%%\n", (int)MASK,
-                h[5], tot / (double)h[5], 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot,
+        fprintf(stderr, "wgrad_dma<%d> waves %llu avg cycles %.0f: vmcnt-wait %.1f%% mask+barrier %.1f%% issue %.1f%% (of which DMA + descriptors %.1f%%) compute %.1f%% rest %.1f%%\n", (int)MASK,
+                h[5], tot / (double)h[5], 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[6] / tot, 100.0 * h[4] / tot,
                 100.0 * (tot - h[1] - h[2] - h[3] - h[4]) / tot);
     }
 #endif

@@ -10,7 +10,7 @@ template <int N, int MODE>
 __global__ void k(const float* src, unsigned long long* out, float* sink, unsigned stride_bytes, int waves) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)blockIdx.x * (stride_bytes / 4) * N * waves), 0, stride_bytes * N * waves, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)blockIdx.x * (MODE == 2 ? 0 : (stride_bytes / 4) * N * waves) + (MODE == 2 ? (size_t)(blockIdx.x % 64) * 2359296 : 0)), 0, MODE == 2 ? 9437184u : stride_bytes * N * waves, 0x00020000);
     f32x4 acc = {0, 0, 0, 0};
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -18,8 +18,15 @@ __global__ void k(const float* src, unsigned long long* out, float* sink, unsign
     if (wave < waves) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const unsigned off = (unsigned)((wave * N + i) * stride_bytes + lane * 16);
-            if (MODE == 0)
+            unsigned off = (unsigned)((wave * N + i) * stride_bytes + lane * 16);
+            if (MODE == 2) {
+                // the x-tile pattern of the conv / wgrad kernels: quads of rows of 10 quads (160 B), row pitch 1 KB,
+                // 41 quads per channel (4 rows + pad), channel pitch 256 KB, tile origin 16 B before a 128-B boundary
+                const int q = (wave * N + i) * 64 + lane;
+                const int ch = q / 41, within = q % 41, row = within / 10, col = within % 10;
+                off = (unsigned)(ch * 262144 + row * 1024 + col * 16 + 112);
+            }
+            if (MODE == 0 || MODE == 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(smem + (wave * N + i) * 256), 16, off, 0, 0, 0);
             else {
                 const unsigned u0 = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
@@ -65,6 +72,9 @@ int main() {
         run<4, 0>("lds-dma", src, 1024, 1, warm);
         run<12, 0>("lds-dma", src, 1024, 1, warm);
         run<12, 0>("lds-dma", src, 1024, 4, warm);
+        run<12, 2>("lds-dma-tile", src, 1024, 1, warm);
+        run<12, 2>("lds-dma-tile", src, 1024, 4, warm);
+        run<5, 2>("lds-dma-tile", src, 1024, 4, warm);
         run<1, 1>("vgpr", src, 1024, 1, warm);
         run<4, 1>("vgpr", src, 1024, 1, warm);
         run<12, 1>("vgpr", src, 1024, 1, warm);
