@@ -316,9 +316,10 @@ skip_fold = _os.environ.get("YNET_SKIP_FOLD", "1") != "0"
 
 
 def _skip_register(x: torch.Tensor):
-    if len(_skip_registry) > 64:
-        for k in [k for k, e in _skip_registry.items() if e.ref() is None]:
-            del _skip_registry[k]
+    # entries of finished steps (tensor gone, or the pool's backward ran) go, together with any gradient handed over
+    # to a pool whose backward never ran (pruned graphs)
+    for k in [k for k, e in _skip_registry.items() if e.ref() is None or e.consumed]:
+        del _skip_registry[k]
     e = _SkipEntry()
     e.ref, e.shape, e.stash, e.consumed = weakref.ref(x), tuple(x.shape), [], False
     _skip_registry[x.data_ptr()] = e
