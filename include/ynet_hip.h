@@ -110,6 +110,13 @@ int ynet_avgpool_pyramid(const float* x, float* const* outs, int nlev, long long
 long long ynet_bce_workspace_bytes(void);
 int ynet_bce_logits_fwd(const float* x, const float* t, long long n, float* loss, void* workspace, void* stream);
 int ynet_bce_logits_bwd(const float* x, const float* t, const float* grad_out, float* dx, long long n, void* stream);
+/* The training form: the same loss, and in the same pass dx = (sigmoid(x) - t) * expected_grad / n, where
+ * expected_grad is the upstream gradient the caller expects (loss_scale in utils/train_epoch.py:94,106).
+ * ynet_bce_grad_rescale then multiplies dx by grad_out[0] / expected_grad on the device -- a no-op launch
+ * when the expectation was right, so the logits are read once per step instead of twice. */
+int ynet_bce_logits_fwd_grad(const float* x, const float* t, long long n, float expected_grad, float* loss, float* dx,
+                             void* workspace, void* stream);
+int ynet_bce_grad_rescale(float* dx, const float* grad_out, float expected_grad, long long n, void* stream);
 
 /* ---- goal / trajectory read-out -------------------------------------------------------------- */
 /* SoftArgmax2D.forward (utils/softargmax.py:55-81; models/ynet.py:582-583): x [B][C][H][W] with

@@ -347,34 +347,72 @@ __device__ __forceinline__ float wave_max(float v) {
 //   l = (1 - t) * x - log_sigmoid(x),  log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
 //   dl/dx = (sigmoid(x) - t) * g / n
 // ------------------------------------------------------------------------------------------------
+// One element of the loss (and of its gradient).  e = exp(-|x|) is shared by both:
+//   log1p(e) = log(w) * e / (w - 1), w = fl(1 + e)   (w - 1 is exact; the ratio undoes the rounding of 1 + e)
+//   sigmoid(x) = x >= 0 ? 1 / w' : e / w'            (w' = 1 + e)
+// exp and the two reciprocals are the hardware approximations (<= 1 ulp each; the element's absolute
+// error stays below 1e-7, and the mean is accumulated in fp64) -- with libm's expf / log1pf and IEEE
+// divisions the kernel is VALU bound at half the HBM rate.
+template <bool GRAD>
+__device__ __forceinline__ float bce_element(float x, float t, float gs, float& d) {
+    const float e = __expf(-fabsf(x));
+    const float w = 1.f + e;
+    const float r = __frcp_rn(w);
+    const float wm1 = w - 1.f;
+    const float l1p = wm1 == 0.f ? e : logf(w) * (e * __frcp_rn(wm1));
+    if (GRAD) d = ((x >= 0.f ? r : e * r) - t) * gs;
+    return (1.f - t) * x - (fminf(x, 0.f) - l1p);
+}
+
+// GRAD: also writes dx = (sigmoid(x) - t) * gs in the same pass (gs = the expected upstream gradient / n).
+template <bool GRAD>
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
-                                                      long long n, double* __restrict__ partial) {
+                                                      long long n, double* __restrict__ partial,
+                                                      float* __restrict__ dx, float gs) {
     __shared__ double ws[4];
     double acc = 0.0;
     const long long n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const float4* t4 = reinterpret_cast<const float4*>(t);
+    float4* d4 = reinterpret_cast<float4*>(dx);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const float4 xv = x4[i], tv = t4[i];
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ts[4] = {tv.x, tv.y, tv.z, tv.w};
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float ls = fminf(xs[k], 0.f) - log1pf(expf(-fabsf(xs[k])));
-            s += (1.f - ts[k]) * xs[k] - ls;
-        }
+        float4 o;
+        float s = bce_element<GRAD>(xv.x, tv.x, gs, o.x);
+        s += bce_element<GRAD>(xv.y, tv.y, gs, o.y);
+        s += bce_element<GRAD>(xv.z, tv.z, gs, o.z);
+        s += bce_element<GRAD>(xv.w, tv.w, gs, o.w);
+        if (GRAD) d4[i] = o;
         acc += (double)s;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long long i = (n4 << 2) + threadIdx.x;
-        const float ls = fminf(x[i], 0.f) - log1pf(expf(-fabsf(x[i])));
-        acc += (double)((1.f - t[i]) * x[i] - ls);
+        float d;
+        acc += (double)bce_element<GRAD>(x[i], t[i], gs, d);
+        if (GRAD) dx[i] = d;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// dx *= g[0] / expected, and nothing at all when the upstream gradient is the expected one.
+__global__ __launch_bounds__(256) void bce_rescale_kernel(float* __restrict__ dx, const float* __restrict__ g,
+                                                          float expected, long long n) {
+    const float gv = g[0];
+    if (gv == expected) return;
+    const float f = gv / expected;
+    const long long n4 = n >> 2;
+    float4* d4 = reinterpret_cast<float4*>(dx);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        float4 v = d4[i];
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        d4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dx[(n4 << 2) + threadIdx.x] *= f;
 }
 
 __global__ __launch_bounds__(256) void bce_finish_kernel(const double* __restrict__ partial, int nparts, long long n,
@@ -707,9 +745,31 @@ int ynet_bce_logits_fwd(const float* x, const float* t, long long n, float* loss
     YNET_REQUIRE(x && t && loss && workspace && n > 0, "bce_logits_fwd: bad arguments");
     YNET_REQUIRE((((uintptr_t)x | (uintptr_t)t) & 15) == 0, "bce_logits_fwd: inputs must be 16-byte aligned");
     const int parts = grid_for(n / 4 + 1, 256, YNET_BCE_PARTS);
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, x, t, n, (double*)workspace);
+    hipLaunchKernelGGL(bce_fwd_kernel<false>, dim3(parts), dim3(256), 0, (hipStream_t)stream, x, t, n, (double*)workspace,
+                       (float*)nullptr, 0.f);
     hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, parts, n, loss);
     return ynet_check_launch("bce_logits_fwd");
+}
+
+int ynet_bce_logits_fwd_grad(const float* x, const float* t, long long n, float expected_grad, float* loss, float* dx,
+                             void* workspace, void* stream) {
+    YNET_REQUIRE(x && t && loss && dx && workspace && n > 0, "bce_logits_fwd_grad: bad arguments");
+    YNET_REQUIRE((((uintptr_t)x | (uintptr_t)t | (uintptr_t)dx) & 15) == 0, "bce_logits_fwd_grad: buffers must be 16-byte aligned");
+    YNET_REQUIRE(expected_grad != 0.f && expected_grad == expected_grad, "bce_logits_fwd_grad: the expected gradient must be non-zero");
+    const int parts = grid_for(n / 4 + 1, 256, YNET_BCE_PARTS);
+    hipLaunchKernelGGL(bce_fwd_kernel<true>, dim3(parts), dim3(256), 0, (hipStream_t)stream, x, t, n, (double*)workspace,
+                       dx, expected_grad / (float)n);
+    hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, parts, n, loss);
+    return ynet_check_launch("bce_logits_fwd_grad");
+}
+
+int ynet_bce_grad_rescale(float* dx, const float* grad_out, float expected_grad, long long n, void* stream) {
+    YNET_REQUIRE(dx && grad_out && n > 0, "bce_grad_rescale: bad arguments");
+    YNET_REQUIRE((((uintptr_t)dx) & 15) == 0, "bce_grad_rescale: dx must be 16-byte aligned");
+    YNET_REQUIRE(expected_grad != 0.f && expected_grad == expected_grad, "bce_grad_rescale: the expected gradient must be non-zero");
+    hipLaunchKernelGGL(bce_rescale_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, dx,
+                       grad_out, expected_grad, n);
+    return ynet_check_launch("bce_grad_rescale");
 }
 
 int ynet_bce_logits_bwd(const float* x, const float* t, const float* grad_out, float* dx, long long n, void* stream) {

@@ -26,10 +26,16 @@ from .ynet import YNet
 
 
 class HipBCEWithLogitsLoss(nn.Module):
-    """nn.BCEWithLogitsLoss() (mean) on the fused HIP kernels."""
+    """nn.BCEWithLogitsLoss() (mean) on the fused HIP kernels.  `expected_grad` is the factor the caller is about to
+    multiply the loss by (train_epoch sets it to its loss_scale): the gradient of the logits is then produced in the
+    same pass as the loss.  It is a hint only -- results do not depend on it."""
+
+    def __init__(self):
+        super().__init__()
+        self.expected_grad = 1.0
 
     def forward(self, input, target):
-        return ops.bce_with_logits(input, target)
+        return ops.bce_with_logits(input, target, self.expected_grad)
 
 
 def _mark_bias(module):

@@ -534,8 +534,12 @@ def avgpool_pyramid(x: torch.Tensor, n_levels: int) -> List[torch.Tensor]:
 # BCE-with-logits (mean)
 # ------------------------------------------------------------------------------------------------
 class _BCEFn(torch.autograd.Function):
+    """With a gradient wanted the forward pass writes dx = (sigmoid(x) - t) * expected_grad / n next to the loss, and
+    backward only rescales it on the device when the upstream gradient is not `expected_grad` (train_epoch passes
+    loss_scale): the logits and targets are read once per step."""
+
     @staticmethod
-    def forward(ctx, x, t):
+    def forward(ctx, x, t, expected_grad):
         _need_gpu(x, "bce_with_logits input")
         _need_gpu(t, "bce_with_logits target")
         if x.shape != t.shape:
@@ -544,22 +548,37 @@ class _BCEFn(torch.autograd.Function):
         lib = _lib()
         loss = torch.empty((), device=x.device, dtype=torch.float32)
         ws = torch.empty(lib.ynet_bce_workspace_bytes() // 8, device=x.device, dtype=torch.float64)
-        L.check(lib.ynet_bce_logits_fwd(x.data_ptr(), t.data_ptr(), x.numel(), loss.data_ptr(), ws.data_ptr(), _stream()), lib)
+        ctx.dx = None
+        if ctx.needs_input_grad[0]:
+            expected_grad = float(expected_grad)
+            if not (expected_grad != 0.0 and abs(expected_grad) < float("inf")):
+                expected_grad = 1.0
+            ctx.dx, ctx.expected = torch.empty_like(x), expected_grad
+            L.check(lib.ynet_bce_logits_fwd_grad(x.data_ptr(), t.data_ptr(), x.numel(), expected_grad, loss.data_ptr(),
+                                                 ctx.dx.data_ptr(), ws.data_ptr(), _stream()), lib)
+        else:
+            L.check(lib.ynet_bce_logits_fwd(x.data_ptr(), t.data_ptr(), x.numel(), loss.data_ptr(), ws.data_ptr(), _stream()), lib)
         ctx.save_for_backward(x, t)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         x, t = ctx.saved_tensors
-        dx = torch.empty_like(x)
         lib = _lib()
         g = g.contiguous().float()
-        L.check(lib.ynet_bce_logits_bwd(x.data_ptr(), t.data_ptr(), g.data_ptr(), dx.data_ptr(), x.numel(), _stream()), lib)
-        return dx, None
+        dx, ctx.dx = ctx.dx, None
+        if dx is not None:                      # first backward through this node: the forward pass left the gradient
+            L.check(lib.ynet_bce_grad_rescale(dx.data_ptr(), g.data_ptr(), ctx.expected, x.numel(), _stream()), lib)
+        else:                                   # retain_graph: recompute from the saved logits
+            dx = torch.empty_like(x)
+            L.check(lib.ynet_bce_logits_bwd(x.data_ptr(), t.data_ptr(), g.data_ptr(), dx.data_ptr(), x.numel(), _stream()), lib)
+        return dx, None, None
 
 
-def bce_with_logits(x, t):
-    return _BCEFn.apply(x, t)
+def bce_with_logits(x, t, expected_grad: float = 1.0):
+    """nn.BCEWithLogitsLoss() (mean).  `expected_grad`: the gradient the caller expects to arrive at the loss (a hint:
+    any other value is handled by one more pass over dx in backward)."""
+    return _BCEFn.apply(x, t, expected_grad)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ encoder -> goal decoder -> BCE, waypoint pyramid in one pass, trajectory decoder
 the convs) -> BCE, backward through the hand-written dgrad/wgrad/LoRA kernels, optimizer step,
 soft-argmax ADE/FDE.  ``dp`` (optional, not in the reference) shards every batch over ranks.
 """
+import numpy as np
 import torch
 
 from .. import ops
@@ -73,6 +74,11 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                 gt_waypoint_map.record_stream(s_traj)
                 s_goal.wait_stream(main)
                 s_traj.wait_stream(main)
+                if hasattr(criterion, "expected_grad"):
+                    # d(loss)/d(criterion output) as autograd will compute it (fp32): lets the criterion emit the
+                    # gradient of its logits in the same pass as the loss
+                    up = np.float32(1.0) if dp is None else np.float32(n_local / n_global)
+                    criterion.expected_grad = float(np.float32(up * np.float32(loss_scale)))
                 with torch.cuda.stream(s_goal):
                     pred_goal_map = model.pred_goal(features)
                     goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale

@@ -242,6 +242,29 @@ def test_bce_with_logits(dev):
     ld.backward()
     close(ld, loss.detach(), rtol=2e-6, atol=1e-6, msg="loss")
     close(xd.grad, xc.grad, rtol=1e-5, atol=1e-9, msg="dlogits")
+    # the gradient is written by the forward pass for an *expected* upstream gradient: right, wrong, and reused graphs
+    for expected in (1000.0, 3.0):
+        xe = x.to(dev).requires_grad_(True)
+        le = ops.bce_with_logits(xe, t.to(dev), expected) * 1000
+        le.backward(retain_graph=True)
+        close(le, loss.detach(), rtol=2e-6, atol=1e-6, msg=f"loss (expected_grad {expected})")
+        close(xe.grad, xc.grad, rtol=1e-5, atol=1e-9, msg=f"dlogits (expected_grad {expected})")
+        xe.grad = None
+        le.backward()
+        close(xe.grad, xc.grad, rtol=1e-5, atol=1e-9, msg="dlogits, second backward")
+    # ragged length (not a multiple of 4), wide range of logits, no-grad path
+    xr = torch.linspace(-30, 30, 1027).view(1, 1, 13, 79)
+    tr = torch.rand(1, 1, 13, 79, generator=torch.Generator().manual_seed(3))
+    xrc = xr.clone().requires_grad_(True)
+    lr_ = F.binary_cross_entropy_with_logits(xrc.double(), tr.double())
+    lr_.backward()
+    xrd = xr.to(dev).requires_grad_(True)
+    lrd = ops.bce_with_logits(xrd, tr.to(dev))
+    lrd.backward()
+    close(lrd, lr_.detach().float(), rtol=1e-6, atol=0, msg="ragged loss")
+    close(xrd.grad, xrc.grad, rtol=1e-5, atol=2e-10, msg="ragged dlogits")
+    with torch.no_grad():
+        close(ops.bce_with_logits(xr.to(dev), tr.to(dev)), lr_.detach().float(), rtol=1e-6, atol=0, msg="no-grad loss")
     zero = ops.bce_with_logits(torch.zeros(1, 1, 8, 8, device=dev), torch.zeros(1, 1, 8, 8, device=dev)) * 1000
     assert abs(float(zero) - 1000 * np.log(2)) < 1e-3      # known answer
 
