@@ -10,7 +10,7 @@ template <int N, int MODE>
 __global__ void k(const float* src, unsigned long long* out, float* sink, unsigned stride_bytes, int waves) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)blockIdx.x * (MODE == 2 ? 0 : (stride_bytes / 4) * N * waves) + (MODE == 2 ? (size_t)(blockIdx.x % 64) * 2359296 : 0)), 0, MODE == 2 ? 9437184u : stride_bytes * N * waves, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)blockIdx.x * (MODE >= 2 ? 0 : (stride_bytes / 4) * N * waves) + (MODE >= 2 ? (size_t)(blockIdx.x % 64) * 2359296 : 0)), 0, MODE >= 2 ? 9437184u : stride_bytes * N * waves, 0x00020000);
     f32x4 acc = {0, 0, 0, 0};
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -26,7 +26,22 @@ __global__ void k(const float* src, unsigned long long* out, float* sink, unsign
                 const int ch = q / 41, within = q % 41, row = within / 10, col = within % 10;
                 off = (unsigned)(ch * 262144 + row * 1024 + col * 16 + 112);
             }
-            if (MODE == 0 || MODE == 2)
+            if (MODE == 3) {
+                // the same tile with the lanes permuted so that every quad of lanes reads one aligned 64-byte line:
+                // per channel 4 rows x 8 aligned quads, then the 8 edge quads (column 0 / 9 of each row)
+                const int q = (wave * N + i) * 64 + lane;
+                const int ch = q / 40, within = q % 40;
+                const int row = within < 32 ? within / 8 : (within - 32) / 2;
+                const int col = within < 32 ? 1 + within % 8 : ((within & 1) ? 9 : 0);
+                off = (unsigned)(ch * 262144 + row * 1024 + col * 16 + 112);
+            }
+            if (MODE == 4) {
+                // rows widened to aligned 256-byte spans (16 quads), 4 rows per instruction
+                const int q = (wave * N + i) * 64 + lane;
+                const int ch = q / 64, within = q % 64;
+                off = (unsigned)(ch * 262144 + (within / 16) * 1024 + (within % 16) * 16 + 64);
+            }
+            if (MODE == 0 || MODE >= 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(smem + (wave * N + i) * 256), 16, off, 0, 0, 0);
             else {
                 const unsigned u0 = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
@@ -75,6 +90,11 @@ int main() {
         run<12, 2>("lds-dma-tile", src, 1024, 1, warm);
         run<12, 2>("lds-dma-tile", src, 1024, 4, warm);
         run<5, 2>("lds-dma-tile", src, 1024, 4, warm);
+        run<12, 3>("tile-perm", src, 1024, 1, warm);
+        run<12, 3>("tile-perm", src, 1024, 4, warm);
+        run<5, 3>("tile-perm", src, 1024, 4, warm);
+        run<12, 4>("tile-wide", src, 1024, 1, warm);
+        run<12, 4>("tile-wide", src, 1024, 4, warm);
         run<1, 1>("vgpr", src, 1024, 1, warm);
         run<4, 1>("vgpr", src, 1024, 1, warm);
         run<12, 1>("vgpr", src, 1024, 1, warm);
