@@ -28,9 +28,6 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-#ifndef YNET_DMA_SCHED
-#define YNET_DMA_SCHED 0      // pinned "reads, then MFMAs" groups: measured 0-5 % slower than hipcc's own schedule here
-#endif
 #ifndef YNET_CC_NARROW
 #define YNET_CC_NARROW 8      // input channels staged per chunk by the Cout <= 32 kernels
 #endif
@@ -50,7 +47,7 @@ struct ConvArgs {
     long long partial_cap;  // floats available at `partial`
     int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
     int vec_load;           // 16-byte LDS-DMA of the input tile is legal (W % 4 == 0, aligned sources / mask)
-    int tiles_x, tiles_y, cgroups, ntiles, prio_mode, debug;   // debug: timing ablations only (tools/conv_bench.py)
+    int tiles_x, tiles_y, cgroups, ntiles, debug;   // debug: timing ablations only (tools/conv_bench.py)
 };
 
 // M16 = false: v_mfma_f32_32x32x2_f32, NCB blocks of 32 output channels per workgroup.
@@ -411,14 +408,6 @@ void conv_mfma_kernel(const ConvArgs a) {
     // ---- load cursor (lt, lch) runs one chunk ahead of the compute cursor (ct, cch)
     int lt_idx = tile_first, lch = 0;
     if (lt_idx >= ntiles) return;
-    // Co-resident workgroups that share the matrix pipes round-robin fall into lockstep and then all
-    // stage / store at the same time; a fixed pecking order (one per residency "layer") staggers them.
-    {
-        const int layer = a.prio_mode == 1 ? (blockIdx.x >> 8) & 3 : (a.prio_mode == 2 ? blockIdx.x & 3 : 0);
-        if (layer == 1) __builtin_amdgcn_s_setprio(1);
-        else if (layer == 2) __builtin_amdgcn_s_setprio(2);
-        else if (layer == 3) __builtin_amdgcn_s_setprio(3);
-    }
     TileCoord lt = decode(lt_idx);
     set_goff(lt);
     int lcnt = item_chunks(lt);
@@ -1035,8 +1024,6 @@ static int launch_conv_m(ConvArgs& a, hipStream_t st) {
     }
     YNET_REQUIRE(nt > 0 && nt < (1ll << 31), "conv2d: %lld tiles are out of range", nt);
     a.ntiles = (int)nt;
-    static const int prio_mode = getenv("YNET_CONV_PRIO") ? atoi(getenv("YNET_CONV_PRIO")) : 0;
-    a.prio_mode = prio_mode;
     static const int debug = getenv("YNET_CONV_DEBUG") ? atoi(getenv("YNET_CONV_DEBUG")) : 0;
     a.debug = debug;
     static int slots = 0;          // resident workgroups on the device for this instantiation
@@ -1111,7 +1098,6 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     a.ntiles = (int)nt;
     static const int debug = getenv("YNET_CONV_DEBUG") ? atoi(getenv("YNET_CONV_DEBUG")) : 0;
     a.debug = debug;
-    a.prio_mode = 0;
     static int slots = 0;
     if (slots == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>),

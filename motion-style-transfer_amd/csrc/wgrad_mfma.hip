@@ -22,10 +22,6 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-#ifndef YNET_WG_DEFER
-#define YNET_WG_DEFER 0
-#endif
-
 struct WgradArgs {
     YSrc src[YNET_MAX_SRC];   // x = virtual concat of the sources
     int nsrc, cin;
@@ -37,7 +33,6 @@ struct WgradArgs {
     float* partial_b;         // [nsplit][cout] or NULL
     int B, H, W, cout;
     int tiles_x, tiles_y, ntiles, nsplit, co_blks, ci_blks;
-    int stagger;            // start delay (x 64 cycles) of the workgroup in the odd wave slot of a CU (0: off)
 #ifdef YNET_WG_PROFILE
     unsigned long long* prof;      // development build: per-phase cycle sums
 #endif
@@ -575,16 +570,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         nt.b += step_b + cy;
         return t;
     };
-    // Two workgroups share a CU.  Started together they stay in lockstep -- both queue DMAs, then both stream MFMAs at
-    // half rate -- so the one in the odd wave slot starts half a tile period late and they alternate instead.
-    if (a.stagger > 0) {
-        if (tid == 0) smem[0] = __builtin_bit_cast(float, (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4));   // HW_ID.wave_id
-        __syncthreads();
-        const int slot = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, smem[0]));
-        __syncthreads();
-        if (slot & 1)
-            for (int q = 0; q < a.stagger; ++q) __builtin_amdgcn_s_sleep(1);
-    }
     int tile = split, buf = 0;
     if (tile < a.ntiles) issue(next_tile(), 0);
 #ifdef YNET_WG_PROFILE
@@ -749,8 +734,7 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
     (void)hipMemsetAsync(prof_dev, 0, 64, st);
     a.prof = prof_dev;
 #endif
-    static const int lds_pad = getenv("YNET_WG_LDS_PAD") ? atoi(getenv("YNET_WG_LDS_PAD")) : 0;     // occupancy experiments
-    hipLaunchKernelGGL((wgrad_dma_kernel<MASK, TH_>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES + lds_pad, st, a);
+    hipLaunchKernelGGL((wgrad_dma_kernel<MASK, TH_>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
 #ifdef YNET_WG_PROFILE
     {
         unsigned long long h[8];
@@ -848,8 +832,7 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
         for (int i = 0; i < nsrc; ++i) dma = dma && !misaligned(src[i], src_bs[i]);
         dma = dma && !misaligned(dy, dy_bs) && (mask == nullptr || !misaligned(mask, mask_bs));
     }
-    static const int dma_th = getenv("YNET_WGRAD_TH") ? atoi(getenv("YNET_WGRAD_TH")) : 2;      // rows per tile of the DMA kernel (2: 2 workgroups per CU; 1: 3, more halo traffic -- measured equal)
-    const int th = dma ? (dma_th == 2 ? 2 : 1) : 4;
+    const int th = dma ? 2 : 4;      // rows per tile (one-row tiles: 3 workgroups per CU, more halo traffic -- measured equal)
     a.tiles_x = ceil_div(W, 32);
     a.tiles_y = ceil_div(H, th);
     a.ntiles = wgrad_plan(B, H, W, cout, a.cin, K, th, &a.nsplit);
@@ -859,8 +842,7 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
     hipStream_t st = (hipStream_t)stream;
     if (dma) {
         a.ci_blks = ceil_div(a.cin, 32);
-        if (th == 2) return mask ? launch_wgrad_dma<true, 2>(a, dw, db, st) : launch_wgrad_dma<false, 2>(a, dw, db, st);
-        return mask ? launch_wgrad_dma<true, 1>(a, dw, db, st) : launch_wgrad_dma<false, 1>(a, dw, db, st);
+        return mask ? launch_wgrad_dma<true, 2>(a, dw, db, st) : launch_wgrad_dma<false, 2>(a, dw, db, st);
     }
     switch (K) {
         case 1: return launch_wgrad<1>(a, dw, db, st);
