@@ -70,6 +70,64 @@ def test_conv2d_forward_backward(dev, B, H, W, cs, cout, K, relu):
     close(bd.grad, bc.grad, rtol=1e-4, scale_rel=5e-6, msg="db")
 
 
+def _sweep_cases():
+    """Seeded shapes that walk the dispatcher: every tile-row count, folded tiles of the 8 / 16 wide maps, split-K on small
+    maps, 16- and 32-wide output tiles, ragged widths that fall back to the register-staged kernels, 1..4 sources."""
+    rs = np.random.RandomState(1234)
+    cases = [
+        # B, H, W, sources, cout, K, relu        (targeted: the production tile shapes at reduced batch)
+        (8, 256, 256, [14], 32, 3, True),       # 4-row tiles, 1024+ workgroups
+        (4, 256, 256, [32, 16], 32, 3, True),   # decoder level 4 (48 -> 32)
+        (8, 128, 128, [64, 1], 32, 3, False),
+        (16, 64, 64, [64, 32], 64, 3, True),    # 2-row tiles
+        (32, 32, 32, [64], 64, 3, True),        # 1-row tiles + split-K
+        (32, 16, 16, [128, 2], 64, 3, True),    # folded 2 x 16
+        (32, 8, 8, [65], 130, 3, True),         # folded 4 x 8, odd channels
+        (4, 256, 256, [32], 12, 1, False),      # streaming 1x1 predictor
+        (4, 128, 128, [12], 32, 1, False),
+    ]
+    widths = [4, 8, 12, 16, 20, 28, 32, 36, 48, 64, 72, 100, 128]
+    for _ in range(27):
+        W = int(widths[rs.randint(len(widths))])
+        H = int(rs.choice([1, 2, 3, 5, 8, 16, 17, 32, 40, 64]))
+        K = int(rs.choice([1, 3, 3, 3, 5]))
+        nsrc = int(rs.randint(1, 5))
+        cs = [int(rs.choice([1, 2, 3, 5, 8, 16, 17, 32, 33, 64])) for _ in range(nsrc)]
+        if K == 5:
+            cs = [min(c, 8) for c in cs]
+        cout = int(rs.choice([1, 3, 12, 16, 17, 32, 33, 48, 64, 65, 96, 130]))
+        B = int(rs.choice([1, 2, 3, 5, 9]))
+        cases.append((B, H, W, cs, cout, K, bool(rs.randint(2))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _sweep_cases(), ids=lambda c: "B{}_{}x{}_c{}_o{}_k{}_{}".format(
+    c[0], c[1], c[2], "+".join(map(str, c[3])), c[4], c[5], "relu" if c[6] else "lin"))
+def test_conv2d_dispatch_sweep(dev, case):
+    """Forward, dgrad (all sources), wgrad and bias gradient of every dispatch path against stock torch on the CPU."""
+    B, H, W, cs, cout, K, relu = case
+    ops = pkg("ops")
+    cin = sum(cs)
+    xs = [rnd(B, c, H, W, seed=i + 1) for i, c in enumerate(cs)]
+    w = rnd(cout, cin, K, K, seed=10, scale=1.0 / (cin * K * K) ** 0.5)
+    b = rnd(cout, seed=11, scale=0.1)
+    gy = rnd(B, cout, H, W, seed=12)
+    xc = [x.clone().requires_grad_(True) for x in xs]
+    wc, bc = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(torch.cat(xc, 1), wc, bc, padding=K // 2)
+    y = F.relu(y) if relu else y
+    y.backward(gy)
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    yd = ops.conv2d(ops.lazy_cat(xd), wd, bd, relu, {})
+    yd.backward(gy.to(dev))
+    close(yd, y, msg="y")
+    for i, (a, c) in enumerate(zip(xd, xc)):
+        close(a.grad, c.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx{i}")
+    close(wd.grad, wc.grad, rtol=1e-4, scale_rel=1e-5, msg="dW")
+    close(bd.grad, bc.grad, rtol=1e-4, scale_rel=1e-5, msg="db")
+
+
 def test_conv2d_broadcast_source_and_partial_grads(dev):
     """Semantic map shared by the batch (stride-0 expand) + only some inputs wanting gradients."""
     ops = pkg("ops")
