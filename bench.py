@@ -38,6 +38,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix = fp3
 PEAK_HBM_GBS = 8000.0
 
 
+# Algorithmic work per trajectory of the whole step: conv FLOPs (2 x MACs; forward + dgrad + the
+# wgrads of the trainable convs) and compulsory fp32 HBM traffic with every graph op reading its inputs / writing its
+# outputs once.  C5: encoder + goal decoder once, 20 trajectory-decoder passes.
+STEP_WORK = {"C1": (43.60, 1001.4), "C2": (30.66, 826.8), "C3": (30.66, 826.8), "C4": (112.15, 3545.9), "C5": (140.7, None)}
+
+
 def pkg(sub):
     return importlib.import_module(PKG + "." + sub)
 
@@ -249,6 +255,13 @@ def main():
                    "parallelism": f"dp{N}", "trainable_floats": sum(p.numel() for p in model.parameters() if p.requires_grad)},
         "final_loss": loss,
     }
+    gf, mb = STEP_WORK[args.config]
+    out["step_roofline"] = {      # the whole step against both roofs (per GPU); the dominant kernel's figure is in "roofline"
+        "algorithmic_gflop_per_trajectory": gf, "tflops_per_gpu": value / N * gf / 1e3,
+        "frac_of_fp32_peak": value / N * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+        "algorithmic_mb_per_trajectory": mb,
+        "hbm_gbs_per_gpu": None if mb is None else value / N * mb / 1e3,
+        "frac_of_hbm_peak": None if mb is None else value / N * mb / 1e3 / PEAK_HBM_GBS}
 
     if args.no_roofline:
         pass
