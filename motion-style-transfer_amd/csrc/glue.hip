@@ -4,6 +4,17 @@
 // Reference call sites are cited per kernel; the public C ABI is include/ynet_hip.h.
 #include "ynet_common.h"
 
+// Plane-wise kernels: blockIdx.y walks the (b,c) planes, blockIdx.x the items of a plane -- the item index stays
+// 32-bit and costs one division (by the row length) instead of the three 64-bit divisions of a flat index, which made
+// these kernels VALU-bound at ~3.6 TB/s.
+static inline dim3 plane_grid(long long planes, long long per_plane) {
+    long long gx = (per_plane + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    long long gy = planes < 65535 ? planes : 65535;
+    while (gx * gy > (1ll << 22) && gy > 1) gy = (gy + 1) / 2;
+    return dim3((unsigned)gx, (unsigned)gy);
+}
+
 static inline int grid_for(long long n, int block, int cap = 2048 * 4) {
     long long g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -16,23 +27,20 @@ static inline int grid_for(long long n, int block, int cap = 2048 * 4) {
 // backward recomputes the argmax from x with ATen's rule: first maximum in window scan order.
 // ------------------------------------------------------------------------------------------------
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long N, int H, int W) {
-    const int Ho = H >> 1, Wo = W >> 1;
-    const long long total = N * Ho * Wo;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int xo = (int)(i % Wo);
-        const int yo = (int)((i / Wo) % Ho);
-        const long long n = i / ((long long)Wo * Ho);
-        const float* p = x + (n * H + 2 * yo) * W + 2 * xo;
-        float m = p[0];
-        float v = p[1];
-        m = (v > m || v != v) ? v : m;
-        v = p[W];
-        m = (v > m || v != v) ? v : m;
-        v = p[W + 1];
-        m = (v > m || v != v) ? v : m;
-        y[i] = m;
-    }
+    const int Ho = H >> 1, Wo = W >> 1, per_plane = Ho * Wo;
+    for (long long n = blockIdx.y; n < N; n += gridDim.y)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < per_plane; i += gridDim.x * 256) {
+            const int yo = i / Wo, xo = i - yo * Wo;
+            const float* p = x + (n * H + 2 * yo) * W + 2 * xo;
+            float m = p[0];
+            float v = p[1];
+            m = (v > m || v != v) ? v : m;
+            v = p[W];
+            m = (v > m || v != v) ? v : m;
+            v = p[W + 1];
+            m = (v > m || v != v) ? v : m;
+            y[n * per_plane + i] = m;
+        }
 }
 
 // dx = route(dy) + add0 + add1 (either addend may be NULL): the max-pool backward also folds in the gradients the two
@@ -42,13 +50,11 @@ __global__ void maxpool2_bwd_add_kernel(const float* __restrict__ x, const float
                                         const float* __restrict__ add0, const float* __restrict__ add1,
                                         float* __restrict__ dx, long long N, int H, int W) {
     typedef float f2 __attribute__((ext_vector_type(2)));
-    const int Ho = H >> 1, Wo = W >> 1;
-    const long long total = N * Ho * Wo;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int xo = (int)(i % Wo);
-        const int yo = (int)((i / Wo) % Ho);
-        const long long n = i / ((long long)Wo * Ho);
+    const int Ho = H >> 1, Wo = W >> 1, per_plane = Ho * Wo;
+    for (long long n = blockIdx.y; n < N; n += gridDim.y)
+    for (int ip = blockIdx.x * 256 + threadIdx.x; ip < per_plane; ip += gridDim.x * 256) {
+        const int yo = ip / Wo, xo = ip - yo * Wo;
+        const long long i = n * per_plane + ip;
         const long long base = (n * H + 2 * yo) * W + 2 * xo;
         const f2 t = *reinterpret_cast<const f2*>(x + base), b = *reinterpret_cast<const f2*>(x + base + W);
         float m = t[0];
@@ -138,13 +144,11 @@ __global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __rest
 // 4 consecutive outputs per thread (one 16-byte store); needs W even
 __global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                  long long N, int H, int W) {
-    const int Ho = 2 * H, Wo = 2 * W, Wq = Wo >> 2;
-    const long long total = N * Ho * Wq;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(i % Wq);
-        const int oy = (int)((i / Wq) % Ho);
-        const long long n = i / ((long long)Wq * Ho);
+    const int Ho = 2 * H, Wo = 2 * W, Wq = Wo >> 2, per_plane = Ho * Wq;
+    for (long long n = blockIdx.y; n < N; n += gridDim.y)
+    for (int ip = blockIdx.x * 256 + threadIdx.x; ip < per_plane; ip += gridDim.x * 256) {
+        const int oy = ip / Wq, j = ip - oy * Wq;
+        const long long i = n * per_plane + ip;
         int h0, h1;
         float hl0, hl1;
         up2_src(oy, H, h0, h1, hl0, hl1);
@@ -166,17 +170,58 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_vec_kernel(const float* __
     }
 }
 
+// 2*RI output rows x 4 output columns per thread from RI + 2 input rows x 4 input columns (one 8-byte load + 2 halo
+// loads per row): every store instruction of a wavefront writes 1 KB of one output row, and the load instruction count
+// per store falls from 8 (one output row per thread: bound by its load stream at 3.3 TB/s) to 3 (RI = 2) / 2.25 (RI = 4).
+// Needs W even, H % RI == 0, 16-byte aligned y.  Every output keeps the scalar kernel's expression tree
+// hl0*(wl*A[i0] + wr*A[i1]) + hl1*(wl*B[i0] + wr*B[i1]).
+template <int RI>
+__global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  long long N, int H, int W) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int Wo = 2 * W, Wq = W >> 1, per_plane = (H / RI) * Wq;
+    for (long long n = blockIdx.y; n < N; n += gridDim.y)
+    for (int ip = blockIdx.x * 256 + threadIdx.x; ip < per_plane; ip += gridDim.x * 256) {
+        const int kk = ip / Wq, j = ip - kk * Wq, k = RI * kk;          // input rows k .. k+RI-1 -> output rows 2k .. 2k+2RI-1
+        const float* px = x + n * H * W;
+        const int cl = max(2 * j - 1, 0), cr = min(2 * j + 2, W - 1);
+        float hx[RI + 2][4];
+#pragma unroll
+        for (int r = 0; r < RI + 2; ++r) {
+            const int ir = r == 0 ? max(k - 1, 0) : (r == RI + 1 ? min(k + RI, H - 1) : k + r - 1);
+            const float* row = px + (long long)ir * W;
+            const f2 m = *reinterpret_cast<const f2*>(row + 2 * j);
+            const float c[4] = {row[cl], m[0], m[1], row[cr]};
+            hx[r][0] = j == 0 ? 1.f * c[1] + 0.f * c[2] : 0.25f * c[0] + 0.75f * c[1];      // column 0: source clamps to 0
+            hx[r][1] = 0.75f * c[1] + 0.25f * c[2];
+            hx[r][2] = 0.25f * c[1] + 0.75f * c[2];
+            hx[r][3] = 0.75f * c[2] + 0.25f * c[3];
+        }
+        float* py = y + (n * 2 * H + 2 * k) * Wo + 4 * j;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {          // input row k + r = hx[r + 1]
+            float4 o;
+            float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)         // output row 2(k+r): rows (k+r-1, k+r) x (.25, .75); row 0: (0, 1) x (1, 0)
+                ov[e] = (r == 0 && k == 0) ? 1.f * hx[1][e] + 0.f * hx[2][e] : 0.25f * hx[r][e] + 0.75f * hx[r + 1][e];
+            *reinterpret_cast<float4*>(py + (2 * r) * Wo) = o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = 0.75f * hx[r + 1][e] + 0.25f * hx[r + 2][e];
+            *reinterpret_cast<float4*>(py + (2 * r + 1) * Wo) = o;
+        }
+    }
+}
+
 // 4 consecutive input-gradient pixels per thread; needs W % 4 == 0.  1-D weights of input i over outputs
 // 2i-1 .. 2i+2 are {.25,.75,.75,.25}, except that output 0 / 2W-1 put their whole weight on input 0 / W-1.
 __global__ __launch_bounds__(256) void upsample2x_bwd_vec_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                  long long N, int H, int W) {
-    const int Ho = 2 * H, Wo = 2 * W, Wq = W >> 2;
-    const long long total = N * H * Wq;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(i % Wq);
-        const int iy = (int)((i / Wq) % H);
-        const long long n = i / ((long long)Wq * H);
+    const int Ho = 2 * H, Wo = 2 * W, Wq = W >> 2, per_plane = H * Wq;
+    for (long long n = blockIdx.y; n < N; n += gridDim.y)
+    for (int ip = blockIdx.x * 256 + threadIdx.x; ip < per_plane; ip += gridDim.x * 256) {
+        const int iy = ip / Wq, j = ip - iy * Wq;
+        const long long i = n * per_plane + ip;
         const float* g = dy + n * Ho * Wo;
         float wy[4];
         wy[0] = iy > 0 ? 0.25f : 0.f;
@@ -216,6 +261,58 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_vec_kernel(const float* __
             o[e] = (w0 * col[2 * e] + w1 * col[2 * e + 1]) + (w2 * col[2 * e + 2] + w3 * col[2 * e + 3]);
         }
         reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// RI input-gradient rows x 2 columns per thread from 2*RI + 2 rows x 6 columns of dy (one 16-byte load + 2 halo loads
+// per row): every 16-byte load instruction of a wavefront reads 1 KB of one dy row, and a dy row is fetched by
+// (2*RI + 2) / (2*RI) threads instead of 2.  Needs W even, H % RI == 0, 16-byte aligned dy planes, 8-byte aligned dx.
+template <int RI>
+__global__ __launch_bounds__(256) void upsample2x_bwd_rows_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                  long long N, int H, int W) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int Ho = 2 * H, Wo = 2 * W, Wq = W >> 1, per_plane = (H / RI) * Wq;
+    for (long long n = blockIdx.y; n < N; n += gridDim.y)
+    for (int ip = blockIdx.x * 256 + threadIdx.x; ip < per_plane; ip += gridDim.x * 256) {
+        const int kk = ip / Wq, l = ip - kk * Wq, iy0 = RI * kk;
+        const float* g = dy + n * Ho * Wo;
+        // 1-D weights of input column ix over output columns 2ix-1 .. 2ix+2 ({.25,.75,.75,.25}; the border outputs put
+        // their whole weight on the border input)
+        float wx[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ix = 2 * l + e;
+            wx[e][0] = ix > 0 ? 0.25f : 0.f;
+            wx[e][1] = ix > 0 ? 0.75f : 1.f;
+            wx[e][2] = ix < W - 1 ? 0.75f : 1.f;
+            wx[e][3] = ix < W - 1 ? 0.25f : 0.f;
+        }
+        float h[2 * RI + 2][2];        // horizontally combined dy rows 2*iy0-1 .. 2*iy0+2*RI
+#pragma unroll
+        for (int r = 0; r < 2 * RI + 2; ++r) {
+            const int oy = 2 * iy0 - 1 + r;
+            if (oy < 0 || oy >= Ho) {
+                h[r][0] = h[r][1] = 0.f;
+                continue;
+            }
+            const float* row = g + (long long)oy * Wo + 4 * l;
+            const float4 m = *reinterpret_cast<const float4*>(row);
+            const float c[6] = {l > 0 ? row[-1] : 0.f, m.x, m.y, m.z, m.w, l < Wq - 1 ? row[4] : 0.f};
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                h[r][e] = (wx[e][0] * c[2 * e] + wx[e][1] * c[2 * e + 1]) + (wx[e][2] * c[2 * e + 2] + wx[e][3] * c[2 * e + 3]);
+        }
+#pragma unroll
+        for (int q = 0; q < RI; ++q) {
+            const int iy = iy0 + q;
+            const float w0 = iy > 0 ? 0.25f : 0.f, w1 = iy > 0 ? 0.75f : 1.f;
+            const float w2 = iy < H - 1 ? 0.75f : 1.f, w3 = iy < H - 1 ? 0.25f : 0.f;
+            f2 o;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                o[e] = (w0 * h[2 * q][e] + w1 * h[2 * q + 1][e]) + (w2 * h[2 * q + 2][e] + w3 * h[2 * q + 3][e]);
+            *reinterpret_cast<f2*>(dx + (n * H + iy) * W + 2 * l) = o;
+        }
     }
 }
 
@@ -460,15 +557,28 @@ struct SoftAcc {
     float s, sx, sy;
 };
 
+// exp(t) for t <= 0 in 6 instructions: v_exp_f32 on the rounded product t * log2(e), corrected to first order by the
+// product's exact residual (fma) -- about 1 ulp, against ~12 instructions of libm's expf (range and denormal handling
+// this kernel does not need: terms below 2^-126 of the plane's maximum vanish in the fp32 sums anyway).  t = -inf
+// (running maximum not set yet, or a -inf logit) is clamped and comes out as 0.
+__device__ __forceinline__ float exp_le0(float t) {
+    t = fmaxf(t, -88.f);
+    const float L = 1.44269502162933349609375f, Ll = 1.925963033500011e-8f;      // log2(e) = L + Ll
+    const float p = t * L;
+    const float r = __builtin_fmaf(t, L, -p) + t * Ll;
+    const float e = __builtin_amdgcn_exp2f(p);
+    return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
+}
+
 __device__ __forceinline__ void soft_add(SoftAcc& a, float v, float px, float py) {
     if (v > a.m) {
-        const float r = expf(a.m - v);   // a.m = -inf on the first element -> 0
+        const float r = exp_le0(a.m - v);   // a.m = -inf on the first element -> 0
         a.s *= r;
         a.sx *= r;
         a.sy *= r;
         a.m = v;
     }
-    const float e = expf(v - a.m);
+    const float e = exp_le0(v - a.m);
     a.s += e;
     a.sx += e * px;
     a.sy += e * py;
@@ -486,32 +596,48 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     if ((W & 3) == 0) {
         const int w4 = W >> 2, n4 = n >> 2;
         const float4* p4 = reinterpret_cast<const float4*>(p);
-        auto fold = [&](const float4 v, int i) {
-            const int row = i / w4, col = (i - row * w4) << 2;
+        // (row, first column) of this thread's current vector, advanced by 256 vectors per step without a division
+        const int step_r = 256 / w4, step_c = (256 - step_r * w4) << 2;
+        int row = tid / w4, col = (tid - row * w4) << 2;
+        auto advance = [&]() {
+            row += step_r;
+            col += step_c;
+            if (col >= W) {
+                col -= W;
+                ++row;
+            }
+        };
+        auto fold = [&](const float4 v) {
             // rescale at most once per 16-byte vector
             const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
             if (mx > a.m) {
-                const float r = expf(a.m - mx);
+                const float r = exp_le0(a.m - mx);
                 a.s *= r;
                 a.sx *= r;
                 a.sy *= r;
                 a.m = mx;
             }
-            const float e0 = expf(v.x - a.m), e1 = expf(v.y - a.m), e2 = expf(v.z - a.m), e3 = expf(v.w - a.m);
+            const float e0 = exp_le0(v.x - a.m), e1 = exp_le0(v.y - a.m), e2 = exp_le0(v.z - a.m), e3 = exp_le0(v.w - a.m);
             const float es = (e0 + e1) + (e2 + e3);
             a.s += es;
-            a.sx += (e0 * (float)col + e1 * (float)(col + 1)) + (e2 * (float)(col + 2) + e3 * (float)(col + 3));
+            a.sx += __builtin_fmaf((float)col, es, __builtin_fmaf(3.f, e3, __builtin_fmaf(2.f, e2, e1)));
             a.sy += es * (float)row;
+            advance();
         };
         int i = tid;
-        for (; i + 3 * 256 < n4; i += 4 * 256) {     // four independent 16-byte loads in flight per thread
+        for (; i + 7 * 256 < n4; i += 8 * 256) {     // eight independent 16-byte loads in flight per thread
             const float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
-            fold(v0, i);
-            fold(v1, i + 256);
-            fold(v2, i + 512);
-            fold(v3, i + 768);
+            const float4 v4 = p4[i + 1024], v5 = p4[i + 1280], v6 = p4[i + 1536], v7 = p4[i + 1792];
+            fold(v0);
+            fold(v1);
+            fold(v2);
+            fold(v3);
+            fold(v4);
+            fold(v5);
+            fold(v6);
+            fold(v7);
         }
-        for (; i < n4; i += 256) fold(p4[i], i);
+        for (; i < n4; i += 256) fold(p4[i]);
     } else {
         for (int i = tid; i < n; i += 256) {
             const int row = i / W, col = i - row * W;
@@ -523,7 +649,7 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     if ((tid & 63) == 0) wm[tid >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    const double r = (a.m == -INFINITY) ? 0.0 : (double)expf(a.m - m);
+    const double r = (a.m == -INFINITY) ? 0.0 : (double)exp_le0(a.m - m);
     double s = wave_sum((double)a.s * r), sx = wave_sum((double)a.sx * r), sy = wave_sum((double)a.sy * r);
     if ((tid & 63) == 0) {
         wsum[tid >> 6][0] = s;
@@ -679,7 +805,7 @@ extern "C" {
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
     YNET_REQUIRE(x && y && N > 0 && H >= 2 && W >= 2, "maxpool2_fwd: bad arguments");
     const long long total = N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, plane_grid(N, total / N), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
     return ynet_check_launch("maxpool2_fwd");
 }
 
@@ -696,14 +822,19 @@ int ynet_maxpool2_bwd_add(const float* x, const float* dy, const float* add0, co
     YNET_REQUIRE((H & 1) == 0 && (W & 1) == 0, "maxpool2_bwd_add: H and W must be even (got %dx%d)", H, W);
     YNET_REQUIRE((((uintptr_t)x | (uintptr_t)dx | (uintptr_t)add0 | (uintptr_t)add1) & 7) == 0, "maxpool2_bwd_add: 8-byte aligned planes required");
     const long long total = N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(maxpool2_bwd_add_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, add0, add1, dx, N, H, W);
+    hipLaunchKernelGGL(maxpool2_bwd_add_kernel, plane_grid(N, total / N), dim3(256), 0, (hipStream_t)stream, x, dy, add0, add1, dx, N, H, W);
     return ynet_check_launch("maxpool2_bwd_add");
 }
 
 int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
     YNET_REQUIRE(x && y && N > 0 && H > 0 && W > 0, "upsample2x_fwd: bad arguments");
-    if ((W & 1) == 0 && ((uintptr_t)y & 15) == 0)
-        hipLaunchKernelGGL(upsample2x_fwd_vec_kernel, dim3(grid_for(N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
+    const bool rows_ok = (W & 1) == 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)x) & 7) == 0;
+    if (rows_ok && (H & 3) == 0 && (long long)H * W >= 64 * 64)
+        hipLaunchKernelGGL(upsample2x_fwd_rows_kernel<4>, plane_grid(N, (long long)(H / 4) * (W / 2)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
+    else if (rows_ok && (H & 1) == 0)
+        hipLaunchKernelGGL(upsample2x_fwd_rows_kernel<2>, plane_grid(N, (long long)(H / 2) * (W / 2)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
+    else if ((W & 1) == 0 && ((uintptr_t)y & 15) == 0)
+        hipLaunchKernelGGL(upsample2x_fwd_vec_kernel, plane_grid(N, (long long)H * W), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
     else
         hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(N * H * W * 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W);
     return ynet_check_launch("upsample2x_fwd");
@@ -711,8 +842,13 @@ int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, voi
 
 int ynet_upsample2x_bwd(const float* dy, float* dx, long long N, int H, int W, void* stream) {
     YNET_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0, "upsample2x_bwd: bad arguments");
-    if ((W & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
-        hipLaunchKernelGGL(upsample2x_bwd_vec_kernel, dim3(grid_for(N * H * (W / 4), 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+    const bool rows_ok = (W & 1) == 0 && (((uintptr_t)dy) & 15) == 0 && (((uintptr_t)dx) & 7) == 0;
+    if (rows_ok && (H & 3) == 0 && (long long)H * W >= 64 * 64)
+        hipLaunchKernelGGL(upsample2x_bwd_rows_kernel<4>, plane_grid(N, (long long)(H / 4) * (W / 2)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+    else if (rows_ok && (H & 1) == 0)
+        hipLaunchKernelGGL(upsample2x_bwd_rows_kernel<2>, plane_grid(N, (long long)(H / 2) * (W / 2)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+    else if ((W & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
+        hipLaunchKernelGGL(upsample2x_bwd_vec_kernel, plane_grid(N, (long long)H * (W / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
     else
         hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
     return ynet_check_launch("upsample2x_bwd");

@@ -263,7 +263,7 @@ def test_conv1x1_predictor_kernels(dev, cin, cout, relu):
     close(ops.conv2d(x[:1].to(dev).expand(B, -1, -1, -1), w.to(dev), b.to(dev), relu, {}), y1, msg="1x1 broadcast")
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 8, 16), (1, 2, 1, 1), (1, 4, 5, 3), (2, 16, 32, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 8, 16), (1, 2, 1, 1), (1, 4, 5, 3), (2, 16, 32, 32), (1, 2, 3, 6), (2, 2, 1, 4), (1, 3, 7, 12), (2, 2, 2, 128), (1, 2, 64, 64), (1, 1, 68, 62), (1, 2, 6, 10)])
 def test_upsample2x(dev, shape):
     ops = pkg("ops")
     x = rnd(*shape, seed=1)

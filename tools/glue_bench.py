@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Launch time and HBM rate of the plane-wise glue kernels (development tool, GPU only).
+    python tools/glue_bench.py [B C H W]       (H, W: the LARGE side of the pool / upsample pair)"""
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+ops = importlib.import_module("motion-style-transfer_amd.ops")
+L = ops.L
+lib = ops._lib()
+B, C, H, W = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (32, 32, 256, 256)
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+big = torch.randn(B, C, H, W, device=dev)
+big2, big3, bigo = torch.randn_like(big), torch.randn_like(big), torch.empty_like(big)
+small = torch.randn(B, C, H // 2, W // 2, device=dev)
+smallo = torch.empty_like(small)
+N = B * C
+st = ops._stream
+
+
+def timeit(name, fn, nbytes):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print(f"{name:18s} {B}x{C}x{H}x{W}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s")
+
+
+nb, ns = big.numel() * 4, small.numel() * 4
+timeit("maxpool2_fwd", lambda: L.check(lib.ynet_maxpool2_fwd(big.data_ptr(), smallo.data_ptr(), N, H, W, st()), lib), nb + ns)
+timeit("maxpool2_bwd_add", lambda: L.check(lib.ynet_maxpool2_bwd_add(big.data_ptr(), small.data_ptr(), big2.data_ptr(), big3.data_ptr(),
+                                                                     bigo.data_ptr(), N, H, W, st()), lib), 4 * nb + ns)
+timeit("upsample2x_fwd", lambda: L.check(lib.ynet_upsample2x_fwd(small.data_ptr(), bigo.data_ptr(), N, H // 2, W // 2, st()), lib), nb + ns)
+timeit("upsample2x_bwd", lambda: L.check(lib.ynet_upsample2x_bwd(big.data_ptr(), smallo.data_ptr(), N, H // 2, W // 2, st()), lib), nb + ns)
