@@ -709,6 +709,15 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const float* __restri
     }
     float* o = out + (long long)n * H * W;
     const int total = H * W;
+    if ((W & 3) == 0 && ((reinterpret_cast<uintptr_t>(o)) & 15) == 0) {      // 16-byte stores (the window start is unaligned)
+        const int Wq = W >> 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (total >> 2); i += gridDim.x * 256) {
+            const int y = i / Wq, x = (i - y * Wq) << 2;
+            const float* src = tmpl + (long long)(oy + y) * SW + ox + x;
+            reinterpret_cast<float4*>(o)[i] = make_float4(src[0], src[1], src[2], src[3]);
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int y = i / W, x = i - y * W;
         o[i] = tmpl[(long long)(oy + y) * SW + ox + x];

@@ -41,3 +41,10 @@ timeit("maxpool2_bwd_add", lambda: L.check(lib.ynet_maxpool2_bwd_add(big.data_pt
                                                                      bigo.data_ptr(), N, H, W, st()), lib), 4 * nb + ns)
 timeit("upsample2x_fwd", lambda: L.check(lib.ynet_upsample2x_fwd(small.data_ptr(), bigo.data_ptr(), N, H // 2, W // 2, st()), lib), nb + ns)
 timeit("upsample2x_bwd", lambda: L.check(lib.ynet_upsample2x_bwd(big.data_ptr(), smallo.data_ptr(), N, H // 2, W // 2, st()), lib), nb + ns)
+S = 1050
+tmpl = torch.randn(S, S, device=dev)
+xy = (torch.rand(B * 12, 2, device=dev) * 200 + 20).contiguous()
+pout = torch.empty(B * 12, H, W, device=dev)
+stat = torch.zeros(1, dtype=torch.int32, device=dev)
+timeit("gather_patch", lambda: L.check(lib.ynet_gather_patch(tmpl.data_ptr(), S, S, xy.data_ptr(), pout.data_ptr(), B * 12, H, W,
+                                                             stat.data_ptr(), st()), lib), pout.numel() * 4)
