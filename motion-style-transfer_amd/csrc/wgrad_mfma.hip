@@ -283,7 +283,7 @@ struct WgDmaCfg {
     // (no per-lane predicate = no vector-ALU compare); its surplus lanes carry the out-of-range marker and write
     // zeros into the slack
     static constexpr int XS = 32 * XCH + 128, DS = 32 * DCH + 128;
-    static constexpr int BUF = XS + DS;                  // (the ReLU-mask quads stay in registers)
+    static constexpr int BUF = XS + DS * (MASK ? 2 : 1);     // x tile, dy tile, ReLU-mask tile (the activation y)
     static constexpr int LDS_BYTES = 2 * BUF * 4;
     static constexpr int XI = (32 * XQ + 255) / 256;     // x DMA instructions per thread per tile
     static constexpr int DI = (32 * DQ + 255) / 256;     // dy DMA instructions (and mask loads) per thread per tile
@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     auto xs_of = [&](int b) { return smem + b * C::BUF; };
     auto ds_of = [&](int b) { return smem + b * C::BUF + C::XS; };
+    auto ms_of = [&](int b) { return smem + b * C::BUF + C::XS + C::DS; };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,8 +376,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     // instruction issues once per ~MFMA slot of the other wave on the SIMD: the ~100 of the generic path below
     // took about as long as the tile's 144 MFMAs.)
     // static offsets for a tile of an interior column / the first column (left halo quads zeroed) / the last / both
-    typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
-    wg_u32x4 mq[MASK ? DI : 1];      // ReLU-mask quads of the tile in flight
     unsigned xs_in[XI], xs_l[XI], xs_r[XI], xs_lr[XI], dstat[DI];     // (separate arrays: a 2-D one selected by value goes to scratch)
 #pragma unroll
     for (int k = 0; k < XI; ++k) {
@@ -435,34 +434,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
             if (DI > DFULL && wave == 0) wg_dma16s(r, ds + (DFULL * 256) * 4, dofs[DI - 1], dso);
         }
         if (MASK) {
-            // the mask quads that correspond to this lane's dy DMA lanes go to registers; mask_in_place applies them
-            // to the dy tile in LDS after the wait that precedes the next barrier (no mask image in LDS)
+            // the activation tile lands next to the dy tile; the select happens on the A operand, behind the MFMAs of
+            // the previous K-step.  (Holding the mask quads in registers and rewriting the dy tile in LDS before the
+            // barrier looked equal in an isolated launch but cost 7-19 % per launch inside the training step.)
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(ka->mask + (long long)t.b * ka->mask_bs + (long long)co0 * HW), 0, (unsigned)nco * plane_bytes, 0x00020000);
+            float* ms = ms_of(buf);
 #pragma unroll
-            for (int k = 0; k < DFULL; ++k) mq[k] = __builtin_amdgcn_raw_buffer_load_b128(r, dofs[k], dso, 0);
-            if (DI > DFULL && wave == 0) mq[DI - 1] = __builtin_amdgcn_raw_buffer_load_b128(r, dofs[DI - 1], dso, 0);
+            for (int k = 0; k < DFULL; ++k) wg_dma16s(r, ms + (k * 256 + wave * 64) * 4, dofs[k], dso);
+            if (DI > DFULL && wave == 0) wg_dma16s(r, ms + (DFULL * 256) * 4, dofs[DI - 1], dso);
         }
 #ifdef YNET_WG_PROFILE
         prof_dma += __builtin_amdgcn_s_memtime() - q0;
 #endif
     };
-    auto mask_in_place = [&](int buf) {
-        float* ds = ds_of(buf);
-#pragma unroll
-        for (int k = 0; k < DI; ++k) {
-            const bool part = k >= 32 * DQ / 256;
-            if (!part || wave == 0) {
-                f32x4* p = reinterpret_cast<f32x4*>(ds) + (part ? k * 256 + lane : k * 256 + tid);
-                const f32x4 m = __builtin_bit_cast(f32x4, mq[k]);
-                f32x4 v = *p;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
-                *p = v;
-            }
-        }
-    };
-
     // Queue the DMAs of a tile.  (Handing them out inside the MFMA loop instead was measured 6-15 % slower: a
     // buffer_load ... lds holds the wave's instruction stream for ~50-60 cycles wherever it is placed.)
     auto issue = [&](const WgTile& t, int buf) {
@@ -512,7 +497,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     auto compute = [&](int buf) {
         const float* xb = xs_of(buf) + xoff;
         const float* ab = ds_of(buf) + doff;
-        auto rd_a = [&](int s) { return ab[4 * s]; };     // rows are 32 pixels = 8 K-steps: 4 s is the pixel offset in the tile
+        const float* mb = ms_of(buf) + doff;
+        auto rd_a = [&](int s) {
+            const float v = ab[4 * s];          // rows are 32 pixels = 8 K-steps: 4 s is the pixel offset in the tile
+            if (MASK) return mb[4 * s] > 0.f ? v : 0.f;
+            return v;
+        };
         auto rd_b = [&](int s, float* b) {
             const float* p = xb + (s >> 3) * TCOLS + (s & 7) * 4;
 #pragma unroll
@@ -531,12 +521,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
         for (int t = 0; t < KK; ++t) asm volatile("" : "+v"(b_cur[t]));
         // one K-step: queue the LDS reads of the following step into (a_n, b_n), then the 9 MFMAs of (a_c, b_c)
         auto step = [&](int sn, float a_c, const float* b_c, float& a_n, float* b_n) {
-            a_n = ab[4 * sn];
+            const float v = ab[4 * sn];
+            float m = 1.f;
+            if (MASK) m = mb[4 * sn];
             rd_b(sn, b_n);
             __builtin_amdgcn_sched_barrier(0);      // nothing moves across: reads of the next step, THEN the MFMAs of this one
 #pragma unroll
             for (int t = 0; t < KK; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[t], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            a_n = m > 0.f ? v : 0.f;        // VALU work on the fresh reads goes behind the MFMAs (their data has landed by then)
             bsum += a_c;
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -584,7 +577,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
 #ifdef YNET_WG_PROFILE
         const unsigned long long p1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (MASK) mask_in_place(buf);           // each lane rewrites what its own DMA lanes delivered
         __syncthreads();
 #ifdef YNET_WG_PROFILE
         const unsigned long long p2 = __builtin_amdgcn_s_memtime();
@@ -741,7 +733,7 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
         (void)hipMemcpyAsync(h, prof_dev, 64, hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         const double tot = (double)h[0];
-        fprintf(stderr, "wgrad_dma<%d> waves %llu avg cycles %.0f: vmcnt-wait %.1f%% mask+barrier %.1f%% issue %.1f%% (of which DMA + descriptors %.1f%%) compute %.1f%% rest %.1f%%\n", (int)MASK,
+        fprintf(stderr, "wgrad_dma<%d> waves %llu avg cycles %.0f: vmcnt-wait %.1f%% barrier %.1f%% issue %.1f%% (of which DMA + descriptors %.1f%%) compute %.1f%% rest %.1f%%\n", (int)MASK,
                 h[5], tot / (double)h[5], 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[6] / tot, 100.0 * h[4] / tot,
                 100.0 * (tot - h[1] - h[2] - h[3] - h[4]) / tot);
     }
