@@ -592,6 +592,7 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     const float* p = x + (plane / C) * bs + (plane % C) * (long long)H * W;
     const int tid = threadIdx.x;
     SoftAcc a{-INFINITY, 0.f, 0.f, 0.f};
+    bool poison = false;        // a NaN logit: the reference's softmax makes the whole plane NaN
     const int n = H * W;
     if ((W & 3) == 0) {
         const int w4 = W >> 2, n4 = n >> 2;
@@ -608,6 +609,8 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
             }
         };
         auto fold = [&](const float4 v) {
+            const float chk = (v.x + v.y) + (v.z + v.w);      // NaN for a NaN logit (exp_le0's clamp would hide it)
+            poison = poison || chk != chk;
             // rescale at most once per 16-byte vector
             const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
             if (mx > a.m) {
@@ -641,9 +644,11 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     } else {
         for (int i = tid; i < n; i += 256) {
             const int row = i / W, col = i - row * W;
+            poison = poison || p[i] != p[i];
             soft_add(a, p[i], (float)col, (float)row);
         }
     }
+    if (poison) a.s = __builtin_nanf("");
     // combine: block max, then rescaled sums in fp64
     float m = wave_max(a.m);
     if ((tid & 63) == 0) wm[tid >> 6] = m;
@@ -659,6 +664,7 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     __syncthreads();
     if (tid == 0) {
         s = (wsum[0][0] + wsum[1][0]) + (wsum[2][0] + wsum[3][0]);
+        if (m == INFINITY) s = (double)__builtin_nanf("");      // a +inf logit: exp(inf - inf) = NaN in the reference
         sx = (wsum[0][1] + wsum[1][1]) + (wsum[2][1] + wsum[3][1]);
         sy = (wsum[0][2] + wsum[1][2]) + (wsum[2][2] + wsum[3][2]);
         const double inv = 1.0 / (s + (double)eps);

@@ -339,6 +339,16 @@ def test_softargmax_golden_and_slices(dev):
     close(sl, g.t("softargmax/out")[:, -1:], rtol=1e-5, atol=2e-5, msg="slice")
     y = rnd(2, 3, 17, 23, seed=3, scale=3.0)
     close(ops.softargmax2d(y.to(dev)), O.softargmax2d(y.double()).float(), rtol=1e-5, atol=2e-5, msg="odd width")
+    # non-finite logits behave as in the reference: -inf has weight 0; a NaN or +inf logit makes its plane NaN
+    z = rnd(1, 4, 16, 32, seed=4)
+    z[0, 0, 3, 5] = float("-inf")
+    z[0, 1, 2, 7] = float("nan")
+    z[0, 2, 9, 9] = float("inf")
+    want = O.softargmax2d(z)
+    gotz = ops.softargmax2d(z.to(dev)).cpu()
+    assert torch.isnan(want[0, 1]).all() and torch.isnan(want[0, 2]).all()
+    assert torch.isnan(gotz[0, 1]).all() and torch.isnan(gotz[0, 2]).all()
+    close(gotz[0, [0, 3]], want[0, [0, 3]], rtol=1e-5, atol=2e-5, msg="planes with -inf / finite logits")
     with pytest.raises(ValueError):
         ops.softargmax2d(torch.zeros(3, 4, 4, device=dev))
     with pytest.raises(TypeError):
