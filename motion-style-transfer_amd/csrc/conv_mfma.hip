@@ -1026,7 +1026,8 @@ static int launch_conv_m(ConvArgs& a, hipStream_t st) {
     a.ntiles = (int)nt;
     static const int debug = getenv("YNET_CONV_DEBUG") ? atoi(getenv("YNET_CONV_DEBUG")) : 0;
     a.debug = debug;
-    static int slots = 0;          // resident workgroups on the device for this instantiation
+    static int slots_dev[YNET_MAX_DEV] = {0};          // resident workgroups on the device for this instantiation
+    int& slots = slots_dev[ynet_device_slot()];
     if (slots == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, NCB, R, CC, MASK, M16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -1098,7 +1099,8 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     a.ntiles = (int)nt;
     static const int debug = getenv("YNET_CONV_DEBUG") ? atoi(getenv("YNET_CONV_DEBUG")) : 0;
     a.debug = debug;
-    static int slots = 0;
+    static int slots_dev[YNET_MAX_DEV] = {0};
+    int& slots = slots_dev[ynet_device_slot()];
     if (slots == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);

@@ -709,12 +709,14 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const float* __restri
     const int n = blockIdx.y;
     const int rx = (int)rintf(xy[2 * n]), ry = (int)rintf(xy[2 * n + 1]);
     const int ox = SW / 2 - rx, oy = SH / 2 - ry;
-    if (ox < 0 || oy < 0 || ox + W > SW || oy + H > SH) {
-        if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(status, 1);
-        return;
-    }
     float* o = out + (long long)n * H * W;
     const int total = H * W;
+    if (ox < 0 || oy < 0 || ox + W > SW || oy + H > SH) {
+        // flagged AND zero-filled: the caller's buffer is never left uninitialised (the flag is read at the next sync point)
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(status, 1);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) o[i] = 0.f;
+        return;
+    }
     if ((W & 3) == 0 && ((reinterpret_cast<uintptr_t>(o)) & 15) == 0) {      // 16-byte stores (the window start is unaligned)
         const int Wq = W >> 2;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < (total >> 2); i += gridDim.x * 256) {
@@ -966,10 +968,14 @@ int ynet_sigmoid_temp(const float* x, float* y, long long B, int C, long long HW
 int ynet_gather_patch(const float* tmpl, int SH, int SW, const float* xy, float* out, int N, int H, int W,
                       int* status, void* stream) {
     YNET_REQUIRE(tmpl && xy && out && status, "gather_patch: null pointer");
-    YNET_REQUIRE(N > 0 && N < 65536 && H > 0 && W > 0 && SH >= H && SW >= W, "gather_patch: bad shape N=%d %dx%d in %dx%d", N, H, W, SH, SW);
+    YNET_REQUIRE(N > 0 && H > 0 && W > 0 && SH >= H && SW >= W, "gather_patch: bad shape N=%d %dx%d in %dx%d", N, H, W, SH, SW);
     int gx = (H * W + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(gather_patch_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, tmpl, SH, SW, xy, out, H, W, status);
+    for (int n0 = 0; n0 < N; n0 += 65535) {      // grid.y is limited to 65535 windows per launch
+        const int n = N - n0 < 65535 ? N - n0 : 65535;
+        hipLaunchKernelGGL(gather_patch_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, tmpl, SH, SW, xy + 2ll * n0,
+                           out + (long long)n0 * H * W, H, W, status);
+    }
     return ynet_check_launch("gather_patch");
 }
 
@@ -978,7 +984,8 @@ int ynet_kmeans2d(const float* points, const int* init_idx, float* centers, int*
     YNET_REQUIRE(points && init_idx && centers && status, "kmeans2d: null pointer");
     YNET_REQUIRE(P > 0 && N > 0 && N <= 18000 && K >= 1 && K <= 32 && K <= N, "kmeans2d: bad shape P=%d N=%d K=%d (N <= 18000, K <= 32)", P, N, K);
     const int lds = (2 * N + 64 + 96 + 2) * 4;
-    static bool attr_set = false;
+    static bool attr_dev[YNET_MAX_DEV] = {false};
+    bool& attr_set = attr_dev[ynet_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;

@@ -680,7 +680,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 template <int KS, bool MASK>
 static int launch_wgrad_m(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     using C = WgCfg<KS>;
-    static bool attr_set = false;
+    static bool attr_dev[YNET_MAX_DEV] = {false};
+    bool& attr_set = attr_dev[ynet_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<KS, MASK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -701,7 +702,8 @@ static int launch_wgrad_m(WgradArgs& a, float* dw, float* db, hipStream_t st) {
 template <bool MASK, int TH_>
 static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     using C = WgDmaCfg<MASK, TH_>;
-    static bool attr_set = false;
+    static bool attr_dev[YNET_MAX_DEV] = {false};
+    bool& attr_set = attr_dev[ynet_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<MASK, TH_>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

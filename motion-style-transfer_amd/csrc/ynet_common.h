@@ -34,3 +34,12 @@ int ynet_check_launch(const char* what);
     } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Per-device launch state (function attributes, resident-workgroup counts) is cached per HIP device: a process
+// that drives several GPUs sets the > 64 KB LDS attribute and sizes its persistent grids on each of them.
+#define YNET_MAX_DEV 16
+static inline int ynet_device_slot() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return (d >= 0 && d < YNET_MAX_DEV) ? d : 0;
+}

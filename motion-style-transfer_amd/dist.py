@@ -83,6 +83,17 @@ class DataParallel:
         dist.all_gather(out, pad, group=self.group)
         return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
 
+    def shared_seed(self) -> int:
+        """A random 63-bit seed drawn on rank 0 and broadcast: every rank seeds its scene-shuffling generator with it,
+        so all ranks walk the scenes in the same order (train_epoch shards trajectory[i:i+bs] of the SAME scene)."""
+        dev = self.flat.device
+        t = torch.zeros(1, dtype=torch.int64, device=dev)
+        if self.rank == 0:
+            t[0] = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if self.world > 1:
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return int(t.item())
+
     def shard_sizes(self, n: int) -> List[int]:
         base, extra = divmod(n, self.world)
         return [base + (1 if r < extra else 0) for r in range(self.world)]
@@ -99,7 +110,7 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         if backend is None:
             # YNET_DIST_BACKEND=gloo: development runs of the multi-process path on a box with fewer GPUs than ranks
             backend = os.environ.get("YNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available() and os.environ.get("YNET_BENCH_SINGLE_DEVICE") != "1":
+            torch.cuda.set_device(local)      # every backend: the HIP kernels launch on the current device's streams
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world

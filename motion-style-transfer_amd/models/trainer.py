@@ -126,6 +126,9 @@ class YNetTrainer:
     def __init__(self, params, device=None):
         self.params = params
         self.device = device if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.device = torch.device(self.device)
+        if self.device.type == "cuda" and self.device.index is not None and torch.cuda.is_available():
+            torch.cuda.set_device(self.device)      # the HIP kernels launch on the current device's streams
         print(f"Working on {self.device}")
         self.division_factor = 2 ** len(params["encoder_channels"])
         self.template_size = int(4200 * params["resize_factor"])
@@ -282,7 +285,13 @@ class YNetTrainer:
             if im.shape[-1] % self.division_factor or im.shape[-2] % self.division_factor:
                 raise ValueError(f"scene {k}: {tuple(im.shape)} is not padded to a multiple of {self.division_factor}")
         dataset = SceneDataset(df, resize=resize_factor, total_len=obs_len + pred_len)
-        loader = DataLoader(dataset, batch_size=1, collate_fn=scene_collate, shuffle=(mode == "train"))
+        generator = None
+        if mode == "train" and self.dp is not None:
+            # data-parallel ranks must walk the scenes in the SAME order (train_epoch shards the batches of one scene
+            # over the ranks): the shuffle draws from a generator seeded identically everywhere (seed from rank 0)
+            generator = torch.Generator()
+            generator.manual_seed(self.dp.shared_seed())
+        loader = DataLoader(dataset, batch_size=1, collate_fn=scene_collate, shuffle=(mode == "train"), generator=generator)
         return image_path, loader, None
 
     def load_params(self, path):

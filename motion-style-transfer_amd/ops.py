@@ -32,6 +32,11 @@ def _need_gpu(t: torch.Tensor, what: str):
                            f"(no CPU fallback exists by design)")
     if t.dtype != torch.float32:
         raise TypeError(f"{what}: fp32 expected, got {t.dtype}")
+    # kernels are enqueued on the CURRENT device's stream: a tensor of another GPU would be addressed from the wrong
+    # device's queue.  (YNetTrainer and dist.init_from_env select the device; one process drives one GPU.)
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"{what}: tensor lives on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}; "
+                           f"call torch.cuda.set_device({t.device.index}) (or use `with torch.cuda.device(...)`) first")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -305,14 +310,38 @@ def _cached(cache: dict, weight, lora_a, lora_b, scale, what: str):
 # autograd engine its gradient is summed by two full-size elementwise adds (6 passes over the largest tensors of
 # the step).  Instead: the pool's forward registers its input; a conv backward that produces a gradient for a
 # registered tensor hands it over here (and returns None to autograd); the pool's backward adds the handed-over
-# gradients while it writes its own (ynet_maxpool2_bwd_add).  Always correct: a gradient is only handed over while
-# the pool's backward has not run yet, and only for the very tensor (weak reference, address, shape) the pool saw.
+# gradients while it writes its own (ynet_maxpool2_bwd_add).
+# This is only correct when the backward pass runs the pool's node after the decoders' -- true for a full
+# ``loss.backward()`` (the pool's gradient depends on them) but NOT for pruned graphs such as
+# ``torch.autograd.grad(loss, features[i])`` or ``backward(inputs=...)``, where the pool's backward never runs and
+# a handed-over gradient would be dropped.  The fold is therefore OPT-IN: ``with ops.fold_skip_gradients():`` around
+# forward + backward (utils/train_epoch.py does that); everywhere else autograd sums the gradients itself.
 class _SkipEntry:
     __slots__ = ("ref", "shape", "stash", "consumed")
 
 
 _skip_registry = {}
-skip_fold = _os.environ.get("YNET_SKIP_FOLD", "1") != "0"
+skip_fold = False                                                   # switched on by fold_skip_gradients() only
+_skip_fold_allowed = _os.environ.get("YNET_SKIP_FOLD", "1") != "0"      # YNET_SKIP_FOLD=0: never fold (A/B runs)
+
+
+class fold_skip_gradients:
+    """Context manager: inside it (forward AND the full backward of the same graph) the gradients of the encoder
+    feature maps that feed a max-pool are added inside the pool's backward kernel instead of by autograd."""
+
+    def __enter__(self):
+        global skip_fold
+        self._prev = skip_fold
+        skip_fold = _skip_fold_allowed
+        return self
+
+    def __exit__(self, *exc):
+        global skip_fold
+        skip_fold = self._prev
+        # gradients handed over to a pool whose backward never ran (an exception, a pruned graph) must not linger
+        for k in [k for k, e in _skip_registry.items() if e.consumed or e.ref() is None or e.stash]:
+            del _skip_registry[k]
+        return False
 
 
 def _skip_register(x: torch.Tensor):
@@ -614,6 +643,8 @@ def sigmoid_temp(x: torch.Tensor, channels: Sequence[int], temperature: float) -
     x = x.detach().contiguous()
     B, C, H, W = x.shape
     sel = [int(c) % C for c in channels]
+    if len(sel) > 8:          # the kernel takes up to 8 selected channels per launch
+        return torch.cat([sigmoid_temp(x, sel[i:i + 8], temperature) for i in range(0, len(sel), 8)], dim=1)
     y = torch.empty((B, len(sel), H, W), device=x.device, dtype=torch.float32)
     lib = _lib()
     arr = (ctypes.c_int * len(sel))(*sel)

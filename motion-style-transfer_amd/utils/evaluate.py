@@ -129,6 +129,7 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
                     ade, fde = dp.gather_rows(ade, sizes), dp.gather_rows(fde, sizes)
                 ade_list.append(ade.cpu().numpy())
                 fde_list.append(fde.cpu().numpy())
+                ops.check_patch_status()      # (the batch is synchronised by the copies above: a window that left the template raises here)
             meta_id_list.append(meta_ids)
             scene_id_list.append([scene_id] * n_data)
 
@@ -174,6 +175,8 @@ def ttst_goals(model, wp_sigmoid_last, wp_logits_last, n_goal, rel_thresh, draw=
         draw = sampling(wp_sigmoid_last, num_samples=10000, replacement=True, rel_threshold=rel_thresh).permute(2, 0, 1, 3)
     first = model.softargmax(wp_logits_last)                     # [B,1,2]
     n_people, k = draw.shape[1], n_goal - 1
+    if k == 0:          # n_goal == 1: the soft-argmax goal alone (the reference's cluster loop has nothing to add)
+        return first.unsqueeze(0)
     points = draw[:, :, 0].permute(1, 0, 2).contiguous()         # [B, 10000, 2]
     init = torch.from_numpy(np.stack([np.random.choice(points.shape[1], k, replace=False) for _ in range(n_people)]).astype(np.int32))
     centers, status = ops.kmeans2d(points, init, tol=0.001, iter_limit=1000)

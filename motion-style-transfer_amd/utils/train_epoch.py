@@ -47,55 +47,56 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                 optimizer.zero_grad()
 
             if n_local > 0:
-                # heat-maps: distance map per observed step, Gaussian blob per future step, distance map per waypoint
-                observed_map = gather_patches(input_template, batch[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
-                gt_future = batch[:, obs_len:].to(device)
-                gt_future_map = gather_patches(gt_template, batch[:, obs_len:].reshape(-1, 2), H, W).view(-1, pred_len, H, W)
-                gt_waypoints = batch[:, obs_len:][:, waypoints]
-                gt_waypoint_map = gather_patches(input_template, gt_waypoints.reshape(-1, 2), H, W).view(-1, len(waypoints), H, W)
-                sem1 = semantic_img
-                if network == "embed":      # utils/train_epoch.py:80-83 (before the expand)
-                    sem1 = model.scene_embedding(semantic_img)
-                    observed_map = model.motion_embedding(observed_map)
+                with ops.fold_skip_gradients():      # skip-connection gradients summed inside the max-pool backward
+                    # heat-maps: distance map per observed step, Gaussian blob per future step, distance map per waypoint
+                    observed_map = gather_patches(input_template, batch[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
+                    gt_future = batch[:, obs_len:].to(device)
+                    gt_future_map = gather_patches(gt_template, batch[:, obs_len:].reshape(-1, 2), H, W).view(-1, pred_len, H, W)
+                    gt_waypoints = batch[:, obs_len:][:, waypoints]
+                    gt_waypoint_map = gather_patches(input_template, gt_waypoints.reshape(-1, 2), H, W).view(-1, len(waypoints), H, W)
+                    sem1 = semantic_img
+                    if network == "embed":      # utils/train_epoch.py:80-83 (before the expand)
+                        sem1 = model.scene_embedding(semantic_img)
+                        observed_map = model.motion_embedding(observed_map)
 
-                semantic_map = sem1.expand(n_local, -1, -1, -1)
-                features = model.pred_features(semantic_map, observed_map)
-                # The goal and the trajectory decoder are independent given the features: run them on two
-                # HIP streams so the launch-latency-bound small maps (8^2 .. 32^2) of one overlap the other
-                # (autograd replays each backward op on the stream of its forward op).
-                main = torch.cuda.current_stream(device)
-                s_goal, s_traj = ops.side_streams(device)
-                for f in features:
-                    for t in ops._parts(f):
-                        t.record_stream(s_goal)
-                        t.record_stream(s_traj)
-                gt_future_map.record_stream(s_goal)
-                gt_future_map.record_stream(s_traj)
-                gt_waypoint_map.record_stream(s_traj)
-                s_goal.wait_stream(main)
-                s_traj.wait_stream(main)
-                if hasattr(criterion, "expected_grad"):
-                    # d(loss)/d(criterion output) as autograd will compute it (fp32): lets the criterion emit the
-                    # gradient of its logits in the same pass as the loss
-                    up = np.float32(1.0) if dp is None else np.float32(n_local / n_global)
-                    criterion.expected_grad = float(np.float32(up * np.float32(loss_scale)))
-                with torch.cuda.stream(s_goal):
-                    pred_goal_map = model.pred_goal(features)
-                    goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
-                with torch.cuda.stream(s_traj):
-                    pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
-                    traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]   # concat fused into the convs
-                    pred_traj_map = model.pred_traj(traj_input)
-                    traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
-                main.wait_stream(s_goal)
-                main.wait_stream(s_traj)
-                for t in (pred_goal_map, goal_loss, pred_traj_map, traj_loss):
-                    t.record_stream(main)
+                    semantic_map = sem1.expand(n_local, -1, -1, -1)
+                    features = model.pred_features(semantic_map, observed_map)
+                    # The goal and the trajectory decoder are independent given the features: run them on two
+                    # HIP streams so the launch-latency-bound small maps (8^2 .. 32^2) of one overlap the other
+                    # (autograd replays each backward op on the stream of its forward op).
+                    main = torch.cuda.current_stream(device)
+                    s_goal, s_traj = ops.side_streams(device)
+                    for f in features:
+                        for t in ops._parts(f):
+                            t.record_stream(s_goal)
+                            t.record_stream(s_traj)
+                    gt_future_map.record_stream(s_goal)
+                    gt_future_map.record_stream(s_traj)
+                    gt_waypoint_map.record_stream(s_traj)
+                    s_goal.wait_stream(main)
+                    s_traj.wait_stream(main)
+                    if hasattr(criterion, "expected_grad"):
+                        # d(loss)/d(criterion output) as autograd will compute it (fp32): lets the criterion emit the
+                        # gradient of its logits in the same pass as the loss
+                        up = np.float32(1.0) if dp is None else np.float32(n_local / n_global)
+                        criterion.expected_grad = float(np.float32(up * np.float32(loss_scale)))
+                    with torch.cuda.stream(s_goal):
+                        pred_goal_map = model.pred_goal(features)
+                        goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
+                    with torch.cuda.stream(s_traj):
+                        pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
+                        traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]   # concat fused into the convs
+                        pred_traj_map = model.pred_traj(traj_input)
+                        traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
+                    main.wait_stream(s_goal)
+                    main.wait_stream(s_traj)
+                    for t in (pred_goal_map, goal_loss, pred_traj_map, traj_loss):
+                        t.record_stream(main)
 
-                loss = goal_loss + traj_loss
-                if dp is not None:
-                    loss = loss * (n_local / n_global)      # BCE is a mean: weight by the shard's share
-                loss.backward()
+                    loss = goal_loss + traj_loss
+                    if dp is not None:
+                        loss = loss * (n_local / n_global)      # BCE is a mean: weight by the shard's share
+                    loss.backward()
             else:
                 loss = torch.zeros((), device=device)
             if dp is not None:

@@ -90,3 +90,45 @@ def test_shard_arithmetic():
             cover += list(range(lo, hi))
             assert hi - lo == Fake(r, 4).shard_sizes(n)[r]
         assert cover == list(range(n))
+
+
+def _loader_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import pandas as pd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D = pkg("dist")
+    D.init_from_env("gloo")
+    torch.manual_seed(1000 + 17 * rank)          # the ranks' default generators DIFFER (as in real launches)
+    trn = pkg("models.trainer")
+    params = dict(obs_len=8, pred_len=12, segmentation_model_fp=None, use_features_only=False, n_semantic_classes=6,
+                  encoder_channels=[8, 8, 16, 16, 16], decoder_channels=[16, 16, 16, 8, 8], waypoints=[11],
+                  train_net="mosa_1", position=["0"], network="original", n_fusion=None, resize_factor=0.25)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        t = trn.YNetTrainer(params, device=torch.device("cpu"))
+    t.dp = D.DataParallel([torch.nn.Parameter(torch.zeros(3))])
+    n_scene, per = 7, 2
+    df = pd.DataFrame({"sceneId": np.repeat([f"s{i}" for i in range(n_scene)], per * 20),
+                       "metaId": np.repeat(np.arange(n_scene * per), 20),
+                       "x": np.arange(n_scene * per * 20, dtype=np.float32), "y": 0.0})
+    images = {f"s{i}": torch.zeros(6, 32, 32) for i in range(n_scene)}
+    _, loader, _ = t.prepare_data(df, images, "sdd", "train", 8, 12, 0.25, False)
+    order = [[scene for _, _, scene in loader] for _epoch in range(3)]
+    _, val_loader, _ = t.prepare_data(df, images, "sdd", "val", 8, 12, 0.25, False)
+    torch.save({"order": order, "val": [scene for _, _, scene in val_loader]}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_walk_the_scenes_in_the_same_shuffled_order(tmp_path):
+    """under data parallelism train_epoch shards trajectory[i:i+bs] of ONE scene over the ranks, so
+    every rank's shuffled DataLoader must yield the scenes in the same order although the ranks' default RNGs differ."""
+    out = str(tmp_path / "order.pt")
+    mp.spawn(_loader_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    assert a["order"] == b["order"]
+    assert all(sorted(e) == [f"s{i}" for i in range(7)] for e in a["order"])
+    assert len({tuple(e) for e in a["order"]}) > 1, "epochs should be shuffled differently"
+    assert a["val"] == b["val"] == [f"s{i}" for i in range(7)]

@@ -227,17 +227,28 @@ def test_skip_gradients_fold_into_maxpool_backward(dev):
     loss = F.max_pool2d(f, 2, 2).square().sum() + F.conv2d(f, w1, padding=1).sum() * 0.5 \
         + F.conv2d(torch.cat([f, extra], 1), w2, padding=1).square().sum()
     loss.backward()
+    import contextlib
     for fold in (True, False):
-        ops.skip_fold = fold
-        try:
+        with (ops.fold_skip_gradients() if fold else contextlib.nullcontext()):
+            assert ops.skip_fold == fold
             xd = x.to(dev).requires_grad_(True)
             fd = ops.conv2d(xd, w0.to(dev), None, True, {})
             ld = ops.max_pool2(fd).square().sum() + ops.conv2d(fd, w1.to(dev), None, False, {}).sum() * 0.5 \
                 + ops.conv2d(ops.lazy_cat([fd, extra.to(dev)]), w2.to(dev), None, False, {}).square().sum()
             ld.backward()
-        finally:
-            ops.skip_fold = True
+        assert not ops.skip_fold
         close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx (fold={fold})")
+    # pruned graph (the gradient of a decoder-side loss with respect to the feature map only: the pool's backward
+    # never runs).  Outside fold_skip_gradients() nothing is handed over, so the gradient is complete.
+    fc = F.relu(F.conv2d(x, w0, padding=1)).requires_grad_(True)
+    (gc,) = torch.autograd.grad(F.conv2d(fc, w1, padding=1).square().sum() + F.max_pool2d(fc, 2, 2).sum() * 0.0, fc)
+    xd = x.to(dev).requires_grad_(True)
+    fd = ops.conv2d(xd, w0.to(dev), None, True, {})
+    pooled = ops.max_pool2(fd)                 # registers nothing outside the context
+    (gd,) = torch.autograd.grad(ops.conv2d(fd, w1.to(dev), None, False, {}).square().sum(), fd)
+    close(gd, gc, rtol=1e-4, scale_rel=2e-6, msg="pruned graph")
+    assert not ops._skip_registry
+    del pooled
     # odd spatial size: never registered, plain path
     xo = rnd(1, 3, 7, 9, seed=6)
     xoc = xo.clone().requires_grad_(True)
