@@ -146,10 +146,13 @@ def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0):
     times = []
     t_start = time.perf_counter()
     step = 0
+    first = None
     while True:
         traj = O.synthetic_trajectories(cfg, batch, H, W, 100 + step)
         t0 = time.perf_counter()
         r = O.train_step(sd, cfg, scene, traj, in_t, gt_t, names)
+        if first is None:       # kept for parity_check: the HIP path repeats exactly this step
+            first = {"batch": batch, "loss": float(r["loss"]), "ade": float(r["ade"].mean()), "fde": float(r["fde"].mean())}
         for n in names:
             sd[n], ms[n], vs[n] = O.adam_update(sd[n], r["grads"][n], ms[n], vs[n], step + 1, 1e-3)
         dt = time.perf_counter() - t0
@@ -161,7 +164,20 @@ def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0):
     med = float(np.median(times))
     return {"value": batch / med, "unit": "trajectories/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} steps of batch {batch} after 1 warm-up (oracle/ynet_oracle.py train_step + Adam, "
-                      f"same config and raster size), median step {med * 1e3:.0f} ms"}
+                      f"same config and raster size), median step {med * 1e3:.0f} ms"}, first
+
+
+def parity_check(first, gpu_step):
+    """The HIP path's first step against the CPU oracle's first step on the SAME inputs (state dict seed 0, trajectories
+    seed 100, batch = --cpu-batch): loss to 2e-5 relative, ADE / FDE to 1e-4 (the north-star tolerance)."""
+    ade, fde, loss = gpu_step
+    rel = abs(loss - first["loss"]) / abs(first["loss"])
+    d_ade, d_fde = abs(ade - first["ade"]), abs(fde - first["fde"])
+    return {"batch": first["batch"], "loss_hip": loss, "loss_oracle": first["loss"], "loss_rel_err": rel,
+            "ade_hip": ade, "ade_oracle": first["ade"], "ade_abs_err": d_ade,
+            "fde_hip": fde, "fde_oracle": first["fde"], "fde_abs_err": d_fde,
+            "tolerance": {"loss_rel": 2e-5, "ade_fde_abs": 1e-4},
+            "ok": bool(rel <= 2e-5 and d_ade <= 1e-4 and d_fde <= 1e-4)}
 
 
 def main():
@@ -178,7 +194,19 @@ def main():
     ap.add_argument("--layers", action="store_true", help="print one line per conv launch of the instrumented step (stderr)")
     args = ap.parse_args()
 
-    from oracle import ynet_oracle as O      # cpu_baseline leg + synthetic-input generators only
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL), as CHILD processes
+        # and before this process has made any HIP call, then exit with their code.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
+    from oracle import ynet_oracle as O      # cpu_baseline / parity_check legs + synthetic-input generators only
     D = pkg("dist")
     rank, local, world = D.init_from_env()
     if world != args.gpus:
@@ -255,6 +283,16 @@ def main():
                    "parallelism": f"dp{N}", "trainable_floats": sum(p.numel() for p in model.parameters() if p.requires_grad)},
         "final_loss": loss,
     }
+    # proof of the process group the step ran on: size and backend as torch.distributed reports them, and every rank's device
+    mine = {"rank": rank, "device": str(dev), "name": torch.cuda.get_device_name(dev),
+            "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")), "pid": os.getpid()}
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        out["world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
+                        "allreduce_floats_per_step": int(dp.flat.numel())}
+    else:
+        out["world"] = {"world_size": 1, "backend": None, "ranks": [mine], "allreduce_floats_per_step": 0}
     gf, mb = STEP_WORK[args.config]
     out["step_roofline"] = {      # the whole step against both roofs (per GPU); the dominant kernel's figure is in "roofline"
         "algorithmic_gflop_per_trajectory": gf, "tflops_per_gpu": value / N * gf / 1e3,
@@ -304,6 +342,9 @@ def main():
                 traffic = entry["hbm_bytes_per_launch_fetch_x2" if name.startswith("conv_dma") else "hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                           "traffic_source": None if traffic is None else
+                           "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
+                           "earlier run of the same build; NOT measured in this run)",
                            "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                            "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
@@ -319,7 +360,19 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and N == 1 and not args.no_cpu_baseline and args.config != "C5":
-        out["cpu_baseline"] = cpu_baseline(O, cfg, H, W, args.cpu_batch)
+        out["cpu_baseline"], first = cpu_baseline(O, cfg, H, W, args.cpu_batch)
+        # the same step on the HIP path: fresh model from the same state dict, same trajectories
+        m2 = ynet.YNet(cfg.obs_len, cfg.pred_len, None, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
+                       n_waypoints=len(cfg.waypoints), train_net=cfg.train_net, position=list(cfg.position),
+                       network=cfg.network, n_fusion=cfg.n_fusion)
+        m2.load_state_dict(O.make_state_dict(cfg, seed=0, lora_b_std=0.05), strict=True)
+        trainer.apply_freeze_policy(m2, cfg.train_net, cfg.position, cfg.network)
+        m2.to(dev)
+        traj = O.synthetic_trajectories(cfg, args.cpu_batch, H, W, 100)
+        gpu_step = te.train_epoch(m2, loader_for(traj), images, torch.optim.Adam(m2.parameters(), lr=1e-3), crit,
+                                  cfg.loss_scale, dev, "sdd", None, gt_t, in_t, list(cfg.waypoints), 0, cfg.obs_len,
+                                  cfg.pred_len, args.cpu_batch, 10000, cfg.resize_factor, cfg.network, False)
+        out["parity_check"] = parity_check(first, gpu_step)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

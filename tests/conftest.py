@@ -14,8 +14,40 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 PKG = "motion-style-transfer_amd"
 
 
+_LAUNCHER = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process GPU tests start their ranks through a helper that is forked NOW, before this process initialises
+    # HIP (see tests/_launcher.py).  device_count() does not initialise the GPU.
+    global _LAUNCHER
+    if _LAUNCHER is None and torch.cuda.device_count() > 0:
+        import subprocess
+        _LAUNCHER = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_launcher.py")], stdin=subprocess.PIPE,
+                                     stdout=subprocess.PIPE, text=True, cwd=ROOT)
+
+
+def pytest_unconfigure(config):
+    global _LAUNCHER
+    if _LAUNCHER is not None:
+        try:
+            _LAUNCHER.stdin.close()
+            _LAUNCHER.wait(timeout=10)
+        except Exception:
+            _LAUNCHER.kill()
+        _LAUNCHER = None
+
+
+def launch(argv, env=None, timeout=600):
+    """Run ``argv`` as a child of the pre-GPU launcher helper; returns (returncode, tail of its output)."""
+    import json
+    if _LAUNCHER is None:
+        pytest.skip("no GPU launcher (no HIP device)")
+    _LAUNCHER.stdin.write(json.dumps({"argv": list(argv), "env": env or {}, "timeout": timeout, "cwd": ROOT}) + "\n")
+    _LAUNCHER.stdin.flush()
+    reply = json.loads(_LAUNCHER.stdout.readline())
+    return reply["rc"], reply["tail"]
 
 
 def pkg(sub=""):

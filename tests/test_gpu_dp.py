@@ -1,0 +1,53 @@
+"""The REAL multi-rank product path on the GPU: two fresh processes (torch.distributed.run) run
+utils/train_epoch.train_epoch(dp=...) on the HIP kernels; gradients, loss, metrics and post-Adam weights must equal the
+single-process run of the same epochs.  On a 1-GPU box both ranks share cuda:0 and the collective runs over gloo; the
+arithmetic (shards, B_local/B_global loss weights, expected_grad of the one-pass BCE, empty shards, one all-reduce per
+step, epoch-end (sum, sum, count) reduction) is exactly what RCCL ranks execute.  SURVEY 8(e), utils/train_epoch.py:44."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, launch
+from dp_worker import case_inputs, run_epochs
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+# (rows, batch size): even shards; ragged shards (3 -> 2 + 1) and a ragged last batch; batch of 1 -> rank 1's shard is EMPTY
+@pytest.mark.parametrize("n_rows,batch_size", [(8, 4), (8, 3), (3, 1)])
+def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch_size):
+    out = str(tmp_path / "dp.pt")
+    n_gpu = torch.cuda.device_count()
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    if n_gpu < 2:
+        env.update(YNET_DIST_BACKEND="gloo", YNET_BENCH_SINGLE_DEVICE="1")
+    rc, tail = launch([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                       "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                       os.path.join(ROOT, "tests", "dp_worker.py"), out, str(n_rows), str(batch_size)], env=env, timeout=600)
+    assert rc == 0, tail
+    got = torch.load(out, weights_only=False)
+    assert got["world"]["world_size"] == 2 and len({r["pid"] for r in got["world"]["ranks"]}) == 2
+    assert got["world"]["backend"] == ("nccl" if n_gpu >= 2 else "gloo")
+
+    cfg, sd, scene, traj = case_inputs(n_rows)
+    want = run_epochs(cfg, sd, scene, traj, batch_size, dev, lambda m: None)
+    for (a1, f1, l1), (a0, f0, l0) in zip(got["results"], want["results"]):
+        assert abs(l1 - l0) <= 2e-5 * abs(l0), (l1, l0)
+        assert abs(a1 - a0) <= 1e-4 and abs(f1 - f0) <= 1e-4, ((a1, f1), (a0, f0))
+    for n, w in want["grads"].items():      # gradients of the LAST step (after identical earlier updates)
+        g = got["grads"][n]
+        assert float((g - w).abs().max()) <= 2e-4 * float(w.abs().max()) + 1e-7, n
+    steps = 2 * ((n_rows + batch_size - 1) // batch_size)
+    for n, w in want["weights"].items():    # every Adam step moves a weight by <= lr: the two runs stay within a few % of that
+        big = want["grads"][n].abs() > 1e-3 * want["grads"][n].abs().max()      # (Adam turns a rounding-level gradient into +-lr)
+        d = float((got["weights"][n] - w)[big].abs().max()) if bool(big.any()) else 0.0
+        assert d <= 0.05 * 1e-3 * steps, (n, d)

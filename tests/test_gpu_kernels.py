@@ -98,6 +98,31 @@ def _sweep_cases():
         cout = int(rs.choice([1, 3, 12, 16, 17, 32, 33, 48, 64, 65, 96, 130]))
         B = int(rs.choice([1, 2, 3, 5, 9]))
         cases.append((B, H, W, cs, cout, K, bool(rs.randint(2))))
+    # widths that are NOT multiples of 4 (odd ones included): no 16-byte DMA / stores -> the register-staged conv and
+    # wgrad kernels with scalar epilogue stores (real scenes are padded to multiples of 32, but their deep levels and
+    # any direct caller of the C ABI are not)
+    rs2 = np.random.RandomState(4321)
+    for W in [1, 2, 3, 5, 6, 7, 9, 13, 15, 18, 30, 33, 37, 50, 63, 65, 129]:
+        H = int(rs2.choice([1, 2, 3, 5, 8, 16, 17, 33]))
+        K = int(rs2.choice([1, 3, 3, 3, 5]))
+        nsrc = int(rs2.randint(1, 4))
+        cs = [int(rs2.choice([1, 3, 8, 16, 17, 32, 33, 64])) for _ in range(nsrc)]
+        if K == 5:
+            cs = [min(c, 8) for c in cs]
+        cout = int(rs2.choice([1, 12, 16, 17, 32, 48, 64, 65, 130]))
+        B = int(rs2.choice([1, 2, 3, 5]))
+        cases.append((B, H, W, cs, cout, K, bool(rs2.randint(2))))
+    # the benchmarked batch (B = 32 per GPU; B = 16 at 512^2): persistent grids, rows-per-wave and split-K choices at
+    # the sizes bench.py runs
+    cases += [
+        (32, 256, 256, [32, 16], 32, 3, True),      # decoder.4.0 (48 -> 32), the dominant launch
+        (32, 256, 256, [32], 16, 3, False),         # upsample_conv.4
+        (32, 128, 128, [64], 32, 3, False),         # upsample_conv.3
+        (32, 64, 64, [64, 32, 1], 64, 3, True),     # trajectory decoder.2.0 (97 -> 64)
+        (32, 8, 8, [128], 128, 3, True),            # goal centre, split-K
+        (16, 512, 512, [6], 16, 3, True),           # C4 scene stage 0
+        (32, 256, 256, [32], 12, 1, False),         # predictor
+    ]
     return cases
 
 
