@@ -52,8 +52,8 @@ class DataParallel:
         self.flat.zero_()
         self.bind()
 
-    def allreduce_grads(self, loss: torch.Tensor = None) -> torch.Tensor:
-        """SUM all-reduce of the flat gradient buffer (+ the loss in its last slot); returns the global loss."""
+    def stage(self, loss: torch.Tensor = None):
+        """Before the collective: every p.grad is its view of the flat buffer, the shard-weighted loss sits in the last slot."""
         for p, v in zip(self.params, self._views):      # a rank with an empty shard never ran backward
             if p.grad is None:
                 p.grad = v
@@ -62,9 +62,21 @@ class DataParallel:
                 p.grad = v
         if loss is not None:
             self.flat[-1:].copy_(loss.detach().reshape(1))
+
+    def allreduce(self):
+        """The ONE collective of a step: SUM all-reduce of the flat buffer, in place, on the current stream."""
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def loss_value(self) -> torch.Tensor:
         return self.flat[-1].clone()
+
+    def allreduce_grads(self, loss: torch.Tensor = None) -> torch.Tensor:
+        """stage + allreduce; returns the global loss.  (The captured step runs the three parts separately: the
+        collective stays outside the hipGraphs, utils/step_graph.py.)"""
+        self.stage(loss)
+        self.allreduce()
+        return self.loss_value()
 
     def sum_scalar(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:

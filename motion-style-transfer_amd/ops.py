@@ -655,6 +655,18 @@ def sigmoid_temp(x: torch.Tensor, channels: Sequence[int], temperature: float) -
 _patch_status = {}
 
 
+def check_patch_windows(template_shape, xy, H: int, W: int):
+    """Host-side check that every H x W window around the (x, y) coordinates ``xy`` lies inside the template
+    (the reference would build a ragged patch and fail in torch.stack, utils/image_utils.py:40-63)."""
+    SH, SW = int(template_shape[0]), int(template_shape[1])
+    host = np.asarray(xy.detach().cpu() if torch.is_tensor(xy) else xy, dtype=np.float32).reshape(-1, 2)
+    rx, ry = np.round(host[:, 0]).astype(np.int64), np.round(host[:, 1]).astype(np.int64)
+    ox, oy = SW // 2 - rx, SH // 2 - ry
+    if ((ox < 0) | (oy < 0) | (ox + W > SW) | (oy + H > SH)).any():
+        raise ValueError(f"get_patch: a {H}x{W} window around one of the coordinates leaves the {SH}x{SW} template")
+    return host
+
+
 def gather_patches(template: torch.Tensor, xy, H: int, W: int) -> torch.Tensor:
     """[N,2] (x,y) coordinates -> [N,H,W] windows of `template` (utils/image_utils.py:40-63)."""
     _need_gpu(template, "get_patch template")
@@ -666,11 +678,7 @@ def gather_patches(template: torch.Tensor, xy, H: int, W: int) -> torch.Tensor:
     if torch.is_tensor(xy) and xy.is_cuda:
         coords = xy.detach().reshape(-1, 2).float().contiguous()
     else:
-        host = np.ascontiguousarray(np.asarray(xy.detach().cpu() if torch.is_tensor(xy) else xy, dtype=np.float32).reshape(-1, 2))
-        rx, ry = np.round(host[:, 0]).astype(np.int64), np.round(host[:, 1]).astype(np.int64)
-        ox, oy = SW // 2 - rx, SH // 2 - ry
-        if ((ox < 0) | (oy < 0) | (ox + W > SW) | (oy + H > SH)).any():
-            raise ValueError(f"get_patch: a {H}x{W} window around one of the coordinates leaves the {SH}x{SW} template")
+        host = np.ascontiguousarray(check_patch_windows((SH, SW), xy, H, W))
         coords = torch.from_numpy(host).to(dev, non_blocking=True)
     n = coords.shape[0]
     out = torch.empty((n, H, W), device=dev, dtype=torch.float32)

@@ -1,0 +1,203 @@
+"""hipGraph capture of the training step (new: the reference has no counterpart; SURVEY.md section 7 / DESIGN.md section 5).
+
+The Y-Net step is ~250 short kernel launches.  At the reference's own batch sizes (its scripts train with batch_size 10)
+the kernels finish faster than Python + ctypes + autograd can enqueue them, so the step is captured once per shape and
+replayed with a single launch:
+
+    static inputs   coordinates [n_local, obs+pred, 2] and the scene's semantic map   (copied in before every replay)
+    graph           zero_grad, 3x gather_patch, encoder, both decoders, both losses, backward (dgrad / wgrad / LoRA),
+                    optimizer step, soft-argmax read-out, ADE / FDE
+    static outputs  loss, per-trajectory ADE and FDE
+
+Under data parallelism with more than one rank the collective stays outside the graphs: [zero_grad ... backward] is one
+graph, the all-reduce of the flat gradient buffer runs eagerly on the same stream, [optimizer step, read-out] is a second
+graph.  All graphs of a model share one memory pool (they never run concurrently).  A step is captured on the second
+sighting of its key; the first sighting runs eagerly and is the warm-up that the capture needs (lazy initialisation of
+kernel attributes, optimizer state, packed-filter caches).  Anything that cannot be captured (an optimizer without a
+capturable step, an exception during capture) falls back to the eager step, once, with a warning.
+"""
+import os
+import warnings
+import weakref
+
+import torch
+
+from .. import ops
+
+_caches = weakref.WeakKeyDictionary()      # model -> {id(optimizer): GraphCache}
+_streams = {}
+_wp_index = {}
+
+
+def enabled(flag, device) -> bool:
+    if flag is None:
+        flag = os.environ.get("YNET_STEP_GRAPH", "1") != "0"
+    return bool(flag) and torch.device(device).type == "cuda" and torch.cuda.is_available()
+
+
+def enter_stream(device):
+    """Captures need a non-default stream and autograd's gradient accumulators remember the stream they were created on:
+    in graph mode the whole epoch (eager warm-up steps, captures, replays) runs on one persistent side stream."""
+    device = torch.device(device)
+    cur = torch.cuda.current_stream(device)
+    if cur != torch.cuda.default_stream(device):
+        return None                      # the caller already runs on a side stream: stay there
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _streams.get(idx)
+    if s is None:
+        s = _streams[idx] = torch.cuda.Stream(device=device)
+    s.wait_stream(cur)
+    ctx = torch.cuda.stream(s)
+    ctx.__enter__()
+    return ctx, cur, s
+
+
+def leave_stream(token):
+    if token is None:
+        return
+    ctx, cur, s = token
+    ctx.__exit__(None, None, None)
+    cur.wait_stream(s)
+
+
+def waypoint_index(device, waypoints):
+    """Device index tensor for ``future[:, waypoints]`` (built once, outside any capture: a list index would upload a
+    fresh index tensor from pageable host memory on every call)."""
+    key = (str(device), tuple(int(w) for w in waypoints))
+    t = _wp_index.get(key)
+    if t is None:
+        t = _wp_index[key] = torch.tensor(list(key[1]), dtype=torch.long, device=device)
+    return t
+
+
+def _hyper(optimizer):
+    out = []
+    for g in optimizer.param_groups:
+        out.append(tuple(sorted((k, (tuple(v) if isinstance(v, (list, tuple)) else v)) for k, v in g.items()
+                                if k != "params" and isinstance(v, (int, float, bool, str, type(None), list, tuple)))))
+    return tuple(out)
+
+
+def step_key(scene_image, n_local, n_global, obs_len, pred_len, waypoints, loss_scale, resize_factor, network, criterion,
+             gt_template, input_template, optimizer, dp):
+    return (tuple(scene_image.shape), n_local, n_global, obs_len, pred_len, tuple(waypoints), float(loss_scale),
+            float(resize_factor), network, id(criterion), gt_template.data_ptr(), input_template.data_ptr(),
+            _hyper(optimizer), None if dp is None else (id(dp), dp.world, dp.rank))
+
+
+def cache_for(model, optimizer, device):
+    per_model = _caches.get(model)
+    if per_model is None:
+        per_model = _caches[model] = {}
+    c = per_model.get(id(optimizer))
+    if c is None or c.optimizer() is not optimizer:
+        c = per_model[id(optimizer)] = GraphCache(optimizer)
+    return c
+
+
+def mark_parameters_changed(model):
+    """Replays update the weights without Python seeing it: bump the version counters so that per-layer caches keyed on
+    ``Parameter._version`` (packed / LoRA-composed filters in ops._cached) are rebuilt by the next eager forward."""
+    for p in model.parameters():
+        if p.requires_grad:
+            torch.autograd.graph.increment_version(p)
+
+
+def _make_capturable(optimizer) -> bool:
+    """Adam / AdamW take their capturable form (step counters as device tensors; same update rule); SGD captures as is."""
+    if isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
+        for g in optimizer.param_groups:
+            if g.get("fused"):
+                return False
+            g["capturable"] = True
+        for p, st in optimizer.state.items():
+            if "step" in st and torch.is_tensor(st["step"]) and st["step"].device != p.device:
+                st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+        return True
+    return isinstance(optimizer, torch.optim.SGD)
+
+
+class GraphCache:
+    MAX_ENTRIES = 64
+
+    def __init__(self, optimizer):
+        self.optimizer = weakref.ref(optimizer)
+        self.entries = {}
+        self.pool = None
+        self.last = None
+
+    def lookup(self, key):
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= self.MAX_ENTRIES:      # (scenes of many sizes: forget the oldest shape)
+                self.entries.pop(next(iter(self.entries)))
+            e = self.entries[key] = CapturedStep(self)
+        return e
+
+
+class CapturedStep:
+    def __init__(self, cache):
+        self.cache = cache
+        self.seen = self.ready = self.failed = False
+
+    def capture(self, batch, scene_image, forward_backward, optimizer, dp, finish):
+        dev = scene_image.device
+        try:
+            if not _make_capturable(optimizer):
+                raise RuntimeError(f"{type(optimizer).__name__} has no capturable step")
+            stream = torch.cuda.current_stream(dev)
+            if stream == torch.cuda.default_stream(dev):
+                raise RuntimeError("capture needs a non-default stream")
+            if self.cache.pool is None:
+                self.cache.pool = torch.cuda.graph_pool_handle()
+            self.coords = torch.empty(tuple(batch.shape), device=dev, dtype=torch.float32)
+            self.coords.copy_(batch)
+            self.scene = scene_image.detach().clone()
+            self.scene_src = None
+            self.dp = dp
+            self.split = dp is not None and dp.world > 1
+            self.params = [p for g in optimizer.param_groups for p in g["params"]]
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, pool=self.cache.pool, stream=stream):
+                fb = forward_backward(self.coords, self.scene, False)
+                loss = fb[0].detach()
+                if dp is not None:
+                    dp.stage(loss)
+                if not self.split:
+                    if dp is not None:
+                        loss = dp.loss_value()
+                    optimizer.step()
+                    ade, fde = finish(fb)
+            self.graphs = [g1]
+            if self.split:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=self.cache.pool, stream=stream):
+                    loss = dp.loss_value()
+                    optimizer.step()
+                    ade, fde = finish(fb)
+                self.graphs.append(g2)
+            self.keep = fb                       # activations the second graph / the read-out consume
+            self.grads = [p.grad for p in self.params]
+            self.loss, self.ade, self.fde = loss, ade, fde
+            self.ready = True
+        except Exception as e:      # noqa: BLE001 -- any capture failure means: this shape stays eager
+            self.failed = True
+            self.ready = False
+            warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running it eagerly")
+            if dp is not None:
+                dp.bind()
+
+    def replay(self, batch, scene_image):
+        self.coords.copy_(batch)
+        if self.scene_src is not scene_image:      # a new scene tensor (next epoch, next scene of the same size)
+            self.scene.copy_(scene_image)
+            self.scene_src = scene_image
+        self.graphs[0].replay()
+        if self.split:
+            self.dp.allreduce()
+            self.graphs[1].replay()
+        if self.cache.last is not self:            # p.grad shows the gradients of the step that ran last
+            for p, g in zip(self.params, self.grads):
+                p.grad = g
+            self.cache.last = self
+        return self.loss, self.ade.clone(), self.fde.clone()

@@ -4,125 +4,215 @@ Per batch: heat-maps by one gather launch each (instead of a Python list of slic
 encoder -> goal decoder -> BCE, waypoint pyramid in one pass, trajectory decoder (concat fused into
 the convs) -> BCE, backward through the hand-written dgrad/wgrad/LoRA kernels, optimizer step,
 soft-argmax ADE/FDE.  ``dp`` (optional, not in the reference) shards every batch over ranks.
+
+The step is launch-bound on the host at the reference's own batch sizes (its scripts train with batch_size 10: ~250
+kernel launches of a few microseconds each behind ~6 ms of Python / ctypes / autograd bookkeeping), so by default the
+whole step -- gather, forward, backward, optimizer, read-out -- is captured ONCE per (scene size, shard size, learning
+rate) into a hipGraph and replayed: per step the host copies the [B, T, 2] coordinates into a static buffer and issues
+one graph launch (``utils/step_graph.py``).  The first step of a shape runs eagerly (it is also the warm-up the capture
+needs), the second is captured, later ones replay.  ``graph=False`` / ``YNET_STEP_GRAPH=0`` keeps everything eager; the
+arithmetic is the same kernels in the same order either way.
 """
 import numpy as np
 import torch
 
 from .. import ops
+from . import step_graph
 from .image_utils import gather_patches, swap_pavement_terrain
+
+
+def _step_forward_backward(model, criterion, coords, scene_image, gt_template, input_template, waypoints, obs_len,
+                           pred_len, loss_scale, network, swap_semantic, device, n_local, n_global, dp, overlap):
+    """utils/train_epoch.py:54-110 for one (shard of a) batch: heat-maps, forward, both losses, backward.
+    ``coords`` [n_local, obs+pred, 2]: a host tensor (eager; window checks on the host) or a device tensor (captured
+    step).  Returns (loss as the reference sums it -- shard-weighted under dp --, pred_goal_map, pred_traj_map, gt_future)."""
+    semantic_img = model.adapt_semantic(scene_image)
+    if swap_semantic:
+        semantic_img = swap_pavement_terrain(semantic_img)
+    _, _, H, W = scene_image.shape
+    with ops.fold_skip_gradients():      # skip-connection gradients summed inside the max-pool backward
+        # heat-maps: distance map per observed step, Gaussian blob per future step, distance map per waypoint
+        observed_map = gather_patches(input_template, coords[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
+        gt_future = coords[:, obs_len:].to(device)
+        gt_future_map = gather_patches(gt_template, coords[:, obs_len:].reshape(-1, 2), H, W).view(-1, pred_len, H, W)
+        if coords.is_cuda:      # (a list index would upload an index tensor: not allowed inside a capture)
+            gt_waypoints = coords[:, obs_len:].index_select(1, step_graph.waypoint_index(device, waypoints))
+        else:
+            gt_waypoints = coords[:, obs_len:][:, waypoints]
+        gt_waypoint_map = gather_patches(input_template, gt_waypoints.reshape(-1, 2), H, W).view(-1, len(waypoints), H, W)
+        sem1 = semantic_img
+        if network == "embed":      # utils/train_epoch.py:80-83 (before the expand)
+            sem1 = model.scene_embedding(semantic_img)
+            observed_map = model.motion_embedding(observed_map)
+
+        semantic_map = sem1.expand(n_local, -1, -1, -1)
+        features = model.pred_features(semantic_map, observed_map)
+        if hasattr(criterion, "expected_grad"):
+            # d(loss)/d(criterion output) as autograd will compute it (fp32): lets the criterion emit the
+            # gradient of its logits in the same pass as the loss
+            up = np.float32(1.0) if dp is None else np.float32(n_local / n_global)
+            criterion.expected_grad = float(np.float32(up * np.float32(loss_scale)))
+        if overlap:
+            # The goal and the trajectory decoder are independent given the features: run them on two
+            # HIP streams so the launch-latency-bound small maps (8^2 .. 32^2) of one overlap the other
+            # (autograd replays each backward op on the stream of its forward op).
+            main = torch.cuda.current_stream(device)
+            s_goal, s_traj = ops.side_streams(device)
+            for f in features:
+                for t in ops._parts(f):
+                    t.record_stream(s_goal)
+                    t.record_stream(s_traj)
+            gt_future_map.record_stream(s_goal)
+            gt_future_map.record_stream(s_traj)
+            gt_waypoint_map.record_stream(s_traj)
+            s_goal.wait_stream(main)
+            s_traj.wait_stream(main)
+            with torch.cuda.stream(s_goal):
+                pred_goal_map = model.pred_goal(features)
+                goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
+            with torch.cuda.stream(s_traj):
+                pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
+                traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]   # concat fused into the convs
+                pred_traj_map = model.pred_traj(traj_input)
+                traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
+            main.wait_stream(s_goal)
+            main.wait_stream(s_traj)
+            for t in (pred_goal_map, goal_loss, pred_traj_map, traj_loss):
+                t.record_stream(main)
+        else:
+            pred_goal_map = model.pred_goal(features)
+            goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
+            pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
+            traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]
+            pred_traj_map = model.pred_traj(traj_input)
+            traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
+
+        loss = goal_loss + traj_loss
+        if dp is not None:
+            loss = loss * (n_local / n_global)      # BCE is a mean: weight by the shard's share
+        loss.backward()
+    return loss, pred_goal_map, pred_traj_map, gt_future
+
+
+def _step_metrics(model, pred_goal_map, pred_traj_map, gt_future, resize_factor):
+    """utils/train_epoch.py:118-126: soft-argmax read-out, per-trajectory ADE / FDE."""
+    pred_traj = model.softargmax(pred_traj_map)
+    pred_goal = model.softargmax(pred_goal_map[:, -1:])
+    ade = ((((gt_future - pred_traj) / resize_factor) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
+    fde = ((((gt_future[:, -1:] - pred_goal[:, -1:]) / resize_factor) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
+    return ade, fde
 
 
 def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_scale, device, dataset_name, homo_mat,
                 gt_template, input_template, waypoints, epoch, obs_len, pred_len, batch_size, e_unfreeze,
-                resize_factor, network=None, swap_semantic=False, dp=None):
+                resize_factor, network=None, swap_semantic=False, dp=None, graph=None):
+    device = torch.device(device)
     train_loss = 0
     train_ADE, train_FDE = [], []
     model.train()
     waypoints = list(waypoints)
+    graphs = step_graph.cache_for(model, optimizer, device) if step_graph.enabled(graph, device) else None
+    replayed = False
+    # captured steps need a non-default stream: in graph mode the whole epoch runs on one persistent side stream
+    epoch_stream = step_graph.enter_stream(device) if graphs is not None else None
 
-    for trajectory, meta, scene in train_loader:
-        if epoch < e_unfreeze:
-            model.eval()
-            scene_image = model.segmentation(train_images[scene].to(device).unsqueeze(0))
-            model.train()
-
-        for i in range(0, len(trajectory), batch_size):
-            if epoch >= e_unfreeze:
+    try:
+        for trajectory, meta, scene in train_loader:
+            if epoch < e_unfreeze:
+                model.eval()
                 scene_image = model.segmentation(train_images[scene].to(device).unsqueeze(0))
-            semantic_img = model.adapt_semantic(scene_image)
-            if swap_semantic:
-                semantic_img = swap_pavement_terrain(semantic_img)
-            _, _, H, W = scene_image.shape
+                model.train()
 
-            batch = trajectory[i:i + batch_size]
-            n_global = len(batch)
-            if dp is not None:
-                lo, hi = dp.shard(n_global)
-                batch = batch[lo:hi]
-            n_local = len(batch)
+            for i in range(0, len(trajectory), batch_size):
+                if epoch >= e_unfreeze:
+                    scene_image = model.segmentation(train_images[scene].to(device).unsqueeze(0))
 
-            if dp is not None:
-                dp.zero_grad()
-            else:
-                optimizer.zero_grad()
+                batch = trajectory[i:i + batch_size]
+                n_global = len(batch)
+                if dp is not None:
+                    lo, hi = dp.shard(n_global)
+                    batch = batch[lo:hi]
+                n_local = len(batch)
 
-            if n_local > 0:
-                with ops.fold_skip_gradients():      # skip-connection gradients summed inside the max-pool backward
-                    # heat-maps: distance map per observed step, Gaussian blob per future step, distance map per waypoint
-                    observed_map = gather_patches(input_template, batch[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
-                    gt_future = batch[:, obs_len:].to(device)
-                    gt_future_map = gather_patches(gt_template, batch[:, obs_len:].reshape(-1, 2), H, W).view(-1, pred_len, H, W)
-                    gt_waypoints = batch[:, obs_len:][:, waypoints]
-                    gt_waypoint_map = gather_patches(input_template, gt_waypoints.reshape(-1, 2), H, W).view(-1, len(waypoints), H, W)
-                    sem1 = semantic_img
-                    if network == "embed":      # utils/train_epoch.py:80-83 (before the expand)
-                        sem1 = model.scene_embedding(semantic_img)
-                        observed_map = model.motion_embedding(observed_map)
+                step = None
+                if graphs is not None and n_local > 0 and not swap_semantic and not scene_image.requires_grad:
+                    step = graphs.lookup(step_graph.step_key(
+                        scene_image, n_local, n_global, obs_len, pred_len, waypoints, loss_scale, resize_factor, network,
+                        criterion, gt_template, input_template, optimizer, dp))
 
-                    semantic_map = sem1.expand(n_local, -1, -1, -1)
-                    features = model.pred_features(semantic_map, observed_map)
-                    # The goal and the trajectory decoder are independent given the features: run them on two
-                    # HIP streams so the launch-latency-bound small maps (8^2 .. 32^2) of one overlap the other
-                    # (autograd replays each backward op on the stream of its forward op).
-                    main = torch.cuda.current_stream(device)
-                    s_goal, s_traj = ops.side_streams(device)
-                    for f in features:
-                        for t in ops._parts(f):
-                            t.record_stream(s_goal)
-                            t.record_stream(s_traj)
-                    gt_future_map.record_stream(s_goal)
-                    gt_future_map.record_stream(s_traj)
-                    gt_waypoint_map.record_stream(s_traj)
-                    s_goal.wait_stream(main)
-                    s_traj.wait_stream(main)
-                    if hasattr(criterion, "expected_grad"):
-                        # d(loss)/d(criterion output) as autograd will compute it (fp32): lets the criterion emit the
-                        # gradient of its logits in the same pass as the loss
-                        up = np.float32(1.0) if dp is None else np.float32(n_local / n_global)
-                        criterion.expected_grad = float(np.float32(up * np.float32(loss_scale)))
-                    with torch.cuda.stream(s_goal):
-                        pred_goal_map = model.pred_goal(features)
-                        goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
-                    with torch.cuda.stream(s_traj):
-                        pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
-                        traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]   # concat fused into the convs
-                        pred_traj_map = model.pred_traj(traj_input)
-                        traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
-                    main.wait_stream(s_goal)
-                    main.wait_stream(s_traj)
-                    for t in (pred_goal_map, goal_loss, pred_traj_map, traj_loss):
-                        t.record_stream(main)
-
-                    loss = goal_loss + traj_loss
-                    if dp is not None:
-                        loss = loss * (n_local / n_global)      # BCE is a mean: weight by the shard's share
-                    loss.backward()
-            else:
-                loss = torch.zeros((), device=device)
-            if dp is not None:
-                loss = dp.allreduce_grads(loss)          # ONE collective per step: gradients + loss
-            optimizer.step()
-
-            with torch.no_grad():
-                train_loss += loss
-                if n_local > 0:
-                    pred_traj = model.softargmax(pred_traj_map)
-                    pred_goal = model.softargmax(pred_goal_map[:, -1:])
-                    ade = ((((gt_future - pred_traj) / resize_factor) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
-                    fde = ((((gt_future[:, -1:] - pred_goal[:, -1:]) / resize_factor) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
+                if step is not None and step.ready:
+                    # ---- replay: coordinates (and the scene's semantic map) into the static inputs, one graph launch
+                    _, _, H, W = scene_image.shape
+                    ops.check_patch_windows(input_template.shape, batch, H, W)
+                    loss, ade, fde = step.replay(batch, scene_image)
+                    replayed = True
                 else:
-                    ade = fde = torch.zeros(0, device=device)
-                train_ADE.append(ade)
-                train_FDE.append(fde)
+                    def forward_backward(coords, scene_img, overlap):
+                        if dp is not None:
+                            dp.zero_grad()
+                        else:
+                            optimizer.zero_grad()
+                        return _step_forward_backward(model, criterion, coords, scene_img, gt_template, input_template,
+                                                      waypoints, obs_len, pred_len, loss_scale, network, swap_semantic,
+                                                      device, n_local, n_global, dp, overlap)
 
-    train_ADE, train_FDE = torch.cat(train_ADE), torch.cat(train_FDE)
-    if dp is not None and dp.world > 1:
-        # per-trajectory errors stay local during the epoch; one (sum, sum, count) reduction at its end
-        stats = torch.stack([train_ADE.sum(), train_FDE.sum(),
-                             torch.tensor(float(train_ADE.numel()), device=train_ADE.device)])
-        stats = dp.sum_scalar(stats)
-        train_ADE, train_FDE = stats[0] / stats[2], stats[1] / stats[2]
-    else:
-        train_ADE, train_FDE = train_ADE.mean(), train_FDE.mean()
+                    def finish(fb):
+                        with torch.no_grad():
+                            return _step_metrics(model, fb[1], fb[2], fb[3], resize_factor)
+
+                    if step is not None and step.seen and not step.failed:
+                        # ---- second sighting of this shape: capture, then run the captured step
+                        _, _, H, W = scene_image.shape
+                        ops.check_patch_windows(input_template.shape, batch, H, W)
+                        step.capture(batch, scene_image, forward_backward, optimizer, dp, finish)
+                    if step is not None and step.ready:
+                        loss, ade, fde = step.replay(batch, scene_image)
+                        replayed = True
+                    else:
+                        # ---- eager step (also the warm-up of a later capture)
+                        if step is not None:
+                            step.seen = True
+                        if n_local > 0:
+                            if graphs is not None:
+                                # same code path as the capture: coordinates on the device, windows checked on the host
+                                _, _, H, W = scene_image.shape
+                                ops.check_patch_windows(input_template.shape, batch, H, W)
+                                fb = forward_backward(batch.to(device), scene_image, False)
+                            else:
+                                fb = forward_backward(batch, scene_image, ops.overlap_decoders)
+                            loss = fb[0]
+                        else:
+                            if dp is not None:
+                                dp.zero_grad()
+                            else:
+                                optimizer.zero_grad()
+                            loss = torch.zeros((), device=device)
+                        if dp is not None:
+                            loss = dp.allreduce_grads(loss)          # ONE collective per step: gradients + loss
+                        optimizer.step()
+                        if n_local > 0:
+                            ade, fde = finish(fb)
+                        else:
+                            ade = fde = torch.zeros(0, device=device)
+
+                with torch.no_grad():
+                    train_loss += loss
+                    train_ADE.append(ade)
+                    train_FDE.append(fde)
+
+        train_ADE, train_FDE = torch.cat(train_ADE), torch.cat(train_FDE)
+        if dp is not None and dp.world > 1:
+            # per-trajectory errors stay local during the epoch; one (sum, sum, count) reduction at its end
+            stats = torch.stack([train_ADE.sum(), train_FDE.sum(),
+                                 torch.tensor(float(train_ADE.numel()), device=train_ADE.device)])
+            stats = dp.sum_scalar(stats)
+            train_ADE, train_FDE = stats[0] / stats[2], stats[1] / stats[2]
+        else:
+            train_ADE, train_FDE = train_ADE.mean(), train_FDE.mean()
+    finally:
+        if epoch_stream is not None:
+            step_graph.leave_stream(epoch_stream)
+        if replayed:
+            step_graph.mark_parameters_changed(model)
     ops.check_patch_status()
     return train_ADE.item(), train_FDE.item(), train_loss.item()

@@ -139,14 +139,17 @@ def test_conv2d_dispatch_sweep(dev, case):
     gy = rnd(B, cout, H, W, seed=12)
     xc = [x.clone().requires_grad_(True) for x in xs]
     wc, bc = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    y = F.conv2d(torch.cat(xc, 1), wc, bc, padding=K // 2)
-    y = F.relu(y) if relu else y
-    y.backward(gy)
+    pre = F.conv2d(torch.cat(xc, 1), wc, bc, padding=K // 2)
+    y = F.relu(pre) if relu else pre
     xd = [x.to(dev).requires_grad_(True) for x in xs]
     wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
     yd = ops.conv2d(ops.lazy_cat(xd), wd, bd, relu, {})
     yd.backward(gy.to(dev))
     close(yd, y, msg="y")
+    # The ReLU gradient is discontinuous at 0: among 10^7..10^8 outputs a handful of pre-activations round to opposite
+    # sides of 0 on the CPU and on the GPU (|pre| ~ 1e-8) and each such element changes 9 * Cin input gradients by O(1).
+    # The backward pass is therefore checked against stock torch driven with the DEVICE's own mask (y > 0).
+    pre.backward(gy * (yd.detach().cpu() > 0).float() if relu else gy)
     for i, (a, c) in enumerate(zip(xd, xc)):
         close(a.grad, c.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx{i}")
     close(wd.grad, wc.grad, rtol=1e-4, scale_rel=1e-5, msg="dW")
