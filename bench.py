@@ -246,13 +246,13 @@ def main():
                                  20, 1, cfg.obs_len, B * N, cfg.resize_factor, cfg.temperature, dp=dp)
         return a, f, 0.0
 
-    def run(n_steps, seed):
+    def run(n_steps, seed, graph=None):
         if args.config == "C5":
             return run_eval(n_steps, seed)
         traj = O.synthetic_trajectories(cfg, B * N * n_steps, H, W, seed)
         return te.train_epoch(model, loader_for(traj), images, opt, crit, cfg.loss_scale, dev, "sdd", None, gt_t, in_t,
                               list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B * N, 10000, cfg.resize_factor,
-                              cfg.network, False, dp=dp)
+                              cfg.network, False, dp=dp, graph=graph)
 
     def fence():
         torch.cuda.synchronize()
@@ -282,6 +282,7 @@ def main():
                    "obs_len": cfg.obs_len, "pred_len": cfg.pred_len, "train_net": cfg.train_net,
                    "parallelism": f"dp{N}", "trainable_floats": sum(p.numel() for p in model.parameters() if p.requires_grad)},
         "final_loss": loss,
+        "step_launch": "hipGraph replay" if pkg("utils.step_graph").enabled(None, dev) and args.config != "C5" else "eager",
     }
     # proof of the process group the step ran on: size and backend as torch.distributed reports them, and every rank's device
     mine = {"rank": rank, "device": str(dev), "name": torch.cuda.get_device_name(dev),
@@ -322,7 +323,7 @@ def main():
     elif rank == 0:
         ops.overlap_decoders = False      # kernels are timed in isolation: the two decoder streams run back to back
         with ConvTimer(ops) as ct:
-            run(1, 3)
+            run(1, 3, graph=False)      # eager launches through the timed wrapper (the timed region replays the hipGraph)
         ops.overlap_decoders = True
         agg = ct.summary()
         if args.layers:
@@ -356,7 +357,7 @@ def main():
         total_conv_ms = sum(v["ms"] for v in agg.values())
         out["conv_share_of_step"] = total_conv_ms / out["ms_per_step"]
     else:
-        run(1, 3)      # keep ranks in lock-step with rank 0's instrumented step (collectives inside)
+        run(1, 3, graph=False)      # keep ranks in lock-step with rank 0's instrumented step (collectives inside)
     if world > 1:
         dist.barrier()
     if rank == 0 and N == 1 and not args.no_cpu_baseline and args.config != "C5":

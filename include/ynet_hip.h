@@ -148,6 +148,30 @@ int ynet_gather_patch(const float* tmpl, int SH, int SW, const float* xy, float*
 int ynet_kmeans2d(const float* points, const int* init_idx, float* centers, int* status, int P, int N, int K, float tol,
                   int iter_limit, void* stream);
 
+/* ---- goal / waypoint sampling ------------------------------------------------------------------ */
+/* torch.multinomial as utils/image_utils.py:110-135 (`sampling`) calls it, with a DOCUMENTED generator so that the CPU
+ * restatement (oracle/ynet_oracle.py: device_multinomial) reproduces every draw from `seed` alone.
+ * prob: `rows` rows of n non-negative floats, `row_stride` floats apart; out [rows][K] int64 element indices.
+ * Philox4x32-10, key = (seed low word, seed high word), counter = (element or sample index, 0, row, stream);
+ * u = ((x0 >> 5) * 2^26 + (x1 >> 6) + 0.5) * 2^-53 from the first two output words.
+ *   replacement = 0 (stream 0): exponential race -- key_i = p_i / -log(u_i) in fp64, the K largest keys in descending
+ *     order, ties to the smaller index; K <= min(48, n).
+ *   replacement = 1 (stream 1): inverse CDF in fp64 -- the row is cut into 256 contiguous segments of ceil(n / 256)
+ *     elements, summed sequentially; sample j = first element whose running sum >= u_j * total.
+ * rel_threshold > 0 zeroes entries below rel_threshold * max(row) first (image_utils.py:113-118).
+ * *status (device int, zero it first) becomes 1 if a row has too few (replacement: no) positive entries. */
+int ynet_multinomial(const float* prob, long long rows, long long row_stride, int n, int K, int replacement,
+                     float rel_threshold, unsigned long long seed, long long* out, int* status, void* stream);
+/* Conditioned waypoint sampling prior (utils/evaluate.py:9-34 torch_multivariate_gaussian_heatmap, 198-211): for row r
+ * (person r % n_persons) the anisotropic Gaussian centred at mean_xy[r] with its long axis along dist_xy[r], std
+ * (|dist| + 5) / sigma_factor along it and that / ratio across (rot: axes swapped), on linspace(0, H, H) x
+ * linspace(0, W, W), multiplied by the sigmoid map sig + (r % n_persons) * sig_batch_stride and normalised to sum 1
+ * -> out_map [rows][H][W] (optional) and its expectation (sum x * map, sum y * map) -> out_xy [rows][2] (optional).
+ * fp64 per pixel. */
+int ynet_cws_prior(const float* sig, long long sig_batch_stride, int n_persons, const float* mean_xy, const float* dist_xy,
+                   int rows, int H, int W, float sigma_factor, float ratio, int rot, float* out_map, float* out_xy,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -708,9 +708,63 @@ def kmeans2d(points: torch.Tensor, init_idx: torch.Tensor, tol: float = 1e-3, it
     return centers, status
 
 
+_sample_status = {}
+
+
+def _status_flag(store, dev):
+    st = store.get(dev)
+    if st is None:
+        st = store[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
+    return st
+
+
+def multinomial(prob: torch.Tensor, num_samples: int, replacement: bool = False, rel_threshold=None, seed: int = 0) -> torch.Tensor:
+    """torch.multinomial(prob [rows, n], num_samples, replacement) on the device with the documented Philox4x32-10
+    generator of ynet_multinomial (include/ynet_hip.h): the draws are a pure function of (prob, seed), reproduced on
+    the CPU by oracle/ynet_oracle.py:device_multinomial.  -> int64 [rows, num_samples]."""
+    _need_gpu(prob, "multinomial")
+    if prob.dim() != 2:
+        raise ValueError("multinomial: expected a [rows, n] matrix")
+    rows, n = prob.shape
+    if prob.stride(1) != 1:
+        prob = prob.contiguous()
+    out = torch.empty((rows, num_samples), device=prob.device, dtype=torch.int64)
+    st = _status_flag(_sample_status, prob.device)
+    lib = _lib()
+    L.check(lib.ynet_multinomial(prob.data_ptr(), rows, prob.stride(0) if rows > 1 else n, n, int(num_samples),
+                                 1 if replacement else 0, float(rel_threshold or 0.0), int(seed) & (2 ** 64 - 1),
+                                 out.data_ptr(), st.data_ptr(), _stream()), lib)
+    return out
+
+
+def cws_prior(sig: torch.Tensor, mean_xy: torch.Tensor, dist_xy: torch.Tensor, sigma_factor: float, ratio: float, rot: bool,
+              want_map: bool = False, want_xy: bool = True):
+    """Conditioned-waypoint-sampling prior (utils/evaluate.py:9-34, 198-211) for rows = mean_xy.shape[0] (a multiple of the
+    B persons of sig [B, H, W]; row r uses person r % B): (normalised map [rows,H,W] or None, expectation [rows,2] or None)."""
+    _need_gpu(sig, "cws_prior sigmoid map")
+    B, H, W = sig.shape
+    if sig.stride(2) != 1 or sig.stride(1) != W:
+        sig = sig.contiguous()
+    mean_xy, dist_xy = mean_xy.detach().float().contiguous(), dist_xy.detach().float().contiguous()
+    rows = mean_xy.shape[0]
+    if rows % B or tuple(dist_xy.shape) != (rows, 2) or tuple(mean_xy.shape) != (rows, 2):
+        raise ValueError(f"cws_prior: {rows} rows for {B} persons")
+    out_map = torch.empty((rows, H, W), device=sig.device, dtype=torch.float32) if want_map else None
+    out_xy = torch.empty((rows, 2), device=sig.device, dtype=torch.float32) if want_xy else None
+    lib = _lib()
+    L.check(lib.ynet_cws_prior(sig.data_ptr(), sig.stride(0) if B > 1 else H * W, B, mean_xy.data_ptr(), dist_xy.data_ptr(),
+                               rows, H, W, float(sigma_factor), float(ratio), 1 if rot else 0,
+                               out_map.data_ptr() if want_map else None, out_xy.data_ptr() if want_xy else None, _stream()), lib)
+    return out_map, out_xy
+
+
 def check_patch_status():
     """Raise if a device-side coordinate ever left the template (checked at sync points)."""
     for dev, st in _patch_status.items():
         if int(st.item()) != 0:
             st.zero_()
             raise ValueError("get_patch: a window left the template (device-side coordinates)")
+    for dev, st in _sample_status.items():
+        if int(st.item()) != 0:
+            st.zero_()
+            raise RuntimeError("invalid multinomial distribution (a row with too few positive entries)")

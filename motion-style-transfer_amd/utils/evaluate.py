@@ -189,46 +189,45 @@ def ttst_goals(model, wp_sigmoid_last, wp_logits_last, n_goal, rel_thresh, draw=
 def cws_gaussians(mean_xy, H, W, dist, sigma_factor, ratio, rot):
     """torch_multivariate_gaussian_heatmap (utils/evaluate.py:9-34) for all N persons at once: anisotropic Gaussians
     centred at mean_xy [N,2], long axis along dist [N,2], std (|dist| + 5) / sigma_factor along it and that / ratio
-    across, on linspace(0, H, H) x linspace(0, W, W), each normalised to sum 1.  -> [N,H,W]."""
-    dev = mean_xy.device
-    ax = torch.linspace(0, H, H, device=dev).view(1, H) - mean_xy[:, 1:2]         # [N,H]
-    ay = torch.linspace(0, W, W, device=dev).view(1, W) - mean_xy[:, 0:1]         # [N,W]
-    mesh = torch.stack([ay.unsqueeze(1).expand(-1, H, -1), ax.unsqueeze(2).expand(-1, -1, W)], dim=-1)   # [N,H,W,2] = (x, y) offsets
-    rad = torch.atan2(dist[:, 0], dist[:, 1])
-    c, s = torch.cos(rad), torch.sin(rad)
-    R = torch.stack([torch.stack([c, s], dim=-1), torch.stack([-s, c], dim=-1)], dim=-2)                  # [N,2,2]
-    if rot:
-        R = torch.matmul(torch.tensor([[0.0, -1.0], [1.0, 0.0]], device=dev), R)
-    norm = dist.square().sum(-1).sqrt() + 5
-    cov = torch.zeros(len(norm), 2, 2, device=dev)
-    cov[:, 0, 0] = (norm / sigma_factor / ratio) ** 2
-    cov[:, 1, 1] = (norm / sigma_factor) ** 2
-    T = torch.matmul(torch.matmul(R, cov), R.transpose(1, 2))
-    Tinv = torch.inverse(T)
-    k = torch.exp(-0.5 * (torch.einsum("nhwi,nij->nhwj", mesh, Tinv) * mesh).sum(-1))
-    return k / k.sum(dim=(1, 2), keepdim=True)
+    across, on linspace(0, H, H) x linspace(0, W, W), each normalised to sum 1.  -> [N,H,W]  (ynet_cws_prior with an
+    all-ones sigmoid map)."""
+    ones = torch.ones((1, H, W), device=mean_xy.device)
+    return ops.cws_prior(ones, mean_xy, dist, sigma_factor, ratio, rot, want_map=True, want_xy=False)[0]
 
 
 def cws_waypoints(model, wp_sigmoid, goal_samples, last_observed, n_goal, n_traj, sigma_factor, ratio, rot):
-    """Conditioned waypoint sampling (utils/evaluate.py:172-224), batched over the persons of a batch: waypoints are
-    drawn backwards from the goal; the sigmoid map of waypoint w is multiplied by a Gaussian centred at
-    goal + (last_observed - goal) / (w + 2) and renormalised; the first n_goal trajectories take its expectation,
-    later ones one thresholded sample.  -> [n_goal * n_traj, B, n_waypoints, 2]."""
-    _, nwp, H, W = wp_sigmoid.shape
-    goals = goal_samples.repeat(n_traj, 1, 1, 1)
-    out = []
-    for g_num, wp in enumerate(goals.squeeze(2)):
-        chain = [wp]
+    """Conditioned waypoint sampling (utils/evaluate.py:172-224): waypoints are drawn backwards from the goal; the
+    sigmoid map of waypoint w is multiplied by a Gaussian centred at goal + (last_observed - goal) / (w + 2) and
+    renormalised; the first n_goal trajectories take its expectation, later ones one thresholded sample.
+    The reference loops over goal samples and persons in Python; here the n_goal expectation chains run as ONE
+    ynet_cws_prior launch per waypoint (rows = n_goal * B, fp64 per pixel), the sampled chains one launch per goal
+    sample (their draws stay in the reference's order).  -> [n_goal * n_traj, B, n_waypoints, 2]."""
+    B, nwp, H, W = wp_sigmoid.shape
+    goals = goal_samples.repeat(n_traj, 1, 1, 1).squeeze(2)           # [K, B, 2]
+    K = goals.shape[0]
+    chains = [None] * K
+    # ---- trajectories of the first set (g_num < n_goal): expectations, batched over the goal samples
+    n_det = min(n_goal, K)
+    wp = goals[:n_det].reshape(-1, 2)                                  # row r = g * B + person
+    last = last_observed.repeat(n_det, 1)
+    det = [wp]
+    for w in reversed(range(nwp - 1)):
+        distance = last - wp
+        _, wp = ops.cws_prior(wp_sigmoid[:, w], wp + distance * (1 / (w + 2)), distance, sigma_factor, ratio, rot)
+        det.append(wp)
+    det = torch.stack(det[::-1]).view(nwp, n_det, B, 2).permute(1, 2, 0, 3)      # [n_det, B, nwp, 2]
+    for g in range(n_det):
+        chains[g] = det[g]
+    # ---- later sets: one thresholded sample per waypoint, in the reference's order
+    for g_num in range(n_det, K):
+        wp = goals[g_num]
         traj_idx = g_num // n_goal
+        chain = [wp]
         for w in reversed(range(nwp - 1)):
             distance = last_observed - wp
-            maps = cws_gaussians(wp + distance * (1 / (w + 2)), H, W, distance, sigma_factor - traj_idx, ratio, rot)
-            m = wp_sigmoid[:, w] * maps
-            m = (m.flatten(1) / m.flatten(1).sum(-1, keepdim=True)).view_as(m)
-            if traj_idx == 0:
-                wp = model.softargmax_on_softmax_map(m.unsqueeze(0)).squeeze(0)
-            else:
-                wp = sampling(m.unsqueeze(1), num_samples=1, rel_threshold=0.05).permute(2, 0, 1, 3).squeeze(2).squeeze(0)
+            m, _ = ops.cws_prior(wp_sigmoid[:, w], wp + distance * (1 / (w + 2)), distance, sigma_factor - traj_idx, ratio, rot,
+                                 want_map=True, want_xy=False)
+            wp = sampling(m.unsqueeze(1), num_samples=1, rel_threshold=0.05).permute(2, 0, 1, 3).squeeze(2).squeeze(0)
             chain.append(wp)
-        out.append(torch.stack(chain[::-1]).permute(1, 0, 2))
-    return torch.stack(out)
+        chains[g_num] = torch.stack(chain[::-1]).permute(1, 0, 2)
+    return torch.stack(chains)

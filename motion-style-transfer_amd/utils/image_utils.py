@@ -5,10 +5,12 @@
   get_patch        : same signature/return type as the reference (a list of [H,W] tensors) but the
       windows come from ONE ynet_gather_patch launch (utils/image_utils.py:40-63).
   gather_patches   : the same without the list, [N,H,W] contiguous (what train_epoch/evaluate use).
-  sampling         : torch.multinomial on the device (utils/image_utils.py:110-135); kept in torch
-      so the RNG stream stays torch's.
+  sampling         : multinomial goal / waypoint sampling (utils/image_utils.py:110-135) by ynet_multinomial, a
+      device sampler with a documented counter-based generator (YNET_SAMPLER=torch: torch.multinomial instead).
 Image file I/O (resize / pad / preprocess_image_for_segmentation) needs cv2 + smp and is out of scope.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -46,14 +48,28 @@ def get_patch(template, traj, H, W):
     return list(gather_patches(template, traj, H, W).unbind(0))
 
 
-def sampling(probability_map, num_samples, rel_threshold=None, replacement=False):
+# "device": ynet_multinomial (Philox4x32-10, documented in include/ynet_hip.h; a pure function of the map and a seed that
+# each call draws from torch's default CPU generator, so torch.manual_seed() makes a sweep reproducible and the CPU
+# oracle can replay it).  "torch": torch.multinomial on the device (torch's own Philox stream).
+SAMPLER = os.environ.get("YNET_SAMPLER", "device")
+
+
+def draw_seed() -> int:
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def sampling(probability_map, num_samples, rel_threshold=None, replacement=False, seed=None):
+    """utils/image_utils.py:110-135: [B,C,H,W] maps -> [B,C,num_samples,2] (x, y) pixel coordinates."""
     b, c, h, w = probability_map.shape
     prob = probability_map.reshape(b * c, -1)
-    if rel_threshold is not None:
-        keep = prob >= prob.max(dim=1, keepdim=True)[0] * rel_threshold
-        prob = prob * keep.int()
-        prob = prob / prob.sum()
-    idx = torch.multinomial(prob, num_samples=num_samples, replacement=replacement)
+    if SAMPLER == "device" and probability_map.is_cuda and (replacement or num_samples <= min(48, h * w)):
+        idx = ops.multinomial(prob, num_samples, replacement, rel_threshold, draw_seed() if seed is None else seed)
+    else:
+        if rel_threshold is not None:
+            keep = prob >= prob.max(dim=1, keepdim=True)[0] * rel_threshold
+            prob = prob * keep.int()
+            prob = prob / prob.sum()
+        idx = torch.multinomial(prob, num_samples=num_samples, replacement=replacement)
     idx = idx.view(b, c, -1).float()
     return torch.stack([idx % w, torch.floor(idx / w)], dim=3)
 

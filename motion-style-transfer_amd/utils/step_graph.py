@@ -16,6 +16,7 @@ sighting of its key; the first sighting runs eagerly and is the warm-up that the
 kernel attributes, optimizer state, packed-filter caches).  Anything that cannot be captured (an optimizer without a
 capturable step, an exception during capture) falls back to the eager step, once, with a warning.
 """
+import gc
 import os
 import warnings
 import weakref
@@ -142,6 +143,18 @@ class CapturedStep:
 
     def capture(self, batch, scene_image, forward_backward, optimizer, dp, finish):
         dev = scene_image.device
+        # No cyclic garbage collection while a capture is open: a collection may destroy unrelated HIP objects (an older
+        # model's graphs and their memory pool), and hipGraphExecDestroy / hipFree inside an open capture abort the process.
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture(batch, scene_image, forward_backward, optimizer, dp, finish, dev)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
+
+    def _capture(self, batch, scene_image, forward_backward, optimizer, dp, finish, dev):
         try:
             if not _make_capturable(optimizer):
                 raise RuntimeError(f"{type(optimizer).__name__} has no capturable step")

@@ -504,6 +504,11 @@ def sample_coords(prob: Tensor, num_samples: int, generator=None, rel_threshold:
     the sum over ALL planes (as the reference does: multinomial only needs per-row proportions)."""
     b, c, h, w = prob.shape
     pm = prob.reshape(b * c, -1)
+    if DEVICE_SAMPLER:      # the product's documented sampler (one 62-bit seed per call, drawn like utils/image_utils.py:draw_seed)
+        seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
+        idx = device_multinomial(pm, num_samples, replacement, rel_threshold, seed)
+        idx = idx.view(b, c, num_samples).float()
+        return torch.stack([idx % w, torch.floor(idx / w)], dim=-1)
     if rel_threshold is not None:
         mask = pm < pm.max(dim=1)[0].unsqueeze(1) * rel_threshold
         pm = pm * (~mask).int()
@@ -511,6 +516,83 @@ def sample_coords(prob: Tensor, num_samples: int, generator=None, rel_threshold:
     idx = torch.multinomial(pm, num_samples, replacement=replacement, generator=generator)
     idx = idx.view(b, c, num_samples).float()
     return torch.stack([idx % w, torch.floor(idx / w)], dim=-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# The product's device sampler, restated (include/ynet_hip.h: ynet_multinomial).  The REFERENCE samples with
+# torch.multinomial, whose stream differs per device and build; the product documents its own counter-based generator
+# so that this CPU restatement reproduces every draw from the seed alone -- that is what makes an un-forced sweep
+# checkable.  Philox4x32-10, key = (seed low, seed high), counter = (element / sample, 0, row, stream).
+# ----------------------------------------------------------------------------------------------
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    M = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & M for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M
+        n1 = p1 & M
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M
+        n3 = p0 & M
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    return c0, c1
+
+
+def _philox_uniform(elem, row: int, stream: int, seed: int) -> np.ndarray:
+    elem = np.asarray(elem, dtype=np.uint64)
+    x0, x1 = _philox4x32_10(elem, np.zeros_like(elem), np.full_like(elem, row), np.full_like(elem, stream),
+                            seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return ((x0 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (x1 >> np.uint64(6)).astype(np.float64) + 0.5) / 9007199254740992.0
+
+
+def device_multinomial(prob: Tensor, num_samples: int, replacement: bool = False, rel_threshold: Optional[float] = None,
+                       seed: int = 0) -> Tensor:
+    """ynet_multinomial on the CPU: prob [rows, n] -> int64 [rows, num_samples]."""
+    P = prob.detach().cpu().numpy().astype(np.float32)
+    rows, n = P.shape
+    out = np.zeros((rows, num_samples), dtype=np.int64)
+    for r in range(rows):
+        p = P[r].copy()
+        if rel_threshold:
+            cut = np.float32(p.max()) * np.float32(rel_threshold)
+            p[p < cut] = 0.0
+        p[~(p > 0)] = 0.0
+        p64 = p.astype(np.float64)
+        if not replacement:
+            u = _philox_uniform(np.arange(n), r, 0, seed)
+            with np.errstate(divide="ignore"):
+                key = np.where(p64 > 0, p64 / -np.log(u), -1.0)
+            order = np.lexsort((np.arange(n), -key))          # descending key, ties to the smaller index
+            if key[order[num_samples - 1]] <= 0:
+                raise RuntimeError("invalid multinomial distribution (too few positive entries)")
+            out[r] = order[:num_samples]
+        else:
+            seg = (n + 255) // 256
+            m = np.zeros(256 * seg, dtype=np.float64)
+            m[:n] = p64
+            m = m.reshape(256, seg)
+            totals = np.cumsum(m, axis=1)[:, -1]              # sequential sums (np.cumsum accumulates in order)
+            seg_off = np.concatenate([[0.0], np.cumsum(totals)])
+            total = seg_off[256]
+            if not total > 0:
+                raise RuntimeError("invalid multinomial distribution (no positive entry)")
+            target = _philox_uniform(np.arange(num_samples), r, 1, seed) * total
+            t = np.minimum(np.searchsorted(seg_off[1:], target, side="left"), 255)
+            run = np.cumsum(np.concatenate([seg_off[:256, None], m], axis=1), axis=1)[:, 1:]     # seg_off[t] + p0 + p1 + ...
+            for j in range(num_samples):
+                tj = int(t[j])
+                i = int(np.searchsorted(run[tj], target[j], side="left"))
+                if i >= seg or tj * seg + i >= n:
+                    pos = np.nonzero(m[tj] > 0)[0]
+                    i = int(pos[-1]) if len(pos) else -tj * seg
+                out[r, j] = tj * seg + i
+    return torch.from_numpy(out)
+
+
+DEVICE_SAMPLER = False      # True: sample_coords draws with device_multinomial (one seed per call from the torch generator)
 
 
 def kmeans_lloyd(X: Tensor, k: int, tol: float = 1e-3, iter_limit: int = 1000) -> Tensor:

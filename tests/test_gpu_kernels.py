@@ -427,3 +427,59 @@ def test_gather_patch_golden(dev):
             assert torch.equal(got.cpu(), want), name       # bit-exact incl. round-half-even (10.5 -> 10, 11.5 -> 12)
     with pytest.raises(ValueError):
         ops.gather_patches(O.dist_template(64).to(dev), np.array([[40.0, 0.0]], dtype=np.float32), 32, 32)
+
+
+@pytest.mark.parametrize("rows,n,K,replacement,thr", [
+    (6, 64 * 64, 20, False, None), (3, 256 * 256, 20, False, None), (5, 40 * 72, 1, False, 0.05), (2, 100, 48, False, None),
+    (4, 64 * 64, 10000, True, 0.002), (2, 256 * 256, 10000, True, 0.01), (3, 777, 50, True, None)])
+def test_device_multinomial_matches_its_cpu_restatement(dev, rows, n, K, replacement, thr):
+    """ynet_multinomial (Philox4x32-10 exponential race / inverse CDF) == oracle.device_multinomial, draw for draw."""
+    ops = pkg("ops")
+    gen = torch.Generator().manual_seed(n + K)
+    prob = torch.sigmoid(torch.randn(rows, n, generator=gen) * 3)
+    prob[0, : n // 3] = 0.0                                  # zero-probability entries never win
+    seed = 0x1234567 * (K + 1) + 0x9ABCDEF012345
+    want = O.device_multinomial(prob, K, replacement, thr, seed)
+    got = ops.multinomial(prob.to(dev), K, replacement, thr, seed).cpu()
+    assert torch.equal(got, want), int((got != want).sum())
+    if not replacement:
+        assert all(len(set(r.tolist())) == K for r in got)  # without replacement: distinct
+    assert bool((prob.gather(1, got) > 0).all())
+    # a strided view (every second row of a wider matrix) is read in place
+    wide = torch.stack([prob, prob.flip(0)], dim=1).reshape(2 * rows, n).to(dev)
+    got2 = ops.multinomial(wide[::2], K, replacement, thr, seed).cpu()
+    assert torch.equal(got2, want)
+
+
+def test_device_multinomial_frequencies(dev):
+    """Sanity of the sampler itself (not only of its restatement): empirical frequencies follow the probabilities."""
+    ops = pkg("ops")
+    p = torch.tensor([[0.05, 0.15, 0.0, 0.3, 0.5]]).to(dev)
+    with_rep = ops.multinomial(p, 40000, True, None, 11).cpu().flatten()
+    np.testing.assert_allclose(np.bincount(with_rep.numpy(), minlength=5) / 40000, p.cpu().numpy()[0], atol=0.01)
+    first = torch.cat([ops.multinomial(p.expand(2000, -1).contiguous(), 1, False, None, s).cpu() for s in range(3)]).flatten()
+    np.testing.assert_allclose(np.bincount(first.numpy(), minlength=5) / 6000, p.cpu().numpy()[0], atol=0.02)
+    ops.check_patch_status()
+    ops.multinomial(torch.zeros(1, 8, device=dev), 1, True, None, 1)      # an all-zero row is reported
+    with pytest.raises(RuntimeError, match="invalid multinomial"):
+        ops.check_patch_status()
+
+
+@pytest.mark.parametrize("H,W,rot", [(64, 64, False), (64, 96, True), (256, 256, True)])
+def test_cws_prior_matches_the_reference_gaussian(dev, H, W, rot):
+    """ynet_cws_prior (fp64 per pixel) against the oracle's restatement of torch_multivariate_gaussian_heatmap
+    (utils/evaluate.py:9-34) times the sigmoid map, normalised, and its expectation."""
+    ops = pkg("ops")
+    gen = torch.Generator().manual_seed(H + W)
+    B, G = 3, 2
+    sig = torch.sigmoid(torch.randn(B, H, W, generator=gen))
+    mean = torch.rand(G * B, 2, generator=gen) * torch.tensor([W * 0.6, H * 0.6]) + torch.tensor([W * 0.2, H * 0.2])
+    dist = (torch.rand(G * B, 2, generator=gen) - 0.5) * 60
+    maps, xy = ops.cws_prior(sig.to(dev), mean.to(dev), dist.to(dev), 6.0, 2.0, rot, want_map=True, want_xy=True)
+    for r in range(G * B):
+        k = O.cws_gaussian(mean[r], H, W, dist[r], 6.0, 2.0, rot)
+        mm = sig[r % B] * k
+        mm = mm / mm.sum()
+        want_xy = O.softargmax_on_map(mm[None, None])[0, 0]
+        np.testing.assert_allclose(maps[r].cpu().numpy(), mm.numpy(), rtol=2e-4, atol=1e-9)
+        np.testing.assert_allclose(xy[r].cpu().numpy(), want_xy.numpy(), rtol=0, atol=2e-5 * max(H, W) / 64)

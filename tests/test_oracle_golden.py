@@ -143,3 +143,26 @@ def test_fullsize_weight_checksums():
     assert abs(chk - float(z["C2_sdd_short_mosa1/weight_checksum"])) <= 1e-9 * chk
     assert sum(sd[n].numel() for n in O.trainable_names(cfg, sd)) == 8190
     assert sum(v.numel() for k, v in sd.items() if "lora" not in k) == 1641381
+
+
+def test_device_sampler_restatement_known_answers():
+    """Philox4x32-10 of the product's documented sampler against the Random123 known-answer vectors, and the sampler's
+    frequencies (oracle.device_multinomial is what the GPU kernel ynet_multinomial is compared with, draw for draw)."""
+    import numpy as np
+    x0, x1 = O._philox4x32_10(np.array([0]), np.array([0]), np.array([0]), np.array([0]), 0, 0)
+    assert (int(x0[0]), int(x1[0])) == (0x6627E8D5, 0xE169C58D)
+    f = 0xFFFFFFFF
+    x0, x1 = O._philox4x32_10(np.array([f]), np.array([f]), np.array([f]), np.array([f]), f, f)
+    assert (int(x0[0]), int(x1[0])) == (0x408F276D, 0x41C83B0E)
+    x0, x1 = O._philox4x32_10(np.array([0x243F6A88]), np.array([0x85A308D3]), np.array([0x13198A2E]), np.array([0x03707344]),
+                              0xA4093822, 0x299F31D0)
+    assert (int(x0[0]), int(x1[0])) == (0xD16CFE09, 0x94FDCCEB)
+    q = torch.tensor([[0.1, 0.2, 0.0, 0.3, 0.4]])
+    c = O.device_multinomial(q, 20000, True, None, 7)[0].numpy()
+    np.testing.assert_allclose(np.bincount(c, minlength=5) / 20000, q[0].numpy(), atol=0.012)
+    first = np.array([int(O.device_multinomial(q, 1, False, None, s)[0, 0]) for s in range(1500)])
+    np.testing.assert_allclose(np.bincount(first, minlength=5) / 1500, q[0].numpy(), atol=0.04)
+    w = O.device_multinomial(q, 4, False, None, 3)[0].tolist()
+    assert sorted(w) == [0, 1, 3, 4]                          # without replacement: the zero entry never wins
+    thr = O.device_multinomial(q, 3000, True, 0.6, 5)[0].numpy()   # entries below 0.6 * max = 0.24 are zeroed: 0.3 and 0.4 remain
+    assert set(thr.tolist()) == {3, 4}
