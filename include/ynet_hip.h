@@ -118,6 +118,19 @@ int ynet_bce_logits_fwd_grad(const float* x, const float* t, long long n, float 
                              void* workspace, void* stream);
 int ynet_bce_grad_rescale(float* dx, const float* grad_out, float expected_grad, long long n, void* stream);
 
+/* Predictor + criterion in ONE pass over the last decoder activation (models/ynet.py:450-451,469 `self.predictor(x)`
+ * followed by utils/train_epoch.py:93-94,105-106 `criterion(pred_map, gt_map)`, and the predictor's dgrad of the
+ * backward pass): y = conv1x1(x, w) + bias [B][cout][HW]; loss[0] = mean BCE-with-logits(y, target);
+ * dy = (sigmoid(y) - target) * expected_grad / n (optional output, wanted when the predictor trains);
+ * dx = conv1x1^T(dy) [B][cin][HW] (optional output: the gradient handed to decoder.4.2).  wp = ynet_pack_weight(w, mode 0)
+ * of the 1x1 filter; cout <= 32, HW % 4 == 0, 16-byte aligned tensors.  workspace: ynet_pred_bce_workspace_bytes()
+ * bytes, ZEROED before the first use (the kernel leaves its ticket counter at zero).  ynet_bce_grad_rescale corrects
+ * dx / dy when the upstream gradient turns out not to be expected_grad. */
+long long ynet_pred_bce_workspace_bytes(void);
+int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target,
+                  float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, long long HW,
+                  float expected_grad, void* stream);
+
 /* ---- goal / trajectory read-out -------------------------------------------------------------- */
 /* SoftArgmax2D.forward (utils/softargmax.py:55-81; models/ynet.py:582-583): x [B][C][H][W] with
  * batch stride `batch_stride` elements (so a channel slice such as pred_goal_map[:, -1:] needs no

@@ -46,6 +46,8 @@ SIGNATURES = {
     "ynet_bce_logits_bwd": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_fp]),
     "ynet_bce_logits_fwd_grad": (c_i, [c_fp, c_fp, c_ll, c_f, c_fp, c_fp, c_fp, c_fp]),
     "ynet_bce_grad_rescale": (c_i, [c_fp, c_fp, c_f, c_ll, c_fp]),
+    "ynet_pred_bce_workspace_bytes": (c_ll, []),
+    "ynet_pred_bce": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_ll, c_f, c_fp]),
     "ynet_softargmax2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, c_i, c_i, c_fp]),
     "ynet_sigmoid_temp": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, PI, c_i, c_f, c_fp]),
     "ynet_gather_patch": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),

@@ -495,6 +495,129 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Predictor + criterion in one pass (models/ynet.py:450-451,469 `self.predictor(x)`; utils/train_epoch.py:93-94,
+// 105-106 `criterion(pred_map, gt_map) * loss_scale`; and, for the backward pass, the predictor's dgrad):
+//   y[co]      = bias[co] + sum_ci w[co][ci] * x[ci]                 (the 1x1 predictor, fp32 FMA chain over ci in order)
+//   loss      += BCE-with-logits(y[co], t[co])                       (fp64 block partials, summed by the last block)
+//   dy[co]     = (sigmoid(y[co]) - t[co]) * gs                       (gs = expected upstream gradient / n)
+//   dx[ci]     = sum_co w[co][ci] * dy[co]                           (written when the decoder needs a gradient)
+// The activation x (32 channels at full resolution, the largest tensor of the step) is read ONCE; unfused it is read by
+// the predictor, the logits are written, re-read by the loss, dy is written, re-read by the predictor's dgrad: 88
+// channel planes of HBM traffic instead of 124, and three launches less per decoder.  One thread owns PX consecutive
+// pixels and every output channel; filter rows come through scalar loads.
+// ------------------------------------------------------------------------------------------------
+struct PredBceArgs {
+    const float* x;
+    long long x_bs;
+    const float* wp;        // packed [cin_pad][cout_pad] (forward layout of a 1x1 filter)
+    const float* bias;
+    const float* t;         // [B][cout][HW]
+    float* y;               // [B][cout][HW] logits
+    float* dx;              // [B][cin][HW] or NULL
+    float* dy;              // [B][cout][HW] or NULL (wanted when the predictor itself trains)
+    double* partial;        // [gridDim.x]
+    unsigned* ticket;
+    float* loss;
+    int cin, cout, cout_pad, B;
+    long long hw4, n;       // H*W/4, number of loss elements
+    float gs;
+};
+
+typedef const __attribute__((address_space(4))) float* glue_const_f32_ptr;      // uniform reads -> scalar loads
+
+template <int CT, int PX>
+__global__ __launch_bounds__(256) void pred_bce_kernel(const PredBceArgs a) {
+    typedef float vec_t __attribute__((ext_vector_type(PX)));
+    __shared__ double ws[4];
+    __shared__ unsigned last;
+    const long long hwv = a.hw4 * (4 / PX);
+    const long long total = (long long)a.B * hwv;
+    const glue_const_f32_ptr w = (glue_const_f32_ptr)a.wp, bias = (glue_const_f32_ptr)a.bias;
+    double acc_loss = 0.0;
+    for (long long q = blockIdx.x * 256ll + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const int b = (int)(q / hwv);
+        const long long p = q - (long long)b * hwv;
+        const vec_t* xp = reinterpret_cast<const vec_t*>(a.x + (long long)b * a.x_bs) + p;
+        vec_t acc[CT];
+#pragma unroll
+        for (int co = 0; co < CT; ++co) {
+            const float bv = (a.bias != nullptr && co < a.cout) ? bias[co] : 0.f;
+#pragma unroll
+            for (int e = 0; e < PX; ++e) acc[co][e] = bv;
+        }
+#pragma unroll 2
+        for (int ci = 0; ci < a.cin; ++ci) {
+            const vec_t v = xp[(long long)ci * hwv];
+#pragma unroll
+            for (int co = 0; co < CT; ++co) {
+                const float wv = w[ci * a.cout_pad + co];
+#pragma unroll
+                for (int e = 0; e < PX; ++e) acc[co][e] = __builtin_fmaf(v[e], wv, acc[co][e]);
+            }
+        }
+        const long long obase = (long long)b * a.cout * hwv + p;
+        float s = 0.f;
+#pragma unroll
+        for (int co = 0; co < CT; ++co) {
+            if (co < a.cout) {
+                const vec_t tv = reinterpret_cast<const vec_t*>(a.t)[obase + (long long)co * hwv];
+                reinterpret_cast<vec_t*>(a.y)[obase + (long long)co * hwv] = acc[co];
+                vec_t d;
+#pragma unroll
+                for (int e = 0; e < PX; ++e) {
+                    float de;
+                    s += bce_element<true>(acc[co][e], tv[e], a.gs, de);
+                    d[e] = de;
+                }
+                acc[co] = d;        // the accumulator now holds dy
+                if (a.dy != nullptr) reinterpret_cast<vec_t*>(a.dy)[obase + (long long)co * hwv] = d;
+            } else {
+#pragma unroll
+                for (int e = 0; e < PX; ++e) acc[co][e] = 0.f;
+            }
+        }
+        acc_loss += (double)s;
+        if (a.dx != nullptr) {
+            vec_t* dp = reinterpret_cast<vec_t*>(a.dx + (long long)b * a.cin * (hwv * PX)) + p;
+#pragma unroll 2
+            for (int ci = 0; ci < a.cin; ++ci) {
+                vec_t o;
+#pragma unroll
+                for (int e = 0; e < PX; ++e) o[e] = 0.f;
+#pragma unroll
+                for (int co = 0; co < CT; ++co) {
+                    const float wv = w[ci * a.cout_pad + co];      // (zero in the padded columns)
+#pragma unroll
+                    for (int e = 0; e < PX; ++e) o[e] = __builtin_fmaf(acc[co][e], wv, o[e]);
+                }
+                dp[(long long)ci * hwv] = o;
+            }
+        }
+    }
+    acc_loss = wave_sum(acc_loss);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc_loss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+        __threadfence();
+        last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last) {         // the last block to finish sums the partials in a fixed order: bitwise reproducible
+        __threadfence();
+        double t = 0.0;
+        for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += ((volatile double*)a.partial)[i];
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.loss[0] = (float)(((ws[0] + ws[1]) + (ws[2] + ws[3])) / (double)a.n);
+            *a.ticket = 0u;     // ready for the next launch on this workspace
+        }
+    }
+}
+
 // dx *= g[0] / expected, and nothing at all when the upstream gradient is the expected one.
 __global__ __launch_bounds__(256) void bce_rescale_kernel(float* __restrict__ dx, const float* __restrict__ g,
                                                           float expected, long long n) {
@@ -893,6 +1016,45 @@ int ynet_avgpool_pyramid(const float* x, float* const* outs, int nlev, long long
 #define YNET_BCE_PARTS 1024
 
 long long ynet_bce_workspace_bytes(void) { return YNET_BCE_PARTS * (long long)sizeof(double); }
+
+/* workspace: [YNET_BCE_PARTS] doubles + a ticket counter that must be ZERO before the first launch (the kernel resets it) */
+long long ynet_pred_bce_workspace_bytes(void) { return YNET_BCE_PARTS * (long long)sizeof(double) + 16; }
+
+int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target,
+                  float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, long long HW,
+                  float expected_grad, void* stream) {
+    YNET_REQUIRE(x && wp && target && y && loss && workspace, "pred_bce: null pointer");
+    YNET_REQUIRE(B > 0 && cin > 0 && cout > 0 && cout <= 32 && HW > 0 && (HW & 3) == 0, "pred_bce: bad shape B=%d cin=%d cout=%d HW=%lld (cout <= 32, HW %% 4 == 0)", B, cin, cout, HW);
+    YNET_REQUIRE((((uintptr_t)x | (uintptr_t)target | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dy) & 15) == 0 && (x_batch_stride & 3) == 0,
+                 "pred_bce: tensors must be 16-byte aligned");
+    PredBceArgs a{};
+    a.x = x;
+    a.x_bs = x_batch_stride;
+    a.wp = wp;
+    a.bias = bias;
+    a.t = target;
+    a.y = y;
+    a.dx = dx;
+    a.dy = dy;
+    a.partial = (double*)workspace;
+    a.ticket = (unsigned*)((char*)workspace + YNET_BCE_PARTS * sizeof(double));
+    a.loss = loss;
+    a.cin = cin;
+    a.cout = cout;
+    a.cout_pad = ceil_div(cout, 64) * 64;
+    a.B = B;
+    a.hw4 = HW / 4;
+    a.n = (long long)B * cout * HW;
+    a.gs = expected_grad / (float)a.n;
+    if (cout <= 16) {
+        const int parts = grid_for((long long)B * a.hw4, 256, YNET_BCE_PARTS);
+        hipLaunchKernelGGL((pred_bce_kernel<16, 4>), dim3(parts), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        const int parts = grid_for((long long)B * a.hw4 * 2, 256, YNET_BCE_PARTS);
+        hipLaunchKernelGGL((pred_bce_kernel<32, 2>), dim3(parts), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return ynet_check_launch("pred_bce");
+}
 
 int ynet_bce_logits_fwd(const float* x, const float* t, long long n, float* loss, void* workspace, void* stream) {
     YNET_REQUIRE(x && t && loss && workspace && n > 0, "bce_logits_fwd: bad arguments");

@@ -30,11 +30,17 @@ class HipBCEWithLogitsLoss(nn.Module):
     multiply the loss by (train_epoch sets it to its loss_scale): the gradient of the logits is then produced in the
     same pass as the loss.  It is a hint only -- results do not depend on it."""
 
+    fuses_with_predictor = True      # a YNetDecoder told about the target (models/ynet.py: announce_bce_target) computes the
+                                     # loss in its predictor kernel; forward() then only hands that value out
+
     def __init__(self):
         super().__init__()
         self.expected_grad = 1.0
 
     def forward(self, input, target):
+        fused = getattr(input, "_ynet_fused_bce", None)
+        if fused is not None and fused[0] is target and fused[2] == float(self.expected_grad):
+            return fused[1]
         return ops.bce_with_logits(input, target, self.expected_grad)
 
 

@@ -374,6 +374,11 @@ class YNetDecoder(nn.Module):
             for a, b in zip(in_channels, decoder_channels)])
         self.predictor = HipConv2d(decoder_channels[-1], output_len, kernel_size=1, stride=1, padding=0)
 
+    # Set by `announce_bce_target` (utils/train_epoch.py): the criterion that will be applied to this decoder's output
+    # and its target.  The predictor then runs fused with the loss and with its own dgrad (ynet_pred_bce: the last
+    # activation is read once instead of three times); the logits it returns carry the loss for the criterion.
+    _bce = None
+
     def forward(self, features):
         features = features[::-1]
         x = self.center(features[0])
@@ -381,7 +386,33 @@ class YNetDecoder(nn.Module):
             x = ops.upsample2x(x)
             x = up(x)
             x = d(ops.lazy_cat([x, f]))
+        bce = self._bce
+        if (bce is not None and torch.is_grad_enabled() and type(self.predictor) is HipConv2d
+                and ops.pred_bce_supported(x, self.predictor.weight)):
+            target, expected = bce
+            y, loss = ops.pred_bce(x, self.predictor.weight, self.predictor.bias, target, expected, self.predictor._packed)
+            y._ynet_fused_bce = (target, loss, float(expected))
+            return y
         return self.predictor(x)
+
+
+class announce_bce_target:
+    """``with announce_bce_target(decoder, criterion, target): maps = decoder(features)`` -- tells a YNetDecoder which
+    BCE-with-logits target its output is about to be compared with, so that predictor, loss and the predictor's dgrad
+    run as one kernel.  ``criterion(maps, target)`` afterwards returns the loss computed in that pass
+    (models/trainer.py: HipBCEWithLogitsLoss); any other use of the maps is unaffected."""
+
+    def __init__(self, decoder, criterion, target):
+        self.decoder = decoder
+        self.spec = (target, getattr(criterion, "expected_grad", 1.0)) if getattr(criterion, "fuses_with_predictor", False) else None
+
+    def __enter__(self):
+        self.decoder._bce = self.spec
+        return self
+
+    def __exit__(self, *exc):
+        self.decoder._bce = None
+        return False
 
 
 class YNet(nn.Module):

@@ -443,22 +443,29 @@ class _Conv2dFn(torch.autograd.Function):
         want_w = need[1] or (ctx.has_lora and (need[3] or need[4]))
         want_b = ctx.has_bias and need[2]
         if want_w or want_b:
-            lib = _lib()
-            descs = [(s.data_ptr(), s.shape[1], (s.stride(0) if s.shape[0] > 1 else s.shape[1] * H * W)) for s in srcs]
-            sp, sc, sb = _arrays(descs)
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            d_b = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_b else None
-            ws = torch.empty(lib.ynet_conv2d_wgrad_workspace_floats(B, H, W, cout, cin, k), device=dy.device,
-                             dtype=torch.float32)
-            L.check(lib.ynet_conv2d_wgrad(sp, sc, sb, len(descs), dy.data_ptr(), cout * H * W,
-                                          mask[0] if mask else None, mask[1] if mask else 0,
-                                          dw.data_ptr(), d_b.data_ptr() if want_b else None, ws.data_ptr(),
-                                          B, H, W, cout, k, _stream()), lib)
+            dw, d_b = conv2d_wgrad_raw(srcs, dy, mask, weight, want_b)
             if ctx.has_lora and (need[3] or need[4]):
                 d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
             if need[1]:
                 d_w = dw
         return (None, d_w, d_b, d_a if need[3] else None, d_bm if need[4] else None, *d_srcs)
+
+
+def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b):
+    """(dW, db or None) of conv(cat(srcs), W) for the output gradient dy [B,cout,H,W] (masked where mask's plane <= 0)."""
+    lib = _lib()
+    cout, cin, k, _ = weight.shape
+    B, _, H, W = dy.shape
+    descs = [(s.data_ptr(), s.shape[1], (s.stride(0) if s.shape[0] > 1 else s.shape[1] * H * W)) for s in srcs]
+    sp, sc, sb = _arrays(descs)
+    dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    d_b = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_b else None
+    ws = torch.empty(lib.ynet_conv2d_wgrad_workspace_floats(B, H, W, cout, cin, k), device=dy.device, dtype=torch.float32)
+    L.check(lib.ynet_conv2d_wgrad(sp, sc, sb, len(descs), dy.data_ptr(), cout * H * W,
+                                  mask[0] if mask else None, mask[1] if mask else 0,
+                                  dw.data_ptr(), d_b.data_ptr() if want_b else None, ws.data_ptr(),
+                                  B, H, W, cout, k, _stream()), lib)
+    return dw, d_b
 
 
 def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0):
@@ -602,6 +609,80 @@ class _BCEFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             L.check(lib.ynet_bce_logits_bwd(x.data_ptr(), t.data_ptr(), g.data_ptr(), dx.data_ptr(), x.numel(), _stream()), lib)
         return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# 1x1 predictor + BCE-with-logits (+ the predictor's dgrad) in one pass
+# ------------------------------------------------------------------------------------------------
+_pred_bce_ws = {}
+
+
+class _PredBCEFn(torch.autograd.Function):
+    """(logits, loss) = (conv1x1(x, W) + b, mean BCE(logits, target)).  The forward kernel also leaves the gradients
+    for the upstream gradient `expected_grad` of the loss: dx for the decoder (the predictor's dgrad) and, when the
+    predictor trains, dlogits for its wgrad.  The logits are returned for the read-out only (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, target, expected_grad, cache):
+        _need_gpu(x, "pred_bce input")
+        _need_gpu(target, "pred_bce target")
+        x, target = x.contiguous(), target.contiguous()
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        if tuple(target.shape) != (B, cout, H, W):
+            raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({(B, cout, H, W)})")
+        lib = _lib()
+        wp = _cached(cache, weight, None, None, 1.0, "fwd")
+        y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        key = (x.device, torch.cuda.current_stream().cuda_stream)
+        ws = _pred_bce_ws.get(key)
+        if ws is None:
+            ws = _pred_bce_ws[key] = torch.zeros(lib.ynet_pred_bce_workspace_bytes() // 8 + 1, device=x.device, dtype=torch.float64)
+        expected_grad = float(expected_grad)
+        if not (expected_grad != 0.0 and abs(expected_grad) < float("inf")):
+            expected_grad = 1.0
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
+        ctx.dx = torch.empty_like(x) if need_x else None
+        ctx.dy = torch.empty_like(y) if need_w else None
+        L.check(lib.ynet_pred_bce(x.data_ptr(), cin * H * W, wp.data_ptr(), bias.detach().data_ptr() if bias is not None else None,
+                                  target.data_ptr(), y.data_ptr(), loss.data_ptr(),
+                                  ctx.dx.data_ptr() if need_x else None, ctx.dy.data_ptr() if need_w else None,
+                                  ws.data_ptr(), B, cin, cout, H * W, expected_grad, _stream()), lib)
+        ctx.expected = expected_grad
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        ctx.mark_non_differentiable(y)
+        return y, loss
+
+    @staticmethod
+    def backward(ctx, _gy, g):
+        x, weight = ctx.saved_tensors
+        lib = _lib()
+        g = g.contiguous().float()
+        dx, dy, ctx.dx, ctx.dy = ctx.dx, ctx.dy, None, None
+        if (ctx.needs_input_grad[0] and dx is None) or ((ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and dy is None):
+            raise RuntimeError("pred_bce: backward through the fused predictor + criterion runs once (no retain_graph)")
+        d_w = d_b = None
+        if dx is not None:
+            L.check(lib.ynet_bce_grad_rescale(dx.data_ptr(), g.data_ptr(), ctx.expected, dx.numel(), _stream()), lib)
+        if dy is not None:
+            L.check(lib.ynet_bce_grad_rescale(dy.data_ptr(), g.data_ptr(), ctx.expected, dy.numel(), _stream()), lib)
+            d_w, d_b = conv2d_wgrad_raw([x], dy, None, weight, ctx.has_bias and ctx.needs_input_grad[2])
+            if not ctx.needs_input_grad[1]:
+                d_w = None
+        return dx, d_w, d_b, None, None, None
+
+
+def pred_bce(x, weight, bias, target, expected_grad: float, cache: dict):
+    """(predictor(x), BCEWithLogitsLoss()(predictor(x), target)) in one pass over x (see ynet_pred_bce)."""
+    return _PredBCEFn.apply(x, weight, bias, target, expected_grad, cache)
+
+
+def pred_bce_supported(x, weight) -> bool:
+    return (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and (x.shape[2] * x.shape[3]) % 4 == 0
+            and weight.shape[0] <= 32 and tuple(weight.shape[2:]) == (1, 1))
 
 
 def bce_with_logits(x, t, expected_grad: float = 1.0):

@@ -104,15 +104,24 @@ def mark_parameters_changed(model):
             torch.autograd.graph.increment_version(p)
 
 
-def _make_capturable(optimizer) -> bool:
-    """Adam / AdamW take their capturable form (step counters as device tensors; same update rule); SGD captures as is."""
+def _make_capturable(optimizer, fused: bool = True) -> bool:
+    """Adam / AdamW take a capturable form (step counters as device tensors; same update rule): the FUSED multi-tensor
+    kernel when every parameter is an fp32 device tensor -- one launch per step; the foreach form computes its bias
+    corrections with ~3 tiny launches per parameter once the step counters live on the device -- else the capturable
+    foreach form.  SGD captures as it is."""
     if isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        can_fuse = fused and all(p.is_cuda and p.dtype == torch.float32 for p in params) and \
+            not any(g.get("amsgrad") or g.get("maximize") or g.get("differentiable") for g in optimizer.param_groups)
         for g in optimizer.param_groups:
-            if g.get("fused"):
-                return False
-            g["capturable"] = True
+            if can_fuse:
+                g["fused"], g["foreach"], g["capturable"] = True, False, False
+            else:
+                g["fused"], g["capturable"] = False, True
+                if g.get("foreach") is False:
+                    g["foreach"] = None
         for p, st in optimizer.state.items():
-            if "step" in st and torch.is_tensor(st["step"]) and st["step"].device != p.device:
+            if "step" in st and torch.is_tensor(st["step"]) and (st["step"].device != p.device or st["step"].dtype != torch.float32):
                 st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
         return True
     return isinstance(optimizer, torch.optim.SGD)
@@ -126,6 +135,7 @@ class GraphCache:
         self.entries = {}
         self.pool = None
         self.last = None
+        self.fused_ok = os.environ.get("YNET_FUSED_ADAM", "1") != "0"
 
     def lookup(self, key):
         e = self.entries.get(key)
@@ -149,14 +159,19 @@ class CapturedStep:
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
-            self._capture(batch, scene_image, forward_backward, optimizer, dp, finish, dev)
+            for fused in ((True, False) if self.cache.fused_ok else (False,)):
+                self.failed = False
+                self._capture(batch, scene_image, forward_backward, optimizer, dp, finish, dev, fused)
+                if self.ready:
+                    break
+                self.cache.fused_ok = False      # (a build without the fused kernel: capturable foreach from now on)
         finally:
             if gc_was_enabled:
                 gc.enable()
 
-    def _capture(self, batch, scene_image, forward_backward, optimizer, dp, finish, dev):
+    def _capture(self, batch, scene_image, forward_backward, optimizer, dp, finish, dev, fused):
         try:
-            if not _make_capturable(optimizer):
+            if not _make_capturable(optimizer, fused):
                 raise RuntimeError(f"{type(optimizer).__name__} has no capturable step")
             stream = torch.cuda.current_stream(dev)
             if stream == torch.cuda.default_stream(dev):

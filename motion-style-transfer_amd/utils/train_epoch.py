@@ -18,6 +18,7 @@ import torch
 
 from .. import ops
 from . import step_graph
+from ..models.ynet import announce_bce_target
 from .image_utils import gather_patches, swap_pavement_terrain
 
 
@@ -68,23 +69,28 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
             s_goal.wait_stream(main)
             s_traj.wait_stream(main)
             with torch.cuda.stream(s_goal):
-                pred_goal_map = model.pred_goal(features)
+                with announce_bce_target(model.goal_decoder, criterion, gt_future_map):
+                    pred_goal_map = model.pred_goal(features)
                 goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
             with torch.cuda.stream(s_traj):
                 pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
                 traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]   # concat fused into the convs
-                pred_traj_map = model.pred_traj(traj_input)
+                with announce_bce_target(model.traj_decoder, criterion, gt_future_map):
+                    pred_traj_map = model.pred_traj(traj_input)
                 traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
             main.wait_stream(s_goal)
             main.wait_stream(s_traj)
             for t in (pred_goal_map, goal_loss, pred_traj_map, traj_loss):
                 t.record_stream(main)
         else:
-            pred_goal_map = model.pred_goal(features)
+            # (the decoders are told their BCE target: predictor, loss and the predictor's dgrad run as one kernel)
+            with announce_bce_target(model.goal_decoder, criterion, gt_future_map):
+                pred_goal_map = model.pred_goal(features)
             goal_loss = criterion(pred_goal_map, gt_future_map) * loss_scale
             pyramid = ops.avgpool_pyramid(gt_waypoint_map, len(features))
             traj_input = [ops.lazy_cat([f, g]) for f, g in zip(features, pyramid)]
-            pred_traj_map = model.pred_traj(traj_input)
+            with announce_bce_target(model.traj_decoder, criterion, gt_future_map):
+                pred_traj_map = model.pred_traj(traj_input)
             traj_loss = criterion(pred_traj_map, gt_future_map) * loss_scale
 
         loss = goal_loss + traj_loss

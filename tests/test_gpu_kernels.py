@@ -483,3 +483,32 @@ def test_cws_prior_matches_the_reference_gaussian(dev, H, W, rot):
         want_xy = O.softargmax_on_map(mm[None, None])[0, 0]
         np.testing.assert_allclose(maps[r].cpu().numpy(), mm.numpy(), rtol=2e-4, atol=1e-9)
         np.testing.assert_allclose(xy[r].cpu().numpy(), want_xy.numpy(), rtol=0, atol=2e-5 * max(H, W) / 64)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,train_pred,scale,up", [
+    (3, 32, 12, 16, 24, False, 1000.0, 1000.0), (2, 32, 30, 32, 32, True, 1000.0, 1000.0), (2, 8, 12, 8, 8, True, 1000.0, 250.0),
+    (1, 16, 1, 4, 4, True, 1.0, 1.0)])
+def test_fused_predictor_and_bce(dev, B, cin, cout, H, W, train_pred, scale, up):
+    """ynet_pred_bce: 1x1 predictor + BCEWithLogitsLoss (mean) + the predictor's dgrad (+ dlogits for its wgrad) in
+    one pass, against stock torch; `up` != scale exercises the rescale of the pre-computed gradients."""
+    ops = pkg("ops")
+    x = rnd(B, cin, H, W, seed=1).relu()
+    w, b = rnd(cout, cin, 1, 1, seed=2, scale=0.3), rnd(cout, seed=3, scale=0.1)
+    t = torch.rand(B, cout, H, W, generator=torch.Generator().manual_seed(4)) * 0.01
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(train_pred), b.clone().requires_grad_(train_pred)
+    yc = F.conv2d(xc, wc, bc)
+    lc = F.binary_cross_entropy_with_logits(yc, t) * scale
+    lc.backward()
+    xd, wd, bd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(train_pred), b.to(dev).requires_grad_(train_pred)
+    yd, ld = ops.pred_bce(xd, wd, bd, t.to(dev), up, {})
+    (ld * scale).backward()
+    close(yd, yc, msg="logits")
+    assert abs(float(ld) * scale - float(lc)) <= 2e-6 * abs(float(lc)), (float(ld) * scale, float(lc))
+    close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg="dx")
+    if train_pred:
+        close(wd.grad, wc.grad, rtol=1e-4, scale_rel=1e-5, msg="dW")
+        close(bd.grad, bc.grad, rtol=1e-4, scale_rel=1e-5, msg="db")
+    assert not yd.requires_grad
+    # twice in a row on the same stream: the workspace ticket was reset by the kernel
+    y2, l2 = ops.pred_bce(x.to(dev), w.to(dev), b.to(dev), t.to(dev), up, {})
+    assert torch.equal(y2, yd) and float(l2) == float(ld)
