@@ -17,6 +17,7 @@ Reference: models/ynet.py:15-131 (Adapter, AdapterBlock, AdapterLayer), 134-151 
 (Embedding), 170-283 (YNetEncoder/L/B), 286-395 (YNetEncoderFusion), 398-471 (YNetDecoder), 474-600 (YNet).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -404,7 +405,8 @@ class announce_bce_target:
 
     def __init__(self, decoder, criterion, target):
         self.decoder = decoder
-        self.spec = (target, getattr(criterion, "expected_grad", 1.0)) if getattr(criterion, "fuses_with_predictor", False) else None
+        on = getattr(criterion, "fuses_with_predictor", False) and os.environ.get("YNET_PRED_BCE", "1") != "0"
+        self.spec = (target, getattr(criterion, "expected_grad", 1.0)) if on else None
 
     def __enter__(self):
         self.decoder._bce = self.spec

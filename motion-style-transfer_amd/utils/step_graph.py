@@ -75,15 +75,16 @@ def _hyper(optimizer):
     out = []
     for g in optimizer.param_groups:
         out.append(tuple(sorted((k, (tuple(v) if isinstance(v, (list, tuple)) else v)) for k, v in g.items()
-                                if k != "params" and isinstance(v, (int, float, bool, str, type(None), list, tuple)))))
+                                if k not in ("params", "fused", "foreach", "capturable")
+                                and isinstance(v, (int, float, bool, str, type(None), list, tuple)))))
     return tuple(out)
 
 
 def step_key(scene_image, n_local, n_global, obs_len, pred_len, waypoints, loss_scale, resize_factor, network, criterion,
-             gt_template, input_template, optimizer, dp):
+             gt_template, input_template, optimizer, dp, model_token=None):
     return (tuple(scene_image.shape), n_local, n_global, obs_len, pred_len, tuple(waypoints), float(loss_scale),
             float(resize_factor), network, id(criterion), gt_template.data_ptr(), input_template.data_ptr(),
-            _hyper(optimizer), None if dp is None else (id(dp), dp.world, dp.rank))
+            _hyper(optimizer), None if dp is None else (id(dp), dp.world, dp.rank), model_token)
 
 
 def cache_for(model, optimizer, device):
@@ -96,12 +97,27 @@ def cache_for(model, optimizer, device):
     return c
 
 
-def mark_parameters_changed(model):
-    """Replays update the weights without Python seeing it: bump the version counters so that per-layer caches keyed on
-    ``Parameter._version`` (packed / LoRA-composed filters in ops._cached) are rebuilt by the next eager forward."""
-    for p in model.parameters():
+def mark_parameters_changed(params):
+    """A replayed optimizer step updates the weights without Python seeing it (and the fused multi-tensor Adam does not
+    bump version counters even eagerly): bump them, so that per-layer caches keyed on ``Parameter._version`` (packed /
+    LoRA-composed filters in ops._cached) are rebuilt by the next eager forward -- and by the next CAPTURE, whose graph
+    must contain the compose / pack launches of every trainable layer."""
+    for p in params:
         if p.requires_grad:
             torch.autograd.graph.increment_version(p)
+
+
+def model_state_token(model):
+    """Part of a step's key: which tensors train, and the in-place history of the frozen ones.  A captured step reads the
+    packed filters of frozen layers from buffers written once; if frozen weights are replaced (load_state_dict between
+    two train() calls) or the freeze policy changes, the step must be captured again."""
+    flags, frozen = 0, 0
+    for i, p in enumerate(model.parameters()):
+        if p.requires_grad:
+            flags ^= hash((i, True))
+        else:
+            frozen += p._version
+    return flags, frozen
 
 
 def _make_capturable(optimizer, fused: bool = True) -> bool:
@@ -115,7 +131,7 @@ def _make_capturable(optimizer, fused: bool = True) -> bool:
             not any(g.get("amsgrad") or g.get("maximize") or g.get("differentiable") for g in optimizer.param_groups)
         for g in optimizer.param_groups:
             if can_fuse:
-                g["fused"], g["foreach"], g["capturable"] = True, False, False
+                g["fused"], g["foreach"], g["capturable"] = True, False, True
             else:
                 g["fused"], g["capturable"] = False, True
                 if g.get("foreach") is False:
@@ -165,6 +181,7 @@ class CapturedStep:
                 if self.ready:
                     break
                 self.cache.fused_ok = False      # (a build without the fused kernel: capturable foreach from now on)
+                self.cache.pool = None           # a failed capture leaves its memory pool unusable: start a fresh one
         finally:
             if gc_was_enabled:
                 gc.enable()
@@ -224,6 +241,7 @@ class CapturedStep:
         if self.split:
             self.dp.allreduce()
             self.graphs[1].replay()
+        mark_parameters_changed(self.params)
         if self.cache.last is not self:            # p.grad shows the gradients of the step that ran last
             for p, g in zip(self.params, self.grads):
                 p.grad = g

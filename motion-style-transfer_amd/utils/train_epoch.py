@@ -118,7 +118,7 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
     model.train()
     waypoints = list(waypoints)
     graphs = step_graph.cache_for(model, optimizer, device) if step_graph.enabled(graph, device) else None
-    replayed = False
+    model_token = step_graph.model_state_token(model) if graphs is not None else None
     # captured steps need a non-default stream: in graph mode the whole epoch runs on one persistent side stream
     epoch_stream = step_graph.enter_stream(device) if graphs is not None else None
 
@@ -144,14 +144,13 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                 if graphs is not None and n_local > 0 and not swap_semantic and not scene_image.requires_grad:
                     step = graphs.lookup(step_graph.step_key(
                         scene_image, n_local, n_global, obs_len, pred_len, waypoints, loss_scale, resize_factor, network,
-                        criterion, gt_template, input_template, optimizer, dp))
+                        criterion, gt_template, input_template, optimizer, dp, model_token))
 
                 if step is not None and step.ready:
                     # ---- replay: coordinates (and the scene's semantic map) into the static inputs, one graph launch
                     _, _, H, W = scene_image.shape
                     ops.check_patch_windows(input_template.shape, batch, H, W)
                     loss, ade, fde = step.replay(batch, scene_image)
-                    replayed = True
                 else:
                     def forward_backward(coords, scene_img, overlap):
                         if dp is not None:
@@ -173,7 +172,6 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                         step.capture(batch, scene_image, forward_backward, optimizer, dp, finish)
                     if step is not None and step.ready:
                         loss, ade, fde = step.replay(batch, scene_image)
-                        replayed = True
                     else:
                         # ---- eager step (also the warm-up of a later capture)
                         if step is not None:
@@ -196,6 +194,8 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                         if dp is not None:
                             loss = dp.allreduce_grads(loss)          # ONE collective per step: gradients + loss
                         optimizer.step()
+                        if graphs is not None:      # (see step_graph.mark_parameters_changed)
+                            step_graph.mark_parameters_changed(p for g in optimizer.param_groups for p in g["params"])
                         if n_local > 0:
                             ade, fde = finish(fb)
                         else:
@@ -218,7 +218,5 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
     finally:
         if epoch_stream is not None:
             step_graph.leave_stream(epoch_stream)
-        if replayed:
-            step_graph.mark_parameters_changed(model)
     ops.check_patch_status()
     return train_ADE.item(), train_FDE.item(), train_loss.item()
