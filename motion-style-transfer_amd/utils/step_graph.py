@@ -25,6 +25,10 @@ import torch
 
 from .. import ops
 
+# Goal / trajectory decoder on two forked streams INSIDE the captured step: the graph then has two parallel branches
+# (the launch-latency-bound 8^2 .. 32^2 layers of one decoder can run beside the other's).  YNET_GRAPH_OVERLAP=0: one chain.
+OVERLAP_DECODERS = os.environ.get("YNET_GRAPH_OVERLAP", "1") != "0"
+
 _caches = weakref.WeakKeyDictionary()      # model -> {id(optimizer): GraphCache}
 _streams = {}
 _wp_index = {}
@@ -204,7 +208,7 @@ class CapturedStep:
             self.params = [p for g in optimizer.param_groups for p in g["params"]]
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, pool=self.cache.pool, stream=stream):
-                fb = forward_backward(self.coords, self.scene, False)
+                fb = forward_backward(self.coords, self.scene, OVERLAP_DECODERS)
                 loss = fb[0].detach()
                 if dp is not None:
                     dp.stage(loss)

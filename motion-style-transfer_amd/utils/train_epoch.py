@@ -181,7 +181,7 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                                 # same code path as the capture: coordinates on the device, windows checked on the host
                                 _, _, H, W = scene_image.shape
                                 ops.check_patch_windows(input_template.shape, batch, H, W)
-                                fb = forward_backward(batch.to(device), scene_image, False)
+                                fb = forward_backward(batch.to(device), scene_image, step_graph.OVERLAP_DECODERS)
                             else:
                                 fb = forward_backward(batch, scene_image, ops.overlap_decoders)
                             loss = fb[0]
