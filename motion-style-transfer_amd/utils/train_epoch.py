@@ -23,10 +23,13 @@ from .image_utils import gather_patches, swap_pavement_terrain
 
 
 def _step_forward_backward(model, criterion, coords, scene_image, gt_template, input_template, waypoints, obs_len,
-                           pred_len, loss_scale, network, swap_semantic, device, n_local, n_global, dp, overlap):
+                           pred_len, loss_scale, network, swap_semantic, device, n_local, n_global, dp, overlap,
+                           resize_factor=1.0, branches=False):
     """utils/train_epoch.py:54-110 for one (shard of a) batch: heat-maps, forward, both losses, backward.
     ``coords`` [n_local, obs+pred, 2]: a host tensor (eager; window checks on the host) or a device tensor (captured
-    step).  Returns (loss as the reference sums it -- shard-weighted under dp --, pred_goal_map, pred_traj_map, gt_future)."""
+    step).  Returns (loss as the reference sums it -- shard-weighted under dp --, pred_goal_map, pred_traj_map, gt_future,
+    (ade, fde) or None).  ``branches`` (captured steps): besides the two decoders, the read-out and the filter gradients
+    run on forked streams, i.e. as parallel branches of the hipGraph."""
     semantic_img = model.adapt_semantic(scene_image)
     if swap_semantic:
         semantic_img = swap_pavement_terrain(semantic_img)
@@ -96,8 +99,23 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
         loss = goal_loss + traj_loss
         if dp is not None:
             loss = loss * (n_local / n_global)      # BCE is a mean: weight by the shard's share
-        loss.backward()
-    return loss, pred_goal_map, pred_traj_map, gt_future
+        early = None
+        if overlap and branches:
+            # the read-out depends on the forward pass only: a third branch beside the backward pass
+            s_m = ops.side_streams(device, 2)
+            s_m.wait_stream(torch.cuda.current_stream(device))
+            for t in (pred_goal_map, pred_traj_map, gt_future):
+                t.record_stream(s_m)
+            with torch.cuda.stream(s_m), torch.no_grad():
+                early = _step_metrics(model, pred_goal_map, pred_traj_map, gt_future, resize_factor)
+        with ops.fork_wgrad(overlap and branches):      # filter gradients: a branch beside the dgrad chain
+            loss.backward()
+        if early is not None:
+            cur = torch.cuda.current_stream(device)
+            cur.wait_stream(s_m)
+            for t in early:
+                t.record_stream(cur)
+    return loss, pred_goal_map, pred_traj_map, gt_future, early
 
 
 def _step_metrics(model, pred_goal_map, pred_traj_map, gt_future, resize_factor):
@@ -159,9 +177,12 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                             optimizer.zero_grad()
                         return _step_forward_backward(model, criterion, coords, scene_img, gt_template, input_template,
                                                       waypoints, obs_len, pred_len, loss_scale, network, swap_semantic,
-                                                      device, n_local, n_global, dp, overlap)
+                                                      device, n_local, n_global, dp, overlap, resize_factor,
+                                                      branches=graphs is not None and step_graph.OVERLAP_DECODERS)
 
                     def finish(fb):
+                        if fb[4] is not None:
+                            return fb[4]
                         with torch.no_grad():
                             return _step_metrics(model, fb[1], fb[2], fb[3], resize_factor)
 
