@@ -397,7 +397,6 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.meta = meta
         ctx.n_src = len(srcs)
         ctx.has_bias = bias is not None
-        ctx.bias_ref = bias          # (the Parameter itself: the forked wgrad branch delivers its gradient directly)
         ctx.has_lora = lora_a is not None
         ctx.save_for_backward(weight, lora_a, lora_b, y if relu else None, *keep)
         ctx.w_key = _weight_key(weight, lora_a, lora_b)
@@ -444,75 +443,12 @@ class _Conv2dFn(torch.autograd.Function):
         want_w = need[1] or (ctx.has_lora and (need[3] or need[4]))
         want_b = ctx.has_bias and need[2]
         if want_w or want_b:
-            fork = _wgrad_fork.get("on") and any(d is not None for d in d_srcs)
-            cur = torch.cuda.current_stream(dy.device)
-            side = cur
-            if fork:
-                # The filter gradient is off the critical path (only the optimizer consumes it): it goes to a side
-                # stream -- a parallel branch of the captured step -- while the dgrad chain continues on this one; the
-                # branch delivers the gradient into p.grad itself (what AccumulateGrad would do) and is joined after
-                # the backward pass (join_wgrad_streams).
-                side = _wgrad_side_stream(dy.device)
-                side.wait_stream(cur)
-                for t in (dy, y, *srcs):
-                    if t is not None:
-                        t.record_stream(side)
-            with torch.cuda.stream(side):
-                dw, d_b = conv2d_wgrad_raw(srcs, dy, mask, weight, want_b)
-                if ctx.has_lora and (need[3] or need[4]):
-                    d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
-                if need[1]:
-                    d_w = dw
-                if fork:
-                    for p_, g_, wanted in ((weight, d_w, need[1]), (ctx.bias_ref, d_b, want_b), (lora_a, d_a, need[3]), (lora_b, d_bm, need[4])):
-                        if wanted and g_ is not None:
-                            if p_.grad is None:
-                                p_.grad = g_
-                            else:
-                                p_.grad.add_(g_)
-                    d_w = d_b = d_a = d_bm = None
-                    _wgrad_fork["used"].add(side)
+            dw, d_b = conv2d_wgrad_raw(srcs, dy, mask, weight, want_b)
+            if ctx.has_lora and (need[3] or need[4]):
+                d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
+            if need[1]:
+                d_w = dw
         return (None, d_w, d_b, d_a if need[3] else None, d_bm if need[4] else None, *d_srcs)
-
-
-# ---- filter gradients on a side stream (utils/train_epoch.py switches this on inside a captured step)
-_wgrad_fork = {"on": False, "used": set()}
-_wgrad_streams = {}
-
-
-def _wgrad_side_stream(device):
-    dev = torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _wgrad_streams:
-        _wgrad_streams[key] = torch.cuda.Stream(device=dev)
-    return _wgrad_streams[key]
-
-
-class fork_wgrad:
-    """Inside this context a conv backward that also produces a dgrad runs its wgrad (+ LoRA gradient) on a side
-    stream and writes the result into ``p.grad`` itself; ``join_wgrad_streams`` (called after ``loss.backward()``)
-    makes the current stream wait for those branches.  Only valid when nothing else reads the parameter gradients
-    before the join (no gradient hooks): utils/train_epoch.py uses it for its own steps."""
-
-    def __init__(self, on=True):
-        self.on = bool(on)
-
-    def __enter__(self):
-        self._prev = _wgrad_fork["on"]
-        _wgrad_fork["on"] = self.on
-        return self
-
-    def __exit__(self, *exc):
-        _wgrad_fork["on"] = self._prev
-        join_wgrad_streams()
-        return False
-
-
-def join_wgrad_streams():
-    cur = torch.cuda.current_stream()
-    for s in list(_wgrad_fork["used"]):
-        cur.wait_stream(s)
-    _wgrad_fork["used"].clear()
 
 
 def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b):

@@ -28,8 +28,8 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
     """utils/train_epoch.py:54-110 for one (shard of a) batch: heat-maps, forward, both losses, backward.
     ``coords`` [n_local, obs+pred, 2]: a host tensor (eager; window checks on the host) or a device tensor (captured
     step).  Returns (loss as the reference sums it -- shard-weighted under dp --, pred_goal_map, pred_traj_map, gt_future,
-    (ade, fde) or None).  ``branches`` (captured steps): besides the two decoders, the read-out and the filter gradients
-    run on forked streams, i.e. as parallel branches of the hipGraph."""
+    (ade, fde) or None).  ``branches`` (captured steps): besides the two decoders, the read-out runs on a forked stream,
+    i.e. as a parallel branch of the hipGraph beside the backward pass."""
     semantic_img = model.adapt_semantic(scene_image)
     if swap_semantic:
         semantic_img = swap_pavement_terrain(semantic_img)
@@ -108,8 +108,9 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
                 t.record_stream(s_m)
             with torch.cuda.stream(s_m), torch.no_grad():
                 early = _step_metrics(model, pred_goal_map, pred_traj_map, gt_future, resize_factor)
-        with ops.fork_wgrad(overlap and branches):      # filter gradients: a branch beside the dgrad chain
-            loss.backward()
+        # (filter gradients on a fourth branch beside the dgrad chain were measured: no gain at C2, 5 % slower at C1 --
+        # both are MFMA-bound and compete for the same CUs)
+        loss.backward()
         if early is not None:
             cur = torch.cuda.current_stream(device)
             cur.wait_stream(s_m)
