@@ -150,6 +150,15 @@ int ynet_sigmoid_temp(const float* x, float* y, long long B, int C, long long HW
 int ynet_gather_patch(const float* tmpl, int SH, int SW, const float* xy, float* out, int N, int H, int W,
                       int* status, void* stream);
 
+/* The same windows WITHOUT the S x S templates (create_dist_mat / create_gaussian_heatmap_template,
+ * utils/image_utils.py:15-37, are functions of the distance to the rounded coordinate):
+ *   kind 0: out[n,y,x] = (float)(sqrt((double)((y-ry)^2 + (x-rx)^2)) / dmax * 2), dmax = sqrt(2) * (S / 2) in fp64 --
+ *           bit-identical to the float64 NumPy template cast to fp32;
+ *   kind 1: the kernlen x kernlen Gaussian blob (`blob`, device, fp32 values of the template) placed at (rx, ry), 0 elsewhere.
+ * S is the size of the virtual template: a window that would leave it is flagged in *status and zero-filled. */
+int ynet_heatmap_analytic(const float* xy, float* out, int N, int H, int W, int S, int kind, double dmax,
+                          const float* blob, int kernlen, int* status, void* stream);
+
 /* ---- test-time sampling trick ------------------------------------------------------------------ */
 /* kmeans (utils/kmeans.py:22-108) as evaluate() calls it for TTST (utils/evaluate.py:146-152): Lloyd's algorithm on
  * P independent sets of N 2-D points with integer-valued coordinates (sampled pixels), K clusters each.

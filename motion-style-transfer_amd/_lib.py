@@ -51,6 +51,7 @@ SIGNATURES = {
     "ynet_softargmax2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, c_i, c_i, c_fp]),
     "ynet_sigmoid_temp": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, PI, c_i, c_f, c_fp]),
     "ynet_gather_patch": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "ynet_heatmap_analytic": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, ctypes.c_double, c_fp, c_i, c_fp, c_fp]),
     "ynet_kmeans2d": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, ctypes.c_float, c_i, c_fp]),
     "ynet_multinomial": (c_i, [c_fp, c_ll, c_ll, c_i, c_i, c_i, c_f, ctypes.c_ulonglong, c_fp, c_fp, c_fp]),
     "ynet_cws_prior": (c_i, [c_fp, c_ll, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_i, c_fp, c_fp, c_fp]),

@@ -857,6 +857,50 @@ __global__ __launch_bounds__(256) void gather_patch_kernel(const float* __restri
 
 
 // ------------------------------------------------------------------------------------------------
+// get_patch WITHOUT the S x S templates: the window of create_dist_mat around (rx, ry) is the
+// normalised Euclidean distance to that point, and the window of the Gaussian template is the kernlen x kernlen blob
+// (a 3.8 KB table) placed at it -- nothing else of the 4.4 / 7.7 MB templates is ever read.
+//   kind 0: out[n,y,x] = (float)( sqrt((double)((y-ry)^2 + (x-rx)^2)) / dmax * 2 )      utils/image_utils.py:30-37
+//           (integer radicand, IEEE fp64 sqrt and division, then ONE rounding to fp32: bit-identical to the float64
+//            NumPy template cast by torch.Tensor(...); dmax = the template's maximum = sqrt(2) * (S // 2) in fp64)
+//   kind 1: out[n,y,x] = blob[y-ry+m/2][x-rx+m/2] inside the blob, 0 elsewhere                utils/image_utils.py:15-27
+// The window must still lie inside the virtual template (the reference slices it): flagged + zero-filled otherwise.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heatmap_analytic_kernel(const float* __restrict__ xy, float* __restrict__ out, int H, int W,
+                                                               int S, int kind, double dmax, const float* __restrict__ blob,
+                                                               int m, int* __restrict__ status) {
+    const int n = blockIdx.y;
+    const int rx = (int)rintf(xy[2 * n]), ry = (int)rintf(xy[2 * n + 1]);
+    const int ox = S / 2 - rx, oy = S / 2 - ry;
+    float* o = out + (long long)n * H * W;
+    const int total = H * W;
+    if (ox < 0 || oy < 0 || ox + W > S || oy + H > S) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicExch(status, 1);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) o[i] = 0.f;
+        return;
+    }
+    auto value = [&](int y, int x) -> float {
+        const int dy = y - ry, dx = x - rx;
+        if (kind == 0) return (float)(sqrt((double)((long long)dy * dy + (long long)dx * dx)) / dmax * 2.0);
+        // the template carries the blob at [S/2 - m/2, S/2 + (m+1)/2): template index S/2 - ry + y -> blob row dy + m/2
+        const int by = dy + m / 2, bx = dx + m / 2;
+        return (by >= 0 && by < m && bx >= 0 && bx < m) ? blob[by * m + bx] : 0.f;
+    };
+    if ((W & 3) == 0 && ((reinterpret_cast<uintptr_t>(o)) & 15) == 0) {
+        const int Wq = W >> 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (total >> 2); i += gridDim.x * 256) {
+            const int y = i / Wq, x = (i - y * Wq) << 2;
+            reinterpret_cast<float4*>(o)[i] = make_float4(value(y, x), value(y, x + 1), value(y, x + 2), value(y, x + 3));
+        }
+        return;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int y = i / W;
+        o[i] = value(y, i - y * W);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // TTST (utils/evaluate.py:134-161, utils/kmeans.py:22-108): Lloyd's k-means of the N = 10000 goal samples of one
 // person, one workgroup per person, the whole iteration on chip.  Points are pixel coordinates (integer valued), so
 // cluster sums are exact in int32 whatever the summation order and the result does not depend on the thread count:
@@ -1139,6 +1183,22 @@ int ynet_gather_patch(const float* tmpl, int SH, int SW, const float* xy, float*
                            out + (long long)n0 * H * W, H, W, status);
     }
     return ynet_check_launch("gather_patch");
+}
+
+int ynet_heatmap_analytic(const float* xy, float* out, int N, int H, int W, int S, int kind, double dmax,
+                          const float* blob, int kernlen, int* status, void* stream) {
+    YNET_REQUIRE(xy && out && status, "heatmap_analytic: null pointer");
+    YNET_REQUIRE(N > 0 && H > 0 && W > 0 && S >= H && S >= W, "heatmap_analytic: bad shape N=%d %dx%d in %d", N, H, W, S);
+    YNET_REQUIRE(kind == 0 ? dmax > 0.0 : (kind == 1 && blob != nullptr && kernlen > 0 && kernlen <= S),
+                 "heatmap_analytic: kind 0 needs dmax > 0, kind 1 a blob table");
+    int gx = (H * W + 255) / 256;
+    if (gx > 64) gx = 64;
+    for (int n0 = 0; n0 < N; n0 += 65535) {
+        const int n = N - n0 < 65535 ? N - n0 : 65535;
+        hipLaunchKernelGGL(heatmap_analytic_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, xy + 2ll * n0,
+                           out + (long long)n0 * H * W, H, W, S, kind, dmax, blob, kernlen, status);
+    }
+    return ynet_check_launch("heatmap_analytic");
 }
 
 int ynet_kmeans2d(const float* points, const int* init_idx, float* centers, int* status, int P, int N, int K, float tol,

@@ -7,6 +7,7 @@ Differences, all outside the arithmetic: image files are not decoded here (cv2/s
 ``prepare_data`` takes a dict {scene_id: float tensor [C,H,W]} in place of an image directory; an
 optional ``dp`` (dist.DataParallel) shards batches over the GPUs of a node.
 """
+import os
 import pathlib
 import re
 from collections import OrderedDict, deque
@@ -20,7 +21,8 @@ from tqdm import tqdm
 from .. import ops
 from ..utils.dataloader import SceneDataset, scene_collate
 from ..utils.evaluate import evaluate
-from ..utils.image_utils import create_dist_mat, create_gaussian_heatmap_template
+from ..utils.image_utils import (analytic_dist_template, analytic_gaussian_template, create_dist_mat,
+                                 create_gaussian_heatmap_template)
 from ..utils.train_epoch import train_epoch
 from .ynet import YNet
 
@@ -149,11 +151,21 @@ class YNetTrainer:
 
     # ------------------------------------------------------------------------------------------
     def templates(self, kernlen=None, nsig=None):
-        input_template = torch.Tensor(create_dist_mat(size=self.template_size)).to(self.device)
+        """models/trainer.py:60-62, 209-211.  On the GPU the templates are analytic (ops.AnalyticTemplate: the windows
+        get_patch slices out of them are computed in the kernel, bit-identical, and the 4.4 / 7.7 MB arrays are never
+        built); YNET_ANALYTIC_HEATMAPS=0 keeps the materialised tensors."""
+        analytic = self.device.type == "cuda" and os.environ.get("YNET_ANALYTIC_HEATMAPS", "1") != "0"
+        if analytic:
+            input_template = analytic_dist_template(self.template_size, self.device)
+        else:
+            input_template = torch.Tensor(create_dist_mat(size=self.template_size)).to(self.device)
         if kernlen is None:
             return input_template
-        gt_template = torch.Tensor(create_gaussian_heatmap_template(
-            size=self.template_size, kernlen=kernlen, nsig=nsig, normalize=False)).to(self.device)
+        if analytic:
+            gt_template = analytic_gaussian_template(self.template_size, kernlen, nsig, False, self.device)
+        else:
+            gt_template = torch.Tensor(create_gaussian_heatmap_template(
+                size=self.template_size, kernlen=kernlen, nsig=nsig, normalize=False)).to(self.device)
         return input_template, gt_template
 
     def train(self, df_train, df_val, train_image_path, val_image_path, experiment_name):

@@ -748,8 +748,63 @@ def check_patch_windows(template_shape, xy, H: int, W: int):
     return host
 
 
-def gather_patches(template: torch.Tensor, xy, H: int, W: int) -> torch.Tensor:
+class AnalyticTemplate:
+    """A heat-map template that is never materialised: ``gather_patches`` computes its windows in
+    the kernel (ynet_heatmap_analytic), bit-identical to slicing the S x S array of utils/image_utils.py:15-37.
+    kind 'dist': create_dist_mat(size) (normalised distance); kind 'gaussian': create_gaussian_heatmap_template(size,
+    kernlen, nsig, normalize) -- only its kernlen x kernlen blob is kept (fp32, on the device)."""
+
+    def __init__(self, kind: str, size: int, device, blob=None, normalize: bool = True):
+        if kind not in ("dist", "gaussian"):
+            raise ValueError("AnalyticTemplate: kind must be 'dist' or 'gaussian'")
+        self.kind, self.size, self.device = kind, int(size), torch.device(device)
+        self.shape = torch.Size((self.size, self.size))
+        self.dtype = torch.float32
+        self.normalize = bool(normalize)
+        half = self.size // 2
+        self.dmax = float(np.sqrt(np.float64(2 * half * half))) if normalize else 0.0
+        if kind == "dist" and not normalize:
+            raise ValueError("AnalyticTemplate: the un-normalised distance map is not on the Y-Net path")
+        self.blob = None
+        if kind == "gaussian":
+            b = np.asarray(blob, dtype=np.float64)
+            self.blob = torch.from_numpy(b.astype(np.float32)).contiguous().to(self.device)      # same cast as torch.Tensor(template)
+        self.is_cuda = self.device.type == "cuda"
+
+    def data_ptr(self):
+        return id(self)
+
+    def dim(self):
+        return 2
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        out = AnalyticTemplate.__new__(AnalyticTemplate)
+        out.__dict__.update(self.__dict__)
+        out.device, out.is_cuda = device, device.type == "cuda"
+        out.blob = None if self.blob is None else self.blob.to(device)
+        return out
+
+    def materialize(self) -> torch.Tensor:
+        """The S x S tensor the reference would hold (tests / callers that index the template directly)."""
+        S = self.size
+        if self.kind == "dist":
+            off = np.arange(S, dtype=np.int64) - S // 2
+            d = np.sqrt((off[:, None] ** 2 + off[None, :] ** 2).astype(np.float64))
+            return torch.Tensor(d / d.max() * 2).to(self.device)
+        t = torch.zeros(S, S)
+        m = self.blob.shape[0]
+        lo = S // 2 - m // 2
+        t[lo:lo + m, lo:lo + m] = self.blob.cpu()
+        return t.to(self.device)
+
+
+def gather_patches(template, xy, H: int, W: int) -> torch.Tensor:
     """[N,2] (x,y) coordinates -> [N,H,W] windows of `template` (utils/image_utils.py:40-63)."""
+    if isinstance(template, AnalyticTemplate):
+        return _analytic_patches(template, xy, H, W)
     _need_gpu(template, "get_patch template")
     if template.dim() != 2:
         raise ValueError("get_patch: template must be 2-D")
@@ -769,6 +824,26 @@ def gather_patches(template: torch.Tensor, xy, H: int, W: int) -> torch.Tensor:
     lib = _lib()
     L.check(lib.ynet_gather_patch(template.data_ptr(), SH, SW, coords.data_ptr(), out.data_ptr(), n, H, W,
                                   st.data_ptr(), _stream()), lib)
+    return out
+
+
+def _analytic_patches(t: AnalyticTemplate, xy, H: int, W: int) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("get_patch: the MI355X path runs on HIP devices only (no CPU fallback exists by design)")
+    dev = t.device
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"get_patch: template lives on {dev} but the current HIP device is cuda:{torch.cuda.current_device()}")
+    if torch.is_tensor(xy) and xy.is_cuda:
+        coords = xy.detach().reshape(-1, 2).float().contiguous()
+    else:
+        coords = torch.from_numpy(np.ascontiguousarray(check_patch_windows(t.shape, xy, H, W))).to(dev, non_blocking=True)
+    n = coords.shape[0]
+    out = torch.empty((n, H, W), device=dev, dtype=torch.float32)
+    st = _status_flag(_patch_status, dev)
+    lib = _lib()
+    L.check(lib.ynet_heatmap_analytic(coords.data_ptr(), out.data_ptr(), n, H, W, t.size, 0 if t.kind == "dist" else 1, t.dmax,
+                                      t.blob.data_ptr() if t.blob is not None else None,
+                                      t.blob.shape[0] if t.blob is not None else 0, st.data_ptr(), _stream()), lib)
     return out
 
 

@@ -39,6 +39,20 @@ def create_dist_mat(size, normalize=True):
     return dist / dist.max() * 2 if normalize else dist
 
 
+def analytic_dist_template(size, device):
+    """create_dist_mat(size) as an ops.AnalyticTemplate: windows are computed in the kernel, bit-identical to slices of
+    the float64 -> fp32 array, and the S x S array is never built."""
+    return ops.AnalyticTemplate("dist", size, device)
+
+
+def analytic_gaussian_template(size, kernlen=81, nsig=4, normalize=True, device="cuda"):
+    """create_gaussian_heatmap_template(...) as an ops.AnalyticTemplate (only its kernlen x kernlen blob is kept)."""
+    blob = gkern(kernlen=kernlen, nsig=nsig)
+    if normalize:
+        blob = blob / blob.max()
+    return ops.AnalyticTemplate("gaussian", size, device, blob=blob, normalize=normalize)
+
+
 def gather_patches(template, traj, H, W):
     """template [S,S] (device), traj [N,2] (x,y) -> [N,H,W] device tensor."""
     return ops.gather_patches(template, traj, H, W)

@@ -512,3 +512,30 @@ def test_fused_predictor_and_bce(dev, B, cin, cout, H, W, train_pred, scale, up)
     # twice in a row on the same stream: the workspace ticket was reset by the kernel
     y2, l2 = ops.pred_bce(x.to(dev), w.to(dev), b.to(dev), t.to(dev), up, {})
     assert torch.equal(y2, yd) and float(l2) == float(ld)
+
+
+@pytest.mark.parametrize("S,H,W", [(1050, 256, 256), (1386, 512, 512), (1050, 96, 160), (1386, 37, 50)])
+def test_analytic_heatmaps_are_bit_identical_to_template_slices(dev, S, H, W):
+    """the windows get_patch slices out of create_dist_mat / create_gaussian_heatmap_template
+    (utils/image_utils.py:15-63), computed in the kernel from the coordinate alone (fp64 sqrt / division rounded once to
+    fp32; the 31 x 31 blob as a table) -- bit for bit the slices of the float64 NumPy templates cast to fp32."""
+    ops, iu = pkg("ops"), pkg("utils.image_utils")
+    gen = torch.Generator().manual_seed(S + H)
+    xy = torch.rand(40, 2, generator=gen) * torch.tensor([W * 1.0, H * 1.0])
+    xy[0] = torch.tensor([0.5, 1.5])                       # round-half-even corners
+    xy[1] = torch.tensor([W - 0.5, H - 1.49])
+    xy[2] = torch.tensor([2.5, 3.5])
+    for kind, tmpl, ana in (
+            ("dist", torch.Tensor(iu.create_dist_mat(size=S)), iu.analytic_dist_template(S, dev)),
+            ("gauss", torch.Tensor(iu.create_gaussian_heatmap_template(size=S, kernlen=31, nsig=4, normalize=False)),
+             iu.analytic_gaussian_template(S, 31, 4, False, dev)),
+            ("gauss_norm", torch.Tensor(iu.create_gaussian_heatmap_template(size=S, kernlen=31, nsig=4, normalize=True)),
+             iu.analytic_gaussian_template(S, 31, 4, True, dev))):
+        want = ops.gather_patches(tmpl.to(dev), xy, H, W)
+        got = ops.gather_patches(ana, xy, H, W)
+        assert torch.equal(got, want), (kind, float((got - want).abs().max()))
+        got_dev = ops.gather_patches(ana, xy.to(dev), H, W)          # device-side coordinates (captured steps)
+        assert torch.equal(got_dev, want), kind
+        assert torch.equal(ana.materialize().cpu(), tmpl), kind
+    with pytest.raises(ValueError, match="leaves"):
+        ops.gather_patches(iu.analytic_dist_template(S, dev), torch.tensor([[S * 1.0, 0.0]]), H, W)

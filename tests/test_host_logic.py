@@ -167,3 +167,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no fallback"):
         L.load()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+def test_checkpoints_round_trip_through_the_reference():
+    """oracle/check_ckpt_roundtrip.py: product-written full / delta checkpoints load into the REFERENCE's YNetTrainer
+    (load_params / load_separated_params, models/trainer.py:586-614) and reference-written ones into the product,
+    every tensor bit-identical (six train_net modes)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "check_ckpt_roundtrip.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all cases identical in both directions" in r.stdout

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round profile (run on the GPU box through gpurun; results land in gpurun_out/prof_<tag>/, tools/pmc_aggregate.py and a
+# copy step turn them into the files committed under profiles/):
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'
+#  1. rocprofv3 --kernel-trace --stats of `python3 bench.py` as the driver runs it (captured step, parallel branches)
+#  2. the same with YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1: eager launches on one stream = isolated per-kernel durations,
+#     the condition under which bench.py times the dominant kernel for its `roofline` object
+#  3. PMC passes FETCH_SIZE / WRITE_SIZE (separate passes, never combined with a trace domain) of the eager serial run
+#  4. bench lines: C2 (default, with cpu_baseline + parity_check), C2 at the reference scripts' batch 10, C1, C3, C4, C5
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py"
+rm -rf /tmp/tr_*
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_graph -o t -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > "$OUT/trace_graph.log" 2>&1
+echo "trace graph rc=$?"; python3 "$R/tools/trace_summary.py" /tmp/tr_graph "$OUT/${TAG}_bench_C2" --tail-frac 0.6 > "$OUT/timeline_graph.txt"
+export YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_serial -o t -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > "$OUT/trace_serial.log" 2>&1
+echo "trace serial rc=$?"; python3 "$R/tools/trace_summary.py" /tmp/tr_serial "$OUT/${TAG}_bench_C2_serial" --tail-frac 0.6 > "$OUT/timeline_serial.txt"
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > "$OUT/fetch.log" 2>&1
+echo "fetch rc=$?"
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > "$OUT/write.log" 2>&1
+echo "write rc=$?"
+unset YNET_STEP_GRAPH YNET_SERIAL_DECODERS
+cd "$R"
+$B --steps 30 --warmup 5 > "$OUT/${TAG}_bench_C2_line.json" 2> "$OUT/bench_C2.err"; echo "C2 rc=$?"
+$B --steps 30 --warmup 5 --batch 10 --no-cpu-baseline > "$OUT/${TAG}_bench_C2_batch10_line.json" 2> "$OUT/bench_C2_b10.err"; echo "C2 b10 rc=$?"
+YNET_STEP_GRAPH=0 $B --steps 30 --warmup 5 --batch 10 --no-cpu-baseline --no-roofline > "$OUT/${TAG}_bench_C2_batch10_eager_line.json" 2>/dev/null
+for c in C1 C3 C4 C5; do
+  $B --steps 20 --warmup 5 --config $c --no-cpu-baseline > "$OUT/${TAG}_bench_${c}_line.json" 2> "$OUT/bench_$c.err"; echo "$c rc=$?"
+done
+ls -la "$OUT"
