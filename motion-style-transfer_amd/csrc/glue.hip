@@ -3,6 +3,7 @@
 // (16-byte where alignment allows), wavefront (64-lane) shuffles for reductions.
 // Reference call sites are cited per kernel; the public C ABI is include/ynet_hip.h.
 #include "ynet_common.h"
+#include <stdlib.h>
 
 // Plane-wise kernels: blockIdx.y walks the (b,c) planes, blockIdx.x the items of a plane -- the item index stays
 // 32-bit and costs one division (by the row length) instead of the three 64-bit divisions of a flat index, which made
@@ -526,8 +527,10 @@ struct PredBceArgs {
 
 typedef const __attribute__((address_space(4))) float* glue_const_f32_ptr;      // uniform reads -> scalar loads
 
+// (4 workgroups per CU = 4 waves per SIMD: <= 128 VGPRs.  Left alone hipcc hoists the loads of both loops and takes 175
+// registers -- 2 waves per SIMD, too few to hide the HBM latency of a streaming kernel: 213 -> see DESIGN.md)
 template <int CT, int PX>
-__global__ __launch_bounds__(256) void pred_bce_kernel(const PredBceArgs a) {
+__global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2))) void pred_bce_kernel(const PredBceArgs a) {
     typedef float vec_t __attribute__((ext_vector_type(PX)));
     __shared__ double ws[4];
     __shared__ unsigned last;
@@ -546,14 +549,27 @@ __global__ __launch_bounds__(256) void pred_bce_kernel(const PredBceArgs a) {
 #pragma unroll
             for (int e = 0; e < PX; ++e) acc[co][e] = bv;
         }
-#pragma unroll 2
-        for (int ci = 0; ci < a.cin; ++ci) {
-            const vec_t v = xp[(long long)ci * hwv];
+        // NB input planes are fetched before their FMAs start: a streaming kernel lives on bytes in flight (with two
+        // loads per thread outstanding it reached 3.3 TB/s -- Little's law at ~2.5 us of loaded HBM latency)
+        constexpr int NB = 8;
+#pragma unroll 1
+        for (int c0 = 0; c0 < a.cin; c0 += NB) {
+            vec_t v[NB];
 #pragma unroll
-            for (int co = 0; co < CT; ++co) {
-                const float wv = w[ci * a.cout_pad + co];
+            for (int k = 0; k < NB; ++k) {
+                const int ci = c0 + k < a.cin ? c0 + k : a.cin - 1;      // (clamped: the surplus products are skipped below)
+                v[k] = xp[(long long)ci * hwv];
+            }
 #pragma unroll
-                for (int e = 0; e < PX; ++e) acc[co][e] = __builtin_fmaf(v[e], wv, acc[co][e]);
+            for (int k = 0; k < NB; ++k) {
+                if (c0 + k < a.cin) {
+#pragma unroll
+                    for (int co = 0; co < CT; ++co) {
+                        const float wv = w[(c0 + k) * a.cout_pad + co];
+#pragma unroll
+                        for (int e = 0; e < PX; ++e) acc[co][e] = __builtin_fmaf(v[k][e], wv, acc[co][e]);
+                    }
+                }
             }
         }
         const long long obase = (long long)b * a.cout * hwv + p;
@@ -1090,13 +1106,14 @@ int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, con
     a.hw4 = HW / 4;
     a.n = (long long)B * cout * HW;
     a.gs = expected_grad / (float)a.n;
-    if (cout <= 16) {
-        const int parts = grid_for((long long)B * a.hw4, 256, YNET_BCE_PARTS);
-        hipLaunchKernelGGL((pred_bce_kernel<16, 4>), dim3(parts), dim3(256), 0, (hipStream_t)stream, a);
-    } else {
-        const int parts = grid_for((long long)B * a.hw4 * 2, 256, YNET_BCE_PARTS);
-        hipLaunchKernelGGL((pred_bce_kernel<32, 2>), dim3(parts), dim3(256), 0, (hipStream_t)stream, a);
-    }
+    // exact channel counts for the two prediction horizons of the shipped configs (12 and 30 steps): no padded FMAs
+    const int parts4 = grid_for((long long)B * a.hw4, 256, YNET_BCE_PARTS), parts2 = grid_for((long long)B * a.hw4 * 2, 256, YNET_BCE_PARTS);
+    static const int px2 = getenv("YNET_PRED_PX2") ? atoi(getenv("YNET_PRED_PX2")) : 0;
+    if (cout == 12 && px2) hipLaunchKernelGGL((pred_bce_kernel<12, 2>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
+    else if (cout == 12) hipLaunchKernelGGL((pred_bce_kernel<12, 4>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);
+    else if (cout <= 16) hipLaunchKernelGGL((pred_bce_kernel<16, 4>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);
+    else if (cout == 30) hipLaunchKernelGGL((pred_bce_kernel<30, 2>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((pred_bce_kernel<32, 2>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
     return ynet_check_launch("pred_bce");
 }
 

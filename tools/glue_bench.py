@@ -48,3 +48,23 @@ pout = torch.empty(B * 12, H, W, device=dev)
 stat = torch.zeros(1, dtype=torch.int32, device=dev)
 timeit("gather_patch", lambda: L.check(lib.ynet_gather_patch(tmpl.data_ptr(), S, S, xy.data_ptr(), pout.data_ptr(), B * 12, H, W,
                                                              stat.data_ptr(), st()), lib), pout.numel() * 4)
+# fused predictor + BCE (+ predictor dgrad) against the three launches it replaces
+for cout in (12, 30):
+    x32 = torch.randn(B, 32, H, W, device=dev).relu_()
+    w = torch.randn(cout, 32, 1, 1, device=dev) * 0.2
+    bias = torch.randn(cout, device=dev) * 0.1
+    tgt = torch.rand(B, cout, H, W, device=dev) * 0.01
+    wp, wpd = ops.pack_weight(w, 0), ops.pack_weight(w, 1)
+    y, dxo, dyo = torch.empty(B, cout, H, W, device=dev), torch.empty_like(x32), torch.empty(B, cout, H, W, device=dev)
+    loss = torch.empty((), device=dev)
+    ws = torch.zeros(lib.ynet_pred_bce_workspace_bytes() // 8 + 1, device=dev, dtype=torch.float64)
+    planes = (32 + cout + cout + 32) * B * H * W * 4
+    timeit(f"pred_bce cout={cout}", lambda: L.check(lib.ynet_pred_bce(x32.data_ptr(), 32 * H * W, wp.data_ptr(), bias.data_ptr(), tgt.data_ptr(), y.data_ptr(),
+                                                                    loss.data_ptr(), dxo.data_ptr(), None, ws.data_ptr(), B, 32, cout, H * W, 1000.0, st()), lib), planes)
+    bws = torch.empty(lib.ynet_bce_workspace_bytes() // 8, device=dev, dtype=torch.float64)
+
+    def unfused():
+        ops.conv2d_raw([(x32.data_ptr(), 32, 32 * H * W)], None, wp, bias, [(y.data_ptr(), cout, cout * H * W)], B, H, W, 1, False)
+        L.check(lib.ynet_bce_logits_fwd_grad(y.data_ptr(), tgt.data_ptr(), y.numel(), 1000.0, loss.data_ptr(), dyo.data_ptr(), bws.data_ptr(), st()), lib)
+        ops.conv2d_raw([(dyo.data_ptr(), cout, cout * H * W)], None, wpd, None, [(dxo.data_ptr(), 32, 32 * H * W)], B, H, W, 1, False)
+    timeit(f"unfused   cout={cout}", unfused, (32 + cout + 3 * cout + cout + 32) * B * H * W * 4)
