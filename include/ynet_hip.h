@@ -194,6 +194,28 @@ int ynet_cws_prior(const float* sig, long long sig_batch_stride, int n_persons, 
                    int rows, int H, int W, float sigma_factor, float ratio, int rot, float* out_map, float* out_xy,
                    void* stream);
 
+/* ---- data-parallel exchange (new: the reference is single-process) --------------- */
+/* One-shot all-reduce(SUM) of the flat trainable-gradient buffer among the GPUs of ONE node: every rank publishes its
+ * buffer in a mailbox the other ranks map through HIP IPC (peer access over xGMI) and reads the N - 1 peers directly --
+ * one hop instead of a ring's 2 (N - 1) -- summing in rank order, so all ranks obtain bit-identical results.
+ *   ynet_comm_create(rank, world, max_floats, &comm)   allocate this rank's mailbox (world <= 16)
+ *   ynet_comm_export(comm, handle)                     its IPC handle, ynet_comm_handle_bytes() bytes; exchange the handles
+ *                                                      out of band (motion-style-transfer_amd/dist.py: all_gather_object)
+ *   ynet_comm_connect(comm, handles)                   `world` handles in rank order (the own entry is ignored)
+ *   ynet_allreduce_sum(comm, buf, n, stream)           in place, n <= max_floats; collective: every rank calls it the same
+ *                                                      number of times; NOT capturable into a hipGraph (epoch argument)
+ *   ynet_comm_status(comm)                             1 if a wait for a peer ever timed out (~20 s), else 0; synchronises
+ *   ynet_comm_destroy(comm)
+ * torch.distributed (RCCL) remains the default transport of dist.DataParallel; this path is selected with
+ * YNET_ALLREDUCE=oneshot. */
+long long ynet_comm_handle_bytes(void);
+int ynet_comm_create(int rank, int world, long long max_floats, void** comm_out);
+int ynet_comm_export(void* comm, void* handle_out);
+int ynet_comm_connect(void* comm, const void* handles);
+int ynet_allreduce_sum(void* comm, float* buf, long long n, void* stream);
+int ynet_comm_status(void* comm);
+int ynet_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,13 @@ SIGNATURES = {
     "ynet_gather_patch": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "ynet_heatmap_analytic": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, ctypes.c_double, c_fp, c_i, c_fp, c_fp]),
     "ynet_kmeans2d": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, ctypes.c_float, c_i, c_fp]),
+    "ynet_comm_handle_bytes": (c_ll, []),
+    "ynet_comm_create": (c_i, [c_i, c_i, c_ll, PP]),
+    "ynet_comm_export": (c_i, [c_fp, c_fp]),
+    "ynet_comm_connect": (c_i, [c_fp, c_fp]),
+    "ynet_allreduce_sum": (c_i, [c_fp, c_fp, c_ll, c_fp]),
+    "ynet_comm_status": (c_i, [c_fp]),
+    "ynet_comm_destroy": (c_i, [c_fp]),
     "ynet_multinomial": (c_i, [c_fp, c_ll, c_ll, c_i, c_i, c_i, c_f, ctypes.c_ulonglong, c_fp, c_fp, c_fp]),
     "ynet_cws_prior": (c_i, [c_fp, c_ll, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_i, c_fp, c_fp, c_fp]),
 }

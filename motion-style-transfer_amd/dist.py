@@ -17,10 +17,15 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, collective=None):
+        """``collective``: "rccl" (torch.distributed all_reduce: RCCL over xGMI, or gloo in tests; the default) or "oneshot"
+        (ynet_allreduce_sum: every rank reads its peers' buffers through HIP IPC in one hop, rank-ordered sums; one node,
+        <= 16 ranks; default when YNET_ALLREDUCE=oneshot).  torch.distributed stays the control plane either way."""
         if not dist.is_initialized():
             raise RuntimeError("DataParallel needs an initialised torch.distributed process group")
         self.group = group
+        self.collective = collective or os.environ.get("YNET_ALLREDUCE", "rccl")
+        self._comm = None
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -35,6 +40,30 @@ class DataParallel:
             self._views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.bind()
+        if self.collective == "oneshot" and self.world > 1:
+            self._connect_oneshot()
+
+    def _connect_oneshot(self):
+        import ctypes
+        from . import _lib as L
+        if not self.flat.is_cuda:
+            raise RuntimeError("the one-shot all-reduce exchanges device buffers: parameters must live on a HIP device")
+        lib = L.load()
+        comm = ctypes.c_void_p()
+        L.check(lib.ynet_comm_create(self.rank, self.world, self.flat.numel(), ctypes.byref(comm)), lib)
+        nb = lib.ynet_comm_handle_bytes()
+        mine = ctypes.create_string_buffer(nb)
+        L.check(lib.ynet_comm_export(comm, mine), lib)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine.raw, group=self.group)       # control plane: torch.distributed
+        L.check(lib.ynet_comm_connect(comm, b"".join(handles)), lib)
+        dist.barrier(group=self.group)
+        self._comm, self._lib = comm, lib
+
+    def close(self):
+        if self._comm is not None:
+            self._lib.ynet_comm_destroy(self._comm)
+            self._comm = None
 
     # -- sharding ---------------------------------------------------------------------------
     def shard(self, n: int) -> Tuple[int, int]:
@@ -66,7 +95,12 @@ class DataParallel:
     def allreduce(self):
         """The ONE collective of a step: SUM all-reduce of the flat buffer, in place, on the current stream."""
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self._comm is not None:
+                from . import _lib as L
+                L.check(self._lib.ynet_allreduce_sum(self._comm, self.flat.data_ptr(), self.flat.numel(),
+                                                     torch.cuda.current_stream(self.flat.device).cuda_stream), self._lib)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def loss_value(self) -> torch.Tensor:
         return self.flat[-1].clone()

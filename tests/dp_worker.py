@@ -61,7 +61,8 @@ def main():
     info = [None] * world
     dist.all_gather_object(info, {"rank": rank, "device": str(dev), "pid": os.getpid()})
     if rank == 0:
-        res["world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": info}
+        res["world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": info,
+                        "collective": os.environ.get("YNET_ALLREDUCE", "rccl")}
         torch.save(res, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -22,12 +22,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-# (rows, batch size): even shards; ragged shards (3 -> 2 + 1) and a ragged last batch; batch of 1 -> rank 1's shard is EMPTY
-@pytest.mark.parametrize("n_rows,batch_size", [(8, 4), (8, 3), (3, 1)])
-def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch_size):
+# (rows, batch size): even shards; ragged shards (3 -> 2 + 1) and a ragged last batch; batch of 1 -> rank 1's shard is EMPTY.
+# collective "oneshot": ynet_allreduce_sum (HIP-IPC mailboxes, one hop, rank-ordered sums) instead of torch.distributed.
+@pytest.mark.parametrize("n_rows,batch_size,collective", [(8, 4, "rccl"), (8, 3, "rccl"), (3, 1, "rccl"), (8, 3, "oneshot"), (3, 1, "oneshot")])
+def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch_size, collective):
     out = str(tmp_path / "dp.pt")
     n_gpu = torch.cuda.device_count()
-    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "YNET_ALLREDUCE": collective}
     if n_gpu < 2:
         env.update(YNET_DIST_BACKEND="gloo", YNET_BENCH_SINGLE_DEVICE="1")
     rc, tail = launch([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
@@ -37,6 +38,7 @@ def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch
     got = torch.load(out, weights_only=False)
     assert got["world"]["world_size"] == 2 and len({r["pid"] for r in got["world"]["ranks"]}) == 2
     assert got["world"]["backend"] == ("nccl" if n_gpu >= 2 else "gloo")
+    assert got["world"]["collective"] == collective
 
     cfg, sd, scene, traj = case_inputs(n_rows)
     want = run_epochs(cfg, sd, scene, traj, batch_size, dev, lambda m: None)
