@@ -57,6 +57,14 @@ def main():
             hist[k] += 1
         return {"kernels": len(rs), "busy_ms": busy / 1e6, "wall_ms": wall / 1e6, "busy_over_wall": busy / wall,
                 "gap_ms_total": sum(gaps) / 1e6, "gap_us_median": statistics.median(gaps) / 1e3 if gaps else 0, "gap_hist": hist}
+    if "--dump" in sys.argv:        # timeline of the last `--dump N` kernels: start offset, duration, concurrency
+        k = int(sys.argv[sys.argv.index("--dump") + 1])
+        last = rows[-k:]
+        t0 = last[0][1]
+        with open(out + "_dump.txt", "w") as f:
+            for i, (n, a, b) in enumerate(last):
+                conc = sum(1 for (_, a2, b2) in last[max(0, i - 8):i + 8] if a2 < b and b2 > a) - 1
+                f.write(f"{(a - t0) / 1e3:10.1f} us  +{(b - a) / 1e3:8.1f} us  x{conc}  {n[:90]}\n")
     tail = rows[int(len(rows) * (1 - frac)):]
     json.dump({"all": span(rows), f"last_{frac}": span(tail)}, open(out + "_timeline.json", "w"), indent=1)
     print(open(out + "_timeline.json").read())
