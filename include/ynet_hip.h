@@ -70,15 +70,6 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
                       const float* dy, long long dy_bs, const float* mask, long long mask_bs,
                       float* dw, float* db, float* workspace, int B, int H, int W, int cout, int K,
                       void* stream);
-/* The same for an adapted (MoSA / LoRA) conv: the launch that reduces the partial sums of dW also projects it onto the
- * adapter -- d_a = scale * lora_B^T dWm [r*K][cin*K], d_b = scale * dWm lora_A^T [cout*K][r*K], dWm = dW viewed as
- * [cout*K][cin*K] (loralib 0.1.1 Conv2d; models/ynet.py:141-144) -- instead of a second (ynet_lora_grad) launch chain.
- * `ticket`: a device counter that is zero before the call and left at zero; r * K <= 24. */
-int ynet_conv2d_wgrad_lora(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
-                           const float* dy, long long dy_bs, const float* mask, long long mask_bs,
-                           float* dw, float* db, float* workspace, int B, int H, int W, int cout, int K,
-                           const float* lora_a, const float* lora_b, float scale, int r, float* d_a, float* d_b,
-                           unsigned* ticket, void* stream);
 
 /* ---- MoSA / LoRA (loralib==0.1.1 Conv2d, call site models/ynet.py:141-144) -------------------
  * lora_a [r*K][cin*K], lora_b [cout*K][r*K], scale = lora_alpha / r (lora_alpha = 1).

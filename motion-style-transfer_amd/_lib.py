@@ -32,8 +32,6 @@ SIGNATURES = {
     "ynet_conv2d_wgrad_workspace_floats": (c_ll, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_wgrad": (c_i, [PP, PI, PLL, c_i, c_fp, c_ll, c_fp, c_ll, c_fp, c_fp, c_fp,
                                 c_i, c_i, c_i, c_i, c_i, c_fp]),
-    "ynet_conv2d_wgrad_lora": (c_i, [PP, PI, PLL, c_i, c_fp, c_ll, c_fp, c_ll, c_fp, c_fp, c_fp,
-                                     c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_f, c_i, c_fp, c_fp, c_fp, c_fp]),
     "ynet_lora_compose": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_grad": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_compose_pack": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),

@@ -55,11 +55,19 @@ __global__ __launch_bounds__(64) void small_gemm2_mfma_kernel(const GemmArgs g0,
     const int r = lane & 15, kq = lane >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int am = m0 + r, bn = n0 + r;
-    for (int k0 = 0; k0 < g.K; k0 += 4) {
-        const int k = k0 + kq;
-        const float a = (am < g.M && k < g.K) ? g.A[am * g.sam + k * g.sak] : 0.f;
-        const float b = (bn < g.N && k < g.K) ? g.B[k * g.sbk + bn * g.sbn] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    // the operand loads of 8 K-steps are issued together: one round trip to L2 per 8 MFMAs instead of one per MFMA
+    // (K = Cout*k = 96 .. 192 here: 48 dependent round trips took 16-20 us per layer, on the critical path of the
+    // encoder's backward pass)
+    for (int k0 = 0; k0 < g.K; k0 += 32) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq;
+            a[u] = (am < g.M && k < g.K) ? g.A[am * g.sam + k * g.sak] : 0.f;
+            b[u] = (bn < g.N && k < g.K) ? g.B[k * g.sbk + bn * g.sbn] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -677,113 +677,6 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
-// Reduction of the wgrad partials AND the LoRA projections of the reduced gradient in one launch (the adapted encoder
-// convs of train_net = mosa_*: dW itself is not a trainable tensor, only dA = s * B^T dWm and dB = s * dWm A^T are;
-// lora.hip has the algebra).  Every block reduces its share of dW exactly like reduce_partials_kernel; the LAST block to
-// finish (ticket) then owns the complete dW (147 KB at most, L2-resident) and computes both projections on the vector
-// ALUs: dA[j][n] by one thread per column n (coalesced rows of dW), dB[m][j] by one wavefront per row m.  This replaces
-// a chain of three launches (reduce, dA / dB GEMM tiles with 48 dependent K-steps of strided loads: 16-20 us) that sat
-// on the critical path of the encoder's backward pass.  Fixed summation orders: bitwise reproducible.
-struct LoraTail {
-    const float* lora_a;    // [Kd][N]
-    const float* lora_b;    // [M][Kd]
-    float* d_a;             // [Kd][N]
-    float* d_b;             // [M][Kd]
-    unsigned* ticket;       // device counter, zero before the launch; left at zero
-    int M, N, Kd;           // M = cout * K, N = cin * K, Kd = r * K
-    float scale;
-};
-#define YNET_LORA_KD_MAX 24
-
-__global__ __launch_bounds__(256) void reduce_partials_lora_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                                   long long n, int nsplit, const LoraTail t) {
-    __shared__ float red[8][32];
-    __shared__ unsigned last;
-    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
-    for (long long base = blockIdx.x * 32ll; base < n; base += (long long)gridDim.x * 32) {
-        const long long i = base + o;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if (i < n) {
-            int s = g;
-            for (; s + 24 < nsplit; s += 32) {
-                s0 += partial[(long long)s * n + i];
-                s1 += partial[(long long)(s + 8) * n + i];
-                s2 += partial[(long long)(s + 16) * n + i];
-                s3 += partial[(long long)(s + 24) * n + i];
-            }
-            for (; s < nsplit; s += 8) s0 += partial[(long long)s * n + i];
-        }
-        red[g][o] = (s0 + s1) + (s2 + s3);
-        __syncthreads();
-        if (g == 0 && i < n) {
-            float v = red[0][o];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) v += red[q][o];
-            out[i] = v;
-        }
-        __syncthreads();
-    }
-    __threadfence();
-    if (threadIdx.x == 0) last = (atomicAdd(t.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    const volatile float* dw = out;        // written by the other blocks of this launch: read past this CU's L1
-    const int M = t.M, N = t.N, Kd = t.Kd;
-    // dA[j][col] = s * sum_m B[m][j] * dW[m][col]
-    for (int col = threadIdx.x; col < N; col += 256) {
-        float acc[YNET_LORA_KD_MAX];
-#pragma unroll
-        for (int j = 0; j < YNET_LORA_KD_MAX; ++j) acc[j] = 0.f;
-        for (int m = 0; m < M; ++m) {
-            const float v = dw[(long long)m * N + col];
-#pragma unroll
-            for (int j = 0; j < YNET_LORA_KD_MAX; ++j)
-                if (j < Kd) acc[j] = __builtin_fmaf(t.lora_b[m * Kd + j], v, acc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < YNET_LORA_KD_MAX; ++j)
-            if (j < Kd) t.d_a[(long long)j * N + col] = t.scale * acc[j];
-    }
-    // dB[m][j] = s * sum_col dW[m][col] * A[j][col]: one wavefront per row
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int m = wave; m < M; m += 4) {
-        float acc[YNET_LORA_KD_MAX];
-#pragma unroll
-        for (int j = 0; j < YNET_LORA_KD_MAX; ++j) acc[j] = 0.f;
-        for (int col = lane; col < N; col += 64) {
-            const float v = dw[(long long)m * N + col];
-#pragma unroll
-            for (int j = 0; j < YNET_LORA_KD_MAX; ++j)
-                if (j < Kd) acc[j] = __builtin_fmaf(v, t.lora_a[(long long)j * N + col], acc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < YNET_LORA_KD_MAX; ++j) {
-            if (j < Kd) {
-                float v = acc[j];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                if (lane == 0) t.d_b[(long long)m * Kd + j] = t.scale * v;
-            }
-        }
-    }
-    if (threadIdx.x == 0) *t.ticket = 0u;
-}
-
-// the LoRA tail of the call in flight (set by ynet_conv2d_wgrad_lora around the common implementation)
-static thread_local const LoraTail* g_lora_tail = nullptr;
-
-static int launch_reduce(const WgradArgs& a, float* dw, float* db, long long nw, hipStream_t st) {
-    int grid = (int)((nw + 31) / 32);
-    if (grid > 4096) grid = 4096;
-    if (g_lora_tail != nullptr)
-        hipLaunchKernelGGL(reduce_partials_lora_kernel, dim3(grid), dim3(256), 0, st, a.partial_w, dw, nw, a.nsplit, *g_lora_tail);
-    else
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, a.partial_w, dw, nw, a.nsplit);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.partial_b, db, (long long)a.cout, a.nsplit);
-    return ynet_check_launch("conv2d_wgrad(reduce)");
-}
-
 template <int KS, bool MASK>
 static int launch_wgrad_m(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     using C = WgCfg<KS>;
@@ -798,7 +691,12 @@ static int launch_wgrad_m(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<KS, MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
     int rc = ynet_check_launch("conv2d_wgrad");
     if (rc) return rc;
-    return launch_reduce(a, dw, db, (long long)a.cout * a.cin * C::KK, st);
+    const long long nw = (long long)a.cout * a.cin * C::KK;
+    int grid = (int)((nw + 31) / 32);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, a.partial_w, dw, nw, a.nsplit);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.partial_b, db, (long long)a.cout, a.nsplit);
+    return ynet_check_launch("conv2d_wgrad(reduce)");
 }
 
 template <bool MASK, int TH_>
@@ -853,7 +751,12 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
     }
     int rc = ynet_check_launch("conv2d_wgrad");
     if (rc) return rc;
-    return launch_reduce(a, dw, db, (long long)a.cout * a.cin * 9, st);
+    const long long nw = (long long)a.cout * a.cin * 9;
+    int grid = (int)((nw + 31) / 32);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, a.partial_w, dw, nw, a.nsplit);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.partial_b, db, (long long)a.cout, a.nsplit);
+    return ynet_check_launch("conv2d_wgrad(reduce)");
 }
 
 template <int KS>
@@ -941,34 +844,6 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
         case 5: return launch_wgrad<5>(a, dw, db, st);
         default: ynet_set_error("conv2d_wgrad: kernel size %d not supported (1, 3, 5)", K); return 1;
     }
-}
-
-// ynet_conv2d_wgrad for an adapted (MoSA / LoRA) conv: dW goes to `dw` as before, and the same reduction launch also
-// writes dA = s * B^T dWm and dB = s * dWm A^T (lora_a [r*K][cin*K], lora_b [cout*K][r*K]); `ticket` is a device
-// counter that is zero before the call (the kernel leaves it at zero).
-int ynet_conv2d_wgrad_lora(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
-                           const float* dy, long long dy_bs, const float* mask, long long mask_bs,
-                           float* dw, float* db, float* workspace, int B, int H, int W, int cout, int K,
-                           const float* lora_a, const float* lora_b, float scale, int r, float* d_a, float* d_b,
-                           unsigned* ticket, void* stream) {
-    YNET_REQUIRE(lora_a && lora_b && d_a && d_b && ticket, "conv2d_wgrad_lora: null pointer");
-    YNET_REQUIRE(r > 0 && r * K <= YNET_LORA_KD_MAX, "conv2d_wgrad_lora: rank * K = %d exceeds %d", r * K, YNET_LORA_KD_MAX);
-    int cin = 0;
-    for (int i = 0; i < nsrc && i < YNET_MAX_SRC; ++i) cin += src_c[i];
-    LoraTail t{};
-    t.lora_a = lora_a;
-    t.lora_b = lora_b;
-    t.d_a = d_a;
-    t.d_b = d_b;
-    t.ticket = ticket;
-    t.M = cout * K;
-    t.N = cin * K;
-    t.Kd = r * K;
-    t.scale = scale;
-    g_lora_tail = &t;
-    const int rc = ynet_conv2d_wgrad(src, src_c, src_bs, nsrc, dy, dy_bs, mask, mask_bs, dw, db, workspace, B, H, W, cout, K, stream);
-    g_lora_tail = nullptr;
-    return rc;
 }
 
 }  // extern "C"

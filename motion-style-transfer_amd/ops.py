@@ -303,6 +303,15 @@ def _cached(cache: dict, weight, lora_a, lora_b, scale, what: str):
     return cache[what]
 
 
+def refresh_lora_filters(model):
+    """Compose W + BA*s and write both packed filter layouts of every adapted (LoRA) conv of `model` whose parameters
+    changed since its last compose -- what each conv would do itself at its first use in a step; doing it up front lets
+    the caller run these tiny launches beside other work instead of between the encoder's convolutions."""
+    for m in model.modules():
+        if getattr(m, "r", 0) and hasattr(m, "lora_A") and hasattr(m, "_packed"):
+            _cached(m._packed, m.weight, m.lora_A, m.lora_B, m.scaling, "fwd")
+
+
 # ------------------------------------------------------------------------------------------------
 # Skip-connection gradients folded into the max-pool backward
 # ------------------------------------------------------------------------------------------------
@@ -443,24 +452,16 @@ class _Conv2dFn(torch.autograd.Function):
         want_w = need[1] or (ctx.has_lora and (need[3] or need[4]))
         want_b = ctx.has_bias and need[2]
         if want_w or want_b:
-            if ctx.has_lora and (need[3] or need[4]) and lora_a.shape[0] <= 24:
-                # reduction of the wgrad partials + both LoRA projections in one launch
-                dw, d_b, d_a, d_bm = conv2d_wgrad_raw(srcs, dy, mask, weight, want_b, lora=(lora_a.detach(), lora_b.detach(), scale))
-            else:
-                dw, d_b = conv2d_wgrad_raw(srcs, dy, mask, weight, want_b)
-                if ctx.has_lora and (need[3] or need[4]):
-                    d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
+            dw, d_b = conv2d_wgrad_raw(srcs, dy, mask, weight, want_b)
+            if ctx.has_lora and (need[3] or need[4]):
+                d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
             if need[1]:
                 d_w = dw
         return (None, d_w, d_b, d_a if need[3] else None, d_bm if need[4] else None, *d_srcs)
 
 
-_wgrad_tickets = {}
-
-
-def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b, lora=None):
-    """(dW, db or None) of conv(cat(srcs), W) for the output gradient dy [B,cout,H,W] (masked where mask's plane <= 0);
-    with lora = (lora_A, lora_B, scale) also (dA, dB), projected inside the launch that reduces dW."""
+def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b):
+    """(dW, db or None) of conv(cat(srcs), W) for the output gradient dy [B,cout,H,W] (masked where mask's plane <= 0)."""
     lib = _lib()
     cout, cin, k, _ = weight.shape
     B, _, H, W = dy.shape
@@ -469,20 +470,6 @@ def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b, lora=None):
     dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
     d_b = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_b else None
     ws = torch.empty(lib.ynet_conv2d_wgrad_workspace_floats(B, H, W, cout, cin, k), device=dy.device, dtype=torch.float32)
-    if lora is not None:
-        la, lb, scale = lora
-        la, lb = la.contiguous(), lb.contiguous()
-        d_a, d_bm = torch.empty_like(la), torch.empty_like(lb)
-        key = (dy.device, torch.cuda.current_stream().cuda_stream)
-        tk = _wgrad_tickets.get(key)
-        if tk is None:
-            tk = _wgrad_tickets[key] = torch.zeros(4, device=dy.device, dtype=torch.int32)
-        L.check(lib.ynet_conv2d_wgrad_lora(sp, sc, sb, len(descs), dy.data_ptr(), cout * H * W,
-                                           mask[0] if mask else None, mask[1] if mask else 0,
-                                           dw.data_ptr(), d_b.data_ptr() if want_b else None, ws.data_ptr(),
-                                           B, H, W, cout, k, la.data_ptr(), lb.data_ptr(), float(scale), la.shape[0] // k,
-                                           d_a.data_ptr(), d_bm.data_ptr(), tk.data_ptr(), _stream()), lib)
-        return dw, d_b, d_a, d_bm
     L.check(lib.ynet_conv2d_wgrad(sp, sc, sb, len(descs), dy.data_ptr(), cout * H * W,
                                   mask[0] if mask else None, mask[1] if mask else 0,
                                   dw.data_ptr(), d_b.data_ptr() if want_b else None, ws.data_ptr(),

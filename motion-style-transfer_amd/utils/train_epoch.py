@@ -36,14 +36,33 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
     _, _, H, W = scene_image.shape
     with ops.fold_skip_gradients():      # skip-connection gradients summed inside the max-pool backward
         # heat-maps: distance map per observed step, Gaussian blob per future step, distance map per waypoint
+        def target_maps():
+            gt_map = gather_patches(gt_template, coords[:, obs_len:].reshape(-1, 2), H, W).view(-1, pred_len, H, W)
+            if coords.is_cuda:      # (a list index would upload an index tensor: not allowed inside a capture)
+                wps = coords[:, obs_len:].index_select(1, step_graph.waypoint_index(device, waypoints))
+            else:
+                wps = coords[:, obs_len:][:, waypoints]
+            return gt_map, gather_patches(input_template, wps.reshape(-1, 2), H, W).view(-1, len(waypoints), H, W)
+
+        side = None
+        if overlap and branches:
+            # Off the encoder's critical path, on a forked stream (a branch of the captured step): the target / way-point
+            # maps (needed by the decoders and the losses only) and the composed filters W + BA*s of the adapted convs
+            # (they depend on the weights alone; each conv then finds its packed filter up to date).
+            main0 = torch.cuda.current_stream(device)
+            side = ops.side_streams(device, 2)
+            side.wait_stream(main0)
+            with torch.cuda.stream(side):
+                gt_future_map, gt_waypoint_map = target_maps()
+                ops.refresh_lora_filters(model)
+            for t in (gt_future_map, gt_waypoint_map):
+                t.record_stream(main0)
         observed_map = gather_patches(input_template, coords[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
         gt_future = coords[:, obs_len:].to(device)
-        gt_future_map = gather_patches(gt_template, coords[:, obs_len:].reshape(-1, 2), H, W).view(-1, pred_len, H, W)
-        if coords.is_cuda:      # (a list index would upload an index tensor: not allowed inside a capture)
-            gt_waypoints = coords[:, obs_len:].index_select(1, step_graph.waypoint_index(device, waypoints))
+        if side is None:
+            gt_future_map, gt_waypoint_map = target_maps()
         else:
-            gt_waypoints = coords[:, obs_len:][:, waypoints]
-        gt_waypoint_map = gather_patches(input_template, gt_waypoints.reshape(-1, 2), H, W).view(-1, len(waypoints), H, W)
+            main0.wait_stream(side)      # (the composes are tiny: joined here; the encoder's first conv needs its filter)
         sem1 = semantic_img
         if network == "embed":      # utils/train_epoch.py:80-83 (before the expand)
             sem1 = model.scene_embedding(semantic_img)
