@@ -87,6 +87,11 @@ int ynet_lora_grad(const float* dw, const float* lora_a, const float* lora_b, fl
  * reused for the same layer every step). */
 int ynet_lora_compose_pack(const float* w, const float* lora_a, const float* lora_b, float scale, float* wp_fwd,
                            float* wp_dgrad, int cout, int cin, int K, int r, void* stream);
+/* The same for n <= 16 layers in ONE launch (every argument a host array of n entries): all adapted convs of an encoder
+ * are composed at the start of a step instead of one by one between its convolutions. */
+int ynet_lora_compose_pack_multi(int n, const float* const* w, const float* const* lora_a, const float* const* lora_b,
+                                 const float* scale, float* const* wp_fwd, float* const* wp_dgrad, const int* cout,
+                                 const int* cin, const int* K, const int* r, void* stream);
 
 /* ---- pooling / resampling ------------------------------------------------------------------- */
 /* nn.MaxPool2d(2,2) (models/ynet.py:202,215,326,340,354,367); N = B*C planes of H x W. */

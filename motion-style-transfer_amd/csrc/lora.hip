@@ -118,6 +118,44 @@ __global__ __launch_bounds__(64) void lora_compose_pack_kernel(const ComposePack
     }
 }
 
+// All adapted convs of a model in ONE launch (blockIdx.y = layer): the 9 composes of a mosa_* encoder are ~5 us launches
+// each; issued one by one in front of their convs they sit on the critical path of the encoder's forward pass.
+#define YNET_LORA_MULTI_MAX 16
+struct ComposePackMulti {
+    ComposePackArgs layer[YNET_LORA_MULTI_MAX];
+    int tiles[YNET_LORA_MULTI_MAX];
+};
+
+__global__ __launch_bounds__(64) void lora_compose_pack_multi_kernel(const ComposePackMulti mm) {
+    const ComposePackArgs& g = mm.layer[blockIdx.y];
+    if ((int)blockIdx.x >= mm.tiles[blockIdx.y]) return;
+    const int M = g.cout * g.K, N = g.cin * g.K, Kd = g.r * g.K;
+    const int lane = threadIdx.x;
+    const int tiles_n = (N + 15) / 16;
+    const int m0 = ((int)blockIdx.x / tiles_n) * 16, n0 = ((int)blockIdx.x % tiles_n) * 16;
+    const int r = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int am = m0 + r, bn = n0 + r;
+    for (int k0 = 0; k0 < Kd; k0 += 4) {
+        const int k = k0 + kq;
+        const float a = (am < M && k < Kd) ? g.lora_b[am * Kd + k] : 0.f;
+        const float b = (bn < N && k < Kd) ? g.lora_a[k * N + bn] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + kq * 4 + q, n = n0 + r;
+        if (m < M && n < N) {
+            const int flat = m * N + n;
+            const float v = g.scale * acc[q] + g.w[flat];
+            const int co = flat / (g.cin * g.KK), rem = flat - co * g.cin * g.KK;
+            const int ci = rem / g.KK, t = rem - ci * g.KK;
+            g.wp_fwd[((long long)ci * g.KK + t) * g.fwd_cols + co] = v;
+            g.wp_dgrad[((long long)co * g.KK + (g.KK - 1 - t)) * g.dgrad_cols + ci] = v;
+        }
+    }
+}
+
 static int run_gemm(const GemmArgs& g, hipStream_t st, const char* what) {
     const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
     hipLaunchKernelGGL(small_gemm_mfma_kernel, dim3(tiles), dim3(64), 0, st, g);
@@ -201,6 +239,38 @@ int ynet_lora_compose_pack(const float* w, const float* lora_a, const float* lor
     const int tiles = ((cout * K + 15) / 16) * ((cin * K + 15) / 16);
     hipLaunchKernelGGL(lora_compose_pack_kernel, dim3(tiles), dim3(64), 0, (hipStream_t)stream, g);
     return ynet_check_launch("lora_compose_pack");
+}
+
+// ynet_lora_compose_pack for `n` layers (n <= 16) in one launch; every argument is a HOST array of n entries.
+int ynet_lora_compose_pack_multi(int n, const float* const* w, const float* const* lora_a, const float* const* lora_b,
+                                 const float* scale, float* const* wp_fwd, float* const* wp_dgrad, const int* cout,
+                                 const int* cin, const int* K, const int* r, void* stream) {
+    YNET_REQUIRE(n >= 1 && n <= YNET_LORA_MULTI_MAX, "lora_compose_pack_multi: 1..%d layers per call (got %d)", YNET_LORA_MULTI_MAX, n);
+    YNET_REQUIRE(w && lora_a && lora_b && scale && wp_fwd && wp_dgrad && cout && cin && K && r, "lora_compose_pack_multi: null pointer");
+    ComposePackMulti mm{};
+    int max_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        YNET_REQUIRE(w[i] && lora_a[i] && lora_b[i] && wp_fwd[i] && wp_dgrad[i], "lora_compose_pack_multi: null pointer (layer %d)", i);
+        YNET_REQUIRE(cout[i] > 0 && cin[i] > 0 && (K[i] == 1 || K[i] == 3 || K[i] == 5) && r[i] > 0, "lora_compose_pack_multi: bad shape (layer %d)", i);
+        ComposePackArgs& g = mm.layer[i];
+        g.w = w[i];
+        g.lora_a = lora_a[i];
+        g.lora_b = lora_b[i];
+        g.wp_fwd = wp_fwd[i];
+        g.wp_dgrad = wp_dgrad[i];
+        g.cout = cout[i];
+        g.cin = cin[i];
+        g.K = K[i];
+        g.KK = K[i] * K[i];
+        g.r = r[i];
+        g.fwd_cols = (cout[i] + 63) / 64 * 64;
+        g.dgrad_cols = (cin[i] + 63) / 64 * 64;
+        g.scale = scale[i];
+        mm.tiles[i] = ((cout[i] * K[i] + 15) / 16) * ((cin[i] * K[i] + 15) / 16);
+        if (mm.tiles[i] > max_tiles) max_tiles = mm.tiles[i];
+    }
+    hipLaunchKernelGGL(lora_compose_pack_multi_kernel, dim3(max_tiles, n), dim3(64), 0, (hipStream_t)stream, mm);
+    return ynet_check_launch("lora_compose_pack_multi");
 }
 
 }  // extern "C"

@@ -47,22 +47,20 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
         side = None
         if overlap and branches:
             # Off the encoder's critical path, on a forked stream (a branch of the captured step): the target / way-point
-            # maps (needed by the decoders and the losses only) and the composed filters W + BA*s of the adapted convs
-            # (they depend on the weights alone; each conv then finds its packed filter up to date).
+            # maps, needed by the decoders and the losses only.
             main0 = torch.cuda.current_stream(device)
             side = ops.side_streams(device, 2)
             side.wait_stream(main0)
             with torch.cuda.stream(side):
                 gt_future_map, gt_waypoint_map = target_maps()
-                ops.refresh_lora_filters(model)
             for t in (gt_future_map, gt_waypoint_map):
                 t.record_stream(main0)
+        ops.refresh_lora_filters(model)      # every adapted conv's W + BA*s in one launch, ahead of the encoder
         observed_map = gather_patches(input_template, coords[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
         gt_future = coords[:, obs_len:].to(device)
         if side is None:
             gt_future_map, gt_waypoint_map = target_maps()
-        else:
-            main0.wait_stream(side)      # (the composes are tiny: joined here; the encoder's first conv needs its filter)
+        join_targets = side is not None
         sem1 = semantic_img
         if network == "embed":      # utils/train_epoch.py:80-83 (before the expand)
             sem1 = model.scene_embedding(semantic_img)
@@ -70,6 +68,8 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
 
         semantic_map = sem1.expand(n_local, -1, -1, -1)
         features = model.pred_features(semantic_map, observed_map)
+        if join_targets:
+            torch.cuda.current_stream(device).wait_stream(side)      # the decoders and the losses need the target maps
         if hasattr(criterion, "expected_grad"):
             # d(loss)/d(criterion output) as autograd will compute it (fp32): lets the criterion emit the
             # gradient of its logits in the same pass as the loss
