@@ -2,10 +2,10 @@
 # SQ counter passes over the C2 bench (development aid): where do the conv / wgrad kernels wait?
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/pmc_sq
+OUT=$R/gpurun_out/pmc_sq_${1:-r02}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-export YNET_SERIAL_DECODERS=1
+export YNET_SERIAL_DECODERS=1 YNET_STEP_GRAPH=0      # eager launches on one stream: one counter sample per isolated kernel
 i=0
 for grp in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU" \
