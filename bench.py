@@ -348,6 +348,9 @@ def main():
                 traffic = entry["hbm_bytes_per_launch_fetch_x2" if name.startswith("conv_dma") else "hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                           "profile": "profiles/r02_bench_C2_serial_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command "
+                                      "with YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1: the same isolated launches); "
+                                      "profiles/r02_bench_C2_kernel_stats.csv is the default command (captured step, concurrent branches)",
                            "traffic_source": None if traffic is None else
                            "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
                            "earlier run of the same build; NOT measured in this run)",

@@ -157,8 +157,10 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
     waypoints = list(waypoints)
     graphs = step_graph.cache_for(model, optimizer, device) if step_graph.enabled(graph, device) else None
     model_token = step_graph.model_state_token(model) if graphs is not None else None
-    # captured steps need a non-default stream: in graph mode the whole epoch runs on one persistent side stream
-    epoch_stream = step_graph.enter_stream(device) if graphs is not None else None
+    # Captured steps need a non-default stream, and autograd's gradient accumulators remember the stream of their first
+    # backward pass: every epoch -- captured or eager -- runs on the same persistent side stream (the caller's stream
+    # waits for it at the end), so that eager and captured epochs of one model can alternate freely.
+    epoch_stream = step_graph.enter_stream(device) if device.type == "cuda" and torch.cuda.is_available() else None
 
     try:
         for trajectory, meta, scene in train_loader:
