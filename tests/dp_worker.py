@@ -44,8 +44,21 @@ def run_epochs(cfg, sd, scene, traj, batch_size, dev, dp_factory, n_epochs=2, gr
                                       batch_size, 10000, cfg.resize_factor, cfg.network, False, dp=dp, **kw))
     named = dict(model.named_parameters())
     names = [n for n, p in named.items() if p.requires_grad]
-    return {"results": results, "weights": {n: named[n].detach().cpu().clone() for n in names},
-            "grads": {n: named[n].grad.detach().cpu().clone() for n in names}}
+    out = {"results": results, "weights": {n: named[n].detach().cpu().clone() for n in names},
+           "grads": {n: named[n].grad.detach().cpu().clone() for n in names}}
+    # the evaluation sweep under the same sharding (utils/evaluate.py dp= branch: shard, per-rank decoder passes, gather_rows);
+    # the sampled way-points are injected so that every world size sees the same draws
+    ev = pkg("utils.evaluate")
+    g = torch.Generator().manual_seed(3)
+    H, W = scene.shape[-2:]
+    K, n = 4, traj.shape[0]
+    forced = {b: torch.stack([torch.rand(K, min(batch_size, n - b), len(cfg.waypoints), generator=g) * (W - 1),
+                              torch.rand(K, min(batch_size, n - b), len(cfg.waypoints), generator=g) * (H - 1)], dim=-1).round()
+              for b in range(0, n, batch_size)}
+    ade, fde, df, _ = ev.evaluate(model, loader, {"scene0": scene[0]}, dev, "sdd", None, in_t, list(cfg.waypoints), "test", K, 1,
+                                  cfg.obs_len, batch_size, cfg.resize_factor, cfg.temperature, forced_samples=forced, dp=dp)
+    out["eval"] = (ade, fde, df["ade"].to_numpy().copy(), df["fde"].to_numpy().copy())
+    return out
 
 
 def main():

@@ -48,6 +48,11 @@ def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch
     for n, w in want["grads"].items():      # gradients of the LAST step (after identical earlier updates)
         g = got["grads"][n]
         assert float((g - w).abs().max()) <= 2e-4 * float(w.abs().max()) + 1e-7, n
+    # evaluate(dp=) after the training epochs: the gathered per-trajectory errors equal the single-process sweep
+    import numpy as np
+    np.testing.assert_allclose(got["eval"][2], want["eval"][2], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(got["eval"][3], want["eval"][3], rtol=0, atol=1e-4)
+    assert abs(got["eval"][0] - want["eval"][0]) <= 1e-4 and abs(got["eval"][1] - want["eval"][1]) <= 1e-4
     steps = 2 * ((n_rows + batch_size - 1) // batch_size)
     for n, w in want["weights"].items():    # every Adam step moves a weight by <= lr: the two runs stay within a few % of that
         big = want["grads"][n].abs() > 1e-3 * want["grads"][n].abs().max()      # (Adam turns a rounding-level gradient into +-lr)
