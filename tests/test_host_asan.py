@@ -12,6 +12,7 @@ from conftest import ROOT
 
 CSRC = os.path.join(ROOT, "motion-style-transfer_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
+ASAN_DIR = os.path.join(ROOT, "build", "asan")      # (build/ is git- and gpurun-ignored)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
@@ -22,7 +23,7 @@ def test_host_paths_are_clean_under_asan(tmp_path):
     clang = "/opt/rocm/lib/llvm/bin/clang++"
     r = subprocess.run([clang if os.path.exists(clang) else shutil.which("clang++") or HIPCC, "-std=c++17", "-O1", "-g",
                         "-fsanitize=address", "-shared-libsan", os.path.join(ROOT, "tools", "asan_host_driver.cpp"),
-                        "-L" + os.path.join(CSRC, "asan"), "-lynet_hip_asan", "-Wl,-rpath," + os.path.join(CSRC, "asan"),
+                        "-L" + ASAN_DIR, "-lynet_hip_asan", "-Wl,-rpath," + ASAN_DIR,
                         "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     import glob
