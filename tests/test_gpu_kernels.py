@@ -514,7 +514,7 @@ def test_fused_predictor_and_bce(dev, B, cin, cout, H, W, train_pred, scale, up)
     assert torch.equal(y2, yd) and float(l2) == float(ld)
 
 
-@pytest.mark.parametrize("S,H,W", [(1050, 256, 256), (1386, 512, 512), (1050, 96, 160), (1386, 37, 50)])
+@pytest.mark.parametrize("S,H,W", [(1050, 256, 256), (1386, 512, 512), (1050, 96, 160), (1386, 37, 50), (75, 16, 24)])
 def test_analytic_heatmaps_are_bit_identical_to_template_slices(dev, S, H, W):
     """the windows get_patch slices out of create_dist_mat / create_gaussian_heatmap_template
     (utils/image_utils.py:15-63), computed in the kernel from the coordinate alone (fp64 sqrt / division rounded once to

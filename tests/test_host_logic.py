@@ -180,3 +180,33 @@ def test_checkpoints_round_trip_through_the_reference():
     r = subprocess.run([sys.executable, os.path.join(root, "oracle", "check_ckpt_roundtrip.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all cases identical in both directions" in r.stdout
+
+
+def test_step_graph_keys():
+    """utils/step_graph.py host logic (no GPU): the optimizer part of a step's key ignores the flags the capture flips
+    itself (fused / foreach / capturable) but follows the learning rate; the model token follows the freeze pattern and
+    in-place changes of FROZEN weights only (trainable ones change every step)."""
+    sg = pkg("utils.step_graph")
+    g = Golden("tiny_short_mosa1")
+    model = build_model(g.cfg(), g.state_dict(), "cpu")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    h0 = sg._hyper(opt)
+    for grp in opt.param_groups:
+        grp["fused"], grp["foreach"], grp["capturable"] = True, False, True
+    assert sg._hyper(opt) == h0
+    opt.param_groups[0]["lr"] = 1e-4
+    assert sg._hyper(opt) != h0
+    t0 = sg.model_state_token(model)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    frozen = [p for p in model.parameters() if not p.requires_grad]
+    with torch.no_grad():
+        trainable[0].add_(1.0)
+    assert sg.model_state_token(model) == t0
+    with torch.no_grad():
+        frozen[0].add_(1.0)                       # e.g. load_state_dict between two train() calls
+    assert sg.model_state_token(model) != t0
+    t1 = sg.model_state_token(model)
+    frozen[1].requires_grad = True                # a different freeze policy
+    assert sg.model_state_token(model) != t1
+    assert not sg.enabled(None, torch.device("cpu")) and not sg.enabled(True, "cpu")
+    assert sg.waypoint_index("cpu", [14, 29]).tolist() == [14, 29]
