@@ -206,8 +206,11 @@ class CapturedStep:
             self.dp = dp
             self.split = dp is not None and dp.world > 1
             self.params = [p for g in optimizer.param_groups for p in g["params"]]
+            # Under a multi-rank process group other threads (the NCCL / RCCL watchdog) may query events while this thread
+            # captures: only the capturing thread is held to capture-safe calls then.
+            mode = "thread_local" if self.split else "global"
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, pool=self.cache.pool, stream=stream):
+            with torch.cuda.graph(g1, pool=self.cache.pool, stream=stream, capture_error_mode=mode):
                 fb = forward_backward(self.coords, self.scene, OVERLAP_DECODERS)
                 loss = fb[0].detach()
                 if dp is not None:
@@ -220,7 +223,7 @@ class CapturedStep:
             self.graphs = [g1]
             if self.split:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=self.cache.pool, stream=stream):
+                with torch.cuda.graph(g2, pool=self.cache.pool, stream=stream, capture_error_mode=mode):
                     loss = dp.loss_value()
                     optimizer.step()
                     ade, fde = finish(fb)
