@@ -1108,9 +1108,7 @@ int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, con
     a.gs = expected_grad / (float)a.n;
     // exact channel counts for the two prediction horizons of the shipped configs (12 and 30 steps): no padded FMAs
     const int parts4 = grid_for((long long)B * a.hw4, 256, YNET_BCE_PARTS), parts2 = grid_for((long long)B * a.hw4 * 2, 256, YNET_BCE_PARTS);
-    static const int px2 = getenv("YNET_PRED_PX2") ? atoi(getenv("YNET_PRED_PX2")) : 0;
-    if (cout == 12 && px2) hipLaunchKernelGGL((pred_bce_kernel<12, 2>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
-    else if (cout == 12) hipLaunchKernelGGL((pred_bce_kernel<12, 4>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);
+    if (cout == 12) hipLaunchKernelGGL((pred_bce_kernel<12, 4>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);      // (2 pixels per thread: measured equal)
     else if (cout <= 16) hipLaunchKernelGGL((pred_bce_kernel<16, 4>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);
     else if (cout == 30) hipLaunchKernelGGL((pred_bce_kernel<30, 2>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((pred_bce_kernel<32, 2>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
