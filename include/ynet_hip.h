@@ -54,6 +54,17 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                 int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
                 void* stream);
+/* ynet_conv2d with one destination, no mask, plus a precomputed additive term: y = [relu](conv(cat(src...), wp) + bias +
+ * addend[b % addend_bmod]), addend [images][cout][H][W] with batch stride addend_bs (addend_bmod = 0: one image per batch
+ * item).  Convolution is linear in its input channels: the part over inputs that REPEAT along the batch -- the encoder
+ * features that the K goal samples of a trajectory share in utils/evaluate.py:248-266 -- is computed once per trajectory
+ * and added here, instead of K times inside the channel loop (dec.4.0 of the trajectory decoder: 32 of its 50 input
+ * channels).  Served by the large-map 3x3 kernels only: ask ynet_conv2d_add_supported(B, H, W, cout, K) first. */
+int ynet_conv2d_add_supported(int B, int H, int W, int cout, int K);
+int ynet_conv2d_add(const float* const* src, const int* src_c, const long long* src_bs, const int* src_bmod, int nsrc,
+                    const float* wp, const float* bias, float* dst, int cout, long long dst_bs,
+                    int B, int H, int W, int K, int relu, const float* addend, long long addend_bs, int addend_bmod,
+                    void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19  ->  conv_mfma_kernel<K, tiles, rows,

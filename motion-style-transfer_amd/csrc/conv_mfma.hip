@@ -45,6 +45,9 @@ struct ConvArgs {
     int ksplit, cps;        // split of the input-channel chunks over workgroups (small maps): chunks per split
     float* partial;         // [ksplit][B][cout][H][W] raw partial sums when ksplit > 1 (NULL: never split)
     long long partial_cap;  // floats available at `partial`
+    const float* addend;    // optional [images][cout][H][W] term added before the ReLU (conv_dma_kernel<..., ADD = true>):
+    long long addend_bs;    //   y = relu(conv(x) + bias + addend[b % addend_bmod]) -- the part of a convolution over inputs that
+    int addend_bmod;        //   repeat along the batch (evaluate()'s K goal samples share the encoder features), computed once
     int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
     int vec_load;           // 16-byte LDS-DMA of the input tile is legal (W % 4 == 0, aligned sources / mask)
     int tiles_x, tiles_y, cgroups, ntiles, debug;   // debug: timing ablations only (tools/conv_bench.py)
@@ -544,8 +547,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sgpr_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0u, 0x00020000);
 }
 
-template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
-__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, bool ADD>
+__device__ __forceinline__ void conv_dma_body() {
     using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
     constexpr int KS = 3, PAD = 1, KK = 9, TH = C::TH, TW = C::TW;
     constexpr int TCOLS = C::TCOLS, PLANE = C::PLANE, CB = C::CB, CHS = C::CHS, XI = C::XI;
@@ -836,16 +839,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
     // the range check), the row goes into the scalar offset: ~10 vector-ALU instructions per destination.
     auto epilogue = [&](const TileCoord& t) {
         const conv_kargs_t ke = conv_kargs();
-        if (ke->relu && ksplit == 1) {
-#pragma unroll
-            for (int i = 0; i < NCB; ++i)
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][r][g][e] = acc[i][r][g][e] < 0.f ? 0.f : acc[i][r][g][e];
-        }
         unsigned lo[NCB][2];       // ((16 i + r16) * HW + row-in-unit * W + x) * 4 for the two pixel groups, marker when x >= W
 #pragma unroll
         for (int i = 0; i < NCB; ++i)
@@ -857,6 +850,34 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
             }
         const int ybase = t.y0 + wave * R * FOLD;    // (H % FOLD == 0: a row unit lies wholly inside or outside the image)
         const int c_lo = t.cg * CB;        // first output channel of this tile
+        if constexpr (ADD) {
+            // + the batch-shared part of the convolution (see ConvArgs::addend): the tile of image b % bmod, read with the
+            // addressing of the stores below (lanes past the image / past cout fall outside the descriptor and add 0)
+            const int abm = ke->addend_bmod;
+            const float* ap = ke->addend + (long long)(abm > 0 ? t.b % abm : t.b) * ke->addend_bs;
+            const __amdgpu_buffer_rsrc_t ra = sgpr_rsrc(ap, (unsigned)ke->cout * plane_bytes);
+            const unsigned ub = (unsigned)(c_lo * HW + ybase * W) * 4u;
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const unsigned vo = lo[i][g] + ub;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (ybase + r * FOLD < H)
+                            acc[i][r][g] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, vo, (unsigned)(r * FOLD * W) * 4u, 0));
+                }
+        }
+        if (ke->relu && ksplit == 1) {
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][r][g][e] = acc[i][r][g][e] < 0.f ? 0.f : acc[i][r][g][e];
+        }
         auto store_all = [&](__amdgpu_buffer_rsrc_t rd, unsigned ubase) {
             // ubase = ((c_lo - first channel of the destination) * HW + ybase * W) * 4, modulo 2^32
 #pragma unroll
@@ -955,6 +976,17 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
             }
         }
     }
+}
+
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
+    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, false>();
+}
+
+// the same with the batch-shared additive term (ConvArgs::addend) in the epilogue
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
+__global__ __launch_bounds__(256, 2) void conv_dma_add_kernel(const ConvArgs) {
+    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, true>();
 }
 
 // Split of the input-channel loop over workgroups for launches with fewer work items than CUs.
@@ -1078,9 +1110,13 @@ static int pick_rows(const ConvArgs& a, int cb) {
     return 1;
 }
 
-template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, bool ADD = false>
 static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
+    const auto KERNEL = [] {       // (if constexpr: only the wanted instantiation is compiled)
+        if constexpr (ADD) return &conv_dma_add_kernel<NCB, R, CC, MASK, X4, FOLD>;
+        else return &conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>;
+    }();
     a.tiles_x = ceil_div(a.W, C::TW);
     a.tiles_y = ceil_div(a.H, C::TH);
     a.cgroups = ceil_div(a.cout, C::CB);
@@ -1089,7 +1125,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         int nchunks = 0;
         for (int i = 0; i < a.nsrc; ++i) nchunks += ceil_div(a.src[i].c, CC);
         a.ksplit = 1;
-        if (a.partial != nullptr) a.ksplit = conv_ksplit(nt, nchunks);
+        if (a.partial != nullptr && !ADD) a.ksplit = conv_ksplit(nt, nchunks);
         while (a.ksplit > 1 && (long long)a.ksplit * a.B * a.cout * a.H * a.W > a.partial_cap) --a.ksplit;
         a.cps = ceil_div(nchunks, a.ksplit);
         a.ksplit = ceil_div(nchunks, a.cps);
@@ -1102,10 +1138,10 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     static int slots_dev[YNET_MAX_DEV] = {0};
     int& slots = slots_dev[ynet_device_slot()];
     if (slots == 0) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         int per_cu = 0, dev = 0, cus = 256;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>, 256, C::LDS_BYTES);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, C::LDS_BYTES);
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (per_cu < 1) per_cu = 1;
@@ -1113,7 +1149,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         slots = per_cu * cus;
     }
     const long long nblk = nt < slots ? nt : slots;
-    hipLaunchKernelGGL((conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((KERNEL), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
     if (a.ksplit > 1) {
         SplitReduceArgs r{};
         r.partial = a.partial;
@@ -1277,6 +1313,19 @@ static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
     static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 0;
+    if (a.addend != nullptr) {
+        // the additive term is implemented by the large-map LDS-DMA kernels only (what evaluate()'s shared skip features
+        // need); callers ask ynet_conv2d_add_supported first
+        const int rows_a = (nt16 == 2 || nt16 == 4) ? pick_rows(a, 16 * nt16) : 0;
+        const bool ok = use_dma && use_x4 && a.vec_store && a.vec_load && a.mask == nullptr && a.ndst == 1 && conv_fold(a.H, a.W) == 1 &&
+                        rows_a >= 2 && (reinterpret_cast<uintptr_t>(a.addend) & 15) == 0 && (a.addend_bs & 3) == 0;
+        if (!ok) {
+            ynet_set_error("conv2d_add: shape B=%d %dx%d cout=%d is not served by the additive-term kernels", a.B, a.H, a.W, a.cout);
+            return 1;
+        }
+        if (nt16 == 2) return rows_a == 4 ? launch_dma_m<2, 4, 4, false, true, 1, true>(a, st) : launch_dma_m<2, 2, 4, false, true, 1, true>(a, st);
+        return launch_dma_m<4, 2, 4, false, true, 1, true>(a, st);
+    }
     if (nt16 && use_dma && use_x4 && a.vec_store && a.vec_load) {
         const int fold = conv_fold(a.H, a.W);
         if (fold > 1) {
@@ -1395,11 +1444,11 @@ long long ynet_conv2d_workspace_floats(int B, int H, int W, int cout) {
     return 8ll * B * cout * H * W;
 }
 
-int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, const int* src_bmod, int nsrc,
-                const float* mask, long long mask_bs, const float* wp, const float* bias,
-                float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
-                int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
-                void* stream) {
+static int conv2d_impl(const float* const* src, const int* src_c, const long long* src_bs, const int* src_bmod, int nsrc,
+                       const float* mask, long long mask_bs, const float* wp, const float* bias,
+                       float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
+                       int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
+                       const float* addend, long long addend_bs, int addend_bmod, void* stream) {
     YNET_REQUIRE(nsrc >= 1 && nsrc <= YNET_MAX_SRC && ndst >= 1 && ndst <= YNET_MAX_SRC,
                  "conv2d: 1..%d sources/destinations supported (got %d/%d)", YNET_MAX_SRC, nsrc, ndst);
     YNET_REQUIRE(B > 0 && H > 0 && W > 0, "conv2d: empty problem B=%d H=%d W=%d", B, H, W);
@@ -1433,6 +1482,9 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
     }
     a.mask = mask;
     a.mask_bs = mask_bs;
+    a.addend = addend;
+    a.addend_bs = addend_bs;
+    a.addend_bmod = addend_bmod;
     a.wp = wp;
     a.bias = bias;
     a.B = B;
@@ -1449,6 +1501,45 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
         if ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) || (a.src[i].bs & 3)) a.vec_load = 0;
     if (mask && ((reinterpret_cast<uintptr_t>(mask) & 15) || (mask_bs & 3))) a.vec_load = 0;
     return conv_dispatch(a, K, (hipStream_t)stream);
+}
+
+int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_bs, const int* src_bmod, int nsrc,
+                const float* mask, long long mask_bs, const float* wp, const float* bias,
+                float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
+                int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
+                void* stream) {
+    return conv2d_impl(src, src_c, src_bs, src_bmod, nsrc, mask, mask_bs, wp, bias, dst, dst_c, dst_bs, ndst, B, H, W, K, relu,
+                       workspace, workspace_floats, nullptr, 0, 0, stream);
+}
+
+// 1 if ynet_conv2d_add serves this problem (3x3, Cout 17..32 or 49..64, W % 4 == 0, a map large enough for two-row units)
+int ynet_conv2d_add_supported(int B, int H, int W, int cout, int K) {
+    ConvArgs a{};
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.cout = cout;
+    const int nt16 = m16_tiles(K, cout);
+    static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
+    static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
+    if (!(use_dma && use_x4) || K != 3 || (W & 3) || (nt16 != 2 && nt16 != 4) || conv_fold(H, W) != 1) return 0;
+    return pick_rows(a, 16 * nt16) >= 2 ? 1 : 0;
+}
+
+// y = [relu](conv(cat(src...), wp) + bias + addend[b % addend_bmod]): ynet_conv2d with one destination, no mask, plus a
+// precomputed term [images][cout][H][W] (batch stride addend_bs, addend_bmod > 0: that many images repeating along the
+// batch) -- the part of the convolution over inputs that repeat along the batch, computed once (utils/evaluate.py: the K
+// goal samples of a trajectory share its encoder features).
+int ynet_conv2d_add(const float* const* src, const int* src_c, const long long* src_bs, const int* src_bmod, int nsrc,
+                    const float* wp, const float* bias, float* dst, int cout, long long dst_bs,
+                    int B, int H, int W, int K, int relu, const float* addend, long long addend_bs, int addend_bmod,
+                    void* stream) {
+    YNET_REQUIRE(addend != nullptr && dst != nullptr && addend_bmod >= 0, "conv2d_add: null pointer / negative modulus");
+    float* dsts[1] = {dst};
+    const int dc[1] = {cout};
+    const long long db[1] = {dst_bs};
+    return conv2d_impl(src, src_c, src_bs, src_bmod, nsrc, nullptr, 0, wp, bias, dsts, dc, db, 1, B, H, W, K, relu, nullptr, 0,
+                       addend, addend_bs, addend_bmod, stream);
 }
 
 }  // extern "C"

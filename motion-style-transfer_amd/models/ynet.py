@@ -380,13 +380,26 @@ class YNetDecoder(nn.Module):
     # activation is read once instead of three times); the logits it returns carry the loss for the criterion.
     _bce = None
 
+    # utils/evaluate.py runs the K goal samples of a trajectory as a batch whose encoder features REPEAT along it
+    # (ops.BatchRepeat).  A convolution is linear in its input channels, so the part of decoder[i][0] over those repeated
+    # skip features is the same for all K samples: `share_skip_features` computes it once per trajectory batch
+    # (ops.shared_conv_term) and the per-sample launches convolve only the up-sampled path and the way-point channels
+    # (ynet_conv2d_add).  At the top level that is 32 of 50 input channels of the largest layer of the sweep.
+    _shared_terms = None
+
+    def share_skip_features(self, features):
+        """Context manager: precompute the skip-feature terms of decoder[i][0] for the encoder features `features`
+        (list of 6, finest first, as model.pred_features returns them) -- for the levels the additive kernels serve."""
+        return _SharedSkipTerms(self, features)
+
     def forward(self, features):
         features = features[::-1]
         x = self.center(features[0])
-        for f, d, up in zip(features[1:], self.decoder, self.upsample_conv):
+        for lvl, (f, d, up) in enumerate(zip(features[1:], self.decoder, self.upsample_conv)):
             x = ops.upsample2x(x)
             x = up(x)
-            x = d(ops.lazy_cat([x, f]))
+            y = self._first_conv_shared(lvl, d, x, f)
+            x = d[2](y, relu=True) if y is not None else d(ops.lazy_cat([x, f]))
         bce = self._bce
         if (bce is not None and torch.is_grad_enabled() and type(self.predictor) is HipConv2d
                 and ops.pred_bce_supported(x, self.predictor.weight)):
@@ -395,6 +408,54 @@ class YNetDecoder(nn.Module):
             y._ynet_fused_bce = (target, loss, float(expected))
             return y
         return self.predictor(x)
+
+
+    def _first_conv_shared(self, lvl, d, x, f):
+        """decoder[lvl][0] + ReLU through the shared-term kernel, or None when it does not apply to this call."""
+        terms = self._shared_terms
+        if terms is None or lvl not in terms or torch.is_grad_enabled() or not isinstance(f, ops.LazyCat):
+            return None
+        term, src = terms[lvl]
+        parts = f.parts
+        rep = parts[0]
+        shared, times = (rep.tensor, rep.times) if isinstance(rep, ops.BatchRepeat) else (rep, 1)      # (one sample per pass: no repeat)
+        conv0 = d[0]
+        if not (shared is src and type(conv0) is HipConv2d and torch.is_tensor(x)
+                and all(torch.is_tensor(p) for p in parts[1:]) and isinstance(d[1], nn.ReLU)):
+            return None
+        B, cx, H, W = x.shape
+        if B != shared.shape[0] * times or not ops.conv2d_add_supported(B, H, W, conv0.out_channels, 3):
+            return None
+        cf = shared.shape[1]
+        return ops.conv2d_shared_term(shared, times, [x, *parts[1:]], conv0.weight, conv0.bias, True, conv0._packed,
+                                      term, cx, cx + cf)
+
+
+class _SharedSkipTerms:
+    def __init__(self, decoder, features):
+        self.decoder, self.features = decoder, features
+
+    def __enter__(self):
+        dec = self.decoder
+        terms = {}
+        if not torch.is_grad_enabled() and os.environ.get("YNET_SHARED_SKIP", "1") != "0":
+            feats = self.features[::-1]
+            for lvl, (f, d, up) in enumerate(zip(feats[1:], dec.decoder, dec.upsample_conv)):
+                conv0 = d[0]
+                if not (torch.is_tensor(f) and f.is_cuda and type(conv0) is HipConv2d and conv0.kernel_size[0] == 3):
+                    continue
+                B, cf, H, W = f.shape
+                # (the per-sample launches have a multiple of B images: a level the kernels serve at B is served at k * B)
+                if W % 4 or not ops.conv2d_add_supported(B, H, W, conv0.out_channels, 3):
+                    continue
+                cx = up.out_channels
+                terms[lvl] = (ops.shared_conv_term(f, conv0.weight, cx, cx + cf, conv0._packed), f)
+        dec._shared_terms = terms or None
+        return self
+
+    def __exit__(self, *exc):
+        self.decoder._shared_terms = None
+        return False
 
 
 class announce_bce_target:

@@ -269,6 +269,50 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
                             ws.data_ptr() if ws is not None else None, nws, _stream()), lib)
 
 
+def conv2d_add_supported(B: int, H: int, W: int, cout: int, K: int) -> bool:
+    return bool(_lib().ynet_conv2d_add_supported(int(B), int(H), int(W), int(cout), int(K)))
+
+
+def conv2d_shared_term(x, x_times: int, rest, weight, bias, relu: bool, cache: dict, term: torch.Tensor, c0: int, c1: int):
+    """relu(conv(cat(rest_a, repeat(x), rest_b), W) + b) for an input whose channels [c0, c1) repeat along the batch
+    (`x` [Bs,c1-c0,H,W] shared by `x_times` batch items each): `term` = conv(x, W[:, c0:c1]) was computed once
+    (shared_conv_term); only the other channels go through the convolution here (ynet_conv2d_add).  Inference only.
+    `rest`: the non-repeating parts in channel order (tensors [B,*,H,W], B = Bs * x_times)."""
+    parts = [p for p in rest]
+    for t in parts + [term]:
+        _need_gpu(t, "conv2d_shared_term")
+    cout, cin, k, _ = weight.shape
+    B, _, H, W = parts[0].shape
+    wkey = ("rest", c0, c1, weight.data_ptr(), weight._version)
+    if cache.get("rest_key") != wkey:
+        with torch.no_grad():
+            w_rest = torch.cat([weight[:, :c0], weight[:, c1:]], dim=1).contiguous()
+            cache["rest_key"], cache["rest_wp"] = wkey, pack_weight(w_rest, 0)
+    descs = []
+    for p_ in parts:
+        t, c, bs = _plane_desc(p_.detach(), "conv2d_shared_term input")
+        descs.append((t.data_ptr(), c, bs))
+    if sum(d[1] for d in descs) != cin - (c1 - c0):
+        raise ValueError("conv2d_shared_term: channel counts do not add up")
+    y = torch.empty((B, cout, H, W), device=weight.device, dtype=torch.float32)
+    lib = _lib()
+    sp, sc, sb = _arrays(descs)
+    L.check(lib.ynet_conv2d_add(sp, sc, sb, None, len(descs), cache["rest_wp"].data_ptr(),
+                                bias.detach().data_ptr() if bias is not None else None, y.data_ptr(), cout, cout * H * W,
+                                B, H, W, k, 1 if relu else 0, term.data_ptr(), cout * H * W, term.shape[0], _stream()), lib)
+    return y
+
+
+def shared_conv_term(x: torch.Tensor, weight, c0: int, c1: int, cache: dict) -> torch.Tensor:
+    """conv(x, W[:, c0:c1]) without bias / ReLU: the batch-shared part of a convolution (see conv2d_shared_term)."""
+    wkey = ("shared", c0, c1, weight.data_ptr(), weight._version)
+    if cache.get("shared_key") != wkey:
+        with torch.no_grad():
+            cache["shared_key"], cache["shared_w"], cache["shared_pack"] = wkey, weight[:, c0:c1].contiguous(), {}
+    with torch.no_grad():
+        return conv2d(x.detach(), cache["shared_w"], None, False, cache["shared_pack"])
+
+
 def _weight_key(weight, lora_a, lora_b):
     key = (weight.data_ptr(), weight._version)
     if lora_a is not None:

@@ -99,14 +99,16 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
                     K = waypoint_samples.shape[0]
                     G = max(1, min(K, max_effective_batch // max(n_local, 1)))
                     trajs_samples = []
-                    for k0 in range(0, K, G):
-                        g = min(G, K - k0)
-                        coords = waypoint_samples[k0:k0 + g].reshape(-1, 2)            # [g * n_local * n_wp, 2]
-                        waypoint_map = gather_patches(input_template, coords, H, W).view(g * n_local, n_wp, H, W)
-                        pyramid = ops.avgpool_pyramid(waypoint_map, len(features))
-                        traj_input = [ops.lazy_cat([ops.batch_repeat(f, g), p]) for f, p in zip(features, pyramid)]
-                        pred_traj = model.softargmax(model.pred_traj(traj_input))       # [g * n_local, pred, 2]
-                        trajs_samples.append(pred_traj.view(g, n_local, -1, 2))
+                    # (the skip-feature part of each decoder level's first conv is the same for all K samples: once per batch)
+                    with model.traj_decoder.share_skip_features(features):
+                        for k0 in range(0, K, G):
+                            g = min(G, K - k0)
+                            coords = waypoint_samples[k0:k0 + g].reshape(-1, 2)            # [g * n_local * n_wp, 2]
+                            waypoint_map = gather_patches(input_template, coords, H, W).view(g * n_local, n_wp, H, W)
+                            pyramid = ops.avgpool_pyramid(waypoint_map, len(features))
+                            traj_input = [ops.lazy_cat([ops.batch_repeat(f, g), p]) for f, p in zip(features, pyramid)]
+                            pred_traj = model.softargmax(model.pred_traj(traj_input))       # [g * n_local, pred, 2]
+                            trajs_samples.append(pred_traj.view(g, n_local, -1, 2))
                     trajs_samples = torch.cat(trajs_samples)
                     gt_goal = gt_future[:, -1:]
                     if dataset_name == "eth":

@@ -539,3 +539,24 @@ def test_analytic_heatmaps_are_bit_identical_to_template_slices(dev, S, H, W):
         assert torch.equal(ana.materialize().cpu(), tmpl), kind
     with pytest.raises(ValueError, match="leaves"):
         ops.gather_patches(iu.analytic_dist_template(S, dev), torch.tensor([[S * 1.0, 0.0]]), H, W)
+
+
+@pytest.mark.parametrize("Bs,times,H,W,cx,cf,cw,cout", [(4, 4, 64, 64, 32, 64, 2, 64), (2, 10, 128, 128, 32, 32, 1, 32), (3, 1, 256, 256, 16, 32, 2, 32)])
+def test_conv_with_batch_shared_term(dev, Bs, times, H, W, cx, cf, cw, cout):
+    """ynet_conv2d_add: relu(conv(cat(x, repeat(feat), wp), W) + b) computed as the per-sample convolution over (x, wp) plus
+    a term conv(feat, W[:, cx:cx+cf]) that is evaluated once for the Bs shared images (utils/evaluate.py's K goal samples)."""
+    ops = pkg("ops")
+    B = Bs * times
+    x, feat, wp = rnd(B, cx, H, W, seed=1), rnd(Bs, cf, H, W, seed=2), rnd(B, cw, H, W, seed=3)
+    cin = cx + cf + cw
+    w, b = rnd(cout, cin, 3, 3, seed=4, scale=1.0 / (cin * 9) ** 0.5), rnd(cout, seed=5, scale=0.1)
+    want = F.relu(F.conv2d(torch.cat([x, feat.repeat(times, 1, 1, 1), wp], 1), w, b, padding=1))
+    assert ops.conv2d_add_supported(B, H, W, cout, 3)
+    cache = {}
+    with torch.no_grad():
+        term = ops.shared_conv_term(feat.to(dev), w.to(dev), cx, cx + cf, cache)
+        got = ops.conv2d_shared_term(feat.to(dev), times, [x.to(dev), wp.to(dev)], w.to(dev), b.to(dev), True, cache, term, cx, cx + cf)
+        full = ops.conv2d(ops.lazy_cat([x.to(dev), ops.batch_repeat(feat.to(dev), times), wp.to(dev)]), w.to(dev), b.to(dev), True, {})
+    close(got, want, msg="shared-term conv")
+    close(got, full, rtol=2e-5, atol=1e-5, msg="vs the full conv on the same device")
+    assert not ops.conv2d_add_supported(B, 8, 8, cout, 3)          # small maps keep the plain kernels
