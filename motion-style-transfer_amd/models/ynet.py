@@ -420,7 +420,8 @@ class YNetDecoder(nn.Module):
         rep = parts[0]
         shared, times = (rep.tensor, rep.times) if isinstance(rep, ops.BatchRepeat) else (rep, 1)      # (one sample per pass: no repeat)
         conv0 = d[0]
-        if not (shared is src and type(conv0) is HipConv2d and torch.is_tensor(x)
+        same = torch.is_tensor(shared) and shared.data_ptr() == src.data_ptr() and shared.shape == src.shape      # (BatchRepeat holds a detached alias)
+        if not (same and type(conv0) is HipConv2d and torch.is_tensor(x)
                 and all(torch.is_tensor(p) for p in parts[1:]) and isinstance(d[1], nn.ReLU)):
             return None
         B, cx, H, W = x.shape

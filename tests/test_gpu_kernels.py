@@ -541,7 +541,7 @@ def test_analytic_heatmaps_are_bit_identical_to_template_slices(dev, S, H, W):
         ops.gather_patches(iu.analytic_dist_template(S, dev), torch.tensor([[S * 1.0, 0.0]]), H, W)
 
 
-@pytest.mark.parametrize("Bs,times,H,W,cx,cf,cw,cout", [(4, 4, 64, 64, 32, 64, 2, 64), (2, 10, 128, 128, 32, 32, 1, 32), (3, 1, 256, 256, 16, 32, 2, 32)])
+@pytest.mark.parametrize("Bs,times,H,W,cx,cf,cw,cout", [(8, 4, 64, 64, 32, 64, 2, 64), (2, 10, 128, 128, 32, 32, 1, 32), (3, 1, 256, 256, 16, 32, 2, 32)])
 def test_conv_with_batch_shared_term(dev, Bs, times, H, W, cx, cf, cw, cout):
     """ynet_conv2d_add: relu(conv(cat(x, repeat(feat), wp), W) + b) computed as the per-sample convolution over (x, wp) plus
     a term conv(feat, W[:, cx:cx+cf]) that is evaluated once for the Bs shared images (utils/evaluate.py's K goal samples)."""
