@@ -55,6 +55,11 @@ int main() {
     EXPECT_REJECT(ynet_conv2d(null_srcs, &one, &bs, nullptr, 1, nullptr, 0, cfp, nullptr, dsts, &one, &bs, 1, 1, 4, 4, 3, 0, nullptr, 0, nullptr));
     EXPECT_REJECT(ynet_conv2d(srcs, &one, &bs, nullptr, 1, nullptr, 0, cfp, nullptr, dsts, &one, &bs, 1, 0, 4, 4, 3, 0, nullptr, 0, nullptr));    // B = 0
     EXPECT_REJECT(ynet_conv2d(srcs, &one, &bs, nullptr, 1, nullptr, 0, cfp, nullptr, dsts, &one, &bs, 9, 1, 4, 4, 3, 0, nullptr, 0, nullptr));    // 9 destinations
+    EXPECT_REJECT(ynet_conv2d_add(srcs, &one, &bs, nullptr, 1, cfp, nullptr, fp, 32, 16, 1, 4, 4, 3, 1, nullptr, 16, 0, nullptr));      // no addend
+    EXPECT_REJECT(ynet_conv2d_add(srcs, &one, &bs, nullptr, 1, cfp, nullptr, fp, 32, 16, 1, 8, 8, 3, 1, cfp, 16, 1, nullptr));          // a map the additive kernels do not serve
+    for (int b : {1, 32, 256})
+        for (int hw : {8, 32, 64, 256})
+            for (int cout : {12, 32, 48, 64}) acc += ynet_conv2d_add_supported(b, hw, hw, cout, 3);
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 0, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 7, cfp, 4, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_lora_compose(nullptr, cfp, cfp, 1.f, fp, 4, 4, 3, 1, nullptr));
