@@ -416,20 +416,25 @@ class YNetDecoder(nn.Module):
         if terms is None or lvl not in terms or torch.is_grad_enabled() or not isinstance(f, ops.LazyCat):
             return None
         term, src = terms[lvl]
+        src_parts = ops._parts(src)              # one tensor, or the (scene, motion) pair of the fusion encoder
         parts = f.parts
-        rep = parts[0]
-        shared, times = (rep.tensor, rep.times) if isinstance(rep, ops.BatchRepeat) else (rep, 1)      # (one sample per pass: no repeat)
+        if len(parts) <= len(src_parts):
+            return None
+        lead, rest = parts[:len(src_parts)], parts[len(src_parts):]
+        times = lead[0].times if isinstance(lead[0], ops.BatchRepeat) else 1      # (one sample per pass: no repeat)
+        for p_, s_ in zip(lead, src_parts):      # the leading parts must be the registered features (BatchRepeat holds a detached alias)
+            t_ = p_.tensor if isinstance(p_, ops.BatchRepeat) else p_
+            if not (torch.is_tensor(t_) and t_.data_ptr() == s_.data_ptr() and t_.shape == s_.shape
+                    and (p_.times if isinstance(p_, ops.BatchRepeat) else 1) == times):
+                return None
         conv0 = d[0]
-        same = torch.is_tensor(shared) and shared.data_ptr() == src.data_ptr() and shared.shape == src.shape      # (BatchRepeat holds a detached alias)
-        if not (same and type(conv0) is HipConv2d and torch.is_tensor(x)
-                and all(torch.is_tensor(p) for p in parts[1:]) and isinstance(d[1], nn.ReLU)):
+        if not (type(conv0) is HipConv2d and torch.is_tensor(x) and all(torch.is_tensor(p) for p in rest) and isinstance(d[1], nn.ReLU)):
             return None
         B, cx, H, W = x.shape
-        if B != shared.shape[0] * times or not ops.conv2d_add_supported(B, H, W, conv0.out_channels, 3):
+        if B != src_parts[0].shape[0] * times or not ops.conv2d_add_supported(B, H, W, conv0.out_channels, 3):
             return None
-        cf = shared.shape[1]
-        return ops.conv2d_shared_term(shared, times, [x, *parts[1:]], conv0.weight, conv0.bias, True, conv0._packed,
-                                      term, cx, cx + cf)
+        cf = sum(s_.shape[1] for s_ in src_parts)
+        return ops.conv2d_shared_term(None, times, [x, *rest], conv0.weight, conv0.bias, True, conv0._packed, term, cx, cx + cf)
 
 
 class _SharedSkipTerms:
@@ -443,9 +448,11 @@ class _SharedSkipTerms:
             feats = self.features[::-1]
             for lvl, (f, d, up) in enumerate(zip(feats[1:], dec.decoder, dec.upsample_conv)):
                 conv0 = d[0]
-                if not (torch.is_tensor(f) and f.is_cuda and type(conv0) is HipConv2d and conv0.kernel_size[0] == 3):
+                fparts = ops._parts(f)
+                if not (all(torch.is_tensor(t) and t.is_cuda for t in fparts) and type(conv0) is HipConv2d and conv0.kernel_size[0] == 3):
                     continue
-                B, cf, H, W = f.shape
+                B, _, H, W = fparts[0].shape
+                cf = sum(t.shape[1] for t in fparts)
                 # (the per-sample launches have a multiple of B images: a level the kernels serve at B is served at k * B)
                 if W % 4 or not ops.conv2d_add_supported(B, H, W, conv0.out_channels, 3):
                     continue

@@ -275,7 +275,8 @@ def conv2d_add_supported(B: int, H: int, W: int, cout: int, K: int) -> bool:
 
 def conv2d_shared_term(x, x_times: int, rest, weight, bias, relu: bool, cache: dict, term: torch.Tensor, c0: int, c1: int):
     """relu(conv(cat(rest_a, repeat(x), rest_b), W) + b) for an input whose channels [c0, c1) repeat along the batch
-    (`x` [Bs,c1-c0,H,W] shared by `x_times` batch items each): `term` = conv(x, W[:, c0:c1]) was computed once
+    (`x` [Bs,c1-c0,H,W] shared by `x_times` batch items each; only its term is needed here, `x` may be None):
+    `term` = conv(x, W[:, c0:c1]) was computed once
     (shared_conv_term); only the other channels go through the convolution here (ynet_conv2d_add).  Inference only.
     `rest`: the non-repeating parts in channel order (tensors [B,*,H,W], B = Bs * x_times)."""
     parts = [p for p in rest]
@@ -310,7 +311,7 @@ def shared_conv_term(x: torch.Tensor, weight, c0: int, c1: int, cache: dict) -> 
         with torch.no_grad():
             cache["shared_key"], cache["shared_w"], cache["shared_pack"] = wkey, weight[:, c0:c1].contiguous(), {}
     with torch.no_grad():
-        return conv2d(x.detach(), cache["shared_w"], None, False, cache["shared_pack"])
+        return conv2d(x if isinstance(x, LazyCat) else x.detach(), cache["shared_w"], None, False, cache["shared_pack"])
 
 
 def _weight_key(weight, lora_a, lora_b):

@@ -555,7 +555,7 @@ def test_conv_with_batch_shared_term(dev, Bs, times, H, W, cx, cf, cw, cout):
     cache = {}
     with torch.no_grad():
         term = ops.shared_conv_term(feat.to(dev), w.to(dev), cx, cx + cf, cache)
-        got = ops.conv2d_shared_term(feat.to(dev), times, [x.to(dev), wp.to(dev)], w.to(dev), b.to(dev), True, cache, term, cx, cx + cf)
+        got = ops.conv2d_shared_term(None, times, [x.to(dev), wp.to(dev)], w.to(dev), b.to(dev), True, cache, term, cx, cx + cf)
         full = ops.conv2d(ops.lazy_cat([x.to(dev), ops.batch_repeat(feat.to(dev), times), wp.to(dev)]), w.to(dev), b.to(dev), True, {})
     close(got, want, msg="shared-term conv")
     close(got, full, rtol=2e-5, atol=1e-5, msg="vs the full conv on the same device")
