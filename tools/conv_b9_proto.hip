@@ -1,0 +1,319 @@
+// Prototype: 3x3 convolution with fp32 operands split EXACTLY into three bf16 planes and all nine
+// partial products accumulated in fp32 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16; 16x the fp32 MFMA rate, so 16/9
+// of it after the split).  Activations stay fp32 NCHW in HBM: a workgroup loads its input tile into registers, splits it
+// (x = hi + mid + lo, every piece the top 8 mantissa bits of what is left; exact), and writes the pieces channel-interleaved
+// ([cblk][plane][row][col][8 ch] bf16) to LDS, where a lane's MFMA fragment (8 consecutive k = 8 channels of one pixel and
+// tap) is one ds_read_b128.  Filters are split and laid out in fragment order once, on the host here.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/conv_b9 tools/conv_b9_proto.hip && /tmp/conv_b9 [B Cin Cout H W]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define TR 4            // output rows per workgroup (one per wave)
+#define TC 128          // output columns per workgroup (4 MFMA blocks of 32 pixels per wave)
+#define LROWS (TR + 2)
+#define LCOLS (TC + 2)
+#define PLANE_U (LROWS * LCOLS)            // 16-byte units per (cblk, plane)
+#define LDS_BYTES (2 * 3 * PLANE_U * 16)   // 74,880
+
+struct Args {
+    const float* x;
+    const u32x4* wpk;      // [chunk][tap][plane][cb][64 lanes] fragments
+    const float* bias;
+    float* y;
+    int B, Cin, Cout, H, W, relu, ntiles;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = v[2 * p], b = v[2 * p + 1];
+        const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+        hi[p] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+        const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u), rb = b - __builtin_bit_cast(float, ub & 0xffff0000u);
+        const unsigned ura = __builtin_bit_cast(unsigned, ra), urb = __builtin_bit_cast(unsigned, rb);
+        mid[p] = __builtin_amdgcn_perm(urb, ura, 0x07060302u);
+        const float sa = ra - __builtin_bit_cast(float, ura & 0xffff0000u), sb = rb - __builtin_bit_cast(float, urb & 0xffff0000u);
+        lo[p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
+    }
+}
+
+template <int NCB, int DIAG>
+__global__ __launch_bounds__(256, 2) void conv_b9_kernel(const Args a) {
+    extern __shared__ u32x4 tile[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int nchunk = a.Cin / 16;
+    const int tiles_x = W / TC, tiles_y = H / TR;
+
+    // staging geometry of this thread (the same for every tile): 6 main items (2 lines per round) + the halo columns
+    const int line_hi = tid >> 7, mcol = tid & 127;
+    float v[7][8];
+    unsigned voff[7];
+    unsigned lofs[7];
+
+    f32x16 acc[4][NCB];
+    int tile_id = blockIdx.x;
+    int b = 0, row0 = 0, col0 = 0;
+    auto set_tile = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+        b = t / (tiles_x * tiles_y);
+        row0 = ty * TR;
+        col0 = tx * TC;
+    };
+    auto prep = [&](int tb_row0, int tb_col0) {
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            int line, lcol, gcol;
+            bool ok = true;
+            if (s < 6) {
+                line = 2 * s + line_hi;
+                lcol = mcol + 1;
+                gcol = tb_col0 + mcol;
+            } else {
+                line = tid >> 1;
+                lcol = (tid & 1) ? LCOLS - 1 : 0;
+                gcol = (tid & 1) ? tb_col0 + TC : tb_col0 - 1;
+                ok = tid < 24 && gcol >= 0 && gcol < W;
+                if (line > 11) line = 11;
+            }
+            const int cblk = line >= LROWS ? 1 : 0, r = line - cblk * LROWS;
+            const int grow = tb_row0 - 1 + r;
+            ok = ok && grow >= 0 && grow < H;
+            voff[s] = ok ? (unsigned)((cblk * 8 * HW + grow * W + gcol) * 4) : 0xfffffff0u;
+            lofs[s] = (s < 6 || tid < 24) ? (unsigned)(((cblk * 3) * PLANE_U + r * LCOLS + lcol) * 16) : 0xffffffffu;
+        }
+    };
+    auto issue_loads = [&](int tb, int c) {
+        const __amdgpu_buffer_rsrc_t rx = rsrc(a.x + (long long)tb * a.Cin * HW, (unsigned)(a.Cin * HW) * 4u);
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff[s], (unsigned)((c * 16 + j) * HW) * 4u, 0));
+    };
+
+    if (tile_id >= a.ntiles) return;
+    set_tile(tile_id);
+    prep(row0, col0);
+    issue_loads(b, 0);
+    const __amdgpu_buffer_rsrc_t rw = rsrc(a.wpk, (unsigned)(nchunk * 9 * 3 * NCB * 64 * 16));
+    const unsigned char* lbase = reinterpret_cast<const unsigned char*>(tile);
+    const unsigned rd_base = (unsigned)((((lane >> 5) * 3) * PLANE_U + wave * LCOLS + (lane & 31)) * 16);
+
+    bf16x8 wf[2][3][NCB];
+    while (true) {
+        for (int c = 0; c < nchunk; ++c) {
+            if (c == 0) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            acc[nb][cb][i] = a.bias ? a.bias[cb * 32 + (i / 4) * 8 + (lane >> 5) * 4 + (i % 4)] : 0.f;
+            }
+            auto load_w = [&](int t, int buf) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        if (DIAG < 3 || (t < 2 && c == 0))
+                            wf[buf][pl][cb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                rw, (unsigned)lane * 16u, (unsigned)((((c * 9 + t) * 3 + pl) * NCB + cb) * 64) * 16u, 0));
+            };
+            load_w(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();            // the previous chunk's fragment reads are done
+            if (DIAG < 2) {
+#pragma unroll
+                for (int s = 0; s < 7; ++s) {
+                    u32x4 hi, mid, lo;
+                    split8(v[s], hi, mid, lo);
+                    if (s < 6 || tid < 24) {
+                        u32x4* d = reinterpret_cast<u32x4*>(const_cast<unsigned char*>(lbase) + lofs[s]);
+                        d[0] = hi;
+                        d[PLANE_U] = mid;
+                        d[2 * PLANE_U] = lo;
+                    }
+                }
+            }
+            __syncthreads();
+            load_w(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // next chunk (or the next tile's first chunk) into registers while this one is multiplied: ONE issue site
+            // (two would make the compiler merge the staging registers with copies behind a vmcnt(0))
+            const bool last_chunk = c + 1 == nchunk;
+            const int next_tile = tile_id + (int)gridDim.x;
+            int ld_b = b, ld_c = c + 1;
+            if (last_chunk) {
+                ld_c = 0;
+                if (next_tile < a.ntiles) {
+                    const int tx = next_tile % tiles_x, ty = (next_tile / tiles_x) % tiles_y;
+                    ld_b = next_tile / (tiles_x * tiles_y);
+                    prep(ty * TR, tx * TC);
+                } else {
+                    prep(-1000000, 0);      // nothing follows: every row out of range, the loads return zeros
+                }
+            }
+            if (DIAG < 2) issue_loads(ld_b, ld_c);
+            __builtin_amdgcn_sched_barrier(0);
+            // Fragment pipeline: the 12 pixel fragments of a tap (4 blocks x 3 planes) live in ONE register set; a plane's
+            // four registers are re-loaded for the next tap as soon as its 12 MFMAs have been issued.  Consecutive MFMAs go
+            // to the four different accumulators (a dependent 32x32x16 chain would run at half rate).
+            bf16x8 xf[4][3];
+            auto read_x = [&](int t, int pl) {
+                const int ky = t / 3, kx = t % 3;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    xf[nb][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                        lbase + rd_base + (unsigned)((pl * PLANE_U + ky * LCOLS + kx + nb * 32) * 16)));
+            };
+            read_x(0, 2); read_x(0, 1); read_x(0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t >= 1 && t + 1 < 9) load_w(t + 1, (t + 1) & 1);
+#pragma unroll
+                for (int j = 2; j >= 0; --j) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (DIAG != 1) {
+#pragma unroll
+                        for (int i = 2; i >= 0; --i)
+#pragma unroll
+                            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                                for (int nb = 0; nb < 4; ++nb)
+                                    acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t & 1][i][cb], xf[nb][j], acc[nb][cb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < 9) read_x(t + 1, j);
+                }
+            }
+        }
+        // ---- epilogue: ReLU, store (lane = pixel column, registers = 16 output channels)
+        if (DIAG < 4 || acc[0][0][0] == 123.f) {
+            const __amdgpu_buffer_rsrc_t ry = rsrc(a.y + (long long)b * a.Cout * HW, (unsigned)(a.Cout * HW) * 4u);
+            const unsigned vo = (unsigned)(((lane >> 5) * 4 * HW + (row0 + wave) * W + col0 + (lane & 31)) * 4);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float r = acc[nb][cb][i];
+                        if (a.relu) r = r > 0.f ? r : 0.f;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), ry, vo,
+                                                              (unsigned)((cb * 32 + (i / 4) * 8 + (i % 4)) * HW + nb * 32) * 4u, 0);
+                    }
+        }
+        tile_id += (int)gridDim.x;
+        if (tile_id >= a.ntiles) break;
+        set_tile(tile_id);
+    }
+}
+
+// ---------------------------------------------------------------- host
+static void split3(float x, unsigned short out[3]) {
+    for (int p = 0; p < 3; ++p) {
+        unsigned u;
+        memcpy(&u, &x, 4);
+        u &= 0xffff0000u;
+        float h;
+        memcpy(&h, &u, 4);
+        out[p] = (unsigned short)(u >> 16);
+        x -= h;
+    }
+}
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+    int B = 32, Cin = 32, Cout = 32, H = 256, W = 256;
+    if (argc >= 6) { B = atoi(argv[1]); Cin = atoi(argv[2]); Cout = atoi(argv[3]); H = atoi(argv[4]); W = atoi(argv[5]); }
+    if (Cin % 16 || Cout % 32 || H % TR || W % TC || Cout > 64) { printf("unsupported shape\n"); return 1; }
+    const int NCB = Cout / 32, nchunk = Cin / 16;
+    const size_t nx = (size_t)B * Cin * H * W, ny = (size_t)B * Cout * H * W, nw = (size_t)Cout * Cin * 9;
+    std::vector<float> hx(nx), hw(nw), hb(Cout), hy(ny);
+    srand(1);
+    for (auto& f : hx) { f = (float)rand() / RAND_MAX; f = f < 0.4f ? 0.f : f * 2.f - 0.8f; }   // post-ReLU like
+    for (auto& f : hw) f = ((float)rand() / RAND_MAX - 0.5f) * 0.2f;
+    for (auto& f : hb) f = ((float)rand() / RAND_MAX - 0.5f) * 0.1f;
+    std::vector<unsigned short> hpk((size_t)nchunk * 9 * 3 * NCB * 64 * 8);
+    for (int c = 0; c < nchunk; ++c)
+        for (int t = 0; t < 9; ++t)
+            for (int cb = 0; cb < NCB; ++cb)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = cb * 32 + (l & 31), ci = c * 16 + 8 * (l >> 5) + j;
+                        unsigned short s3[3];
+                        split3(hw[((size_t)co * Cin + ci) * 9 + t], s3);
+                        for (int pl = 0; pl < 3; ++pl)
+                            hpk[((((size_t)(c * 9 + t) * 3 + pl) * NCB + cb) * 64 + l) * 8 + j] = s3[pl];
+                    }
+    float *dx, *dy, *db;
+    u32x4* dw;
+    CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dy, ny * 4)); CK(hipMalloc(&db, Cout * 4)); CK(hipMalloc(&dw, hpk.size() * 2));
+    CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hpk.data(), hpk.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), Cout * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dy, 0xff, ny * 4));
+    Args a{dx, dw, db, dy, B, Cin, Cout, H, W, 1, B * (H / TR) * (W / TC)};
+    const int diag = getenv("DIAG") ? atoi(getenv("DIAG")) : 0;
+    auto kern = NCB == 2 ? conv_b9_kernel<2, 0> : diag == 1 ? conv_b9_kernel<1, 1> : diag == 2 ? conv_b9_kernel<1, 2> : diag == 3 ? conv_b9_kernel<1, 3> : diag == 4 ? conv_b9_kernel<1, 4> : conv_b9_kernel<1, 0>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    int grid = a.ntiles < 512 ? a.ntiles : 512;
+    if (getenv("GRID")) grid = atoi(getenv("GRID"));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, a);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hy.data(), dy, ny * 4, hipMemcpyDeviceToHost));
+    // check a sample of outputs against fp64 (and count how an fp32 FMA chain in the reference order does)
+    double worst = 0, worst32 = 0, ref_max = 0;
+    srand(7);
+    for (int n = 0; n < 20000; ++n) {
+        int bb = rand() % B, co = rand() % Cout, yy = rand() % H, xx = rand() % W;
+        if (n < 2000) { yy = (n & 1) ? H - 1 - (n % 3) : n % 3; xx = ((n & 2) ? W - 1 - (n % 5) : (n % 5) + ((n & 4) ? TC - 2 : 0)) % W; }
+        double s = hb[co];
+        float s32 = hb[co];
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const int iy = yy + t / 3 - 1, ix = xx + t % 3 - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const float xv = hx[(((size_t)bb * Cin + ci) * H + iy) * W + ix], wv = hw[((size_t)co * Cin + ci) * 9 + t];
+                s += (double)xv * wv;
+                s32 = fmaf(xv, wv, s32);
+            }
+        if (s < 0) { s = 0; }
+        if (s32 < 0) s32 = 0;
+        const double got = hy[(((size_t)bb * Cout + co) * H + yy) * W + xx];
+        worst = fmax(worst, fabs(got - s));
+        worst32 = fmax(worst32, fabs((double)s32 - s));
+        ref_max = fmax(ref_max, fabs(s));
+    }
+    printf("B=%d %d->%d %dx%d  max|err| vs fp64: split-bf16x9 %.3e   fp32 fma chain %.3e   (max |y| %.3f)\n", B, Cin, Cout, H, W, worst, worst32, ref_max);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, a);
+    CK(hipEventRecord(e0));
+    const int reps = 20;
+    for (int rep = 0; rep < reps; ++rep) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, a);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double fl = 2.0 * B * H * W * (double)Cin * Cout * 9;
+    printf("grid %d: %.1f us  %.1f TFLOP/s fp32-equivalent\n", grid, ms * 1e3, fl / ms / 1e9);
+    return 0;
+}
