@@ -28,7 +28,7 @@ struct Args {
     const u32x4* wpk;      // [chunk][tap][plane][cb][64 lanes] fragments
     const float* bias;
     float* y;
-    int B, Cin, Cout, H, W, relu, ntiles;
+    int B, Cin, Cout, H, W, relu, ntiles, skew;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes) {
@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv_b9_kernel(const Args a) {
     };
 
     if (tile_id >= a.ntiles) return;
+    if (a.skew && (blockIdx.x & 256))       // second workgroup of a CU: start half a chunk period late (phases alternate)
+        for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(64);
     set_tile(tile_id);
     prep(row0, col0);
     issue_loads(b, 0);
@@ -268,7 +270,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dw, hpk.data(), hpk.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), Cout * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dy, 0xff, ny * 4));
-    Args a{dx, dw, db, dy, B, Cin, Cout, H, W, 1, B * (H / TR) * (W / TC)};
+    Args a{dx, dw, db, dy, B, Cin, Cout, H, W, 1, B * (H / TR) * (W / TC), getenv("SKEW") ? atoi(getenv("SKEW")) : 0};
     const int diag = getenv("DIAG") ? atoi(getenv("DIAG")) : 0;
     auto kern = NCB == 2 ? conv_b9_kernel<2, 0> : diag == 1 ? conv_b9_kernel<1, 1> : diag == 2 ? conv_b9_kernel<1, 2> : diag == 3 ? conv_b9_kernel<1, 3> : diag == 4 ? conv_b9_kernel<1, 4> : conv_b9_kernel<1, 0>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
