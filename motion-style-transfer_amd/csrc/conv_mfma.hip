@@ -1102,10 +1102,12 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
 static int pick_rows(const ConvArgs& a, int cb) {
     static const int forced = getenv("YNET_CONV_R") ? atoi(getenv("YNET_CONV_R")) : 0;
     if (forced == 1 || forced == 2 || forced == 4) return forced;
+    static const int r4_min = getenv("YNET_CONV_R4_MIN") ? atoi(getenv("YNET_CONV_R4_MIN")) : 1024;
+    static const int r2_min = getenv("YNET_CONV_R2_MIN") ? atoi(getenv("YNET_CONV_R2_MIN")) : 512;
     const long long per_img_x = ceil_div(a.W, 32), cg = ceil_div(a.cout, cb);
     for (int r = 4; r > 1; r >>= 1) {
         const long long nblk = per_img_x * ceil_div(a.H, 4 * r) * cg * a.B;
-        if (nblk >= (r == 4 ? 1024 : 512)) return r;
+        if (nblk >= (r == 4 ? r4_min : r2_min)) return r;
     }
     return 1;
 }
