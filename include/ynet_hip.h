@@ -98,8 +98,10 @@ int ynet_lora_grad(const float* dw, const float* lora_a, const float* lora_b, fl
  * reused for the same layer every step). */
 int ynet_lora_compose_pack(const float* w, const float* lora_a, const float* lora_b, float scale, float* wp_fwd,
                            float* wp_dgrad, int cout, int cin, int K, int r, void* stream);
-/* The same for n <= 16 layers in ONE launch (every argument a host array of n entries): all adapted convs of an encoder
- * are composed at the start of a step instead of one by one between its convolutions. */
+/* The same for n <= 48 layers in ONE launch (every argument a host array of n entries): all adapted convs of an encoder
+ * are composed at the start of a step instead of one by one between its convolutions.  r[i] == 0: layer i has no adapter
+ * (lora_a[i] / lora_b[i] may be NULL) and its weight is packed as it is -- ynet_pack_weight in both modes -- which is how
+ * the 46 trainable convs of train_net = train / all (models/trainer.py:116-195) are re-packed after an optimizer step. */
 int ynet_lora_compose_pack_multi(int n, const float* const* w, const float* const* lora_a, const float* const* lora_b,
                                  const float* scale, float* const* wp_fwd, float* const* wp_dgrad, const int* cout,
                                  const int* cin, const int* K, const int* r, void* stream);

@@ -121,6 +121,9 @@ int ynet_comm_create(int rank, int world, long long max_floats, void** comm_out)
     if (e == hipSuccess) e = hipMemset(c->done_counter, 0, 64);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
+        (void)hipFree(c->local);
+        if (c->done_counter) (void)hipFree(c->done_counter);
+        free(c);
         ynet_set_error("comm_create: initialisation failed: %s", hipGetErrorString(e));
         return 2;
     }

@@ -119,12 +119,15 @@ __global__ __launch_bounds__(64) void lora_compose_pack_kernel(const ComposePack
 }
 
 // All adapted convs of a model in ONE launch (blockIdx.y = layer): the 9 composes of a mosa_* encoder are ~5 us launches
-// each; issued one by one in front of their convs they sit on the critical path of the encoder's forward pass.
-#define YNET_LORA_MULTI_MAX 16
+// each; issued one by one in front of their convs they sit on the critical path of the encoder's forward pass.  Rank 0
+// (no adapter: lora_a / lora_b NULL) packs the plain weight -- the 46 trainable convs of train_net = train / all are
+// re-packed after every optimizer step, 2 launches each when left to ynet_pack_weight.
+#define YNET_LORA_MULTI_MAX 48
 struct ComposePackMulti {
     ComposePackArgs layer[YNET_LORA_MULTI_MAX];
     int tiles[YNET_LORA_MULTI_MAX];
 };
+static_assert(sizeof(ComposePackMulti) <= 4096, "kernel arguments are limited to 4 KB");
 
 __global__ __launch_bounds__(64) void lora_compose_pack_multi_kernel(const ComposePackMulti mm) {
     const ComposePackArgs& g = mm.layer[blockIdx.y];
@@ -241,7 +244,8 @@ int ynet_lora_compose_pack(const float* w, const float* lora_a, const float* lor
     return ynet_check_launch("lora_compose_pack");
 }
 
-// ynet_lora_compose_pack for `n` layers (n <= 16) in one launch; every argument is a HOST array of n entries.
+// ynet_lora_compose_pack for `n` layers (n <= 48) in one launch; every argument is a HOST array of n entries.
+// r[i] == 0: layer i has no adapter (lora_a[i] / lora_b[i] may be NULL), its weight is packed as it is.
 int ynet_lora_compose_pack_multi(int n, const float* const* w, const float* const* lora_a, const float* const* lora_b,
                                  const float* scale, float* const* wp_fwd, float* const* wp_dgrad, const int* cout,
                                  const int* cin, const int* K, const int* r, void* stream) {
@@ -250,8 +254,8 @@ int ynet_lora_compose_pack_multi(int n, const float* const* w, const float* cons
     ComposePackMulti mm{};
     int max_tiles = 0;
     for (int i = 0; i < n; ++i) {
-        YNET_REQUIRE(w[i] && lora_a[i] && lora_b[i] && wp_fwd[i] && wp_dgrad[i], "lora_compose_pack_multi: null pointer (layer %d)", i);
-        YNET_REQUIRE(cout[i] > 0 && cin[i] > 0 && (K[i] == 1 || K[i] == 3 || K[i] == 5) && r[i] > 0, "lora_compose_pack_multi: bad shape (layer %d)", i);
+        YNET_REQUIRE(w[i] && wp_fwd[i] && wp_dgrad[i] && (r[i] == 0 || (lora_a[i] && lora_b[i])), "lora_compose_pack_multi: null pointer (layer %d)", i);
+        YNET_REQUIRE(cout[i] > 0 && cin[i] > 0 && (K[i] == 1 || K[i] == 3 || K[i] == 5) && r[i] >= 0, "lora_compose_pack_multi: bad shape (layer %d)", i);
         ComposePackArgs& g = mm.layer[i];
         g.w = w[i];
         g.lora_a = lora_a[i];

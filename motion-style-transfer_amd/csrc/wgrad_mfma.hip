@@ -648,11 +648,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
 
 // out[i] = sum_s partial[s][i] in a fixed order: thread (o, g) of a block sums the splits s = g mod 8 of output
 // base + o (four independent chains, 128-byte coalesced rows), the eight g are then added in order through LDS.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                              long long n, int nsplit) {
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ partial, float* __restrict__ out, long long n,
+                                                     int nsplit, int block, int nblocks) {
     __shared__ float red[8][32];
     const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
-    for (long long base = blockIdx.x * 32ll; base < n; base += (long long)gridDim.x * 32) {
+    for (long long base = block * 32ll; base < n; base += (long long)nblocks * 32) {
         const long long i = base + o;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (i < n) {
@@ -677,6 +677,23 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
+// One launch for both outputs of a wgrad: blocks [0, gridDim.x - 1) reduce the filter partials, the last block the bias
+// partials (when there are any) -- a second ~5 us launch per trainable conv otherwise.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial_w, float* __restrict__ dw, long long nw,
+                                                              const float* __restrict__ partial_b, float* __restrict__ db, long long nb,
+                                                              int nsplit) {
+    const int wblocks = db ? (int)gridDim.x - 1 : (int)gridDim.x;
+    if ((int)blockIdx.x < wblocks) reduce_partials_body(partial_w, dw, nw, nsplit, (int)blockIdx.x, wblocks);
+    else reduce_partials_body(partial_b, db, nb, nsplit, 0, 1);
+}
+
+static void launch_reduce_partials(const WgradArgs& a, float* dw, float* db, long long nw, hipStream_t st) {
+    int grid = (int)((nw + 31) / 32);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid + (db ? 1 : 0)), dim3(256), 0, st, a.partial_w, dw, nw, a.partial_b, db,
+                       (long long)a.cout, a.nsplit);
+}
+
 template <int KS, bool MASK>
 static int launch_wgrad_m(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     using C = WgCfg<KS>;
@@ -692,10 +709,7 @@ static int launch_wgrad_m(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     int rc = ynet_check_launch("conv2d_wgrad");
     if (rc) return rc;
     const long long nw = (long long)a.cout * a.cin * C::KK;
-    int grid = (int)((nw + 31) / 32);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, a.partial_w, dw, nw, a.nsplit);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.partial_b, db, (long long)a.cout, a.nsplit);
+    launch_reduce_partials(a, dw, db, nw, st);
     return ynet_check_launch("conv2d_wgrad(reduce)");
 }
 
@@ -752,10 +766,7 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
     int rc = ynet_check_launch("conv2d_wgrad");
     if (rc) return rc;
     const long long nw = (long long)a.cout * a.cin * 9;
-    int grid = (int)((nw + 31) / 32);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, a.partial_w, dw, nw, a.nsplit);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.partial_b, db, (long long)a.cout, a.nsplit);
+    launch_reduce_partials(a, dw, db, nw, st);
     return ynet_check_launch("conv2d_wgrad(reduce)");
 }
 

@@ -348,29 +348,41 @@ def _cached(cache: dict, weight, lora_a, lora_b, scale, what: str):
     return cache[what]
 
 
-def refresh_lora_filters(model):
-    """Compose W + BA*s and write both packed filter layouts of every adapted (LoRA) conv of `model` whose parameters
-    changed since its last compose -- what each conv would do itself at its first use in a step -- in ONE launch
-    (ynet_lora_compose_pack_multi) instead of a ~5 us launch in front of each of the encoder's convolutions."""
+MULTI_PACK_MAX = 48      # YNET_LORA_MULTI_MAX (csrc/lora.hip)
+
+
+def refresh_filters(model):
+    """Write both packed filter layouts of every conv of `model` whose parameters changed since its last packing --
+    W + BA*s for an adapted (LoRA) conv, W itself for a plain one -- in ONE launch per 48 layers
+    (ynet_lora_compose_pack_multi) instead of one or two ~5 us launches in front of each convolution: what every conv
+    would do itself at its first use in a step.  Frozen, already packed layers are skipped, so a mosa_* step composes
+    its 9 adapted convs here and a train_net = train / all step re-packs all 46."""
     todo = []
     for m in model.modules():
-        if getattr(m, "r", 0) and hasattr(m, "lora_A") and hasattr(m, "_packed"):
-            cache = m._packed
-            if cache.get("key") != _weight_key(m.weight, m.lora_A, m.lora_B) or "fwd" not in cache:
-                todo.append(m)
+        cache = getattr(m, "_packed", None)
+        if cache is None or not isinstance(getattr(m, "weight", None), torch.Tensor) or m.weight.dim() != 4:
+            continue
+        has_lora = bool(getattr(m, "r", 0)) and hasattr(m, "lora_A")
+        la, lb = (m.lora_A, m.lora_B) if has_lora else (None, None)
+        if cache.get("key") != _weight_key(m.weight, la, lb) or "fwd" not in cache or "dgrad" not in cache:
+            todo.append((m, la, lb))
     if not todo:
         return
     lib = _lib()
     with torch.no_grad():
-        for i0 in range(0, len(todo), 16):
-            part = todo[i0:i0 + 16]
+        for i0 in range(0, len(todo), MULTI_PACK_MAX):
+            part = todo[i0:i0 + MULTI_PACK_MAX]
             n = len(part)
             entries = []
-            for m in part:
+            for m, la, lb in part:
                 w = m.weight.detach()
-                for t, what in ((w, "weight"), (m.lora_A, "lora_A"), (m.lora_B, "lora_B")):
-                    _need_gpu(t, "lora_compose_pack " + what)
+                _need_gpu(w, "refresh_filters weight")
                 cout, cin, k, _ = w.shape
+                r = 0
+                if la is not None:
+                    for t, what in ((la, "lora_A"), (lb, "lora_B")):
+                        _need_gpu(t, "refresh_filters " + what)
+                    r = la.shape[0] // k
                 cache = m._packed
                 bufs = cache.get("lora_bufs")
                 if bufs is not None and (bufs[0].device != w.device or cache.get("lora_shape") != tuple(w.shape)):
@@ -378,21 +390,27 @@ def refresh_lora_filters(model):
                 if bufs is None:
                     bufs = tuple(torch.zeros(lib.ynet_packed_weight_floats(cout, cin, k, mode), device=w.device, dtype=torch.float32)
                                  for mode in (0, 1))
-                entries.append((m, w.contiguous(), m.lora_A.detach().contiguous(), m.lora_B.detach().contiguous(), bufs, cout, cin, k))
+                entries.append((m, w.contiguous(), la.detach().contiguous() if la is not None else None,
+                                lb.detach().contiguous() if lb is not None else None, bufs, cout, cin, k, r,
+                                float(m.scaling) if la is not None else 0.0, la, lb))
             vp = lambda xs: ctypes.cast((_VP * n)(*xs), L.PP)        # noqa: E731
             ia = lambda xs: (ctypes.c_int * n)(*xs)                  # noqa: E731
             L.check(lib.ynet_lora_compose_pack_multi(
-                n, vp([e[1].data_ptr() for e in entries]), vp([e[2].data_ptr() for e in entries]),
-                vp([e[3].data_ptr() for e in entries]), (ctypes.c_float * n)(*[float(e[0].scaling) for e in entries]),
+                n, vp([e[1].data_ptr() for e in entries]), vp([e[2].data_ptr() if e[2] is not None else None for e in entries]),
+                vp([e[3].data_ptr() if e[3] is not None else None for e in entries]), (ctypes.c_float * n)(*[e[9] for e in entries]),
                 vp([e[4][0].data_ptr() for e in entries]), vp([e[4][1].data_ptr() for e in entries]),
                 ia([e[5] for e in entries]), ia([e[6] for e in entries]), ia([e[7] for e in entries]),
-                ia([e[2].shape[0] // e[7] for e in entries]), _stream()), lib)
-            for m, w, _a, _b, bufs, *_ in entries:
+                ia([e[8] for e in entries]), _stream()), lib)
+            for e in entries:
+                m, w, bufs = e[0], e[1], e[4]
                 cache = m._packed
                 cache.clear()
-                cache["key"] = _weight_key(m.weight, m.lora_A, m.lora_B)
+                cache["key"] = _weight_key(m.weight, e[10], e[11])
                 cache["lora_bufs"], cache["lora_shape"] = bufs, tuple(w.shape)
                 cache["fwd"], cache["dgrad"] = bufs
+
+
+refresh_lora_filters = refresh_filters      # (round-2 name)
 
 
 # ------------------------------------------------------------------------------------------------

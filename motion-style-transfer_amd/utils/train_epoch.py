@@ -55,7 +55,7 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
                 gt_future_map, gt_waypoint_map = target_maps()
             for t in (gt_future_map, gt_waypoint_map):
                 t.record_stream(main0)
-        ops.refresh_lora_filters(model)      # every adapted conv's W + BA*s in one launch, ahead of the encoder
+        ops.refresh_filters(model)      # every changed filter (W + BA*s of the adapted convs, W of the trainable plain ones) packed in one launch
         observed_map = gather_patches(input_template, coords[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
         gt_future = coords[:, obs_len:].to(device)
         if side is None:

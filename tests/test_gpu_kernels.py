@@ -225,6 +225,49 @@ def test_lora_conv_end_to_end_and_identity_at_init(dev):
     assert torch.equal(y0, y1)
 
 
+def test_refresh_filters_packs_every_changed_conv_in_one_launch(dev):
+    """ops.refresh_filters (ynet_lora_compose_pack_multi, rank 0 = plain conv) == the per-layer routines, bit for bit;
+    untouched layers are skipped, changed ones are written again into the same buffers."""
+    ops, ynet = pkg("ops"), pkg("models.ynet")
+    torch.manual_seed(3)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = ynet.HipConv2d(14, 32, 3)
+            self.b = ynet.LoRAConv2d(32, 64, 3, r=2)
+            self.c = ynet.HipConv2d(64, 12, 1)
+            self.d = ynet.HipConv2d(7, 9, 5, bias=False)
+            self.e = ynet.LoRAConv2d(33, 16, 3, r=1)
+    net = Net()
+    with torch.no_grad():
+        for m in (net.b, net.e):
+            m.lora_B.normal_(0, 0.05)
+    net.to(dev)
+    ops.refresh_filters(net)
+    for m in (net.a, net.c, net.d):
+        w = m.weight.detach()
+        assert torch.equal(m._packed["fwd"], ops.pack_weight(w, 0)) and torch.equal(m._packed["dgrad"], ops.pack_weight(w, 1))
+    for m in (net.b, net.e):
+        fwd, dgrad = ops.lora_compose_pack(m.weight.detach(), m.lora_A.detach(), m.lora_B.detach(), m.scaling)
+        assert torch.equal(m._packed["fwd"], fwd) and torch.equal(m._packed["dgrad"], dgrad)
+    ptrs = {n: (m._packed["fwd"].data_ptr(), m._packed["dgrad"].data_ptr()) for n, m in net.named_children()}
+    old_c = net.c._packed["fwd"].clone()
+    with torch.no_grad():
+        net.a.weight.mul_(1.5)
+        net.e.lora_A.add_(0.25)
+    ops.refresh_filters(net)
+    assert {n: (m._packed["fwd"].data_ptr(), m._packed["dgrad"].data_ptr()) for n, m in net.named_children()} == ptrs
+    assert torch.equal(net.a._packed["fwd"], ops.pack_weight(net.a.weight.detach(), 0))
+    fwd, dgrad = ops.lora_compose_pack(net.e.weight.detach(), net.e.lora_A.detach(), net.e.lora_B.detach(), net.e.scaling)
+    assert torch.equal(net.e._packed["fwd"], fwd) and torch.equal(net.e._packed["dgrad"], dgrad)
+    assert torch.equal(net.c._packed["fwd"], old_c)
+    # the convs use what refresh_filters wrote
+    x = rnd(2, 14, 16, 16, seed=5).to(dev)
+    y = net.a(x, relu=True)
+    close(y, F.relu(F.conv2d(x.cpu(), net.a.weight.detach().cpu(), net.a.bias.detach().cpu(), padding=1)), msg="conv after refresh")
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 16, 32), (1, 5, 10, 14), (2, 2, 7, 9)])
 def test_maxpool(dev, shape):
     ops = pkg("ops")
