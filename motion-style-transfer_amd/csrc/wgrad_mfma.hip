@@ -759,7 +759,8 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
         (void)hipEventSynchronize(e1);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        fprintf(stderr, "wgrad_dma_kernel<%d> nsplit %d tiles %d blocks %lld: %.1f us\n", (int)MASK, a.nsplit, a.ntiles, nblk, ms * 1e3f);
+        fprintf(stderr, "wgrad_dma_kernel<%d> B %d %dx%d cin %d cout %d nsplit %d tiles %d blocks %lld: %.1f us  %.1f TFLOP/s\n", (int)MASK, a.B, a.H, a.W,
+                a.cin, a.cout, a.nsplit, a.ntiles, nblk, ms * 1e3f, 2.0 * a.B * a.H * a.W * (double)a.cin * a.cout * 9 / (ms * 1e9));
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
