@@ -5,6 +5,7 @@
 #  1. rocprofv3 --kernel-trace --stats of `python3 bench.py` as the driver runs it (captured step, parallel branches)
 #  2. the same with YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1: eager launches on one stream = isolated per-kernel durations,
 #     the condition under which bench.py times the dominant kernel for its `roofline` object
+#  2b. the eager serial trace of C1 (every conv trainable: the wgrad kernels)
 #  3. PMC passes FETCH_SIZE / WRITE_SIZE (separate passes, never combined with a trace domain) of the eager serial run
 #  4. bench lines: C2 (default, with cpu_baseline + parity_check), C2 at the reference scripts' batch 10, C1, C3, C4, C5
 set -u
@@ -20,6 +21,8 @@ echo "trace graph rc=$?"; python3 "$R/tools/trace_summary.py" /tmp/tr_graph "$OU
 export YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_serial -o t -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > "$OUT/trace_serial.log" 2>&1
 echo "trace serial rc=$?"; python3 "$R/tools/trace_summary.py" /tmp/tr_serial "$OUT/${TAG}_bench_C2_serial" --tail-frac 0.6 > "$OUT/timeline_serial.txt"
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_c1 -o t -- $B --config C1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > "$OUT/trace_c1_serial.log" 2>&1
+echo "trace C1 serial rc=$?"; python3 "$R/tools/trace_summary.py" /tmp/tr_c1 "$OUT/${TAG}_bench_C1_serial" --tail-frac 0.6 > "$OUT/timeline_c1_serial.txt"
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > "$OUT/fetch.log" 2>&1
 echo "fetch rc=$?"
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > "$OUT/write.log" 2>&1
