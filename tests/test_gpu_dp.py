@@ -24,20 +24,23 @@ def _free_port():
 
 # (rows, batch size): even shards; ragged shards (3 -> 2 + 1) and a ragged last batch; batch of 1 -> rank 1's shard is EMPTY.
 # collective "oneshot": ynet_allreduce_sum (HIP-IPC mailboxes, one hop, rank-ordered sums) instead of torch.distributed.
-@pytest.mark.parametrize("n_rows,batch_size,collective", [(8, 4, "rccl"), (8, 3, "rccl"), (3, 1, "rccl"), (8, 3, "oneshot"), (3, 1, "oneshot")])
-def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch_size, collective):
+# Four ranks: shards of one trajectory each, and (batch 3) one EMPTY rank in every step -- the rank-ordered sums of the
+# one-shot all-reduce over four mailboxes.
+@pytest.mark.parametrize("n_rows,batch_size,collective,world", [(8, 4, "rccl", 2), (8, 3, "rccl", 2), (3, 1, "rccl", 2), (8, 3, "oneshot", 2),
+                                                                (3, 1, "oneshot", 2), (8, 4, "oneshot", 4), (8, 3, "rccl", 4)])
+def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch_size, collective, world):
     out = str(tmp_path / "dp.pt")
     n_gpu = torch.cuda.device_count()
     env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "YNET_ALLREDUCE": collective}
-    if n_gpu < 2:
+    if n_gpu < world:
         env.update(YNET_DIST_BACKEND="gloo", YNET_BENCH_SINGLE_DEVICE="1")
-    rc, tail = launch([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    rc, tail = launch([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                        os.path.join(ROOT, "tests", "dp_worker.py"), out, str(n_rows), str(batch_size)], env=env, timeout=600)
     assert rc == 0, tail
     got = torch.load(out, weights_only=False)
-    assert got["world"]["world_size"] == 2 and len({r["pid"] for r in got["world"]["ranks"]}) == 2
-    assert got["world"]["backend"] == ("nccl" if n_gpu >= 2 else "gloo")
+    assert got["world"]["world_size"] == world and len({r["pid"] for r in got["world"]["ranks"]}) == world
+    assert got["world"]["backend"] == ("nccl" if n_gpu >= world else "gloo")
     assert got["world"]["collective"] == collective
 
     cfg, sd, scene, traj = case_inputs(n_rows)
