@@ -25,9 +25,9 @@ def _free_port():
 # (rows, batch size): even shards; ragged shards (3 -> 2 + 1) and a ragged last batch; batch of 1 -> rank 1's shard is EMPTY.
 # collective "oneshot": ynet_allreduce_sum (HIP-IPC mailboxes, one hop, rank-ordered sums) instead of torch.distributed.
 # Four ranks: shards of one trajectory each, and (batch 3) one EMPTY rank in every step -- the rank-ordered sums of the
-# one-shot all-reduce over four mailboxes.
+# one-shot all-reduce over four mailboxes; eight ranks (the node size of the north star) with one trajectory each.
 @pytest.mark.parametrize("n_rows,batch_size,collective,world", [(8, 4, "rccl", 2), (8, 3, "rccl", 2), (3, 1, "rccl", 2), (8, 3, "oneshot", 2),
-                                                                (3, 1, "oneshot", 2), (8, 4, "oneshot", 4), (8, 3, "rccl", 4)])
+                                                                (3, 1, "oneshot", 2), (8, 4, "oneshot", 4), (8, 3, "rccl", 4), (8, 8, "oneshot", 8)])
 def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch_size, collective, world):
     out = str(tmp_path / "dp.pt")
     n_gpu = torch.cuda.device_count()
