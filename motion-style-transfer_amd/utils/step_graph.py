@@ -22,6 +22,7 @@ import warnings
 import weakref
 
 import torch
+import torch.distributed as dist
 
 from .. import ops
 
@@ -206,9 +207,10 @@ class CapturedStep:
             self.dp = dp
             self.split = dp is not None and dp.world > 1
             self.params = [p for g in optimizer.param_groups for p in g["params"]]
-            # Under a multi-rank process group other threads (the NCCL / RCCL watchdog) may query events while this thread
-            # captures: only the capturing thread is held to capture-safe calls then.
-            mode = "thread_local" if self.split else "global"
+            # Under a process group other threads (the NCCL / RCCL watchdog) may query events while this thread captures:
+            # only the capturing thread is held to capture-safe calls then.
+            pg = dist.is_available() and dist.is_initialized()
+            mode = "thread_local" if (self.split or pg) else "global"
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, pool=self.cache.pool, stream=stream, capture_error_mode=mode):
                 fb = forward_backward(self.coords, self.scene, OVERLAP_DECODERS)
