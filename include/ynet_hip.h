@@ -155,6 +155,17 @@ int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, con
  * copy) -> out [B][C][2] = (E[x], E[y]) in pixels. */
 int ynet_softargmax2d(const float* x, float* out, long long B, int C, long long batch_stride, int H, int W,
                       void* stream);
+/* The 1x1 predictor (models/ynet.py:469: nn.Conv2d(decoder_channels[-1], pred_len, 1)) followed by SoftArgmax2D
+ * (utils/softargmax.py:55-81) as evaluate() chains them for every trajectory sample (utils/evaluate.py:259-262:
+ * `model.softargmax(model.pred_traj(...))`) in one pass: x [B][cin][H][W] (batch stride x_bs elements), w [cout][cin] the
+ * filter as the checkpoint stores it, bias [cout] or NULL -> out [B][cout][2] = (E[x], E[y]) in pixels.  The logits are
+ * never written.  workspace: ynet_pred_softargmax_workspace_floats(B, H, W) floats, 16-byte aligned.
+ * ynet_pred_softargmax_supported: cin in {8, 16, 32}, cout <= 32, W % 4 == 0, H*W % 128 == 0; other shapes take
+ * ynet_conv2d + ynet_softargmax2d. */
+int ynet_pred_softargmax_supported(int cin, int cout, int H, int W);
+long long ynet_pred_softargmax_workspace_floats(long long B, int H, int W);
+int ynet_pred_softargmax(const float* x, long long x_bs, const float* w, const float* bias, float* out, float* workspace,
+                         long long B, int cin, int cout, int H, int W, void* stream);
 /* sigmoid(pred_goal_map[:, sel] / temperature) (utils/evaluate.py:128-131; models/ynet.py:585-586):
  * x [B][C][HW] -> y [B][nsel][HW]; sel is a HOST array of nsel (<= 8) channel indices. */
 int ynet_sigmoid_temp(const float* x, float* y, long long B, int C, long long HW, const int* sel, int nsel,

@@ -52,6 +52,9 @@ SIGNATURES = {
     "ynet_pred_bce_workspace_bytes": (c_ll, []),
     "ynet_pred_bce": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_ll, c_f, c_fp]),
     "ynet_softargmax2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, c_i, c_i, c_fp]),
+    "ynet_pred_softargmax_supported": (c_i, [c_i, c_i, c_i, c_i]),
+    "ynet_pred_softargmax_workspace_floats": (c_ll, [c_ll, c_i, c_i]),
+    "ynet_pred_softargmax": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_sigmoid_temp": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, PI, c_i, c_f, c_fp]),
     "ynet_gather_patch": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "ynet_heatmap_analytic": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, ctypes.c_double, c_fp, c_i, c_fp, c_fp]),

@@ -813,6 +813,133 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1x1 predictor + SoftArgmax2D in one pass (evaluate()'s K trajectory passes: models/ynet.py:469 followed by
+// utils/softargmax.py:55-81 at utils/evaluate.py:259-262).  Unfused, the [B, pred, H, W] logits are written by the
+// predictor and read back by the soft-argmax -- 2 x 2 GB per 256-image pass of the C5 sweep next to the 2.1 GB of the
+// activation itself -- and nothing else ever looks at them.  Here the logits exist in accumulator registers only:
+//   * the predictor is a [pixels x cin] x [cin x 32] product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32
+//     fma chains like the convolutions): a wave takes 128 consecutive pixels per step -- lane (r, h) loads the 16-byte quad
+//     of pixels 4r .. 4r+3 of input plane 2s + h for each K-step s -- and runs four accumulator tiles (pixel 4i + j in
+//     tile j, row i), the filter column of output channel r staying in registers;
+//   * the result layout puts ONE output channel on every lane (column = lane & 31) with 16 x 4 pixels in its registers,
+//     so the online soft-max state (running maximum, sum e, sum e x, sum e y) is four registers per lane; the two lane
+//     halves are merged at the end of the wave's pixel range and written as one partial per (image, wave, channel);
+//   * pred_softargmax_combine_kernel merges the partials of a plane in fp64 and applies the reference's eps.
+// Same NaN / +inf semantics as softargmax_kernel.  Needs H*W % 128 == 0, 16-byte aligned planes, cin in {8, 16, 32},
+// cout <= 32 (ynet_pred_softargmax_supported); everything else stays on the two launches.
+// ------------------------------------------------------------------------------------------------
+struct PredSoftArgs {
+    const float* x;
+    long long x_bs;
+    const float* w;         // [cout][cin]: the 1x1 filter as the checkpoint stores it
+    const float* bias;      // [cout] or NULL
+    float* partial;         // [B][nchunk][32][4] = (m, s, sx, sy)
+    int cout, H, W, nchunk, gpw;      // gpw = 128-pixel groups per wave, nchunk = waves per image
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void pred_softargmax_kernel(const PredSoftArgs a) {
+    constexpr int KS = CIN / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
+    const int wgs_per_img = (a.nchunk + 3) >> 2;
+    const int b = (int)blockIdx.x / wgs_per_img, ch = ((int)blockIdx.x % wgs_per_img) * 4 + wave;
+    if (ch >= a.nchunk) return;
+    const int HW = a.H * a.W, ngroups = HW >> 7;
+    const int g_lo = ch * a.gpw, g_hi = min(ngroups, g_lo + a.gpw);
+    float wreg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wreg[s] = r < a.cout ? a.w[r * CIN + 2 * s + half] : 0.f;
+    const float bias_v = (a.bias != nullptr && r < a.cout) ? a.bias[r] : 0.f;
+    const float* xb = a.x + (long long)b * a.x_bs + (long long)half * HW + 4 * r;
+    const bool row_uniform = (a.W & 127) == 0;       // a 128-pixel group lies inside one image row
+    SoftAcc st{-INFINITY, 0.f, 0.f, 0.f};
+    bool poison = false;
+    f32x4 v[KS];
+    auto load_group = [&](int g) {
+        const float* p = xb + ((long long)g << 7);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) v[s] = *reinterpret_cast<const f32x4*>(p + (long long)(2 * s) * HW);
+    };
+    if (g_lo < g_hi) load_group(g_lo);
+    for (int g = g_lo; g < g_hi; ++g) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = bias_v;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s][j], wreg[s], acc[j], 0, 0, 0);
+        if (g + 1 < g_hi) load_group(g + 1);        // in flight while this group's logits are folded
+        const int p0 = g << 7;
+        const int row0 = p0 / a.W, col0 = p0 - row0 * a.W;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;      // row of the accumulator tile = quad index inside the group
+            int row = row0, col = col0 + 4 * i;
+            if (!row_uniform) {
+                const int p4 = p0 + 4 * i;
+                row = p4 / a.W;
+                col = p4 - row * a.W;
+            }
+            const float v0 = acc[0][q], v1 = acc[1][q], v2 = acc[2][q], v3 = acc[3][q];
+            const float chk = (v0 + v1) + (v2 + v3);
+            poison = poison || chk != chk;
+            const float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+            if (mx > st.m) {
+                const float rs = exp_le0(st.m - mx);
+                st.s *= rs;
+                st.sx *= rs;
+                st.sy *= rs;
+                st.m = mx;
+            }
+            const float e0 = exp_le0(v0 - st.m), e1 = exp_le0(v1 - st.m), e2 = exp_le0(v2 - st.m), e3 = exp_le0(v3 - st.m);
+            const float es = (e0 + e1) + (e2 + e3);
+            st.s += es;
+            st.sx += __builtin_fmaf((float)col, es, __builtin_fmaf(3.f, e3, __builtin_fmaf(2.f, e2, e1)));
+            st.sy += es * (float)row;
+        }
+    }
+    if (poison) st.s = __builtin_nanf("");
+    // merge the two lane halves (same channel, different pixels), then one partial per (image, wave, channel)
+    const float om = __shfl_xor(st.m, 32), os = __shfl_xor(st.s, 32), osx = __shfl_xor(st.sx, 32), osy = __shfl_xor(st.sy, 32);
+    const float m = fmaxf(st.m, om);
+    const float ra = st.m == -INFINITY ? 0.f : exp_le0(st.m - m), rb = om == -INFINITY ? 0.f : exp_le0(om - m);
+    if (half == 0) {
+        f32x4 o;
+        o[0] = m;
+        o[1] = st.s * ra + os * rb;
+        o[2] = st.sx * ra + osx * rb;
+        o[3] = st.sy * ra + osy * rb;
+        *reinterpret_cast<f32x4*>(a.partial + (((long long)b * a.nchunk + ch) * 32 + r) * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void pred_softargmax_combine_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                      long long B, int cout, int nchunk, float eps) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= B * cout) return;
+    const long long b = i / cout;
+    const int co = (int)(i - b * cout);
+    const float* p = partial + (b * nchunk * 32 + co) * 4;
+    float m = -INFINITY;
+    for (int k = 0; k < nchunk; ++k) m = fmaxf(m, p[(long long)k * 128]);
+    double s = 0.0, sx = 0.0, sy = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const float* q = p + (long long)k * 128;
+        const double rk = q[0] == -INFINITY ? 0.0 : (double)exp_le0(q[0] - m);
+        s += (double)q[1] * rk;
+        sx += (double)q[2] * rk;
+        sy += (double)q[3] * rk;
+    }
+    if (m == INFINITY) s = (double)__builtin_nanf("");      // a +inf logit: exp(inf - inf) = NaN in the reference
+    const double inv = 1.0 / (s + (double)eps);
+    out[i * 2 + 0] = (float)(sx * inv);
+    out[i * 2 + 1] = (float)(sy * inv);
+}
+
+// ------------------------------------------------------------------------------------------------
 // sigmoid(x[:, sel] / T)   (utils/evaluate.py:128-131, models/ynet.py:585-586): channel gather fused
 // ------------------------------------------------------------------------------------------------
 struct SigArgs {
@@ -1163,6 +1290,53 @@ int ynet_softargmax2d(const float* x, float* out, long long B, int C, long long 
     hipLaunchKernelGGL(softargmax_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, out, C,
                        batch_stride, H, W, 1e-6f);
     return ynet_check_launch("softargmax2d");
+}
+
+static void pred_softargmax_plan(int H, int W, int* gpw, int* nchunk) {
+    const int ngroups = (int)(((long long)H * W) >> 7);
+    int g = ngroups / 32;
+    if (g < 1) g = 1;
+    *gpw = g;
+    *nchunk = (ngroups + g - 1) / g;
+}
+
+int ynet_pred_softargmax_supported(int cin, int cout, int H, int W) {
+    return (cin == 8 || cin == 16 || cin == 32) && cout >= 1 && cout <= 32 && H > 0 && W > 0 && (W & 3) == 0 &&
+           (((long long)H * W) & 127) == 0 && (long long)H * W < (1ll << 30);
+}
+
+long long ynet_pred_softargmax_workspace_floats(long long B, int H, int W) {
+    int gpw = 1, nchunk = 1;
+    pred_softargmax_plan(H, W, &gpw, &nchunk);
+    return B * nchunk * 128;
+}
+
+int ynet_pred_softargmax(const float* x, long long x_bs, const float* w, const float* bias, float* out, float* workspace,
+                         long long B, int cin, int cout, int H, int W, void* stream) {
+    YNET_REQUIRE(x && w && out && workspace && B > 0, "pred_softargmax: bad arguments");
+    YNET_REQUIRE(ynet_pred_softargmax_supported(cin, cout, H, W), "pred_softargmax: cin %d cout %d %dx%d is not served (cin 8/16/32, cout <= 32, H*W %% 128 == 0, W %% 4 == 0)", cin, cout, H, W);
+    YNET_REQUIRE((((uintptr_t)x | (uintptr_t)workspace) & 15) == 0 && (x_bs & 3) == 0, "pred_softargmax: x and the workspace must be 16-byte aligned");
+    PredSoftArgs a{};
+    a.x = x;
+    a.x_bs = x_bs;
+    a.w = w;
+    a.bias = bias;
+    a.partial = workspace;
+    a.cout = cout;
+    a.H = H;
+    a.W = W;
+    pred_softargmax_plan(H, W, &a.gpw, &a.nchunk);
+    const long long blocks = B * ((a.nchunk + 3) / 4);
+    YNET_REQUIRE(blocks < (1ll << 31), "pred_softargmax: too many workgroups");
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 32) hipLaunchKernelGGL((pred_softargmax_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (cin == 16) hipLaunchKernelGGL((pred_softargmax_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pred_softargmax_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    int rc = ynet_check_launch("pred_softargmax");
+    if (rc) return rc;
+    hipLaunchKernelGGL(pred_softargmax_combine_kernel, dim3((unsigned)((B * cout + 255) / 256)), dim3(256), 0, st, workspace, out, B, cout,
+                       a.nchunk, 1e-6f);
+    return ynet_check_launch("pred_softargmax(combine)");
 }
 
 int ynet_sigmoid_temp(const float* x, float* y, long long B, int C, long long HW, const int* sel, int nsel,

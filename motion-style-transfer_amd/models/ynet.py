@@ -25,6 +25,9 @@ import torch.nn as nn
 from .. import ops
 from ..utils.softargmax import SoftArgmax2D, create_meshgrid
 
+# YNET_FUSED_READOUT=0: evaluate()'s trajectory passes run predictor and soft-argmax as two launches (A/B runs)
+FUSED_READOUT = os.environ.get("YNET_FUSED_READOUT", "1") != "0"
+
 
 class HipConv2d(nn.Conv2d):
     """nn.Conv2d (stride 1, 'same' padding, K in {1,3,5}) executed by ynet_conv2d."""
@@ -392,7 +395,9 @@ class YNetDecoder(nn.Module):
         (list of 6, finest first, as model.pred_features returns them) -- for the levels the additive kernels serve."""
         return _SharedSkipTerms(self, features)
 
-    def forward(self, features):
+    def forward(self, features, readout=False):
+        """``readout=True`` (inference, the caller only wants ``softargmax`` of the result): where the shape allows it the
+        heat-maps come back as an ``ops.LazyPredictor`` that ``SoftArgmax2D`` evaluates together with the read-out."""
         features = features[::-1]
         x = self.center(features[0])
         for lvl, (f, d, up) in enumerate(zip(features[1:], self.decoder, self.upsample_conv)):
@@ -400,6 +405,11 @@ class YNetDecoder(nn.Module):
             x = up(x)
             y = self._first_conv_shared(lvl, d, x, f)
             x = d[2](y, relu=True) if y is not None else d(ops.lazy_cat([x, f]))
+        if readout:
+            if (FUSED_READOUT and not torch.is_grad_enabled() and type(self.predictor) is HipConv2d
+                    and ops.pred_softargmax_supported(x, self.predictor.weight)):
+                return ops.LazyPredictor(x, self.predictor.weight, self.predictor.bias)
+            return self.predictor(x)
         bce = self._bce
         if (bce is not None and torch.is_grad_enabled() and type(self.predictor) is HipConv2d
                 and ops.pred_bce_supported(x, self.predictor.weight)):
@@ -541,6 +551,10 @@ class YNet(nn.Module):
 
     def pred_traj(self, features):
         return self.traj_decoder(features)
+
+    def pred_traj_coords(self, features):
+        """``softargmax(pred_traj(features))`` (utils/evaluate.py:259-262) without the heat-maps in between."""
+        return self.softargmax_(self.traj_decoder(features, readout=True))
 
     def pred_features(self, scene_map, motion_map):
         if self.network == "fusion":

@@ -821,6 +821,48 @@ def softargmax2d(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class LazyPredictor:
+    """The heat-map logits ``conv1x1(x, weight, bias)`` that nobody needs materialised: what a decoder returns with
+    ``readout=True`` and what ``SoftArgmax2D`` turns into coordinates in one launch (pred_softargmax)."""
+
+    def __init__(self, x, weight, bias):
+        self.x, self.weight, self.bias = x, weight, bias
+
+    @property
+    def shape(self):
+        return (self.x.shape[0], self.weight.shape[0], self.x.shape[2], self.x.shape[3])
+
+
+def pred_softargmax_supported(x, weight) -> bool:
+    """Can ``softargmax2d(conv1x1(x, weight))`` run as one launch (ynet_pred_softargmax)?"""
+    if not (torch.is_tensor(x) and x.dim() == 4 and x.is_cuda and weight.dim() == 4 and weight.shape[2] == 1 and weight.shape[3] == 1):
+        return False
+    _, cin, H, W = x.shape
+    return cin == weight.shape[1] and bool(_lib().ynet_pred_softargmax_supported(int(cin), int(weight.shape[0]), int(H), int(W)))
+
+
+def pred_softargmax(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
+    """SoftArgmax2D(conv1x1(x, weight, bias)): [B,cin,H,W] -> [B,cout,2] (x, y) in pixels without materialising the
+    [B,cout,H,W] logits (models/ynet.py:469 + utils/softargmax.py:55-81 as chained at utils/evaluate.py:259-262).
+    Inference only."""
+    for t, n in ((x, "input"), (weight, "weight")):
+        _need_gpu(t, "pred_softargmax " + n)
+    t, cin, bs = _plane_desc(x.detach(), "pred_softargmax")
+    B, _, H, W = t.shape
+    if bs % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+        bs = cin * H * W
+    cout = weight.shape[0]
+    lib = _lib()
+    w = weight.detach().reshape(cout, cin).contiguous()
+    b = bias.detach().contiguous() if bias is not None else None
+    out = torch.empty((B, cout, 2), device=t.device, dtype=torch.float32)
+    ws = torch.empty(lib.ynet_pred_softargmax_workspace_floats(B, H, W), device=t.device, dtype=torch.float32)
+    L.check(lib.ynet_pred_softargmax(t.data_ptr(), bs, w.data_ptr(), b.data_ptr() if b is not None else None, out.data_ptr(),
+                                     ws.data_ptr(), B, cin, cout, H, W, _stream()), lib)
+    return out
+
+
 def sigmoid(x: torch.Tensor) -> torch.Tensor:
     """Elementwise sigmoid of any tensor (models/ynet.py:585-586) on the same kernel."""
     _need_gpu(x, "sigmoid")

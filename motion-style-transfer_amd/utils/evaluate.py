@@ -107,7 +107,7 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
                             waypoint_map = gather_patches(input_template, coords, H, W).view(g * n_local, n_wp, H, W)
                             pyramid = ops.avgpool_pyramid(waypoint_map, len(features))
                             traj_input = [ops.lazy_cat([ops.batch_repeat(f, g), p]) for f, p in zip(features, pyramid)]
-                            pred_traj = model.softargmax(model.pred_traj(traj_input))       # [g * n_local, pred, 2]
+                            pred_traj = model.pred_traj_coords(traj_input)                  # [g * n_local, pred, 2] = softargmax(pred_traj(.))
                             trajs_samples.append(pred_traj.view(g, n_local, -1, 2))
                     trajs_samples = torch.cat(trajs_samples)
                     gt_goal = gt_future[:, -1:]

@@ -31,6 +31,12 @@ class SoftArgmax2D(nn.Module):
         self.eps = 1e-6
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        if isinstance(input, ops.LazyPredictor):      # logits = conv1x1(x): predictor and read-out in one launch
+            out = ops.pred_softargmax(input.x, input.weight, input.bias)
+            if self.normalized_coordinates:
+                _, _, h, w = input.shape
+                out = out * torch.tensor([2.0 / max(w - 1, 1), 2.0 / max(h - 1, 1)], device=out.device) - 1.0
+            return out
         if not torch.is_tensor(input):
             raise TypeError("Input input type is not a torch.Tensor. Got {}".format(type(input)))
         if not len(input.shape) == 4:

@@ -450,6 +450,46 @@ def test_softargmax_accuracy_vs_fp64(dev):
         assert e_got <= max(2 * e_ref, 2e-5), (scale, e_got, e_ref)
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,scale", [(3, 32, 30, 64, 128, 1.0), (2, 32, 12, 256, 256, 3.0), (2, 8, 12, 32, 32, 2.0),
+                                                  (2, 16, 1, 24, 32, 4.0), (1, 32, 30, 96, 160, 1.0)])
+def test_pred_softargmax_is_conv1x1_then_softargmax(dev, B, cin, cout, H, W, scale):
+    """ynet_pred_softargmax (predictor on the matrix cores, logits in registers only) against the fp64 truth of
+    SoftArgmax2D(conv1x1(x)) and against the two launches it replaces (utils/evaluate.py:259-262)."""
+    ops = pkg("ops")
+    x = F.relu(rnd(B, cin, H, W, seed=1))
+    w, b = rnd(cout, cin, 1, 1, seed=2, scale=scale / cin ** 0.5), rnd(cout, seed=3, scale=0.5)
+    assert ops.pred_softargmax_supported(x.to(dev), w.to(dev))
+    truth = O.softargmax2d(F.conv2d(x.double(), w.double(), b.double()))
+    ref32 = O.softargmax2d(F.conv2d(x, w, b))
+    got = ops.pred_softargmax(x.to(dev), w.to(dev), b.to(dev)).cpu()
+    two = ops.softargmax2d(ops.conv2d(x.to(dev), w.to(dev), b.to(dev), False, {})).cpu()
+    e_ref, e_got, e_two = (float((t.double() - truth).abs().max()) for t in (ref32, got, two))
+    assert e_got <= max(2 * e_ref, 3e-5), (e_got, e_ref, e_two)
+    close(got, two, rtol=0, atol=1e-4, msg="fused vs two launches")
+    # no bias; a batch-strided input (channel slice of a wider tensor)
+    wide = F.relu(rnd(B, cin + 8, H, W, seed=4)).to(dev)
+    got2 = ops.pred_softargmax(wide[:, :cin], w.to(dev), None).cpu()
+    want2 = O.softargmax2d(F.conv2d(wide[:, :cin].cpu().double(), w.double()))
+    close(got2, want2.float(), rtol=0, atol=1e-4, msg="strided, no bias")
+
+
+def test_pred_softargmax_nonfinite_and_unsupported(dev):
+    ops = pkg("ops")
+    x = F.relu(rnd(1, 32, 16, 32, seed=5))
+    w = torch.zeros(4, 32, 1, 1)
+    w[0, 0] = w[1, 1] = w[2, 2] = w[3, 3] = 1.0                      # logits of plane c = input channel c
+    x[0, 0, 3, 5] = float("-inf")
+    x[0, 1, 2, 7] = float("nan")
+    x[0, 2, 9, 9] = float("inf")
+    want = O.softargmax2d(x[:, :4])
+    got = ops.pred_softargmax(x.to(dev), w.to(dev), None).cpu()
+    assert torch.isnan(got[0, 1]).all() and torch.isnan(got[0, 2]).all() and torch.isnan(want[0, 1]).all()
+    close(got[0, [0, 3]], want[0, [0, 3]], rtol=1e-5, atol=2e-5, msg="planes with -inf / finite logits")
+    assert not ops.pred_softargmax_supported(torch.zeros(1, 32, 17, 23, device=dev), w.to(dev))      # H*W % 128 != 0
+    assert not ops.pred_softargmax_supported(torch.zeros(1, 24, 16, 32, device=dev), torch.zeros(4, 24, 1, 1, device=dev))
+    assert not ops.pred_softargmax_supported(torch.zeros(1, 32, 16, 32, device=dev), torch.zeros(33, 32, 1, 1, device=dev))
+
+
 def test_sigmoid_temp(dev):
     ops = pkg("ops")
     x = rnd(3, 30, 16, 32, seed=1, scale=3.0)

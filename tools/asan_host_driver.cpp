@@ -77,6 +77,10 @@ int main() {
     EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 33, 4, 1.f, nullptr));   // cout 33
     EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 6, 1.f, nullptr));   // HW % 4
     EXPECT_REJECT(ynet_softargmax2d(nullptr, fp, 1, 1, 4, 2, 2, nullptr));
+    EXPECT_REJECT(ynet_pred_softargmax(nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1, 32, 12, 16, 32, nullptr));
+    EXPECT_REJECT(ynet_pred_softargmax(fp, 32 * 17 * 23, fp, nullptr, fp, fp, 1, 32, 12, 17, 23, nullptr));      /* H*W % 128 != 0 */
+    if (ynet_pred_softargmax_supported(24, 12, 16, 32) || ynet_pred_softargmax_supported(32, 33, 16, 32) || !ynet_pred_softargmax_supported(32, 30, 256, 256)) { fprintf(stderr, "pred_softargmax_supported\n"); return 1; }
+    if (ynet_pred_softargmax_workspace_floats(4, 256, 256) != 4ll * 32 * 128) { fprintf(stderr, "pred_softargmax workspace\n"); return 1; }
     EXPECT_REJECT(ynet_sigmoid_temp(cfp, fp, 1, 4, 4, &one, 9, 1.f, nullptr));
     EXPECT_REJECT(ynet_sigmoid_temp(cfp, fp, 1, 4, 4, &one, 1, 0.f, nullptr));
     EXPECT_REJECT(ynet_gather_patch(cfp, 8, 8, cfp, fp, 1, 16, 16, &status, nullptr));      // window larger than the template
