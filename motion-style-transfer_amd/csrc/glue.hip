@@ -837,67 +837,82 @@ struct PredSoftArgs {
     int cout, H, W, nchunk, gpw;      // gpw = 128-pixel groups per wave, nchunk = waves per image
 };
 
-template <int CIN>
-__global__ __launch_bounds__(256, 2) void pred_softargmax_kernel(const PredSoftArgs a) {
-    constexpr int KS = CIN / 2;
+template <int CIN, int PT>
+__global__ __launch_bounds__(256, PT == 4 ? 2 : 3) void pred_softargmax_kernel(const PredSoftArgs a) {
+    // PT = accumulator tiles (pixels per lane and K-step): a wave takes 32 * PT consecutive pixels per step.  PT = 4 (16-byte
+    // loads, 236 registers, two waves per SIMD) is the default for cin = 32: 536 us per 256-image pass at C5 against 586 us for
+    // PT = 2 (168 registers, three waves) -- occupancy is not what bounds it: MFMA time (0.24 ms) and the soft-max vector code
+    // (as much again) of one wave run back to back, and the input alone takes 0.39 ms at the streaming rate.
+    constexpr int KS = CIN / 2, GP = 32 * PT;
+    typedef float vec_t __attribute__((ext_vector_type(PT)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, half = lane >> 5;
     const int wgs_per_img = (a.nchunk + 3) >> 2;
     const int b = (int)blockIdx.x / wgs_per_img, ch = ((int)blockIdx.x % wgs_per_img) * 4 + wave;
     if (ch >= a.nchunk) return;
-    const int HW = a.H * a.W, ngroups = HW >> 7;
-    const int g_lo = ch * a.gpw, g_hi = min(ngroups, g_lo + a.gpw);
+    const int HW = a.H * a.W, ngroups = HW / GP;
+    const int gpw = a.gpw * (128 / GP);          // (a.gpw counts 128-pixel groups)
+    const int g_lo = ch * gpw, g_hi = min(ngroups, g_lo + gpw);
     float wreg[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) wreg[s] = r < a.cout ? a.w[r * CIN + 2 * s + half] : 0.f;
     const float bias_v = (a.bias != nullptr && r < a.cout) ? a.bias[r] : 0.f;
-    const float* xb = a.x + (long long)b * a.x_bs + (long long)half * HW + 4 * r;
-    const bool row_uniform = (a.W & 127) == 0;       // a 128-pixel group lies inside one image row
+    const float* xb = a.x + (long long)b * a.x_bs + (long long)half * HW + PT * r;
+    const bool row_uniform = (a.W % GP) == 0;       // a pixel group lies inside one image row
     SoftAcc st{-INFINITY, 0.f, 0.f, 0.f};
     bool poison = false;
-    f32x4 v[KS];
+    vec_t v[KS];
     auto load_group = [&](int g) {
-        const float* p = xb + ((long long)g << 7);
+        const float* p = xb + (long long)g * GP;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) v[s] = *reinterpret_cast<const f32x4*>(p + (long long)(2 * s) * HW);
+        for (int s = 0; s < KS; ++s) v[s] = *reinterpret_cast<const vec_t*>(p + (long long)(2 * s) * HW);
     };
     if (g_lo < g_hi) load_group(g_lo);
     for (int g = g_lo; g < g_hi; ++g) {
-        f32x16 acc[4];
+        f32x16 acc[PT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < PT; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[j][q] = bias_v;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s][j], wreg[s], acc[j], 0, 0, 0);
+            for (int j = 0; j < PT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s][j], wreg[s], acc[j], 0, 0, 0);
         if (g + 1 < g_hi) load_group(g + 1);        // in flight while this group's logits are folded
-        const int p0 = g << 7;
+        const int p0 = g * GP;
         const int row0 = p0 / a.W, col0 = p0 - row0 * a.W;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;      // row of the accumulator tile = quad index inside the group
-            int row = row0, col = col0 + 4 * i;
+            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;      // row of the accumulator tile = index of the pixel PT-tuple
+            int row = row0, col = col0 + PT * i;
             if (!row_uniform) {
-                const int p4 = p0 + 4 * i;
-                row = p4 / a.W;
-                col = p4 - row * a.W;
+                const int pq = p0 + PT * i;
+                row = pq / a.W;
+                col = pq - row * a.W;
             }
-            const float v0 = acc[0][q], v1 = acc[1][q], v2 = acc[2][q], v3 = acc[3][q];
-            const float chk = (v0 + v1) + (v2 + v3);
+            float lv[PT], mx = -INFINITY, chk = 0.f;
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                lv[j] = acc[j][q];
+                mx = fmaxf(mx, lv[j]);
+                chk += lv[j];
+            }
             poison = poison || chk != chk;
-            const float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-            if (mx > st.m) {
+            if (mx > st.m) {            // rescale at most once per pixel tuple
                 const float rs = exp_le0(st.m - mx);
                 st.s *= rs;
                 st.sx *= rs;
                 st.sy *= rs;
                 st.m = mx;
             }
-            const float e0 = exp_le0(v0 - st.m), e1 = exp_le0(v1 - st.m), e2 = exp_le0(v2 - st.m), e3 = exp_le0(v3 - st.m);
-            const float es = (e0 + e1) + (e2 + e3);
+            float es = 0.f, ew = 0.f;
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const float e = exp_le0(lv[j] - st.m);
+                es += e;
+                ew = __builtin_fmaf((float)j, e, ew);
+            }
             st.s += es;
-            st.sx += __builtin_fmaf((float)col, es, __builtin_fmaf(3.f, e3, __builtin_fmaf(2.f, e2, e1)));
+            st.sx += __builtin_fmaf((float)col, es, ew);
             st.sy += es * (float)row;
         }
     }
@@ -1329,9 +1344,11 @@ int ynet_pred_softargmax(const float* x, long long x_bs, const float* w, const f
     const long long blocks = B * ((a.nchunk + 3) / 4);
     YNET_REQUIRE(blocks < (1ll << 31), "pred_softargmax: too many workgroups");
     hipStream_t st = (hipStream_t)stream;
-    if (cin == 32) hipLaunchKernelGGL((pred_softargmax_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else if (cin == 16) hipLaunchKernelGGL((pred_softargmax_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((pred_softargmax_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    static const int pt = getenv("YNET_PRED_SOFT_PT") ? atoi(getenv("YNET_PRED_SOFT_PT")) : 4;      // (2: the half-width variant, measured 8 % slower)
+    if (cin == 32 && pt == 4) hipLaunchKernelGGL((pred_softargmax_kernel<32, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (cin == 32) hipLaunchKernelGGL((pred_softargmax_kernel<32, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (cin == 16) hipLaunchKernelGGL((pred_softargmax_kernel<16, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pred_softargmax_kernel<8, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     int rc = ynet_check_launch("pred_softargmax");
     if (rc) return rc;
     hipLaunchKernelGGL(pred_softargmax_combine_kernel, dim3((unsigned)((B * cout + 255) / 256)), dim3(256), 0, st, workspace, out, B, cout,
