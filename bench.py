@@ -326,11 +326,12 @@ def main():
             # soft-argmax in one pass over the decoder's last activation [B, 32, H, W] (the logits are never written);
             # where that launch does not apply, the soft-argmax over [B, pred, H, W] planes
             cin = int(cfg.dec[-1])
-            x = torch.relu(torch.randn(B, cin, H, W, device=dev))
+            n_img = B * max(1, min(20, 256 // B))      # images per decoder pass of the sweep (evaluate(): max_effective_batch 256)
+            x = torch.relu(torch.randn(n_img, cin, H, W, device=dev))
             wt, bs_ = torch.randn(cfg.pred_len, cin, 1, 1, device=dev) * 0.2, torch.zeros(cfg.pred_len, device=dev)
             fused = ops.pred_softargmax_supported(x, wt) and pkg("models.ynet").FUSED_READOUT
             if not fused:
-                x = torch.randn(B, cfg.pred_len, H, W, device=dev)
+                x = torch.randn(n_img, cfg.pred_len, H, W, device=dev)
             fn = (lambda: ops.pred_softargmax(x, wt, bs_)) if fused else (lambda: ops.softargmax2d(x))
             for _ in range(3):
                 fn()
@@ -345,7 +346,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "pred_softargmax_kernel<32> (+ combine)" if fused else "softargmax_kernel",
                                "achieved": gbs, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": us,
-                               "algorithmic_mb_per_launch": x.numel() * 4 / 1e6,
+                               "algorithmic_mb_per_launch": x.numel() * 4 / 1e6, "images_per_launch": n_img,
                                "note": "20 back-to-back launches between one HIP-event pair; algorithmic bytes = the input tensor "
                                        "read once (outputs are B x pred x 2 floats)"}
     elif rank == 0:
