@@ -27,6 +27,8 @@ from ..utils.softargmax import SoftArgmax2D, create_meshgrid
 
 # YNET_FUSED_READOUT=0: evaluate()'s trajectory passes run predictor and soft-argmax as two launches (A/B runs)
 FUSED_READOUT = os.environ.get("YNET_FUSED_READOUT", "1") != "0"
+# YNET_SHARED_SCENE=0: the fusion encoder's scene branch convolves every copy of a batch-broadcast scene (as the reference does)
+SHARED_SCENE_BRANCH = os.environ.get("YNET_SHARED_SCENE", "1") != "0"
 
 
 class HipConv2d(nn.Conv2d):
@@ -327,10 +329,20 @@ class YNetEncoderFusion(nn.Module):
 
     def forward(self, scene_map, motion_map):
         scene, motion = [], []
-        x = scene_map
+        # The scene branch sees the SAME image for every trajectory of a batch (utils/train_epoch.py:87 expands one scene
+        # to the batch size, and the reference convolves all the copies).  A batch-broadcast input (stride 0) goes through
+        # the branch once; its features are handed on as broadcast views -- the convs read the one image in place and the
+        # expand's backward sums the per-trajectory gradients before they enter the branch: the same values, 1/B of the
+        # branch's forward and backward work.
+        B = scene_map.shape[0]
+        once = SHARED_SCENE_BRANCH and torch.is_tensor(scene_map) and B > 1 and scene_map.stride(0) == 0
+        x = scene_map[:1] if once else scene_map
         for stage in self.scene_stages:
             x = stage(x)
             scene.append(x)
+        last_scene = scene[-1]
+        if once:
+            scene = [t.expand(B, -1, -1, -1) for t in scene]
         x = motion_map
         for stage in self.motion_stages:
             x = stage(x)
@@ -341,7 +353,10 @@ class YNetEncoderFusion(nn.Module):
             if i == 0:
                 # first fused stage starts with a max-pool of the concatenation = concat of the pools
                 mods = list(stage)
-                pooled = ops.lazy_cat([mods[0](p) for p in x.parts])
+                if once:
+                    pooled = ops.lazy_cat([mods[0](last_scene).expand(B, -1, -1, -1), mods[0](x.parts[1])])
+                else:
+                    pooled = ops.lazy_cat([mods[0](p) for p in x.parts])
                 x = pooled
                 j = 1
                 while j < len(mods):
