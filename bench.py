@@ -159,7 +159,7 @@ def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0):
         step += 1
         if step > 1:                    # first step = warm-up
             times.append(dt)
-        if step >= 2 and (time.perf_counter() - t_start > seconds_budget or len(times) >= 5):
+        if step >= 2 and (time.perf_counter() - t_start > seconds_budget or len(times) >= 12):      # ~10-20 s of CPU work
             break
     med = float(np.median(times))
     return {"value": batch / med, "unit": "trajectories/s", "cores": cores, "kind": "port",
