@@ -5,7 +5,7 @@ stream.  There is no CPU path and no ATen fallback: host tensors raise.  torch i
 memory (torch.empty), streams and autograd bookkeeping only.
 """
 import ctypes
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import numpy as np
 import torch

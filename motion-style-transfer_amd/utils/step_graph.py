@@ -24,8 +24,6 @@ import weakref
 import torch
 import torch.distributed as dist
 
-from .. import ops
-
 # Goal / trajectory decoder on two forked streams INSIDE the captured step: the graph then has two parallel branches
 # (the launch-latency-bound 8^2 .. 32^2 layers of one decoder can run beside the other's).  YNET_GRAPH_OVERLAP=0: one chain.
 OVERLAP_DECODERS = os.environ.get("YNET_GRAPH_OVERLAP", "1") != "0"
