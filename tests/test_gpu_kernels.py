@@ -586,7 +586,8 @@ def test_fused_predictor_and_bce(dev, B, cin, cout, H, W, train_pred, scale, up)
     yd, ld = ops.pred_bce(xd, wd, bd, t.to(dev), up, {})
     (ld * scale).backward()
     close(yd, yc, msg="logits")
-    assert abs(float(ld) * scale - float(lc)) <= 2e-6 * abs(float(lc)), (float(ld) * scale, float(lc))
+    ldv, lcv = float(ld.detach()), float(lc.detach())
+    assert abs(ldv * scale - lcv) <= 2e-6 * abs(lcv), (ldv * scale, lcv)
     close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg="dx")
     if train_pred:
         close(wd.grad, wc.grad, rtol=1e-4, scale_rel=1e-5, msg="dW")
