@@ -300,6 +300,12 @@ def main():
         "final_loss": loss,
         "step_launch": "hipGraph replay" if pkg("utils.step_graph").enabled(None, dev) and args.config != "C5" else "eager",
     }
+    if out["step_launch"] != "eager":      # what the step cache really holds: a failed capture means the timed steps ran eagerly
+        sg = pkg("utils.step_graph")
+        entries = [e for c in sg._caches.get(model, {}).values() for e in c.entries.values()]
+        out["step_graphs"] = {"captured": sum(1 for e in entries if e.ready), "failed": sum(1 for e in entries if e.failed)}
+        if not any(e.ready for e in entries):
+            out["step_launch"] = "eager (no step was captured)"
     # proof of the process group the step ran on: size and backend as torch.distributed reports them, and every rank's device
     mine = {"rank": rank, "device": str(dev), "name": torch.cuda.get_device_name(dev),
             "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")), "pid": os.getpid()}
