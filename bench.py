@@ -118,7 +118,90 @@ class ConvTimer:
         return agg
 
 
-def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0):
+class FlopCounter:
+    """Counts the convolution FLOPs (2 x MACs, as SURVEY.md 8d counts them) the product really LAUNCHES in one step: the
+    algorithmic figure of STEP_WORK assumes the reference's graph, while the product executes less where it shares work
+    (Y-Net-Mod's scene branch once per batch; the shared skip terms of the evaluation sweep)."""
+
+    def __init__(self, ops):
+        self.ops, self.flops = ops, 0.0
+        self.saved = {}
+
+    def __enter__(self):
+        ops, me = self.ops, self
+        names = ("conv2d_raw", "conv2d_wgrad_raw", "conv2d_shared_term", "pred_bce", "pred_softargmax")
+        self.saved = {n: getattr(ops, n) for n in names}
+
+        def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
+            dl = list(dsts)
+            while len(dl) > 1 and dl[-1][0] is None:
+                dl.pop()
+            me.flops += 2.0 * B * H * W * sum(s_[1] for s_ in srcs) * sum(d[1] for d in dl) * K * K
+            return me.saved["conv2d_raw"](srcs, mask, wp, bias, dsts, B, H, W, K, relu)
+
+        def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b, *a, **kw):
+            cout, cin, k, _ = weight.shape
+            B, _, H, W = dy.shape
+            me.flops += 2.0 * B * H * W * cin * cout * k * k
+            return me.saved["conv2d_wgrad_raw"](srcs, dy, mask, weight, want_b, *a, **kw)
+
+        def conv2d_shared_term(x, x_times, rest, weight, bias, relu, cache, term, c0, c1):
+            cout, cin, k, _ = weight.shape
+            B, _, H, W = rest[0].shape
+            me.flops += 2.0 * B * H * W * (cin - (c1 - c0)) * cout * k * k
+            return me.saved["conv2d_shared_term"](x, x_times, rest, weight, bias, relu, cache, term, c0, c1)
+
+        def pred_bce(x, weight, bias, target, expected_grad, cache):
+            B, cin, H, W = x.shape
+            me.flops += 2.0 * B * H * W * cin * weight.shape[0] * (2 if x.requires_grad else 1)      # predictor + its dgrad
+            return me.saved["pred_bce"](x, weight, bias, target, expected_grad, cache)
+
+        def pred_softargmax(x, weight, bias):
+            B, cin, H, W = x.shape
+            me.flops += 2.0 * B * H * W * cin * weight.shape[0]
+            return me.saved["pred_softargmax"](x, weight, bias)
+
+        for n, f in (("conv2d_raw", conv2d_raw), ("conv2d_wgrad_raw", conv2d_wgrad_raw), ("conv2d_shared_term", conv2d_shared_term),
+                     ("pred_bce", pred_bce), ("pred_softargmax", pred_softargmax)):
+            setattr(ops, n, f)
+        return self
+
+    def __exit__(self, *a):
+        for n, f in self.saved.items():
+            setattr(self.ops, n, f)
+
+
+def readout_roofline(ops, ynet_mod, cfg, B, H, W, dev):
+    """The HBM-bound kernel of the evaluation sweep, timed in isolation: every trajectory sample's read-out = predictor 1x1 +
+    soft-argmax in one pass over the decoder's last activation [B, 32, H, W] (the logits are never written); where that
+    launch does not apply, the soft-argmax over [B, pred, H, W] planes."""
+    cin = int(cfg.dec[-1])
+    n_img = B * max(1, min(20, 256 // B))      # images per decoder pass of the sweep (evaluate(): max_effective_batch 256)
+    x = torch.relu(torch.randn(n_img, cin, H, W, device=dev))
+    wt, bs_ = torch.randn(cfg.pred_len, cin, 1, 1, device=dev) * 0.2, torch.zeros(cfg.pred_len, device=dev)
+    fused = ops.pred_softargmax_supported(x, wt) and ynet_mod.FUSED_READOUT
+    if not fused:
+        x = torch.randn(n_img, cfg.pred_len, H, W, device=dev)
+    fn = (lambda: ops.pred_softargmax(x, wt, bs_)) if fused else (lambda: ops.softargmax2d(x))
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    gbs = x.numel() * 4 / us / 1e3
+    return {"bound": "hbm", "kernel": f"pred_softargmax_kernel<{cin}> (+ combine)" if fused else "softargmax_kernel",
+            "achieved": gbs, "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": us,
+            "algorithmic_mb_per_launch": x.numel() * 4 / 1e6, "images_per_launch": n_img,
+            "note": "20 back-to-back launches between one HIP-event pair; algorithmic bytes = the input tensor "
+                    "read once (outputs are B x pred x 2 floats)"}
+
+
+def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0, big_batch=None):
     """CPU oracle (port of the reference's ATen-op path) on the host cores: bounded sample."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # torch's intra-op pool degrades badly when oversubscribed (256 threads on the GPU box's host ran
@@ -146,38 +229,60 @@ def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0):
     times = []
     t_start = time.perf_counter()
     step = 0
-    first = None
+    first = []
     while True:
         traj = O.synthetic_trajectories(cfg, batch, H, W, 100 + step)
         t0 = time.perf_counter()
         r = O.train_step(sd, cfg, scene, traj, in_t, gt_t, names)
-        if first is None:       # kept for parity_check: the HIP path repeats exactly this step
-            first = {"batch": batch, "loss": float(r["loss"]), "ade": float(r["ade"].mean()), "fde": float(r["fde"].mean())}
+        if len(first) < 3:       # kept for parity_check: the HIP path repeats exactly these steps (eager, capture, replay)
+            first.append({"batch": batch, "loss": float(r["loss"]), "ade": float(r["ade"].mean()), "fde": float(r["fde"].mean())})
         for n in names:
             sd[n], ms[n], vs[n] = O.adam_update(sd[n], r["grads"][n], ms[n], vs[n], step + 1, 1e-3)
         dt = time.perf_counter() - t0
         step += 1
         if step > 1:                    # first step = warm-up
             times.append(dt)
-        if step >= 2 and (time.perf_counter() - t_start > seconds_budget or len(times) >= 12):      # ~10-20 s of CPU work
+        if step >= 3 and (time.perf_counter() - t_start > seconds_budget or len(times) >= 12):      # ~10-20 s of CPU work
             break
     med = float(np.median(times))
-    return {"value": batch / med, "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} steps of batch {batch} after 1 warm-up (oracle/ynet_oracle.py train_step + Adam, "
-                      f"same config and raster size), median step {med * 1e3:.0f} ms"}, first
+    out = {"value": batch / med, "unit": "trajectories/s", "cores": cores, "kind": "port",
+           "sample": f"{len(times)} steps of batch {batch} after 1 warm-up (oracle/ynet_oracle.py train_step + Adam, "
+                     f"same config and raster size), median step {med * 1e3:.0f} ms; torch.set_num_threads({cores}) = the fastest of "
+                     f"{{8, 16, 32, 64, {avail}}} on a conv probe ({avail} host cores available)"}
+    if big_batch and big_batch != batch:
+        # SURVEY 8(d) names B = 4 and B = 32 for the CPU leg: two steps at the benchmarked batch (first = warm-up)
+        tb = []
+        for i in range(2):
+            traj = O.synthetic_trajectories(cfg, big_batch, H, W, 200 + i)
+            t0 = time.perf_counter()
+            r = O.train_step(sd, cfg, scene, traj, in_t, gt_t, names)
+            for n in names:
+                sd[n], ms[n], vs[n] = O.adam_update(sd[n], r["grads"][n], ms[n], vs[n], step + 1 + i, 1e-3)
+            tb.append(time.perf_counter() - t0)
+        out["at_benchmarked_batch"] = {"batch": big_batch, "value": big_batch / tb[-1], "unit": "trajectories/s",
+                                       "sample": f"2nd of 2 steps of batch {big_batch}, {tb[-1] * 1e3:.0f} ms, same {cores} threads"}
+    return out, first
 
 
-def parity_check(first, gpu_step):
-    """The HIP path's first step against the CPU oracle's first step on the SAME inputs (state dict seed 0, trajectories
-    seed 100, batch = --cpu-batch): loss to 2e-5 relative, ADE / FDE to 1e-4 (the north-star tolerance)."""
-    ade, fde, loss = gpu_step
-    rel = abs(loss - first["loss"]) / abs(first["loss"])
-    d_ade, d_fde = abs(ade - first["ade"]), abs(fde - first["fde"])
-    return {"batch": first["batch"], "loss_hip": loss, "loss_oracle": first["loss"], "loss_rel_err": rel,
-            "ade_hip": ade, "ade_oracle": first["ade"], "ade_abs_err": d_ade,
-            "fde_hip": fde, "fde_oracle": first["fde"], "fde_abs_err": d_fde,
-            "tolerance": {"loss_rel": 2e-5, "ade_fde_abs": 1e-4},
-            "ok": bool(rel <= 2e-5 and d_ade <= 1e-4 and d_fde <= 1e-4)}
+def parity_check(first, gpu_steps, launched):
+    """The HIP path's first THREE steps against the CPU oracle's first three steps on the SAME inputs (state dict seed 0,
+    trajectories seeds 100, 101, 102, batch = --cpu-batch, Adam lr 1e-3 between them): loss to 2e-5 relative, ADE / FDE to
+    1e-4 (the north-star tolerance).  train_epoch runs the three steps of one shape as [eager, capture + replay, replay]:
+    the third one is a pure replay of the captured hipGraph -- the thing the timed region launches."""
+    steps, ok = [], True
+    for want, (ade, fde, loss), how in zip(first, gpu_steps, launched):
+        rel = abs(loss - want["loss"]) / abs(want["loss"])
+        d_ade, d_fde = abs(ade - want["ade"]), abs(fde - want["fde"])
+        good = bool(rel <= 2e-5 and d_ade <= 1e-4 and d_fde <= 1e-4)
+        ok = ok and good
+        steps.append({"launch": how, "loss_hip": loss, "loss_oracle": want["loss"], "loss_rel_err": rel,
+                      "ade_hip": ade, "ade_oracle": want["ade"], "ade_abs_err": d_ade,
+                      "fde_hip": fde, "fde_oracle": want["fde"], "fde_abs_err": d_fde, "ok": good})
+    last = steps[-1]
+    return {"batch": first[0]["batch"], "steps": steps, "step_launch_checked": last["launch"],
+            "loss_rel_err": max(s_["loss_rel_err"] for s_ in steps), "ade_abs_err": max(s_["ade_abs_err"] for s_ in steps),
+            "fde_abs_err": max(s_["fde_abs_err"] for s_ in steps),
+            "tolerance": {"loss_rel": 2e-5, "ade_fde_abs": 1e-4}, "ok": ok}
 
 
 def main():
@@ -191,6 +296,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-repeats", action="store_true", help="time the contract's region only (no two repeat regions)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the short C5 leg of the default run")
     ap.add_argument("--layers", action="store_true", help="print one line per conv launch of the instrumented step (stderr)")
     args = ap.parse_args()
 
@@ -202,9 +309,26 @@ def main():
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
+        import glob
+        import tempfile
+        logs = tempfile.mkdtemp(prefix="ynet_bench_ranks_")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "--log-dir", logs, "--tee", "3",
+               os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.call(cmd)
+        if rc != 0:      # a rank failed: non-zero exit of the launcher, with the tail of every rank's stderr (failing one first)
+            tails = []
+            for f in sorted(glob.glob(os.path.join(logs, "**", "stderr.log"), recursive=True)):
+                with open(f, errors="replace") as fh:
+                    lines = fh.read().splitlines()
+                if lines:
+                    bad = any("Traceback" in ln or "Error" in ln for ln in lines)
+                    tails.append((not bad, f, lines[-25:]))
+            for _, f, lines in sorted(tails):
+                print(f"---- tail of {os.path.relpath(f, logs)}", file=sys.stderr)
+                print("\n".join(lines), file=sys.stderr)
+            print(f"bench.py: a rank failed (torch.distributed.run exit code {rc})", file=sys.stderr)
+        raise SystemExit(rc if rc else 0)
 
     from oracle import ynet_oracle as O      # cpu_baseline / parity_check legs + synthetic-input generators only
     D = pkg("dist")
@@ -264,6 +388,10 @@ def main():
     # (eager launches are the only place where a HIP-event pair brackets one kernel: the timed region replays a captured
     # step with concurrent branches; measured after it the same launches read ~5 % longer on a chip the denser captured
     # work has warmed up).  All ranks run them (collectives inside).
+    # FLOPs the product really launches per step (one counted step; all ranks run it: collectives inside)
+    with FlopCounter(ops) as fc:
+        run(1, 4, graph=False)
+    executed_gflop_per_traj = fc.flops / (B * N) / 1e9 * (1 if args.config != "C5" else 1)
     ct, n_inst = None, 3
     if not args.no_roofline and args.config != "C5":
         ops.overlap_decoders = False      # kernels are timed in isolation: the two decoder streams run back to back
@@ -288,6 +416,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = B * N * args.steps / elapsed
+    # The contract's timed region is the one above (EXACTLY --steps steps); two more identical regions give the spread
+    regions = [elapsed / args.steps * 1e3]
+    for rep in range(0 if args.no_repeats else 2):
+        fence()
+        t0 = time.perf_counter()
+        run(args.steps, 5 + rep)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        regions.append(dt / args.steps * 1e3)
 
     out = {
         "metric": ("trajectories/sec eval sweep K=20 (Y-Net, SDD longterm)" if args.config == "C5"
@@ -298,6 +439,10 @@ def main():
                    "obs_len": cfg.obs_len, "pred_len": cfg.pred_len, "train_net": cfg.train_net,
                    "parallelism": f"dp{N}", "trainable_floats": sum(p.numel() for p in model.parameters() if p.requires_grad)},
         "final_loss": loss,
+        "timed_regions": {"ms_per_step": [round(r_, 4) for r_ in regions], "median_ms_per_step": float(np.median(regions)),
+                          "min_ms_per_step": min(regions), "max_ms_per_step": max(regions),
+                          "median_value": B * N / (float(np.median(regions)) * 1e-3),
+                          "note": "region 0 is the contract's timed region (value / ms_per_step); the others repeat it"},
         "step_launch": "hipGraph replay" if pkg("utils.step_graph").enabled(None, dev) and args.config != "C5" else "eager",
     }
     if out["step_launch"] != "eager":      # what the step cache really holds: a failed capture means the timed steps ran eagerly
@@ -314,12 +459,23 @@ def main():
         dist.all_gather_object(ranks, mine)
         out["world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
                         "allreduce_floats_per_step": int(dp.flat.numel())}
+        # one process per GPU: with at least as many devices as ranks every rank must sit on a device of its own
+        uuids = [r_["uuid"] for r_ in ranks]
+        if torch.cuda.device_count() >= world and os.environ.get("YNET_BENCH_SINGLE_DEVICE") != "1":
+            assert len(set(uuids)) == world, f"ranks share a device: {[(r_['rank'], r_['device'], r_['uuid']) for r_ in ranks]}"
+        out["world"]["distinct_devices"] = len(set(uuids))
     else:
         out["world"] = {"world_size": 1, "backend": None, "ranks": [mine], "allreduce_floats_per_step": 0}
     gf, mb = STEP_WORK[args.config]
     out["step_roofline"] = {      # the whole step against both roofs (per GPU); the dominant kernel's figure is in "roofline"
         "algorithmic_gflop_per_trajectory": gf, "tflops_per_gpu": value / N * gf / 1e3,
         "frac_of_fp32_peak": value / N * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+        # what the launches of one step really compute (counted at the op layer in one eager step; without tile padding):
+        # below the algorithmic figure where the product shares work (C4 scene branch, C5 shared skip terms); only THIS
+        # fraction is hardware utilisation
+        "executed_gflop_per_trajectory": executed_gflop_per_traj,
+        "executed_tflops_per_gpu": value / N * executed_gflop_per_traj / 1e3,
+        "executed_frac_of_fp32_peak": value / N * executed_gflop_per_traj / 1e3 / PEAK_FP32_MFMA_TFLOPS,
         "algorithmic_mb_per_trajectory": mb,
         "hbm_gbs_per_gpu": None if mb is None else value / N * mb / 1e3,
         "frac_of_hbm_peak": None if mb is None else value / N * mb / 1e3 / PEAK_HBM_GBS}
@@ -328,33 +484,7 @@ def main():
         pass
     elif args.config == "C5":
         if rank == 0:
-            # the HBM-bound kernel of the sweep, timed in isolation: every trajectory sample's read-out = predictor 1x1 +
-            # soft-argmax in one pass over the decoder's last activation [B, 32, H, W] (the logits are never written);
-            # where that launch does not apply, the soft-argmax over [B, pred, H, W] planes
-            cin = int(cfg.dec[-1])
-            n_img = B * max(1, min(20, 256 // B))      # images per decoder pass of the sweep (evaluate(): max_effective_batch 256)
-            x = torch.relu(torch.randn(n_img, cin, H, W, device=dev))
-            wt, bs_ = torch.randn(cfg.pred_len, cin, 1, 1, device=dev) * 0.2, torch.zeros(cfg.pred_len, device=dev)
-            fused = ops.pred_softargmax_supported(x, wt) and pkg("models.ynet").FUSED_READOUT
-            if not fused:
-                x = torch.randn(n_img, cfg.pred_len, H, W, device=dev)
-            fn = (lambda: ops.pred_softargmax(x, wt, bs_)) if fused else (lambda: ops.softargmax2d(x))
-            for _ in range(3):
-                fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / 20
-            gbs = x.numel() * 4 / us / 1e3
-            out["roofline"] = {"bound": "hbm", "kernel": "pred_softargmax_kernel<32> (+ combine)" if fused else "softargmax_kernel",
-                               "achieved": gbs, "peak": PEAK_HBM_GBS,
-                               "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": us,
-                               "algorithmic_mb_per_launch": x.numel() * 4 / 1e6, "images_per_launch": n_img,
-                               "note": "20 back-to-back launches between one HIP-event pair; algorithmic bytes = the input tensor "
-                                       "read once (outputs are B x pred x 2 floats)"}
+            out["roofline"] = readout_roofline(ops, pkg("models.ynet"), cfg, B, H, W, dev)
     elif rank == 0:
         agg = ct.summary()
         for v in agg.values():               # per step
@@ -414,21 +544,82 @@ def main():
         total_conv_ms = sum(v["ms"] for v in agg.values())
         out["conv_share_of_step"] = total_conv_ms / out["ms_per_step"]
     if world > 1:
+        # ---- the collective on its own and the split of a replayed step around it (graph A = forward / backward, eager
+        # all-reduce of the flat gradient buffer, graph B = optimizer / read-out), HIP events on the step's stream
+        sgm = pkg("utils.step_graph")
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        probe = dp.flat.clone()
+        keep = dp.flat
+        dp.flat = probe                      # (time the transport on a scratch copy: the gradients stay as they are)
+        for _ in range(5):
+            dp.allreduce()
+        fence()
+        ev0.record()
+        for _ in range(50):
+            dp.allreduce()
+        ev1.record()
+        torch.cuda.synchronize()
+        dp.flat = keep
+        out["world"]["allreduce_us_per_step"] = ev0.elapsed_time(ev1) * 1e3 / 50
+        out["world"]["allreduce_transport"] = "oneshot (ynet_allreduce_sum, HIP IPC)" if dp._comm is not None else f"torch.distributed ({dist.get_backend()})"
+        out["world"]["transport_note"] = dp.transport_note
+        split = None
+        for c in sgm._caches.get(model, {}).values():
+            for e in c.entries.values():
+                if e.ready and getattr(e, "split", False):
+                    split = e.profile_split(10)
+        out["world"]["replayed_step_split_ms"] = split      # {"graph_a", "allreduce", "graph_b"} per step, or None (eager / single graph)
         dist.barrier()
+    if rank == 0 and N == 1 and args.config == "C2" and not args.no_c5:
+        # ---- BASELINE.json's HBM-bound roofline point (configs[4]: K = 20 goal-decoder sweep, B = 128) in the default run:
+        # one warm-up batch + two timed batches of the evaluation sweep, and its read-out kernel timed in isolation
+        cfg5, H5, W5, workload5 = make_cfg(O, "C5")
+        m5 = ynet.YNet(cfg5.obs_len, cfg5.pred_len, None, encoder_channels=list(cfg5.enc), decoder_channels=list(cfg5.dec),
+                       n_waypoints=len(cfg5.waypoints), train_net=cfg5.train_net, position=list(cfg5.position),
+                       network=cfg5.network, n_fusion=cfg5.n_fusion)
+        m5.load_state_dict(O.make_state_dict(cfg5, seed=0), strict=True)
+        m5.to(dev)
+        B5 = 128
+        in5 = O.dist_template(cfg5.template_size).to(dev)
+        img5 = {"scene0": O.synthetic_scene(cfg5, H5, W5, 0)[0].to(dev)}
+
+        def sweep(n_batches, seed):
+            traj = O.synthetic_trajectories(cfg5, B5 * n_batches, H5, W5, seed)
+            return ev.evaluate(m5, loader_for(traj), img5, dev, "sdd", None, in5, list(cfg5.waypoints), "test", 20, 1,
+                               cfg5.obs_len, B5, cfg5.resize_factor, cfg5.temperature)
+        sweep(1, 11)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a5, f5, _, _ = sweep(2, 12)
+        torch.cuda.synchronize()
+        dt5 = time.perf_counter() - t0
+        out["c5"] = {"workload": workload5, "batch": B5, "batches_timed": 2, "value": 2 * B5 / dt5, "unit": "trajectories/s",
+                     "ms_per_batch": dt5 / 2 * 1e3, "ade": float(a5), "fde": float(f5),
+                     "sweep_launch": pkg("utils.evaluate").last_sweep_launch(),
+                     "roofline": readout_roofline(ops, ynet, cfg5, B5, H5, W5, dev)}
+        del m5
     if rank == 0 and N == 1 and not args.no_cpu_baseline and args.config != "C5":
-        out["cpu_baseline"], first = cpu_baseline(O, cfg, H, W, args.cpu_batch)
-        # the same step on the HIP path: fresh model from the same state dict, same trajectories
+        out["cpu_baseline"], first = cpu_baseline(O, cfg, H, W, args.cpu_batch, big_batch=B)
+        # the same three steps on the HIP path: fresh model from the same state dict, same trajectories; one batch per
+        # train_epoch call, so the calls run [eager, capture + replay, replay] and each returns ITS step's loss / ADE / FDE
         m2 = ynet.YNet(cfg.obs_len, cfg.pred_len, None, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
                        n_waypoints=len(cfg.waypoints), train_net=cfg.train_net, position=list(cfg.position),
                        network=cfg.network, n_fusion=cfg.n_fusion)
         m2.load_state_dict(O.make_state_dict(cfg, seed=0, lora_b_std=0.05), strict=True)
         trainer.apply_freeze_policy(m2, cfg.train_net, cfg.position, cfg.network)
         m2.to(dev)
-        traj = O.synthetic_trajectories(cfg, args.cpu_batch, H, W, 100)
-        gpu_step = te.train_epoch(m2, loader_for(traj), images, torch.optim.Adam(m2.parameters(), lr=1e-3), crit,
-                                  cfg.loss_scale, dev, "sdd", None, gt_t, in_t, list(cfg.waypoints), 0, cfg.obs_len,
-                                  cfg.pred_len, args.cpu_batch, 10000, cfg.resize_factor, cfg.network, False)
-        out["parity_check"] = parity_check(first, gpu_step)
+        opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+        sg = pkg("utils.step_graph")
+        gpu_steps, launched = [], []
+        for i in range(len(first)):
+            traj = O.synthetic_trajectories(cfg, args.cpu_batch, H, W, 100 + i)
+            before = sum(1 for c in sg._caches.get(m2, {}).values() for e in c.entries.values() if e.ready)
+            gpu_steps.append(te.train_epoch(m2, loader_for(traj), images, opt2, crit, cfg.loss_scale, dev, "sdd", None, gt_t, in_t,
+                                            list(cfg.waypoints), i, cfg.obs_len, cfg.pred_len, args.cpu_batch, 10000,
+                                            cfg.resize_factor, cfg.network, False))
+            after = sum(1 for c in sg._caches.get(m2, {}).values() for e in c.entries.values() if e.ready)
+            launched.append("replay" if before else ("capture + replay" if after else "eager"))
+        out["parity_check"] = parity_check(first, gpu_steps, launched)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

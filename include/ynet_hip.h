@@ -233,7 +233,10 @@ int ynet_cws_prior(const float* sig, long long sig_batch_stride, int n_persons, 
  *   ynet_comm_connect(comm, handles)                   `world` handles in rank order (the own entry is ignored)
  *   ynet_allreduce_sum(comm, buf, n, stream)           in place, n <= max_floats; collective: every rank calls it the same
  *                                                      number of times; NOT capturable into a hipGraph (epoch argument)
- *   ynet_comm_status(comm)                             1 if a wait for a peer ever timed out (~20 s), else 0; synchronises
+ *   ynet_comm_status(comm)                             1 if a wait for a peer ever timed out (~20 s), else 0; synchronises.
+ *                                                      A timed-out call does NOT leave buf un-reduced silently: the parts that
+ *                                                      could not be reduced and the last element (the loss slot of
+ *                                                      dist.DataParallel) are set to NaN
  *   ynet_comm_destroy(comm)
  * torch.distributed (RCCL) remains the default transport of dist.DataParallel; this path is selected with
  * YNET_ALLREDUCE=oneshot. */

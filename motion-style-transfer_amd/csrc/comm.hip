@@ -16,8 +16,9 @@
 //          its own in rank order and writes buf
 //   Slot reuse is safe with two slots: a rank enters call e only after call e - 1 returned on its stream, call e - 1
 //   needed every peer's flag e - 1, and a peer publishes flag e - 1 only after ITS call e - 2 finished reading.
-// A peer that never arrives (a crashed rank) would spin forever: the wait gives up after ~20 s of s_memrealtime,
-// records the failure in the mailbox and leaves buf untouched; ynet_comm_status reports it.
+// A peer that never arrives (a crashed rank) would spin forever: the wait gives up after ~20 s of s_memrealtime (every
+// workgroup on its own), records the failure in the mailbox and POISONS its part of buf and the loss slot with NaN, so the
+// step cannot silently continue on un-reduced gradients; ynet_comm_status reports it (dist.DataParallel.check raises).
 // The epoch is a kernel argument: the call cannot be captured into a hipGraph (utils/step_graph.py keeps the collective
 // between its two graphs).
 #include "ynet_common.h"
@@ -83,7 +84,16 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const AllreduceA
         }
     }
     __syncthreads();
-    if (failed) return;
+    if (failed) {
+        // A peer never arrived: this workgroup's part of buf cannot be reduced.  Leaving it un-reduced would let the ranks
+        // apply DIFFERENT gradients silently (the replicated Adam states diverge), so the part -- and the loss that rides in
+        // the last slot -- is poisoned with NaN: the step fails loudly on this rank (NaN loss, NaN weights), and
+        // ynet_comm_status / DataParallel.check() report the time-out at the next synchronisation point.
+        const float poison = __builtin_nanf("");
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) a.buf[i] = poison;
+        if (threadIdx.x == 0) a.buf[a.n - 1] = poison;
+        return;
+    }
     __threadfence_system();
     for (long long i = lo + threadIdx.x; i < hi; i += 256) {
         float s = 0.f;

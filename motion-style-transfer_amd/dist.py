@@ -10,10 +10,18 @@ applies the identical Adam update.  The flat buffer is persistent and ``p.grad``
 so the collective runs in place on the compute stream with no packing copies.
 """
 import os
+import weakref
 from typing import List, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def _close_comm(lib, comm):
+    try:
+        lib.ynet_comm_destroy(comm)
+    except Exception:      # noqa: BLE001 -- interpreter teardown
+        pass
 
 
 class DataParallel:
@@ -40,27 +48,92 @@ class DataParallel:
             self._views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.bind()
+        self.transport_note = None          # why the requested transport was not used (bench.py prints it)
         if self.collective == "oneshot" and self.world > 1:
             self._connect_oneshot()
+            self._self_test_oneshot()
+        if self._comm is not None:
+            self._finalizer = weakref.finalize(self, _close_comm, self._lib, self._comm)      # IPC mappings are released at teardown
+
+    def _agree(self, ok: int) -> bool:
+        """Every rank takes the same decision (MIN over ranks), through the control plane."""
+        verdict = torch.tensor([int(ok)], dtype=torch.int32, device=self.flat.device)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.group)
+        return int(verdict.item()) == 1
+
+    def _fall_back(self, what: str, mine_ok: bool, why: str):
+        import warnings
+        self.transport_note = f"one-shot all-reduce {what} failed" + (f" on this rank: {why}" if not mine_ok else " on a peer") + \
+            "; using torch.distributed"
+        warnings.warn(self.transport_note)
+        self.close()
+        self.collective = "rccl"
 
     def _connect_oneshot(self):
+        """Mailbox allocation, handle exchange and IPC mapping; a failure on ANY rank (no fine-grained memory, a handle that
+        cannot be opened) makes ALL ranks fall back to torch.distributed together -- nobody is left waiting at a barrier."""
         import ctypes
         from . import _lib as L
         if not self.flat.is_cuda:
             raise RuntimeError("the one-shot all-reduce exchanges device buffers: parameters must live on a HIP device")
         lib = L.load()
+        self._lib = lib
         comm = ctypes.c_void_p()
-        L.check(lib.ynet_comm_create(self.rank, self.world, self.flat.numel(), ctypes.byref(comm)), lib)
         nb = lib.ynet_comm_handle_bytes()
         mine = ctypes.create_string_buffer(nb)
-        L.check(lib.ynet_comm_export(comm, mine), lib)
+        ok, why = 1, ""
+        try:
+            L.check(lib.ynet_comm_create(self.rank, self.world, self.flat.numel(), ctypes.byref(comm)), lib)
+            self._comm = comm
+            L.check(lib.ynet_comm_export(comm, mine), lib)
+        except Exception as e:      # noqa: BLE001
+            ok, why = 0, f"{type(e).__name__}: {e}"
         handles = [None] * self.world
-        dist.all_gather_object(handles, mine.raw, group=self.group)       # control plane: torch.distributed
-        L.check(lib.ynet_comm_connect(comm, b"".join(handles)), lib)
-        dist.barrier(group=self.group)
-        self._comm, self._lib = comm, lib
+        dist.all_gather_object(handles, mine.raw if ok else b"", group=self.group)       # control plane: torch.distributed
+        if ok and all(len(h) == nb for h in handles):
+            try:
+                L.check(lib.ynet_comm_connect(comm, b"".join(handles)), lib)
+            except Exception as e:      # noqa: BLE001
+                ok, why = 0, f"{type(e).__name__}: {e}"
+        elif ok:
+            ok, why = 0, "a peer exported no handle"
+        if not self._agree(ok):
+            self._fall_back("set-up", bool(ok), why)
+
+    def _self_test_oneshot(self):
+        """Start-up self-test of the one-shot transport: all-reduce a buffer of rank ids (expected: world * (world - 1) / 2
+        in every element, on every rank).  Any failure -- a time-out, wrong sums, an IPC mapping that does not observe the
+        peers -- falls back to torch.distributed (RCCL) on ALL ranks together and records the reason."""
+        if self._comm is None:
+            return
+        ok, why = 1, ""
+        try:
+            probe = torch.full_like(self.flat, float(self.rank))
+            from . import _lib as L
+            L.check(self._lib.ynet_allreduce_sum(self._comm, probe.data_ptr(), probe.numel(),
+                                                 torch.cuda.current_stream(probe.device).cuda_stream), self._lib)
+            want = self.world * (self.world - 1) / 2.0
+            if not bool((probe == want).all()):       # (synchronises; NaN after a time-out compares unequal)
+                ok, why = 0, f"self-test sums differ from {want} (or a peer timed out)"
+            elif self._lib.ynet_comm_status(self._comm) != 0:
+                ok, why = 0, "a wait for a peer timed out"
+        except Exception as e:      # noqa: BLE001
+            ok, why = 0, f"{type(e).__name__}: {e}"
+        if not self._agree(ok):
+            self._fall_back("self-test", bool(ok), why)
+
+    def check(self):
+        """Raise if the one-shot transport ever timed out waiting for a peer (its kernel poisons the gradients and the loss
+        with NaN in that case; this names the cause).  Called at the synchronisation points of an epoch."""
+        if self._comm is not None and self._lib.ynet_comm_status(self._comm) != 0:
+            raise RuntimeError(f"rank {self.rank}: the one-shot all-reduce timed out waiting for a peer (~20 s): the gradients of "
+                               f"that step were not reduced (buffer poisoned with NaN); a rank crashed or stalled")
 
     def close(self):
+        fin = getattr(self, "_finalizer", None)
+        if fin is not None:
+            fin.detach()
+            self._finalizer = None
         if self._comm is not None:
             self._lib.ynet_comm_destroy(self._comm)
             self._comm = None
@@ -113,6 +186,7 @@ class DataParallel:
         return self.loss_value()
 
     def sum_scalar(self, t: torch.Tensor) -> torch.Tensor:
+        self.check()          # (the epoch's synchronisation point)
         if self.world > 1:
             t = t.clone()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -156,7 +230,15 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         if backend is None:
             # YNET_DIST_BACKEND=gloo: development runs of the multi-process path on a box with fewer GPUs than ranks
             backend = os.environ.get("YNET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available() and os.environ.get("YNET_BENCH_SINGLE_DEVICE") != "1":
-            torch.cuda.set_device(local)      # every backend: the HIP kernels launch on the current device's streams
+        # every backend: the HIP kernels launch on the current device's streams.  Only when this rank HAS a device of its own:
+        # CPU-only workers (gloo tests) and boxes with fewer GPUs than ranks (YNET_DIST_BACKEND=gloo development runs, every
+        # rank on device 0) must not touch HIP here / must not get "invalid device ordinal".
+        n_dev = torch.cuda.device_count()
+        if n_dev > 0 and os.environ.get("YNET_BENCH_SINGLE_DEVICE") != "1":
+            if local < n_dev:
+                torch.cuda.set_device(local)
+            elif backend == "nccl":
+                raise RuntimeError(f"LOCAL_RANK {local} but only {n_dev} HIP devices are visible: RCCL needs one GPU per rank "
+                                   f"(YNET_DIST_BACKEND=gloo YNET_BENCH_SINGLE_DEVICE=1 runs every rank on cuda:0)")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world

@@ -41,8 +41,18 @@ class HipBCEWithLogitsLoss(nn.Module):
 
     def forward(self, input, target):
         fused = getattr(input, "_ynet_fused_bce", None)
-        if fused is not None and fused[0] is target and fused[2] == float(self.expected_grad):
-            return fused[1]
+        if fused is not None:
+            # The fused predictor returned these logits as NON-differentiable (its kernel already produced the gradients for
+            # the announced target and upstream gradient): any other use would silently drop the decoder's gradient.
+            same_target = fused[0] is target or (torch.is_tensor(target) and target.data_ptr() == fused[0].data_ptr()
+                                                 and target.shape == fused[0].shape and target.stride() == fused[0].stride())
+            if same_target and fused[2] == float(self.expected_grad):
+                return fused[1]
+            raise RuntimeError(
+                "HipBCEWithLogitsLoss: these maps come from a decoder that was told its BCE target (announce_bce_target) "
+                + ("but are compared with a different target tensor" if not same_target else
+                   f"for the upstream gradient {fused[2]} but expected_grad is now {float(self.expected_grad)}")
+                + "; compute the maps outside announce_bce_target (or set YNET_PRED_BCE=0) for any other use")
         return ops.bce_with_logits(input, target, self.expected_grad)
 
 

@@ -13,6 +13,14 @@ from .. import ops
 from .image_utils import gather_patches, image2world, sampling, swap_pavement_terrain
 
 
+_last_sweep_launch = "eager"
+
+
+def last_sweep_launch() -> str:
+    """How the most recent evaluate() call launched its K-sample decoder passes: "eager" or "hipGraph replay" (bench.py)."""
+    return _last_sweep_launch
+
+
 def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, input_template, waypoints, mode,
              n_goal, n_traj, obs_len, batch_size, resize_factor=0.25, temperature=1, use_TTST=False, use_CWS=False,
              rel_thresh=0.002, CWS_params=None, return_preds=False, return_samples=False, network=None,

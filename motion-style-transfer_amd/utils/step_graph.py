@@ -154,14 +154,26 @@ class GraphCache:
         self.entries = {}
         self.pool = None
         self.last = None
+        self.token = None
         self.fused_ok = os.environ.get("YNET_FUSED_ADAM", "1") != "0"
 
     def lookup(self, key):
+        """Least-recently-used cache of captured steps (a hit moves the entry to the young end: a dataset that cycles through
+        more shapes than MAX_ENTRIES still keeps the frequent ones).  Entries captured for an older model state (another
+        freeze pattern / replaced frozen weights: the last field of the key) can never be looked up again and are dropped
+        as soon as a newer state shows up -- each pins its own scene copy, prediction maps and gradients."""
         e = self.entries.get(key)
-        if e is None:
-            if len(self.entries) >= self.MAX_ENTRIES:      # (scenes of many sizes: forget the oldest shape)
-                self.entries.pop(next(iter(self.entries)))
-            e = self.entries[key] = CapturedStep(self)
+        if e is not None:
+            self.entries[key] = self.entries.pop(key)      # dicts keep insertion order: re-insert = most recently used
+            return e
+        token = key[-1]
+        if token != self.token:
+            for k in [k for k in self.entries if k[-1] != token]:
+                del self.entries[k]
+            self.token = token
+        while len(self.entries) >= self.MAX_ENTRIES:
+            self.entries.pop(next(iter(self.entries)))      # the least recently used shape
+        e = self.entries[key] = CapturedStep(self)
         return e
 
 
@@ -238,6 +250,27 @@ class CapturedStep:
             warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running it eagerly")
             if dp is not None:
                 dp.bind()
+
+    def profile_split(self, n=10):
+        """Per-step time (ms) of the three parts of a split step -- graph A (zero_grad ... backward), the eager all-reduce,
+        graph B (optimizer, read-out) -- from HIP events on the step's stream over `n` replays of the inputs already in the
+        static buffers (bench.py, after its timed region; the weights move on as in any step).  None for a single graph."""
+        if not (self.ready and self.split):
+            return None
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n)]
+        for e in ev:
+            e[0].record()
+            self.graphs[0].replay()
+            e[1].record()
+            self.dp.allreduce()
+            e[2].record()
+            self.graphs[1].replay()
+            e[3].record()
+        torch.cuda.synchronize()
+        mark_parameters_changed(self.params)
+        med = lambda xs: sorted(xs)[len(xs) // 2]      # noqa: E731
+        return {"graph_a": med([e[0].elapsed_time(e[1]) for e in ev]), "allreduce": med([e[1].elapsed_time(e[2]) for e in ev]),
+                "graph_b": med([e[2].elapsed_time(e[3]) for e in ev]), "replays": n}
 
     def replay(self, batch, scene_image):
         self.coords.copy_(batch)

@@ -237,8 +237,10 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                         if dp is not None:
                             loss = dp.allreduce_grads(loss)          # ONE collective per step: gradients + loss
                         optimizer.step()
-                        if graphs is not None:      # (see step_graph.mark_parameters_changed)
-                            step_graph.mark_parameters_changed(p for g in optimizer.param_groups for p in g["params"])
+                        # Always: a fused multi-tensor Adam (the form a capture switches the caller's optimizer to, or a
+                        # user's Adam(fused=True)) updates the weights without bumping Parameter._version, and the caches
+                        # of packed / LoRA-composed filters are keyed on it -- also when this epoch runs with graph=False.
+                        step_graph.mark_parameters_changed(p for g in optimizer.param_groups for p in g["params"])
                         if n_local > 0:
                             ade, fde = finish(fb)
                         else:

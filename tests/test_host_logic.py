@@ -210,3 +210,37 @@ def test_step_graph_keys():
     assert sg.model_state_token(model) != t1
     assert not sg.enabled(None, torch.device("cpu")) and not sg.enabled(True, "cpu")
     assert sg.waypoint_index("cpu", [14, 29]).tolist() == [14, 29]
+
+
+def test_step_graph_cache_is_lru_and_drops_stale_model_states():
+    """a dataset cycling through more step shapes than the cache holds must keep the recently used ones (a hit
+    refreshes the entry), and entries captured for an older model state are dropped when a newer state shows up."""
+    sg = pkg("utils.step_graph")
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+    c = sg.GraphCache(opt)
+    c.MAX_ENTRIES = 4
+    keys = [("shape", i, "tokA") for i in range(4)]
+    first = [c.lookup(k) for k in keys]
+    assert c.lookup(keys[0]) is first[0]                 # hit: refreshed, now the youngest
+    c.lookup(("shape", 4, "tokA"))                       # evicts the least recently used = keys[1]
+    assert keys[1] not in c.entries and keys[0] in c.entries and len(c.entries) == 4
+    assert c.lookup(keys[0]) is first[0]
+    e_new = c.lookup(("shape", 0, "tokB"))               # a new model state: everything captured for tokA can never hit again
+    assert list(c.entries) == [("shape", 0, "tokB")] and c.lookup(("shape", 0, "tokB")) is e_new
+
+
+def test_fused_criterion_refuses_a_foreign_target():
+    """logits returned by the fused predictor + criterion kernel are not differentiable; comparing them with
+    another target (or under another upstream gradient) must raise instead of silently dropping the decoder's gradient."""
+    trn = pkg("models.trainer")
+    crit = trn.HipBCEWithLogitsLoss()
+    crit.expected_grad = 1000.0
+    maps, target = torch.zeros(1, 2, 4, 4), torch.ones(1, 2, 4, 4)
+    maps._ynet_fused_bce = (target, torch.tensor(3.0), 1000.0)
+    assert float(crit(maps, target)) == 3.0
+    assert float(crit(maps, target.view(1, 2, 4, 4))) == 3.0          # a re-viewed alias of the same memory is the same target
+    with pytest.raises(RuntimeError, match="different target"):
+        crit(maps, target.clone())
+    crit.expected_grad = 1.0
+    with pytest.raises(RuntimeError, match="expected_grad"):
+        crit(maps, target)
