@@ -129,7 +129,7 @@ class FlopCounter:
 
     def __enter__(self):
         ops, me = self.ops, self
-        names = ("conv2d_raw", "conv2d_wgrad_raw", "conv2d_shared_term", "pred_bce", "pred_softargmax")
+        names = ("conv2d_raw", "conv2d_wgrad_raw", "lora_conv2d_wgrad_raw", "conv2d_shared_term", "pred_bce", "pred_softargmax")
         self.saved = {n: getattr(ops, n) for n in names}
 
         def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
@@ -144,6 +144,13 @@ class FlopCounter:
             B, _, H, W = dy.shape
             me.flops += 2.0 * B * H * W * cin * cout * k * k
             return me.saved["conv2d_wgrad_raw"](srcs, dy, mask, weight, want_b, *a, **kw)
+
+        def lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a, lora_b, scale):
+            cout, cin, k, _ = weight.shape
+            B, _, H, W = dy.shape
+            r = lora_a.shape[0] // k
+            me.flops += 2.0 * B * H * W * (54 * cin + 18 * cout) * r      # projected planes instead of the full filter gradient
+            return me.saved["lora_conv2d_wgrad_raw"](srcs, dy, mask, weight, lora_a, lora_b, scale)
 
         def conv2d_shared_term(x, x_times, rest, weight, bias, relu, cache, term, c0, c1):
             cout, cin, k, _ = weight.shape
@@ -161,7 +168,8 @@ class FlopCounter:
             me.flops += 2.0 * B * H * W * cin * weight.shape[0]
             return me.saved["pred_softargmax"](x, weight, bias)
 
-        for n, f in (("conv2d_raw", conv2d_raw), ("conv2d_wgrad_raw", conv2d_wgrad_raw), ("conv2d_shared_term", conv2d_shared_term),
+        for n, f in (("conv2d_raw", conv2d_raw), ("conv2d_wgrad_raw", conv2d_wgrad_raw), ("lora_conv2d_wgrad_raw", lora_conv2d_wgrad_raw),
+                     ("conv2d_shared_term", conv2d_shared_term),
                      ("pred_bce", pred_bce), ("pred_softargmax", pred_softargmax)):
             setattr(ops, n, f)
         return self

@@ -106,14 +106,34 @@ int ynet_lora_compose_pack_multi(int n, const float* const* w, const float* cons
                                  const float* scale, float* const* wp_fwd, float* const* wp_dgrad, const int* cout,
                                  const int* cin, const int* K, const int* r, void* stream);
 
+/* Adapter gradients of a 3x3 loralib Conv2d WITHOUT the full filter gradient (models/ynet.py:141-144; replaces the chain
+ * ynet_conv2d_wgrad -> ynet_lora_grad for the adapted convs of train_net = mosa_1):
+ *   d_a [3 r][3 cin] = s * B^T * dWm,  d_b [3 cout][3 r] = s * dWm * A^T,  dWm = dW.view(3 cout, 3 cin)
+ * computed from 9 r planes projected out of x (through lora_A) and out of dy (through lora_B): (54 cin + 18 cout) r MACs
+ * per pixel instead of 9 cin cout, no dW round trip through HBM.  `mask`: the conv's post-ReLU output (dy is zeroed where
+ * it is <= 0) or NULL.  Sources: the virtual concatenation of the conv's inputs, as for ynet_conv2d_wgrad; 16-byte aligned
+ * planes, W % 4 == 0.  workspace: ynet_lora_conv2d_wgrad_workspace_floats(cin, cout) floats.
+ * ynet_lora_conv2d_wgrad_supported: K == 3, r == 1, cin, cout <= 64, W % 4 == 0 (anything else: the two-call chain). */
+int ynet_lora_conv2d_wgrad_supported(int cin, int cout, int K, int r, int W);
+/* ... and where it is also the faster of the two paths (the layers with more than 32 output channels; measured) */
+int ynet_lora_conv2d_wgrad_preferred(int cin, int cout, int K, int r, int W);
+long long ynet_lora_conv2d_wgrad_workspace_floats(int cin, int cout);
+int ynet_lora_conv2d_wgrad(const float* const* src, const int* src_c, const long long* src_bs, int nsrc,
+                           const float* dy, long long dy_batch_stride, const float* mask, long long mask_batch_stride,
+                           const float* lora_a, const float* lora_b, float scale, float* d_a, float* d_b,
+                           float* workspace, int B, int H, int W, int cout, int K, int r, void* stream);
+
 /* ---- pooling / resampling ------------------------------------------------------------------- */
 /* nn.MaxPool2d(2,2) (models/ynet.py:202,215,326,340,354,367); N = B*C planes of H x W. */
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream);
 int ynet_maxpool2_bwd(const float* x, const float* dy, float* dx, long long N, int H, int W, void* stream);
 /* dx = maxpool2_bwd(x, dy) + add0 + add1 (addends may be NULL; even H, W): folds the skip-connection gradients of the
- * two decoders into the pool's backward instead of two autograd adds (utils/train_epoch.py:110 loss.backward()). */
+ * two decoders into the pool's backward instead of two autograd adds (utils/train_epoch.py:110 loss.backward()).
+ * relu_mask != 0: dx is also zeroed where x <= 0 -- x is the post-ReLU output of the conv that receives dx as its output
+ * gradient (models/ynet.py:196-211: nn.ReLU after every encoder conv), so the ReLU backward that conv's dgrad / wgrad
+ * would apply by reading x again is applied here, where x is in registers anyway. */
 int ynet_maxpool2_bwd_add(const float* x, const float* dy, const float* add0, const float* add1, float* dx, long long N,
-                          int H, int W, void* stream);
+                          int H, int W, int relu_mask, void* stream);
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (models/ynet.py:463);
  * H, W are the LOW-resolution sizes in both directions. */
 int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream);
@@ -143,11 +163,13 @@ int ynet_bce_grad_rescale(float* dx, const float* grad_out, float expected_grad,
  * dx = conv1x1^T(dy) [B][cin][HW] (optional output: the gradient handed to decoder.4.2).  wp = ynet_pack_weight(w, mode 0)
  * of the 1x1 filter; cout <= 32, HW % 4 == 0, 16-byte aligned tensors.  workspace: ynet_pred_bce_workspace_bytes()
  * bytes, ZEROED before the first use (the kernel leaves its ticket counter at zero).  ynet_bce_grad_rescale corrects
- * dx / dy when the upstream gradient turns out not to be expected_grad. */
+ * dx / dy when the upstream gradient turns out not to be expected_grad.
+ * dx_relu_mask != 0 (cin <= 32): dx is zeroed where x <= 0 -- the ReLU backward of decoder.4.2 (models/ynet.py:447-449),
+ * whose output x is, applied while x streams through this kernel instead of by that conv's dgrad reading x again. */
 long long ynet_pred_bce_workspace_bytes(void);
 int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target,
                   float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, long long HW,
-                  float expected_grad, void* stream);
+                  float expected_grad, int dx_relu_mask, void* stream);
 
 /* ---- goal / trajectory read-out -------------------------------------------------------------- */
 /* SoftArgmax2D.forward (utils/softargmax.py:55-81; models/ynet.py:582-583): x [B][C][H][W] with
@@ -155,6 +177,14 @@ int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, con
  * copy) -> out [B][C][2] = (E[x], E[y]) in pixels. */
 int ynet_softargmax2d(const float* x, float* out, long long B, int C, long long batch_stride, int H, int W,
                       void* stream);
+
+/* The read-out of a training step (utils/train_epoch.py:118-126) in two launches:
+ *   pred_traj [B][P][2] = SoftArgmax2D(traj_map [B][P][H][W]);  pred_goal [B][1][2] = SoftArgmax2D(goal_map[:, goal_channel])
+ *   ade[b] = mean_p |gt_future[b][p] - pred_traj[b][p]| / resize_factor;  fde[b] = |gt_future[b][P-1] - pred_goal[b][0]| / resize_factor
+ * (the reference: two soft-argmax calls and a dozen elementwise ATen launches). */
+int ynet_train_readout(const float* traj_map, long long traj_batch_stride, const float* goal_map, long long goal_batch_stride,
+                       int goal_channel, const float* gt_future, float* pred_traj, float* pred_goal, float* ade, float* fde,
+                       int B, int P, int H, int W, float resize_factor, void* stream);
 /* The 1x1 predictor (models/ynet.py:469: nn.Conv2d(decoder_channels[-1], pred_len, 1)) followed by SoftArgmax2D
  * (utils/softargmax.py:55-81) as evaluate() chains them for every trajectory sample (utils/evaluate.py:259-262:
  * `model.softargmax(model.pred_traj(...))`) in one pass: x [B][cin][H][W] (batch stride x_bs elements), w [cout][cin] the
@@ -222,6 +252,14 @@ int ynet_multinomial(const float* prob, long long rows, long long row_stride, in
 int ynet_cws_prior(const float* sig, long long sig_batch_stride, int n_persons, const float* mean_xy, const float* dist_xy,
                    int rows, int H, int W, float sigma_factor, float ratio, int rot, float* out_map, float* out_xy,
                    void* stream);
+
+/* ---- scene pre-processing without OpenCV / the segmentation backbone (the pinnable part) ------------- */
+/* pad (utils/image_utils.py:95-107): N planes H x W -> Hp x Wp, zero border at the bottom / right (cv2.copyMakeBorder,
+ * BORDER_CONSTANT); the caller rounds Hp, Wp up to the division factor (32). */
+int ynet_pad2d(const float* x, float* y, long long N, int H, int W, int Hp, int Wp, void* stream);
+/* pad + preprocess_image_for_segmentation(seg_mask = True) (utils/image_utils.py:74-81, 95-107): an int32 label map
+ * [H][W] -> `classes` one-hot fp32 planes [classes][Hp][Wp]; the border is padded BEFORE the encoding, i.e. it is class 0. */
+int ynet_seg_onehot_pad(const int* labels, float* y, int H, int W, int Hp, int Wp, int classes, void* stream);
 
 /* ---- data-parallel exchange (new: the reference is single-process) --------------- */
 /* One-shot all-reduce(SUM) of the flat trainable-gradient buffer among the GPUs of ONE node: every rank publishes its

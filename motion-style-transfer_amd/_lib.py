@@ -36,11 +36,16 @@ SIGNATURES = {
                                 c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_compose": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_grad": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_lora_conv2d_wgrad_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "ynet_lora_conv2d_wgrad_preferred": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "ynet_lora_conv2d_wgrad_workspace_floats": (c_ll, [c_i, c_i]),
+    "ynet_lora_conv2d_wgrad": (c_i, [PP, PI, PLL, c_i, c_fp, c_ll, c_fp, c_ll, c_fp, c_fp, c_f, c_fp, c_fp, c_fp,
+                                     c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_compose_pack": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_compose_pack_multi": (c_i, [c_i, PP, PP, PP, ctypes.POINTER(c_f), PP, PP, PI, PI, PI, PI, c_fp]),
     "ynet_maxpool2_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_maxpool2_bwd": (c_i, [c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
-    "ynet_maxpool2_bwd_add": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
+    "ynet_maxpool2_bwd_add": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_fp]),
     "ynet_upsample2x_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_upsample2x_bwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_avgpool_pyramid": (c_i, [c_fp, PP, c_i, c_ll, c_i, c_i, c_fp]),
@@ -50,11 +55,14 @@ SIGNATURES = {
     "ynet_bce_logits_fwd_grad": (c_i, [c_fp, c_fp, c_ll, c_f, c_fp, c_fp, c_fp, c_fp]),
     "ynet_bce_grad_rescale": (c_i, [c_fp, c_fp, c_f, c_ll, c_fp]),
     "ynet_pred_bce_workspace_bytes": (c_ll, []),
-    "ynet_pred_bce": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_ll, c_f, c_fp]),
+    "ynet_pred_bce": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_ll, c_f, c_i, c_fp]),
     "ynet_softargmax2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, c_i, c_i, c_fp]),
+    "ynet_train_readout": (c_i, [c_fp, c_ll, c_fp, c_ll, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_fp]),
     "ynet_pred_softargmax_supported": (c_i, [c_i, c_i, c_i, c_i]),
     "ynet_pred_softargmax_workspace_floats": (c_ll, [c_ll, c_i, c_i]),
     "ynet_pred_softargmax": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_pad2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_seg_onehot_pad": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_sigmoid_temp": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, PI, c_i, c_f, c_fp]),
     "ynet_gather_patch": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "ynet_heatmap_analytic": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, ctypes.c_double, c_fp, c_i, c_fp, c_fp]),

@@ -1148,10 +1148,6 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (per_cu < 1) per_cu = 1;
         if (cus < 1) cus = 256;
-        // YNET_CONV_WG_PER_CU: cap on the resident persistent workgroups per CU (experiment: leave wave slots to the
-        // HBM-bound kernels of the other graph branch)
-        static const int cap = getenv("YNET_CONV_WG_PER_CU") ? atoi(getenv("YNET_CONV_WG_PER_CU")) : 0;
-        if (cap > 0 && per_cu > cap) per_cu = cap;
         slots = per_cu * cus;
     }
     const long long nblk = nt < slots ? nt : slots;

@@ -47,6 +47,10 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
 // dx = route(dy) + add0 + add1 (either addend may be NULL): the max-pool backward also folds in the gradients the two
 // decoders produced for the same feature map (skip connections), replacing two full-size elementwise adds of the
 // autograd engine.  Even H and W, 8-byte aligned rows.
+// RELU: x is the post-ReLU output of the conv that receives dx as ITS output gradient; that conv's backward would zero
+// dx where x <= 0 (models/ynet.py: nn.ReLU after every encoder conv) by reading x once more next to dx -- x is in this
+// kernel's registers already, so the mask is applied here and the conv runs its unmasked dgrad / wgrad kernels.
+template <bool RELU>
 __global__ void maxpool2_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                         const float* __restrict__ add0, const float* __restrict__ add1,
                                         float* __restrict__ dx, long long N, int H, int W) {
@@ -72,6 +76,12 @@ __global__ void maxpool2_bwd_add_kernel(const float* __restrict__ x, const float
         if (add1) {
             o0 += *reinterpret_cast<const f2*>(add1 + base);
             o1 += *reinterpret_cast<const f2*>(add1 + base + W);
+        }
+        if (RELU) {
+            o0[0] = t[0] > 0.f ? o0[0] : 0.f;
+            o0[1] = t[1] > 0.f ? o0[1] : 0.f;
+            o1[0] = b[0] > 0.f ? o1[0] : 0.f;
+            o1[1] = b[1] > 0.f ? o1[1] : 0.f;
         }
         *reinterpret_cast<f2*>(dx + base) = o0;
         *reinterpret_cast<f2*>(dx + base + W) = o1;
@@ -516,6 +526,7 @@ struct PredBceArgs {
     const float* t;         // [B][cout][HW]
     float* y;               // [B][cout][HW] logits
     float* dx;              // [B][cin][HW] or NULL
+    int relu_mask;          // dx is zeroed where x <= 0 (x = post-ReLU output of the conv that receives dx: see maxpool2_bwd_add_kernel)
     float* dy;              // [B][cout][HW] or NULL (wanted when the predictor itself trains)
     double* partial;        // [gridDim.x]
     unsigned* ticket;
@@ -552,6 +563,9 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
         // NB input planes are fetched before their FMAs start: a streaming kernel lives on bytes in flight (with two
         // loads per thread outstanding it reached 3.3 TB/s -- Little's law at ~2.5 us of loaded HBM latency)
         constexpr int NB = 8;
+        unsigned xpos[PX];          // bit ci: x[ci] > 0 at this thread's pixel e (cin <= 32): the ReLU mask for dx, kept while x streams by
+#pragma unroll
+        for (int e = 0; e < PX; ++e) xpos[e] = 0u;
 #pragma unroll 1
         for (int c0 = 0; c0 < a.cin; c0 += NB) {
             vec_t v[NB];
@@ -559,6 +573,12 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
             for (int k = 0; k < NB; ++k) {
                 const int ci = c0 + k < a.cin ? c0 + k : a.cin - 1;      // (clamped: the surplus products are skipped below)
                 v[k] = xp[(long long)ci * hwv];
+            }
+            if (a.relu_mask) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+#pragma unroll
+                    for (int e = 0; e < PX; ++e) xpos[e] |= (v[k][e] > 0.f ? 1u : 0u) << ((c0 + k) & 31);
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -606,6 +626,10 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
                     const float wv = w[ci * a.cout_pad + co];      // (zero in the padded columns)
 #pragma unroll
                     for (int e = 0; e < PX; ++e) o[e] = __builtin_fmaf(acc[co][e], wv, o[e]);
+                }
+                if (a.relu_mask) {
+#pragma unroll
+                    for (int e = 0; e < PX; ++e) o[e] = ((xpos[e] >> (ci & 31)) & 1u) ? o[e] : 0.f;
                 }
                 dp[(long long)ci * hwv] = o;
             }
@@ -723,12 +747,10 @@ __device__ __forceinline__ void soft_add(SoftAcc& a, float v, float px, float py
     a.sy += e * py;
 }
 
-__global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                         int C, long long bs, int H, int W, float eps) {
+// one workgroup, one plane `p` -> out2[0..1] = (E[x], E[y])
+__device__ __forceinline__ void softargmax_plane(const float* __restrict__ p, float* __restrict__ out2, int H, int W, float eps) {
     __shared__ float wm[4];
     __shared__ double wsum[4][3];
-    const long long plane = blockIdx.x;
-    const float* p = x + (plane / C) * bs + (plane % C) * (long long)H * W;
     const int tid = threadIdx.x;
     SoftAcc a{-INFINITY, 0.f, 0.f, 0.f};
     bool poison = false;        // a NaN logit: the reference's softmax makes the whole plane NaN
@@ -807,9 +829,43 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
         sx = (wsum[0][1] + wsum[1][1]) + (wsum[2][1] + wsum[3][1]);
         sy = (wsum[0][2] + wsum[1][2]) + (wsum[2][2] + wsum[3][2]);
         const double inv = 1.0 / (s + (double)eps);
-        out[plane * 2 + 0] = (float)(sx * inv);
-        out[plane * 2 + 1] = (float)(sy * inv);
+        out2[0] = (float)(sx * inv);
+        out2[1] = (float)(sy * inv);
     }
+}
+
+__global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         int C, long long bs, int H, int W, float eps) {
+    const long long plane = blockIdx.x;
+    softargmax_plane(x + (plane / C) * bs + (plane % C) * (long long)H * W, out + plane * 2, H, W, eps);
+}
+
+// The read-out of a training step (utils/train_epoch.py:118-126) in two launches instead of ~14:
+//   pred_traj = softargmax(pred_traj_map) [B, P, 2];  pred_goal = softargmax(pred_goal_map[:, -1:]) [B, 1, 2]     (this kernel:
+//   the B*P planes of the first map and the last plane of every image of the second, one workgroup each)
+//   ADE[b] = mean_p |gt[b, p] - pred_traj[b, p]| / resize_factor;  FDE[b] = |gt[b, -1] - pred_goal[b, 0]| / resize_factor
+//   (train_readout_finish_kernel; the reference's elementwise chain ((d / rf) ** 2).sum(2) ** 0.5 in the same fp32 order)
+__global__ __launch_bounds__(256) void softargmax_two_kernel(const float* __restrict__ x0, long long bs0, int C0,
+                                                             const float* __restrict__ x1, long long bs1, long long n0,
+                                                             float* __restrict__ out0, float* __restrict__ out1, int H, int W, float eps) {
+    const long long plane = blockIdx.x;
+    if (plane < n0) softargmax_plane(x0 + (plane / C0) * bs0 + (plane % C0) * (long long)H * W, out0 + plane * 2, H, W, eps);
+    else softargmax_plane(x1 + (plane - n0) * bs1, out1 + (plane - n0) * 2, H, W, eps);
+}
+
+__global__ __launch_bounds__(256) void train_readout_finish_kernel(const float* __restrict__ traj, const float* __restrict__ goal,
+                                                                   const float* __restrict__ gt, int B, int P, float rf,
+                                                                   float* __restrict__ ade, float* __restrict__ fde) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float acc = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float dx = (gt[(b * P + p) * 2] - traj[(b * P + p) * 2]) / rf, dy = (gt[(b * P + p) * 2 + 1] - traj[(b * P + p) * 2 + 1]) / rf;
+        acc += __fsqrt_rn(dx * dx + dy * dy);
+    }
+    ade[b] = acc / (float)P;
+    const float gx = (gt[(b * P + P - 1) * 2] - goal[b * 2]) / rf, gy = (gt[(b * P + P - 1) * 2 + 1] - goal[b * 2 + 1]) / rf;
+    fde[b] = __fsqrt_rn(gx * gx + gy * gy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1142,6 +1198,32 @@ __global__ __launch_bounds__(1024) void kmeans2d_kernel(const float* __restrict_
     if (tid == 0) status[person] = (flag[0] == 2 ? 1 : 0) | (flag[1] << 8);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Scene pre-processing, the part that needs neither OpenCV nor the segmentation backbone:
+//   pad(images, division_factor)                          utils/image_utils.py:95-107  zero border at the bottom / right up to a
+//                                                         multiple of the division factor (cv2.copyMakeBorder, BORDER_CONSTANT)
+//   preprocess_image_for_segmentation(seg_mask = True)    utils/image_utils.py:74-81   one-hot planes of a label map
+// The reference pads the LABEL map first (the border gets label 0) and one-hot encodes afterwards, so the border belongs to
+// class 0; the fused kernel reproduces exactly that.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pad2d_kernel(const float* __restrict__ x, float* __restrict__ y, long long N, int H, int W, int Hp, int Wp) {
+    const long long total = N * Hp * Wp;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int px = (int)(i % Wp), py = (int)((i / Wp) % Hp);
+        const long long n = i / ((long long)Wp * Hp);
+        y[i] = (py < H && px < W) ? x[(n * H + py) * W + px] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_onehot_pad_kernel(const int* __restrict__ lab, float* __restrict__ y, int H, int W, int Hp, int Wp, int C) {
+    const long long total = (long long)C * Hp * Wp;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int px = (int)(i % Wp), py = (int)((i / Wp) % Hp), c = (int)(i / ((long long)Wp * Hp));
+        const int v = (py < H && px < W) ? lab[(long long)py * W + px] : 0;      // the padded border carries label 0
+        y[i] = v == c ? 1.f : 0.f;
+    }
+}
+
 extern "C" {
 
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
@@ -1159,12 +1241,15 @@ int ynet_maxpool2_bwd(const float* x, const float* dy, float* dx, long long N, i
 }
 
 int ynet_maxpool2_bwd_add(const float* x, const float* dy, const float* add0, const float* add1, float* dx, long long N,
-                          int H, int W, void* stream) {
+                          int H, int W, int relu_mask, void* stream) {
     YNET_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2, "maxpool2_bwd_add: bad arguments");
     YNET_REQUIRE((H & 1) == 0 && (W & 1) == 0, "maxpool2_bwd_add: H and W must be even (got %dx%d)", H, W);
     YNET_REQUIRE((((uintptr_t)x | (uintptr_t)dx | (uintptr_t)add0 | (uintptr_t)add1) & 7) == 0, "maxpool2_bwd_add: 8-byte aligned planes required");
     const long long total = N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(maxpool2_bwd_add_kernel, plane_grid(N, total / N), dim3(256), 0, (hipStream_t)stream, x, dy, add0, add1, dx, N, H, W);
+    if (relu_mask)
+        hipLaunchKernelGGL(maxpool2_bwd_add_kernel<true>, plane_grid(N, total / N), dim3(256), 0, (hipStream_t)stream, x, dy, add0, add1, dx, N, H, W);
+    else
+        hipLaunchKernelGGL(maxpool2_bwd_add_kernel<false>, plane_grid(N, total / N), dim3(256), 0, (hipStream_t)stream, x, dy, add0, add1, dx, N, H, W);
     return ynet_check_launch("maxpool2_bwd_add");
 }
 
@@ -1224,8 +1309,9 @@ long long ynet_pred_bce_workspace_bytes(void) { return YNET_BCE_PARTS * (long lo
 
 int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target,
                   float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, long long HW,
-                  float expected_grad, void* stream) {
+                  float expected_grad, int dx_relu_mask, void* stream) {
     YNET_REQUIRE(x && wp && target && y && loss && workspace, "pred_bce: null pointer");
+    YNET_REQUIRE(!dx_relu_mask || (dx != nullptr && cin <= 32), "pred_bce: the ReLU mask of dx needs dx and cin <= 32 (got cin = %d)", cin);
     YNET_REQUIRE(B > 0 && cin > 0 && cout > 0 && cout <= 32 && HW > 0 && (HW & 3) == 0, "pred_bce: bad shape B=%d cin=%d cout=%d HW=%lld (cout <= 32, HW %% 4 == 0)", B, cin, cout, HW);
     YNET_REQUIRE((((uintptr_t)x | (uintptr_t)target | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dy) & 15) == 0 && (x_batch_stride & 3) == 0,
                  "pred_bce: tensors must be 16-byte aligned");
@@ -1237,6 +1323,7 @@ int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, con
     a.t = target;
     a.y = y;
     a.dx = dx;
+    a.relu_mask = dx_relu_mask ? 1 : 0;
     a.dy = dy;
     a.partial = (double*)workspace;
     a.ticket = (unsigned*)((char*)workspace + YNET_BCE_PARTS * sizeof(double));
@@ -1305,6 +1392,35 @@ int ynet_softargmax2d(const float* x, float* out, long long B, int C, long long 
     hipLaunchKernelGGL(softargmax_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, out, C,
                        batch_stride, H, W, 1e-6f);
     return ynet_check_launch("softargmax2d");
+}
+
+int ynet_train_readout(const float* traj_map, long long traj_bs, const float* goal_map, long long goal_bs, int goal_channel,
+                       const float* gt_future, float* pred_traj, float* pred_goal, float* ade, float* fde,
+                       int B, int P, int H, int W, float resize_factor, void* stream) {
+    YNET_REQUIRE(traj_map && goal_map && gt_future && pred_traj && pred_goal && ade && fde, "train_readout: null pointer");
+    YNET_REQUIRE(B > 0 && P > 0 && H > 0 && W > 0 && goal_channel >= 0 && resize_factor != 0.f, "train_readout: bad arguments");
+    YNET_REQUIRE((W & 3) != 0 || ((((uintptr_t)traj_map | (uintptr_t)goal_map) & 15) == 0 && ((traj_bs | goal_bs) & 3) == 0 && (((long long)H * W) & 3) == 0),
+                 "train_readout: maps must be 16-byte aligned");
+    const long long n0 = (long long)B * P, planes = n0 + B;
+    YNET_REQUIRE(planes < (1ll << 31), "train_readout: too many planes");
+    hipLaunchKernelGGL(softargmax_two_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, traj_map, traj_bs, P,
+                       goal_map + (long long)goal_channel * H * W, goal_bs, n0, pred_traj, pred_goal, H, W, 1e-6f);
+    hipLaunchKernelGGL(train_readout_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred_traj, pred_goal, gt_future,
+                       B, P, resize_factor, ade, fde);
+    return ynet_check_launch("train_readout");
+}
+
+int ynet_pad2d(const float* x, float* y, long long N, int H, int W, int Hp, int Wp, void* stream) {
+    YNET_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W, "pad2d: bad arguments");
+    hipLaunchKernelGGL(pad2d_kernel, dim3(grid_for(N * Hp * Wp, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, Hp, Wp);
+    return ynet_check_launch("pad2d");
+}
+
+int ynet_seg_onehot_pad(const int* labels, float* y, int H, int W, int Hp, int Wp, int classes, void* stream) {
+    YNET_REQUIRE(labels && y && H > 0 && W > 0 && Hp >= H && Wp >= W && classes > 0, "seg_onehot_pad: bad arguments");
+    hipLaunchKernelGGL(seg_onehot_pad_kernel, dim3(grid_for((long long)classes * Hp * Wp, 256)), dim3(256), 0, (hipStream_t)stream,
+                       labels, y, H, W, Hp, Wp, classes);
+    return ynet_check_launch("seg_onehot_pad");
 }
 
 static void pred_softargmax_plan(int H, int W, int* gpw, int* nchunk) {

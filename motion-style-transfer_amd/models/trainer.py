@@ -13,6 +13,7 @@ import re
 from collections import OrderedDict, deque
 from copy import deepcopy
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch.utils.data import DataLoader
@@ -309,9 +310,24 @@ class YNetTrainer:
             raise ImportError("decoding scene images needs OpenCV + segmentation_models_pytorch (out of scope here): "
                               "pass a dict {scene_id: float tensor [C,H,W]} (pre-processed, padded to a multiple "
                               f"of {self.division_factor}) instead of an image directory")
-        for k, im in image_path.items():
-            if im.shape[-1] % self.division_factor or im.shape[-2] % self.division_factor:
-                raise ValueError(f"scene {k}: {tuple(im.shape)} is not padded to a multiple of {self.division_factor}")
+        # pad (utils/image_utils.py:95-107) and, for raw label maps, the one-hot encoding of
+        # preprocess_image_for_segmentation(seg_mask=True) (image_utils.py:74-81) run on the device; decoding image files,
+        # cv2.resize and the RGB normalisation of the segmentation backbone stay outside (no OpenCV / smp in this image)
+        images = dict(image_path)
+        for k, im in images.items():
+            t = im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im))
+            if t.dim() == 2:            # a label map [H, W]: padded with label 0, then one-hot planes
+                if self.device.type != "cuda":
+                    raise RuntimeError("raw label maps are encoded by the HIP kernels: a HIP device is required")
+                images[k] = ops.seg_onehot_pad(t.to(self.device), classes=self.params.get("n_semantic_classes", 6) if hasattr(self.params, "get") else 6,
+                                               division_factor=self.division_factor)
+            elif t.shape[-1] % self.division_factor or t.shape[-2] % self.division_factor:
+                if not (t.is_cuda or self.device.type == "cuda"):
+                    raise ValueError(f"scene {k}: {tuple(t.shape)} is not padded to a multiple of {self.division_factor}")
+                images[k] = ops.pad_planes(t.to(self.device).float(), self.division_factor)
+            else:
+                images[k] = t
+        image_path = images
         dataset = SceneDataset(df, resize=resize_factor, total_len=obs_len + pred_len)
         generator = None
         if mode == "train" and self.dp is not None:

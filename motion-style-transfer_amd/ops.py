@@ -435,19 +435,51 @@ skip_fold = False                                                   # switched o
 _skip_fold_allowed = _os.environ.get("YNET_SKIP_FOLD", "1") != "0"      # YNET_SKIP_FOLD=0: never fold (A/B runs)
 
 
+# ------------------------------------------------------------------------------------------------
+# ReLU backward applied where a gradient is PRODUCED
+# ------------------------------------------------------------------------------------------------
+# conv + ReLU is one launch here, and the conv's backward zeroes its incoming gradient where the activation y was <= 0 by
+# reading y next to dy (the masked dgrad / wgrad variants: 7-11 % slower, a third tile for the wgrad's DMA stream).  Two
+# producers of such a gradient hold y in registers anyway -- the max-pool backward (y is the pool's input) and the fused
+# predictor + criterion kernel (y is its input x) -- and write the gradient already masked; the conv then runs its
+# unmasked kernels.  Protocol, opt-in like the skip fold (same context manager):
+#   * _Conv2dFn.forward registers the address of every post-ReLU output it produces        (_relu_outputs)
+#   * a producer whose input is such a tensor masks its dx and registers (dx address -> y address, dx version)  (_premasked)
+#   * _Conv2dFn.backward drops its own mask when its dy is registered for ITS y and has not been written since
+#     (an in-place accumulation by the autograd engine bumps the version; a sum into a new tensor has a new address).
+# Masking twice is harmless (idempotent), so every doubt resolves to "mask again".
+_relu_outputs = {}
+_premasked = {}
+premask = False                                                     # switched on by fold_skip_gradients() only
+premask_stats = {"unmasked_backwards": 0}                           # conv backwards that ran without their own mask (tests)
+_premask_allowed = _os.environ.get("YNET_PREMASK", "1") != "0"          # YNET_PREMASK=0: every conv backward masks itself
+
+
+def _is_relu_output(t: torch.Tensor) -> bool:
+    e = _relu_outputs.get(t.data_ptr())
+    return e is not None and e[0]() is not None and e[1] == tuple(t.shape)
+
+
 class fold_skip_gradients:
     """Context manager: inside it (forward AND the full backward of the same graph) the gradients of the encoder
-    feature maps that feed a max-pool are added inside the pool's backward kernel instead of by autograd."""
+    feature maps that feed a max-pool are added inside the pool's backward kernel instead of by autograd, and the
+    ReLU backward of a conv whose output gradient comes from a max-pool backward or from the fused predictor +
+    criterion is applied by that producer (see `_premasked`)."""
 
     def __enter__(self):
-        global skip_fold
-        self._prev = skip_fold
+        global skip_fold, premask
+        self._prev = (skip_fold, premask)
         skip_fold = _skip_fold_allowed
+        premask = _premask_allowed
+        _relu_outputs.clear()
+        _premasked.clear()
         return self
 
     def __exit__(self, *exc):
-        global skip_fold
-        skip_fold = self._prev
+        global skip_fold, premask
+        skip_fold, premask = self._prev
+        _relu_outputs.clear()
+        _premasked.clear()
         # gradients handed over to a pool whose backward never ran (an exception, a pruned graph) must not linger
         for k in [k for k, e in _skip_registry.items() if e.consumed or e.ref() is None or e.stash]:
             del _skip_registry[k]
@@ -510,6 +542,8 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.has_lora = lora_a is not None
         ctx.save_for_backward(weight, lora_a, lora_b, y if relu else None, *keep)
         ctx.w_key = _weight_key(weight, lora_a, lora_b)
+        if relu and premask:
+            _relu_outputs[y.data_ptr()] = (weakref.ref(y), tuple(y.shape))
         return y
 
     @staticmethod
@@ -521,6 +555,11 @@ class _Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous()
         B, _, H, W = dy.shape
         mask = (y.data_ptr(), cout * H * W) if relu else None
+        if relu and _premasked:
+            # the producer of dy already zeroed it where y <= 0 (see `_premasked`): unmasked dgrad / wgrad kernels
+            if _premasked.pop(dy.data_ptr(), None) == (y.data_ptr(), dy._version, tuple(dy.shape)):
+                mask = None
+                premask_stats["unmasked_backwards"] += 1
         need = ctx.needs_input_grad
         need_src = list(need[5:5 + ctx.n_src])
         d_srcs = [None] * ctx.n_src
@@ -553,11 +592,15 @@ class _Conv2dFn(torch.autograd.Function):
         want_w = need[1] or (ctx.has_lora and (need[3] or need[4]))
         want_b = ctx.has_bias and need[2]
         if want_w or want_b:
-            dw, d_b = conv2d_wgrad_raw(srcs, dy, mask, weight, want_b)
-            if ctx.has_lora and (need[3] or need[4]):
-                d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
-            if need[1]:
-                d_w = dw
+            if ctx.has_lora and not need[1] and not want_b and lora_conv2d_wgrad_supported(srcs, dy, weight, lora_a, preferred=True):
+                # only the adapter trains (mosa_*): dA / dB straight from projected planes, no dW (ynet_lora_conv2d_wgrad)
+                d_a, d_bm = lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a.detach(), lora_b.detach(), scale)
+            else:
+                dw, d_b = conv2d_wgrad_raw(srcs, dy, mask, weight, want_b)
+                if ctx.has_lora and (need[3] or need[4]):
+                    d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
+                if need[1]:
+                    d_w = dw
         return (None, d_w, d_b, d_a if need[3] else None, d_bm if need[4] else None, *d_srcs)
 
 
@@ -576,6 +619,43 @@ def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b):
                                   dw.data_ptr(), d_b.data_ptr() if want_b else None, ws.data_ptr(),
                                   B, H, W, cout, k, _stream()), lib)
     return dw, d_b
+
+
+_lora_wg_ws = {}
+
+
+def lora_conv2d_wgrad_supported(srcs, dy, weight, lora_a, preferred: bool = False) -> bool:
+    """Can ynet_lora_conv2d_wgrad serve this layer -- and, with `preferred`, is it the faster path for it (measured)?"""
+    cout, cin, k, _ = weight.shape
+    r = lora_a.shape[0] // k
+    W = dy.shape[3]
+    query = _lib().ynet_lora_conv2d_wgrad_preferred if preferred else _lib().ynet_lora_conv2d_wgrad_supported
+    if not query(int(cin), int(cout), int(k), int(r), int(W)):
+        return False
+    return all(s.data_ptr() % 16 == 0 and (s.shape[0] == 1 or s.stride(0) % 4 == 0) for s in srcs) and dy.data_ptr() % 16 == 0
+
+
+def lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a, lora_b, scale):
+    """(d lora_A, d lora_B) of the adapted conv(cat(srcs), W + s * (B @ A).view(W.shape)) for the output gradient dy, without
+    the filter gradient in between (ynet_lora_conv2d_wgrad; models/ynet.py:141-144)."""
+    lib = _lib()
+    cout, cin, k, _ = weight.shape
+    r = lora_a.shape[0] // k
+    B, _, H, W = dy.shape
+    descs = [(s.data_ptr(), s.shape[1], (s.stride(0) if s.shape[0] > 1 else s.shape[1] * H * W)) for s in srcs]
+    sp, sc, sb = _arrays(descs)
+    la, lb = lora_a.contiguous(), lora_b.contiguous()
+    d_a, d_b = torch.empty_like(la), torch.empty_like(lb)
+    n_ws = lib.ynet_lora_conv2d_wgrad_workspace_floats(cin, cout)
+    key = (dy.device, torch.cuda.current_stream().cuda_stream)      # grow-only scratch per stream (stream-ordered reuse)
+    ws = _lora_wg_ws.get(key)
+    if ws is None or ws.numel() < n_ws:
+        ws = _lora_wg_ws[key] = torch.empty(n_ws, device=dy.device, dtype=torch.float32)
+    L.check(lib.ynet_lora_conv2d_wgrad(sp, sc, sb, len(descs), dy.data_ptr(), cout * H * W,
+                                       mask[0] if mask else None, mask[1] if mask else 0,
+                                       la.data_ptr(), lb.data_ptr(), float(scale), d_a.data_ptr(), d_b.data_ptr(), ws.data_ptr(),
+                                       B, H, W, cout, k, r, _stream()), lib)
+    return d_a, d_b
 
 
 def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0):
@@ -606,6 +686,9 @@ class _MaxPool2Fn(torch.autograd.Function):
         ctx.folds = bool(skip_fold and ctx.needs_input_grad[0] and H % 2 == 0 and W % 2 == 0)
         if ctx.folds:
             _skip_register(x)
+        # x is a post-ReLU conv output: this pool's backward applies that ReLU's backward to the gradient it produces
+        ctx.premask = bool(premask and ctx.needs_input_grad[0] and H % 2 == 0 and W % 2 == 0 and x.data_ptr() % 8 == 0
+                           and _is_relu_output(x))
         return y
 
     @staticmethod
@@ -619,16 +702,19 @@ class _MaxPool2Fn(torch.autograd.Function):
             e = _skip_entry(x)
             if e is not None:
                 adds, e.stash, e.consumed = e.stash, [], True
-        if adds:
+        pm = bool(ctx.premask and premask)
+        if adds or pm:
             cur = torch.cuda.current_stream(dy.device)
             for t, ev in adds:          # produced on the decoders' streams
                 cur.wait_event(ev)
                 t.record_stream(cur)
-            a0 = adds[0][0]
+            a0 = adds[0][0] if adds else None
             a1 = adds[1][0] if len(adds) > 1 else None
-            L.check(lib.ynet_maxpool2_bwd_add(x.data_ptr(), dy.contiguous().data_ptr(), a0.data_ptr(),
+            L.check(lib.ynet_maxpool2_bwd_add(x.data_ptr(), dy.contiguous().data_ptr(), a0.data_ptr() if a0 is not None else None,
                                               a1.data_ptr() if a1 is not None else None, dx.data_ptr(), B * C, H, W,
-                                              _stream()), lib)
+                                              1 if pm else 0, _stream()), lib)
+            if pm:
+                _premasked[dx.data_ptr()] = (x.data_ptr(), dx._version, tuple(dx.shape))
         else:
             L.check(lib.ynet_maxpool2_bwd(x.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), B * C, H, W, _stream()), lib)
         return dx
@@ -756,10 +842,13 @@ class _PredBCEFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
         ctx.dx = torch.empty_like(x) if need_x else None
         ctx.dy = torch.empty_like(y) if need_w else None
+        # x is the post-ReLU output of decoder[4][2]: the kernel writes dx with that ReLU's backward applied
+        ctx.premask_y = x.data_ptr() if (need_x and premask and cin <= 32 and _is_relu_output(x)) else None
         L.check(lib.ynet_pred_bce(x.data_ptr(), cin * H * W, wp.data_ptr(), bias.detach().data_ptr() if bias is not None else None,
                                   target.data_ptr(), y.data_ptr(), loss.data_ptr(),
                                   ctx.dx.data_ptr() if need_x else None, ctx.dy.data_ptr() if need_w else None,
-                                  ws.data_ptr(), B, cin, cout, H * W, expected_grad, _stream()), lib)
+                                  ws.data_ptr(), B, cin, cout, H * W, expected_grad, 1 if ctx.premask_y is not None else 0,
+                                  _stream()), lib)
         ctx.expected = expected_grad
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight)
@@ -777,6 +866,8 @@ class _PredBCEFn(torch.autograd.Function):
         d_w = d_b = None
         if dx is not None:
             L.check(lib.ynet_bce_grad_rescale(dx.data_ptr(), g.data_ptr(), ctx.expected, dx.numel(), _stream()), lib)
+            if ctx.premask_y is not None and premask:
+                _premasked[dx.data_ptr()] = (ctx.premask_y, dx._version, tuple(dx.shape))
         if dy is not None:
             L.check(lib.ynet_bce_grad_rescale(dy.data_ptr(), g.data_ptr(), ctx.expected, dy.numel(), _stream()), lib)
             d_w, d_b = conv2d_wgrad_raw([x], dy, None, weight, ctx.has_bias and ctx.needs_input_grad[2])
@@ -819,6 +910,27 @@ def softargmax2d(x: torch.Tensor) -> torch.Tensor:
     lib = _lib()
     L.check(lib.ynet_softargmax2d(t.data_ptr(), out.data_ptr(), B, c, bs, H, W, _stream()), lib)
     return out
+
+
+def train_readout(pred_traj_map: torch.Tensor, pred_goal_map: torch.Tensor, gt_future: torch.Tensor, resize_factor: float):
+    """utils/train_epoch.py:118-126 in two launches (ynet_train_readout): soft-argmax of every trajectory heat-map and of the
+    goal decoder's last one, then per-trajectory ADE / FDE.  -> (pred_traj [B,P,2], pred_goal [B,1,2], ade [B], fde [B])."""
+    for t, n in ((pred_traj_map, "trajectory maps"), (pred_goal_map, "goal maps"), (gt_future, "ground truth")):
+        _need_gpu(t, "train_readout " + n)
+    tm, gm = pred_traj_map.detach().contiguous(), pred_goal_map.detach().contiguous()
+    B, P, H, W = tm.shape
+    if tuple(gm.shape[0:1] + gm.shape[2:]) != (B, H, W) or tuple(gt_future.shape) != (B, P, 2):
+        raise ValueError(f"train_readout: shapes {tuple(tm.shape)}, {tuple(gm.shape)}, {tuple(gt_future.shape)} do not fit")
+    gt = gt_future.detach().contiguous()
+    dev = tm.device
+    pred_traj = torch.empty((B, P, 2), device=dev, dtype=torch.float32)
+    pred_goal = torch.empty((B, 1, 2), device=dev, dtype=torch.float32)
+    ade, fde = torch.empty(B, device=dev, dtype=torch.float32), torch.empty(B, device=dev, dtype=torch.float32)
+    lib = _lib()
+    L.check(lib.ynet_train_readout(tm.data_ptr(), P * H * W, gm.data_ptr(), gm.shape[1] * H * W, gm.shape[1] - 1, gt.data_ptr(),
+                                   pred_traj.data_ptr(), pred_goal.data_ptr(), ade.data_ptr(), fde.data_ptr(), B, P, H, W,
+                                   float(resize_factor), _stream()), lib)
+    return pred_traj, pred_goal, ade, fde
 
 
 class LazyPredictor:
@@ -997,6 +1109,38 @@ def _analytic_patches(t: AnalyticTemplate, xy, H: int, W: int) -> torch.Tensor:
                                       t.blob.data_ptr() if t.blob is not None else None,
                                       t.blob.shape[0] if t.blob is not None else 0, st.data_ptr(), _stream()), lib)
     return out
+
+
+def pad_planes(x: torch.Tensor, division_factor: int = 32) -> torch.Tensor:
+    """pad (utils/image_utils.py:95-107) of a [..., H, W] device tensor: zero border at the bottom / right up to a multiple of
+    `division_factor` (cv2.copyMakeBorder with BORDER_CONSTANT)."""
+    _need_gpu(x, "pad")
+    H, W = x.shape[-2:]
+    Hp, Wp = -(-H // division_factor) * division_factor, -(-W // division_factor) * division_factor
+    if (Hp, Wp) == (H, W):
+        return x
+    xc = x.contiguous()
+    y = torch.empty(tuple(x.shape[:-2]) + (Hp, Wp), device=x.device, dtype=torch.float32)
+    lib = _lib()
+    L.check(lib.ynet_pad2d(xc.data_ptr(), y.data_ptr(), max(1, xc.numel() // (H * W)), H, W, Hp, Wp, _stream()), lib)
+    return y
+
+
+def seg_onehot_pad(labels: torch.Tensor, classes: int = 6, division_factor: int = 32) -> torch.Tensor:
+    """pad + preprocess_image_for_segmentation(seg_mask=True) (utils/image_utils.py:74-81, 95-107): an integer label map
+    [H, W] on the device -> one-hot fp32 planes [classes, Hp, Wp]; the padded border is class 0 (it is padded before the
+    encoding, as in the reference)."""
+    if not torch.is_tensor(labels) or not labels.is_cuda:
+        raise RuntimeError("seg_onehot_pad: the MI355X path runs on HIP devices only (no CPU fallback exists by design)")
+    if labels.dim() != 2 or labels.is_floating_point() and bool((labels != labels.round()).any()):
+        raise ValueError("seg_onehot_pad: expected a 2-D map of integer class labels")
+    lab = labels.to(torch.int32).contiguous()
+    H, W = lab.shape
+    Hp, Wp = -(-H // division_factor) * division_factor, -(-W // division_factor) * division_factor
+    y = torch.empty((int(classes), Hp, Wp), device=lab.device, dtype=torch.float32)
+    lib = _lib()
+    L.check(lib.ynet_seg_onehot_pad(lab.data_ptr(), y.data_ptr(), H, W, Hp, Wp, int(classes), _stream()), lib)
+    return y
 
 
 def kmeans2d(points: torch.Tensor, init_idx: torch.Tensor, tol: float = 1e-3, iter_limit: int = 1000):

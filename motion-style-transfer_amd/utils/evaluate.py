@@ -5,6 +5,9 @@ decoder, soft-argmax}; best-of-K ADE/FDE.  Same signature and return value as th
 ``forced_samples`` (not in the reference) teacher-forces the sampled way-points for parity tests,
 ``dp`` shards every batch over ranks, ``max_effective_batch`` bounds the K-folding of the decoder passes.
 """
+import contextlib
+import os
+
 import numpy as np
 import pandas as pd
 import torch
@@ -13,6 +16,8 @@ from .. import ops
 from .image_utils import gather_patches, image2world, sampling, swap_pavement_terrain
 
 
+# YNET_SWEEP_STREAMS=0: the K-sample decoder passes of a batch run back to back on one stream
+SWEEP_STREAMS = os.environ.get("YNET_SWEEP_STREAMS", "1") != "0"
 _last_sweep_launch = "eager"
 
 
@@ -107,16 +112,33 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
                     K = waypoint_samples.shape[0]
                     G = max(1, min(K, max_effective_batch // max(n_local, 1)))
                     trajs_samples = []
+                    # The sample groups are independent of each other: they alternate between two HIP streams, so that the
+                    # HBM-bound launches of one pass (bilinear x2, patch gather, pyramid, read-out: ~15 % of a pass) and its
+                    # latency-bound 8^2 .. 32^2 layers run beside the other pass's MFMA-bound convolutions.
+                    two = SWEEP_STREAMS and K > G and torch.device(device).type == "cuda"
+                    global _last_sweep_launch
+                    _last_sweep_launch = "eager, sample groups alternate between two streams" if two else "eager"
+                    main = torch.cuda.current_stream(device) if two else None
+                    lanes = ops.side_streams(device) if two else None
                     # (the skip-feature part of each decoder level's first conv is the same for all K samples: once per batch)
                     with model.traj_decoder.share_skip_features(features):
-                        for k0 in range(0, K, G):
+                        if two:
+                            for st in lanes:
+                                st.wait_stream(main)          # features, shared terms and way-point samples are ready
+                        for idx, k0 in enumerate(range(0, K, G)):
                             g = min(G, K - k0)
-                            coords = waypoint_samples[k0:k0 + g].reshape(-1, 2)            # [g * n_local * n_wp, 2]
-                            waypoint_map = gather_patches(input_template, coords, H, W).view(g * n_local, n_wp, H, W)
-                            pyramid = ops.avgpool_pyramid(waypoint_map, len(features))
-                            traj_input = [ops.lazy_cat([ops.batch_repeat(f, g), p]) for f, p in zip(features, pyramid)]
-                            pred_traj = model.pred_traj_coords(traj_input)                  # [g * n_local, pred, 2] = softargmax(pred_traj(.))
-                            trajs_samples.append(pred_traj.view(g, n_local, -1, 2))
+                            with (torch.cuda.stream(lanes[idx & 1]) if two else contextlib.nullcontext()):
+                                coords = waypoint_samples[k0:k0 + g].reshape(-1, 2)            # [g * n_local * n_wp, 2]
+                                waypoint_map = gather_patches(input_template, coords, H, W).view(g * n_local, n_wp, H, W)
+                                pyramid = ops.avgpool_pyramid(waypoint_map, len(features))
+                                traj_input = [ops.lazy_cat([ops.batch_repeat(f, g), p]) for f, p in zip(features, pyramid)]
+                                pred_traj = model.pred_traj_coords(traj_input)                  # [g * n_local, pred, 2] = softargmax(pred_traj(.))
+                                trajs_samples.append(pred_traj.view(g, n_local, -1, 2))
+                        if two:
+                            for st in lanes:
+                                main.wait_stream(st)
+                            for t in trajs_samples:
+                                t.record_stream(main)
                     trajs_samples = torch.cat(trajs_samples)
                     gt_goal = gt_future[:, -1:]
                     if dataset_name == "eth":

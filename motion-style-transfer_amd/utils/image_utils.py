@@ -7,7 +7,9 @@
   gather_patches   : the same without the list, [N,H,W] contiguous (what train_epoch/evaluate use).
   sampling         : multinomial goal / waypoint sampling (utils/image_utils.py:110-135) by ynet_multinomial, a
       device sampler with a documented counter-based generator (YNET_SAMPLER=torch: torch.multinomial instead).
-Image file I/O (resize / pad / preprocess_image_for_segmentation) needs cv2 + smp and is out of scope.
+  pad / preprocess_image_for_segmentation(seg_mask=True) : the part of the scene pipeline that needs neither OpenCV nor the
+      segmentation backbone (utils/image_utils.py:66-81, 95-107), on the device (ynet_pad2d, ynet_seg_onehot_pad).
+Image decoding, cv2.resize and the smp normalisation of RGB images need cv2 + smp and stay out of scope.
 """
 import os
 
@@ -51,6 +53,33 @@ def analytic_gaussian_template(size, kernlen=81, nsig=4, normalize=True, device=
     if normalize:
         blob = blob / blob.max()
     return ops.AnalyticTemplate("gaussian", size, device, blob=blob, normalize=normalize)
+
+
+def pad(images, division_factor=32):
+    """utils/image_utils.py:95-107, in place on the dict like the reference.  Values: device tensors [H, W] / [C, H, W]
+    (padded by ynet_pad2d) or NumPy arrays [H, W] / [H, W, C] as cv2.imread returns them (np.pad: a constant zero border at the
+    bottom / right is all that cv2.copyMakeBorder(..., BORDER_CONSTANT) does)."""
+    for key, im in images.items():
+        if torch.is_tensor(im):
+            images[key] = ops.pad_planes(im, division_factor) if im.is_floating_point() else \
+                ops.pad_planes(im.float(), division_factor).to(im.dtype)
+        else:
+            H, W = im.shape[:2]
+            Hn, Wn = int(np.ceil(H / division_factor) * division_factor), int(np.ceil(W / division_factor) * division_factor)
+            images[key] = np.pad(im, ((0, Hn - H), (0, Wn - W)) + ((0, 0),) * (im.ndim - 2), mode="constant")
+
+
+def preprocess_image_for_segmentation(images, encoder="resnet101", encoder_weights="imagenet", seg_mask=False, classes=6, device=None):
+    """utils/image_utils.py:66-81 for segmentation MASKS (seg_mask=True): label maps [H, W] (NumPy or tensor) -> one-hot float
+    tensors [classes, H, W] on the device.  The RGB branch applies smp's encoder-specific normalisation and needs
+    segmentation_models_pytorch, which this image does not have."""
+    if not seg_mask:
+        raise ImportError("preprocess_image_for_segmentation(seg_mask=False) needs segmentation_models_pytorch (out of scope here)")
+    for key, im in images.items():
+        lab = im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im))
+        if device is not None:
+            lab = lab.to(device)
+        images[key] = ops.seg_onehot_pad(lab, classes=classes, division_factor=1)
 
 
 def gather_patches(template, traj, H, W):
@@ -116,6 +145,4 @@ def _needs_cv2(name):
     return fn
 
 
-resize = _needs_cv2("resize")
-pad = _needs_cv2("pad")
-preprocess_image_for_segmentation = _needs_cv2("preprocess_image_for_segmentation")
+resize = _needs_cv2("resize")      # cv2.resize (INTER_AREA / INTER_NEAREST): nothing in this image can pin it

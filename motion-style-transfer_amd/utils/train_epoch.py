@@ -13,6 +13,8 @@ one graph launch (``utils/step_graph.py``).  The first step of a shape runs eage
 needs), the second is captured, later ones replay.  ``graph=False`` / ``YNET_STEP_GRAPH=0`` keeps everything eager; the
 arithmetic is the same kernels in the same order either way.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -20,6 +22,10 @@ from .. import ops
 from . import step_graph
 from ..models.ynet import announce_bce_target
 from .image_utils import gather_patches, swap_pavement_terrain
+
+
+# YNET_TRAIN_READOUT=0: the step's read-out runs module by module (two soft-argmax launches + the reference's elementwise chain)
+FUSED_READOUT = os.environ.get("YNET_TRAIN_READOUT", "1") != "0"
 
 
 def _step_forward_backward(model, criterion, coords, scene_image, gt_template, input_template, waypoints, obs_len,
@@ -140,6 +146,13 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
 
 def _step_metrics(model, pred_goal_map, pred_traj_map, gt_future, resize_factor):
     """utils/train_epoch.py:118-126: soft-argmax read-out, per-trajectory ADE / FDE."""
+    sa = getattr(model, "softargmax_", None)
+    if (FUSED_READOUT and sa is not None and not sa.normalized_coordinates and not sa._forward_hooks and not sa._forward_pre_hooks
+            and pred_traj_map.is_cuda and pred_goal_map.shape[0] == pred_traj_map.shape[0] and (pred_traj_map.shape[3] % 4 == 0)):
+        # both soft-argmax calls in one launch, the ADE / FDE arithmetic in a second (ynet_train_readout); a forward hook on
+        # the model's SoftArgmax2D (tests, visualisation) keeps the module-by-module path below
+        _, _, ade, fde = ops.train_readout(pred_traj_map, pred_goal_map, gt_future, resize_factor)
+        return ade, fde
     pred_traj = model.softargmax(pred_traj_map)
     pred_goal = model.softargmax(pred_goal_map[:, -1:])
     ade = ((((gt_future - pred_traj) / resize_factor) ** 2).sum(dim=2) ** 0.5).mean(dim=1)

@@ -202,6 +202,76 @@ def test_lora_compose_and_grad(dev, cout, cin, r):
     close(d_b, bc.grad, rtol=1e-4, scale_rel=2e-6, msg="dB")
 
 
+LORA_WGRAD_CASES = [
+    # B, H, W, [source channels], cout, ReLU mask
+    (2, 16, 32, [14], 32, True),            # tiny; W = one tile
+    (2, 32, 64, [6, 8], 32, True),          # two sources (scene + motion maps of encoder.stages.0.0), 4-row tiles
+    (3, 24, 40, [32], 32, True),            # ragged tile edges (H % 4 != 0 rows past the image, W not a multiple of 32)
+    (2, 16, 16, [64], 64, True),            # 2-row tiles, a map narrower than the tile
+    (2, 32, 32, [32], 64, False),           # no ReLU
+    (1, 8, 8, [64], 64, True),
+    (4, 64, 64, [33], 17, True),            # odd channel counts: 2-row tiles, partial column / channel blocks
+]
+
+
+@pytest.mark.parametrize("B,H,W,cs,cout,relu", LORA_WGRAD_CASES)
+def test_lora_conv2d_wgrad_without_the_filter_gradient(dev, B, H, W, cs, cout, relu):
+    """ynet_lora_conv2d_wgrad (dA / dB of a rank-1 loralib Conv2d from projected planes) against stock autograd through
+    W + (B @ A).view(W.shape) * s, and against the two-call chain ynet_conv2d_wgrad -> ynet_lora_grad it replaces."""
+    ops = pkg("ops")
+    cin, r, k = sum(cs), 1, 3
+    xs = [rnd(B, c, H, W, seed=i + 1) for i, c in enumerate(cs)]
+    w = rnd(cout, cin, k, k, seed=10, scale=1.0 / (cin * 9) ** 0.5)
+    a, bm = rnd(r * k, cin * k, seed=11, scale=0.3), rnd(cout * k, r * k, seed=12, scale=0.1)
+    gy = rnd(B, cout, H, W, seed=13)
+    scale = 1.0 / r
+    ac, bc = a.clone().requires_grad_(True), bm.clone().requires_grad_(True)
+    y = F.conv2d(torch.cat(xs, 1), w + (bc @ ac).view(w.shape) * scale, None, padding=1)
+    y = F.relu(y) if relu else y
+    y.backward(gy)
+    xd = [x.to(dev) for x in xs]
+    yd, gyd = y.detach().to(dev), gy.to(dev)
+    mask = (yd.data_ptr(), cout * H * W) if relu else None
+    assert ops.lora_conv2d_wgrad_supported(xd, gyd, w.to(dev), a.to(dev))
+    d_a, d_b = ops.lora_conv2d_wgrad_raw(xd, gyd, mask, w.to(dev), a.to(dev), bm.to(dev), scale)
+    close(d_a, ac.grad, rtol=2e-4, scale_rel=5e-6, msg="dA vs autograd")
+    close(d_b, bc.grad, rtol=2e-4, scale_rel=5e-6, msg="dB vs autograd")
+    dw, _ = ops.conv2d_wgrad_raw(xd, gyd, mask, w.to(dev), False)
+    e_a, e_b = ops.lora_grad(dw, a.to(dev), bm.to(dev), scale)
+    close(d_a, e_a, rtol=2e-4, scale_rel=5e-6, msg="dA vs the two-call chain")
+    close(d_b, e_b, rtol=2e-4, scale_rel=5e-6, msg="dB vs the two-call chain")
+    # bitwise reproducible (fixed-order reductions, no atomics)
+    f_a, f_b = ops.lora_conv2d_wgrad_raw(xd, gyd, mask, w.to(dev), a.to(dev), bm.to(dev), scale)
+    assert torch.equal(d_a, f_a) and torch.equal(d_b, f_b)
+
+
+def test_lora_conv2d_wgrad_at_the_production_shapes(dev):
+    """The encoder's adapted convs at the benchmarked batch (B = 32: 14 -> 32 @ 256^2 with the batch-broadcast scene as
+    first source, 32 -> 32 @ 128^2, 64 -> 64 @ 64^2 and @ 16^2): against the two-call chain on the device."""
+    ops = pkg("ops")
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for (cs, cout, HW, bcast) in (([6, 8], 32, 256, True), ([32], 32, 128, False), ([64], 64, 64, False), ([64], 64, 16, False)):
+        B, cin = 32, sum(cs)
+        xs = []
+        for i, c in enumerate(cs):
+            if bcast and i == 0:
+                xs.append(torch.randn(1, c, HW, HW, generator=gen).to(dev).expand(B, -1, -1, -1))
+            else:
+                xs.append(torch.randn(B, c, HW, HW, generator=gen).to(dev))
+        yact = torch.randn(B, cout, HW, HW, generator=gen).to(dev).relu_()
+        gy = torch.randn(B, cout, HW, HW, generator=gen).to(dev)
+        w = torch.randn(cout, cin, 3, 3, generator=gen).to(dev)
+        a = (torch.randn(3, 3 * cin, generator=gen) * 0.3).to(dev)
+        bm = (torch.randn(3 * cout, 3, generator=gen) * 0.1).to(dev)
+        mask = (yact.data_ptr(), cout * HW * HW)
+        assert ops.lora_conv2d_wgrad_supported(xs, gy, w, a)
+        d_a, d_b = ops.lora_conv2d_wgrad_raw(xs, gy, mask, w, a, bm, 1.0)
+        dw, _ = ops.conv2d_wgrad_raw(xs, gy, mask, w, False)
+        e_a, e_b = ops.lora_grad(dw, a, bm, 1.0)
+        close(d_a, e_a, rtol=5e-4, scale_rel=2e-5, msg=f"dA {cs}->{cout} @ {HW}")
+        close(d_b, e_b, rtol=5e-4, scale_rel=2e-5, msg=f"dB {cs}->{cout} @ {HW}")
+
+
 def test_lora_conv_end_to_end_and_identity_at_init(dev):
     """loralib semantics through the conv: grads of lora_A/B; zero lora_B == base conv bit-exactly
     (the reference's --init_check, train.py:46-59)."""
@@ -327,6 +397,55 @@ def test_skip_gradients_fold_into_maxpool_backward(dev):
     xod = xo.to(dev).requires_grad_(True)
     ops.max_pool2(ops.conv2d(xod, w0[:, :3].to(dev).contiguous(), None, True, {})).sum().backward()
     close(xod.grad, xoc.grad, rtol=1e-4, scale_rel=2e-6, msg="odd size")
+
+
+def test_relu_backward_applied_by_the_gradient_producers(dev):
+    """the ReLU backward of a conv whose output gradient comes from a max-pool backward (with the
+    decoders' skip gradients folded in) or from the fused predictor + criterion is applied by that producer
+    (ynet_maxpool2_bwd_add relu_mask, ynet_pred_bce dx_relu_mask) and the conv runs its unmasked dgrad / wgrad kernels:
+    same gradients as stock autograd, bit-identical to the consumer-side masks, and the unmasked path is really taken."""
+    ops = pkg("ops")
+    B, H, W = 2, 16, 32
+    x = rnd(B, 6, H, W, seed=1)
+    w0, w1, w2 = rnd(8, 6, 3, 3, seed=2, scale=0.2), rnd(8, 8, 3, 3, seed=3, scale=0.2), rnd(4, 8, 3, 3, seed=4, scale=0.2)
+    wp, bp = rnd(5, 8, 1, 1, seed=5, scale=0.3), rnd(5, seed=6, scale=0.1)
+    t = torch.rand(B, 5, H, W, generator=torch.Generator().manual_seed(7)) * 0.01
+    # stock torch: conv-relu -> {max-pool branch, skip conv, conv-relu -> predictor -> BCE}
+    xc, w0c, w1c = x.clone().requires_grad_(True), w0.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+    f = F.relu(F.conv2d(xc, w0c, padding=1))
+    g = F.relu(F.conv2d(f, w1c, padding=1))
+    loss = F.max_pool2d(f, 2, 2).square().sum() + F.conv2d(f, w2, padding=1).sum() * 0.5 \
+        + F.binary_cross_entropy_with_logits(F.conv2d(g, wp, bp), t) * 1000.0
+    loss.backward()
+    got = {}
+    for on in (True, False):
+        old = ops._premask_allowed
+        ops._premask_allowed = on
+        ops.premask_stats["unmasked_backwards"] = 0
+        try:
+            with ops.fold_skip_gradients():
+                xd, w0d, w1d = x.to(dev).requires_grad_(True), w0.to(dev).requires_grad_(True), w1.to(dev).requires_grad_(True)
+                fd = ops.conv2d(xd, w0d, None, True, {})
+                pooled = ops.max_pool2(fd)          # (the model's order: the pool is created before the decoder-side consumers,
+                gd = ops.conv2d(fd, w1d, None, True, {})      # so its backward runs after theirs and sees every skip gradient)
+                _, ld = ops.pred_bce(gd, wp.to(dev), bp.to(dev), t.to(dev), 1000.0, {})
+                total = pooled.square().sum() + ops.conv2d(fd, w2.to(dev), None, False, {}).sum() * 0.5 + ld * 1000.0
+                total.backward()
+        finally:
+            ops._premask_allowed = old
+        # with the producers masking: both ReLU convs (pool -> conv 0, pred_bce -> conv 1) ran unmasked backwards
+        assert ops.premask_stats["unmasked_backwards"] == (2 if on else 0)
+        assert not ops._premasked and not ops._relu_outputs
+        close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx (premask={on})")
+        close(w0d.grad, w0c.grad, rtol=1e-4, scale_rel=1e-5, msg=f"dW0 (premask={on})")
+        close(w1d.grad, w1c.grad, rtol=1e-4, scale_rel=1e-5, msg=f"dW1 (premask={on})")
+        got[on] = (xd.grad.clone(), w0d.grad.clone(), w1d.grad.clone())
+    for a, b in zip(got[True], got[False]):      # the mask is an exact zeroing wherever it is applied
+        assert torch.equal(a, b)
+    # outside the context nothing is registered and nothing is pre-masked
+    xd = x.to(dev).requires_grad_(True)
+    ops.max_pool2(ops.conv2d(xd, w0.to(dev), None, True, {})).square().sum().backward()
+    assert not ops._premasked and not ops._relu_outputs
 
 
 @pytest.mark.parametrize("cin,cout,relu", [(32, 12, False), (12, 32, False), (32, 30, True), (7, 16, True), (32, 33, False)])
@@ -596,6 +715,53 @@ def test_fused_predictor_and_bce(dev, B, cin, cout, H, W, train_pred, scale, up)
     # twice in a row on the same stream: the workspace ticket was reset by the kernel
     y2, l2 = ops.pred_bce(x.to(dev), w.to(dev), b.to(dev), t.to(dev), up, {})
     assert torch.equal(y2, yd) and float(l2) == float(ld)
+
+
+def test_scene_padding_and_label_one_hot_known_answers(dev):
+    """SURVEY 8(f)-4, the part that needs neither OpenCV nor the segmentation backbone (utils/image_utils.py:74-81, 95-107):
+    zero border at the bottom / right up to a multiple of 32, and the one-hot planes of a label map -- padded BEFORE the
+    encoding, so the border is class 0.  Known answers written out by hand + the NumPy form of the reference's own lines."""
+    ops, iu = pkg("ops"), pkg("utils.image_utils")
+    lab = np.array([[0, 1, 2], [3, 4, 5], [5, 5, 0], [1, 1, 1], [2, 0, 2]], dtype=np.uint8)         # 5 x 3
+    got = ops.seg_onehot_pad(torch.from_numpy(lab).to(dev), classes=6, division_factor=4).cpu().numpy()
+    assert got.shape == (6, 8, 4)
+    padded = np.zeros((8, 4), dtype=np.uint8)
+    padded[:5, :3] = lab                                             # image_utils.pad: border = 0
+    want = np.stack([(padded == v) for v in range(6)], axis=-1).transpose(2, 0, 1).astype("float32")   # image_utils.py:76-80
+    assert np.array_equal(got, want)
+    assert got[0, 7, 3] == 1.0 and got[1:, 5:, :].sum() == 0 and got[:, :5, :3].sum() == 15          # border is class 0 only
+    # through the mirror's own functions (dict in, dict out, in place like the reference)
+    images = {"s": lab.copy()}
+    iu.pad(images, division_factor=4)
+    assert images["s"].shape == (8, 4) and np.array_equal(images["s"], padded)
+    iu.preprocess_image_for_segmentation(images, seg_mask=True, classes=6, device=dev)
+    assert np.array_equal(images["s"].cpu().numpy(), want)
+    # float planes [C, H, W] on the device
+    x = rnd(3, 37, 50, seed=1)
+    y = ops.pad_planes(x.to(dev), 32).cpu()
+    assert y.shape == (3, 64, 64) and torch.equal(y[:, :37, :50], x) and float(y[:, 37:].abs().sum()) == 0 and float(y[:, :, 50:].abs().sum()) == 0
+    assert ops.pad_planes(x[:, :32, :32].contiguous().to(dev), 32).shape == (3, 32, 32)             # already a multiple: unchanged
+    with pytest.raises(ValueError, match="integer class labels"):
+        ops.seg_onehot_pad(torch.rand(4, 4, device=dev), classes=6)
+
+
+@pytest.mark.parametrize("B,P,H,W,rf", [(3, 12, 64, 64, 0.25), (2, 30, 32, 96, 0.33), (5, 1, 16, 16, 1.0)])
+def test_train_readout_in_two_launches(dev, B, P, H, W, rf):
+    """ynet_train_readout (utils/train_epoch.py:118-126): both soft-argmax calls and the ADE / FDE arithmetic against the
+    module-by-module path (SoftArgmax2D + the reference's elementwise chain) and against the fp64 oracle."""
+    ops = pkg("ops")
+    tm, gm = rnd(B, P, H, W, seed=1, scale=3.0), rnd(B, P, H, W, seed=2, scale=3.0)
+    gt = torch.rand(B, P, 2, generator=torch.Generator().manual_seed(3)) * torch.tensor([W * 1.0, H * 1.0])
+    pt, pg, ade, fde = ops.train_readout(tm.to(dev), gm.to(dev), gt.to(dev), rf)
+    want_t, want_g = ops.softargmax2d(tm.to(dev)), ops.softargmax2d(gm.to(dev)[:, -1:])
+    assert torch.equal(pt, want_t) and torch.equal(pg, want_g)          # the same plane code
+    gtd = gt.to(dev)
+    want_ade = ((((gtd - want_t) / rf) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
+    want_fde = ((((gtd[:, -1:] - want_g[:, -1:]) / rf) ** 2).sum(dim=2) ** 0.5).mean(dim=1)
+    close(ade, want_ade, rtol=1e-6, atol=1e-5, msg="ADE vs the elementwise chain")
+    close(fde, want_fde, rtol=1e-6, atol=1e-5, msg="FDE vs the elementwise chain")
+    o_t = O.softargmax2d(tm.double())
+    close(pt, o_t.float(), rtol=0, atol=1e-4, msg="coordinates vs fp64")
 
 
 @pytest.mark.parametrize("S,H,W", [(1050, 256, 256), (1386, 512, 512), (1050, 96, 160), (1386, 37, 50), (75, 16, 24)])

@@ -112,7 +112,9 @@ def test_templates_and_sampling_match_oracle():
     y = iu.swap_pavement_terrain(x.clone())
     assert torch.equal(y[:, 1], x[:, 2]) and torch.equal(y[:, 2], x[:, 1]) and torch.equal(y[:, 0], x[:, 0])
     with pytest.raises(ImportError):
-        iu.pad({}, 32)
+        iu.resize({}, 0.25)                      # cv2.resize: out of scope (nothing here can pin it)
+    with pytest.raises(ImportError):
+        iu.preprocess_image_for_segmentation({}, seg_mask=False)      # the RGB branch needs segmentation_models_pytorch
 
 
 def test_scene_dataset_contract():
@@ -244,3 +246,15 @@ def test_fused_criterion_refuses_a_foreign_target():
     crit.expected_grad = 1.0
     with pytest.raises(RuntimeError, match="expected_grad"):
         crit(maps, target)
+
+
+def test_pad_numpy_branch_matches_copy_make_border_semantics():
+    """utils/image_utils.py:95-107 on NumPy arrays (what cv2.imread hands the reference): bottom / right zero border up to
+    the division factor, 2-D label maps and H x W x C images alike, already-aligned images untouched."""
+    iu = pkg("utils.image_utils")
+    rgb = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    images = {"a": rgb.copy(), "b": np.ones((64, 32), dtype=np.uint8)}
+    iu.pad(images, division_factor=32)
+    assert images["a"].shape == (32, 32, 3) and np.array_equal(images["a"][:5, :7], rgb)
+    assert images["a"][5:].sum() == 0 and images["a"][:, 7:].sum() == 0 and images["a"].dtype == np.uint8
+    assert images["b"].shape == (64, 32) and images["b"].sum() == 64 * 32

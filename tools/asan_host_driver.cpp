@@ -65,6 +65,14 @@ int main() {
     EXPECT_REJECT(ynet_lora_compose(nullptr, cfp, cfp, 1.f, fp, 4, 4, 3, 1, nullptr));
     EXPECT_REJECT(ynet_lora_grad(cfp, cfp, cfp, 1.f, fp, nullptr, 4, 4, 3, 1, nullptr));
     EXPECT_REJECT(ynet_lora_compose_pack(cfp, cfp, cfp, 1.f, fp, fp, 4, 4, 2, 1, nullptr));
+    EXPECT_REJECT(ynet_train_readout(cfp, 16, nullptr, 16, 0, cfp, fp, fp, fp, fp, 1, 1, 4, 4, 1.f, nullptr));           // no goal map
+    EXPECT_REJECT(ynet_train_readout(cfp, 16, cfp, 16, 0, cfp, fp, fp, fp, fp, 1, 1, 4, 4, 0.f, nullptr));               // resize factor 0
+    for (int cin : {1, 6, 14, 32, 33, 64, 65})
+        for (int cout : {1, 16, 32, 64, 130})
+            for (int r : {1, 4}) acc += ynet_lora_conv2d_wgrad_supported(cin, cout, 3, r, 64) + ynet_lora_conv2d_wgrad_preferred(cin, cout, 3, r, 64) + ynet_lora_conv2d_wgrad_workspace_floats(cin, cout);
+    EXPECT_REJECT(ynet_lora_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 4, nullptr, 0, cfp, cfp, 1.f, fp, fp, fp, 1, 4, 4, 4, 3, 1, nullptr));   // no dy
+    EXPECT_REJECT(ynet_lora_conv2d_wgrad(srcs, &one, &bs, 1, cfp, 4, nullptr, 0, cfp, cfp, 1.f, fp, fp, fp, 1, 4, 4, 4, 3, 4, nullptr));       // rank 4
+    EXPECT_REJECT(ynet_lora_conv2d_wgrad(srcs, &one, &bs, 1, cfp, 4, nullptr, 0, cfp, cfp, 1.f, fp, fp, fp, 1, 4, 6, 4, 3, 1, nullptr));       // W % 4
     EXPECT_REJECT(ynet_lora_compose_pack_multi(0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
     EXPECT_REJECT(ynet_lora_compose_pack_multi(99, srcs, srcs, srcs, cfp, dsts, dsts, &one, &one, &one, &one, nullptr));
     EXPECT_REJECT(ynet_maxpool2_fwd(nullptr, fp, 1, 4, 4, nullptr));
@@ -74,8 +82,8 @@ int main() {
     EXPECT_REJECT(ynet_avgpool_pyramid(cfp, dsts, 9, 1, 32, 32, nullptr));
     EXPECT_REJECT(ynet_bce_logits_fwd(cfp, cfp, 0, fp, fp, nullptr));
     EXPECT_REJECT(ynet_bce_logits_fwd_grad(cfp, nullptr, 4, 1.f, fp, fp, fp, nullptr));
-    EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 33, 4, 1.f, nullptr));   // cout 33
-    EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 6, 1.f, nullptr));   // HW % 4
+    EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 33, 4, 1.f, 0, nullptr));   // cout 33
+    EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 6, 1.f, 0, nullptr));   // HW % 4
     EXPECT_REJECT(ynet_softargmax2d(nullptr, fp, 1, 1, 4, 2, 2, nullptr));
     EXPECT_REJECT(ynet_pred_softargmax(nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1, 32, 12, 16, 32, nullptr));
     EXPECT_REJECT(ynet_pred_softargmax(fp, 32 * 17 * 23, fp, nullptr, fp, fp, 1, 32, 12, 17, 23, nullptr));      /* H*W % 128 != 0 */

@@ -38,7 +38,9 @@ def timeit(name, fn, nbytes):
 nb, ns = big.numel() * 4, small.numel() * 4
 timeit("maxpool2_fwd", lambda: L.check(lib.ynet_maxpool2_fwd(big.data_ptr(), smallo.data_ptr(), N, H, W, st()), lib), nb + ns)
 timeit("maxpool2_bwd_add", lambda: L.check(lib.ynet_maxpool2_bwd_add(big.data_ptr(), small.data_ptr(), big2.data_ptr(), big3.data_ptr(),
-                                                                     bigo.data_ptr(), N, H, W, st()), lib), 4 * nb + ns)
+                                                                     bigo.data_ptr(), N, H, W, 0, st()), lib), 4 * nb + ns)
+timeit("maxpool2_bwd_add+relu", lambda: L.check(lib.ynet_maxpool2_bwd_add(big.data_ptr(), small.data_ptr(), big2.data_ptr(), big3.data_ptr(),
+                                                                          bigo.data_ptr(), N, H, W, 1, st()), lib), 4 * nb + ns)
 timeit("upsample2x_fwd", lambda: L.check(lib.ynet_upsample2x_fwd(small.data_ptr(), bigo.data_ptr(), N, H // 2, W // 2, st()), lib), nb + ns)
 timeit("upsample2x_bwd", lambda: L.check(lib.ynet_upsample2x_bwd(big.data_ptr(), smallo.data_ptr(), N, H // 2, W // 2, st()), lib), nb + ns)
 S = 1050
@@ -60,7 +62,9 @@ for cout in (12, 30):
     ws = torch.zeros(lib.ynet_pred_bce_workspace_bytes() // 8 + 1, device=dev, dtype=torch.float64)
     planes = (32 + cout + cout + 32) * B * H * W * 4
     timeit(f"pred_bce cout={cout}", lambda: L.check(lib.ynet_pred_bce(x32.data_ptr(), 32 * H * W, wp.data_ptr(), bias.data_ptr(), tgt.data_ptr(), y.data_ptr(),
-                                                                    loss.data_ptr(), dxo.data_ptr(), None, ws.data_ptr(), B, 32, cout, H * W, 1000.0, st()), lib), planes)
+                                                                    loss.data_ptr(), dxo.data_ptr(), None, ws.data_ptr(), B, 32, cout, H * W, 1000.0, 0, st()), lib), planes)
+    timeit(f"pred_bce cout={cout} + relu mask of dx", lambda: L.check(lib.ynet_pred_bce(x32.data_ptr(), 32 * H * W, wp.data_ptr(), bias.data_ptr(), tgt.data_ptr(), y.data_ptr(),
+                                                                    loss.data_ptr(), dxo.data_ptr(), None, ws.data_ptr(), B, 32, cout, H * W, 1000.0, 1, st()), lib), planes)
     bws = torch.empty(lib.ynet_bce_workspace_bytes() // 8, device=dev, dtype=torch.float64)
 
     def unfused():
