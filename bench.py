@@ -350,6 +350,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if os.environ.get("YNET_BENCH_FAIL_RANK") == str(rank) and world > 1:      # (tests: the launcher must report a dying rank)
+        raise SystemExit(f"rank {rank} fails on purpose (YNET_BENCH_FAIL_RANK)")
     ynet, trainer, te, ops = pkg("models.ynet"), pkg("models.trainer"), pkg("utils.train_epoch"), pkg("ops")
     cfg, H, W, workload = make_cfg(O, args.config)
     if args.batch is None:

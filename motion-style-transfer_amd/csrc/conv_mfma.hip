@@ -1309,9 +1309,26 @@ static int conv_fold(int H, int W) {
     return 1;
 }
 
+// Small and mid-size maps: fewer output channels per workgroup -> more workgroups.  A 64 -> 64 layer on B x 32^2 pixels is 256
+// row units: with all 64 output channels in one workgroup that is ONE workgroup per CU (one wave per SIMD, nothing to hide
+// its staging latency behind); 16 channels per workgroup give four per CU and the same MFMA count in total (the input tile
+// is then staged by four workgroups instead of one -- from L2).  Measured on the captured C2 step (MI355X): target 0 / 512 /
+// 1024 / 2048 / 4096 work items -> 9.78 / 9.69 / 9.63 / 9.56 / 9.55 ms at B = 32 and 4.05 / 3.88 / 3.84 / 3.79 / 3.79 ms at the
+// reference scripts' batch of 10; the 16^2 .. 64^2 layers need less (or no) split of the channel loop with it.
+static int narrow_tiles(const ConvArgs& a, int nt16) {
+    static const int target = getenv("YNET_CONV_NARROW") ? atoi(getenv("YNET_CONV_NARROW")) : 2048;   // wanted work items (0: off)
+    if (target <= 0 || nt16 <= 1) return nt16;
+    const int fold = conv_fold(a.H, a.W);
+    const long long units = (long long)a.B * ceil_div(a.W, 32 / fold) * ceil_div(a.H, 4 * fold);      // one-row-per-wave tiles
+    int n = nt16;
+    while (n > 1 && units * ceil_div(nt16, n) < target) n = n > 2 ? 2 : 1;
+    return n;
+}
+
 static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
     const bool wide = a.cout > 32;
-    const int nt16 = m16_tiles(K, a.cout);
+    const int nt16_full = m16_tiles(K, a.cout);
+    const int nt16 = (a.addend == nullptr) ? narrow_tiles(a, nt16_full) : nt16_full;
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
     static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 0;
@@ -1402,7 +1419,7 @@ int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     a.H = H;
     a.W = W;
     a.cout = cout;
-    const int nt16 = m16_tiles(K, cout);
+    const int nt16 = narrow_tiles(a, m16_tiles(K, cout));
     const int tiles = nt16 ? nt16 : (cout > 32 ? 2 : 1);
     int rows = K == 5 ? 4 : pick_rows(a, nt16 ? 16 * nt16 : 32 * tiles);
     if (nt16 >= 3 && rows == 4) rows = 2;

@@ -117,6 +117,8 @@ class DataParallel:
                 ok, why = 0, f"self-test sums differ from {want} (or a peer timed out)"
             elif self._lib.ynet_comm_status(self._comm) != 0:
                 ok, why = 0, "a wait for a peer timed out"
+            elif os.environ.get("YNET_ONESHOT_FORCE_FAIL") == str(self.rank):      # (tests: the collective fall-back path)
+                ok, why = 0, "forced failure (YNET_ONESHOT_FORCE_FAIL)"
         except Exception as e:      # noqa: BLE001
             ok, why = 0, f"{type(e).__name__}: {e}"
         if not self._agree(ok):

@@ -33,6 +33,7 @@ def run_epochs(cfg, sd, scene, traj, batch_size, dev, dp_factory, n_epochs=2, gr
     model = build_model(cfg, sd, dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     dp = dp_factory(model)
+    transport = None if dp is None else {"collective": dp.collective, "note": dp.transport_note}
     S = cfg.template_size
     in_t, gt_t = O.dist_template(S).to(dev), O.gaussian_template(S, cfg.kernlen, cfg.nsig).to(dev)
     loader = [(traj.clone(), [pd.DataFrame({"metaId": np.arange(traj.shape[0])})], "scene0")]
@@ -58,6 +59,10 @@ def run_epochs(cfg, sd, scene, traj, batch_size, dev, dp_factory, n_epochs=2, gr
     ade, fde, df, _ = ev.evaluate(model, loader, {"scene0": scene[0]}, dev, "sdd", None, in_t, list(cfg.waypoints), "test", K, 1,
                                   cfg.obs_len, batch_size, cfg.resize_factor, cfg.temperature, forced_samples=forced, dp=dp)
     out["eval"] = (ade, fde, df["ade"].to_numpy().copy(), df["fde"].to_numpy().copy())
+    out["transport"] = transport
+    if dp is not None:
+        dp.check()          # a timed-out one-shot all-reduce would raise here (it also poisons the loss with NaN)
+        dp.close()
     return out
 
 
@@ -75,7 +80,8 @@ def main():
     dist.all_gather_object(info, {"rank": rank, "device": str(dev), "pid": os.getpid()})
     if rank == 0:
         res["world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": info,
-                        "collective": os.environ.get("YNET_ALLREDUCE", "rccl")}
+                        "collective": res["transport"]["collective"], "requested": os.environ.get("YNET_ALLREDUCE", "rccl"),
+                        "transport_note": res["transport"]["note"]}
         torch.save(res, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -41,7 +41,7 @@ def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch
     got = torch.load(out, weights_only=False)
     assert got["world"]["world_size"] == world and len({r["pid"] for r in got["world"]["ranks"]}) == world
     assert got["world"]["backend"] == ("nccl" if n_gpu >= world else "gloo")
-    assert got["world"]["collective"] == collective
+    assert got["world"]["collective"] == collective and got["world"]["transport_note"] is None      # (the one-shot start-up self-test passed)
 
     cfg, sd, scene, traj = case_inputs(n_rows)
     want = run_epochs(cfg, sd, scene, traj, batch_size, dev, lambda m: None)
@@ -61,3 +61,37 @@ def test_two_rank_train_epoch_equals_single_process(dev, tmp_path, n_rows, batch
         big = want["grads"][n].abs() > 1e-3 * want["grads"][n].abs().max()      # (Adam turns a rounding-level gradient into +-lr)
         d = float((got["weights"][n] - w)[big].abs().max()) if bool(big.any()) else 0.0
         assert d <= 0.05 * 1e-3 * steps, (n, d)
+
+
+def test_oneshot_self_test_failure_falls_back_to_torch_distributed_on_all_ranks(dev, tmp_path):
+    """the start-up self-test of the one-shot transport (all-reduce of the rank ids); a failure on ONE
+    rank makes EVERY rank fall back to torch.distributed together, the reason is recorded, and the epochs still equal the
+    single-process run."""
+    out = str(tmp_path / "dp.pt")
+    n_gpu = torch.cuda.device_count()
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "YNET_ALLREDUCE": "oneshot", "YNET_ONESHOT_FORCE_FAIL": "1"}
+    if n_gpu < 2:
+        env.update(YNET_DIST_BACKEND="gloo", YNET_BENCH_SINGLE_DEVICE="1")
+    rc, tail = launch([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                       "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                       os.path.join(ROOT, "tests", "dp_worker.py"), out, "8", "3"], env=env, timeout=600)
+    assert rc == 0, tail
+    got = torch.load(out, weights_only=False)
+    assert got["world"]["requested"] == "oneshot" and got["world"]["collective"] == "rccl"
+    assert "self-test failed on a peer" in got["world"]["transport_note"]      # rank 0's view of rank 1's failure
+    cfg, sd, scene, traj = case_inputs(8)
+    want = run_epochs(cfg, sd, scene, traj, 3, dev, lambda m: None)
+    for (a1, f1, l1), (a0, f0, l0) in zip(got["results"], want["results"]):
+        assert abs(l1 - l0) <= 2e-5 * abs(l0) and abs(a1 - a0) <= 1e-4 and abs(f1 - f0) <= 1e-4
+
+
+def test_bench_launcher_reports_a_failing_rank(dev):
+    """`python bench.py --gpus 2` starts its ranks itself; a rank that dies must make the launcher exit non-zero and show that
+    rank's tail (YNET_BENCH_FAIL_RANK is the test hook)."""
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "YNET_BENCH_FAIL_RANK": "1"}
+    if torch.cuda.device_count() < 2:
+        env.update(YNET_DIST_BACKEND="gloo", YNET_BENCH_SINGLE_DEVICE="1")
+    rc, tail = launch([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                       "--no-cpu-baseline", "--no-roofline", "--no-repeats"], env=env, timeout=600)
+    assert rc != 0
+    assert "rank 1 fails on purpose" in tail and "a rank failed" in tail, tail[-1500:]
