@@ -1174,9 +1174,26 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
 // CC = 4 input channels (one K-step of the 16x16x4 MFMA) per chunk: 34-60 KB of LDS for both buffers, so
 // 3-4 workgroups stay resident per CU (measured 5-10 % faster than CC = 8 with 2 resident workgroups).
 // Only the quad-DMA form is instantiated (callers check a.vec_load).
-template <int NCB, int R, int FOLD = 1>
+// Small tiles (one or two rows per wave of <= 32 output channels, folded maps) take DEEPER chunks: a chunk of 4 channels is
+// 18 .. 72 MFMAs per wave there -- 0.3 .. 1 us -- behind a DMA round trip of ~1.3 us that the one-chunk-ahead pipeline cannot
+// hide (a 64 -> 64 layer on a 16^2 map ran 16 chunks x 1.3 us = 21 us for 0.6 GFLOP); YNET_CONV_SMALL_CC chunks of 8 or 16
+// channels make it 8 or 4 round trips (their LDS tiles are small).
+static int small_cc() {
+    static const int cc = getenv("YNET_CONV_SMALL_CC") ? atoi(getenv("YNET_CONV_SMALL_CC")) : 8;
+    return cc;
+}
+
+template <int NCB, int R, int FOLD = 1, int CC = 4>
 static int launch_dma(ConvArgs& a, hipStream_t st) {
-    return a.mask ? launch_dma_m<NCB, R, 4, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, 4, false, true, FOLD>(a, st);
+    return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD>(a, st);
+}
+
+template <int NCB, int R, int FOLD = 1>
+static int launch_dma_small(ConvArgs& a, hipStream_t st) {
+    const int cc = small_cc();
+    if (cc >= 16 && !a.mask) return launch_dma_m<NCB, R, 16, false, true, FOLD>(a, st);      // (a masked dgrad holds CC mask quads in registers: 8 at most)
+    if (cc >= 8) return launch_dma<NCB, R, FOLD, 8>(a, st);
+    return launch_dma<NCB, R, FOLD, 4>(a, st);
 }
 
 // Large maps: rows >= 2 per wave (R = 4 only up to 32 output channels per workgroup: registers).
@@ -1185,14 +1202,19 @@ static int launch_dma_r(ConvArgs& a, hipStream_t st, int rows) {
     if (rows == 4) {
         if constexpr (NCB < 3) return launch_dma<NCB, 4>(a, st);
     }
-    if (rows >= 2) return launch_dma<NCB, 2>(a, st);
-    return launch_dma<NCB, 1>(a, st);
+    if (rows >= 2) {
+        if constexpr (NCB <= 2) return NCB == 1 ? launch_dma_small<NCB, 2>(a, st) : launch_dma<NCB, 2>(a, st);
+        else return launch_dma<NCB, 2>(a, st);
+    }
+    if constexpr (NCB <= 2) return launch_dma_small<NCB, 1>(a, st);
+    else return launch_dma<NCB, 1>(a, st);
 }
 
 // Maps no wider than 16 / 8 pixels: folded row units, one per wave
 template <int NCB>
 static int launch_dma_fold(ConvArgs& a, hipStream_t st, int fold) {
-    return fold == 4 ? launch_dma<NCB, 1, 4>(a, st) : launch_dma<NCB, 1, 2>(a, st);
+    if constexpr (NCB <= 2) return fold == 4 ? launch_dma_small<NCB, 1, 4>(a, st) : launch_dma_small<NCB, 1, 2>(a, st);
+    else return fold == 4 ? launch_dma<NCB, 1, 4>(a, st) : launch_dma<NCB, 1, 2>(a, st);
 }
 
 template <int KS, int NCB, int CC, bool M16 = false>

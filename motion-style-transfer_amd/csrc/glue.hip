@@ -891,7 +891,6 @@ struct PredSoftArgs {
     const float* bias;      // [cout] or NULL
     float* partial;         // [B][nchunk][32][4] = (m, s, sx, sy)
     int cout, H, W, nchunk, gpw;      // gpw = 128-pixel groups per wave, nchunk = waves per image
-    int stagger;                      // s_sleep units (64 cycles) by which every second wave of 256 workgroups starts late
 };
 
 template <int CIN, int PT>
@@ -924,13 +923,6 @@ __global__ __launch_bounds__(256, PT == 4 ? 2 : 3) void pred_softargmax_kernel(c
         for (int s = 0; s < KS; ++s) v[s] = *reinterpret_cast<const vec_t*>(p + (long long)(2 * s) * HW);
     };
     if (g_lo < g_hi) load_group(g_lo);
-    // The two waves of a SIMD (two resident workgroups per CU) run the same program from the same start: both in their matrix
-    // phase, then both in their soft-max vector phase.  Workgroups are dealt to the CUs round robin, so workgroup i and
-    // i + 256 tend to share a CU: the second one starts half a pixel group late and the phases of the pair interleave
-    // (placement is not guaranteed; a wrong guess costs the sleep once per wave and nothing else).
-    if (a.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-        for (int i = 0; i < a.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
-    }
     for (int g = g_lo; g < g_hi; ++g) {
         f32x16 acc[PT];
 #pragma unroll
@@ -1465,8 +1457,6 @@ int ynet_pred_softargmax(const float* x, long long x_bs, const float* w, const f
     a.H = H;
     a.W = W;
     pred_softargmax_plan(H, W, &a.gpw, &a.nchunk);
-    static const int stagger = getenv("YNET_PRED_SOFT_STAGGER") ? atoi(getenv("YNET_PRED_SOFT_STAGGER")) : 0;
-    a.stagger = stagger;
     const long long blocks = B * ((a.nchunk + 3) / 4);
     YNET_REQUIRE(blocks < (1ll << 31), "pred_softargmax: too many workgroups");
     hipStream_t st = (hipStream_t)stream;
