@@ -54,12 +54,13 @@ def counter_means(d, counter):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    to = sys.argv[sys.argv.index("--to") + 1] if "--to" in sys.argv else None      # on the box: only the traffic summary, into that directory
+    stats = [] if to else glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     dst = os.path.join(ROOT, "profiles", f"{tag}_bench_C2_kernel_stats.csv")
     if stats:
         shutil.copy(stats[0], dst)
         print("wrote", dst)
-    elif db_of(os.path.join(src, "trace")):
+    elif not to and db_of(os.path.join(src, "trace")):
         import sqlite3
         import statistics
         con = sqlite3.connect(db_of(os.path.join(src, "trace")))
@@ -85,7 +86,7 @@ def main():
                   "launches_sampled": max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1]),
                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB*1024; x2 FETCH = gfx950 correction for 16-B/lane streams"}
     if out:
-        dst = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        dst = os.path.join(to or os.path.join(ROOT, "profiles"), "pmc_traffic.json")
         with open(dst, "w") as f:
             json.dump(out, f, indent=1)
         print("wrote", dst, len(out), "kernels")
