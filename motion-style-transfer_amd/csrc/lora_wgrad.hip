@@ -424,472 +424,6 @@ __global__ __launch_bounds__(256, (TH == 2 && COS <= 8) ? 3 : 2) void lora_wgrad
     }
 }
 
-// ================================================================================================
-// Second generation: every product on v_mfma_f32_4x4x1_16B_f32 -- 16 independent 4 x 4 x 1 blocks per instruction,
-// D_b[i][j] += A_b[i] * B_b[j], at the same 64 FLOP / clk / SIMD as the other fp32 MFMAs.  Lane map (probed on the box with
-// one-hot operands, tools/mfma4x4_probe.hip): lane 4 b + i supplies A_b[i], lane 4 b + j supplies B_b[j], D_b[i][j] lands in
-// register i of lane 4 b + j.  The adapter rank r = 1 gives every product a dimension of size 3 (q): it takes 3 of the 4 rows
-// of a block (75 %) where the 16-row tiles of the first generation used 9 of 16 AND computed every filter column for all three
-// thirds ii; and the projections leave the vector ALU:
-//   DP[ii][q][p] += B[3 co + ii][q] * dy'[co][p]     block = 4 pixels, A = coefficient column (LDS table), B = dy' (a register:
-//                                                    lane = pixel), one instruction per (co, ii) and 64 pixels
-//   XP[ii][q][p] += A[q][n(u)]     * X_u[p]          block = 4 pixels, A = coefficients, B = x tile (LDS, immediate offsets)
-//   G[q][c]      += DP[ii(c)][q][p] * X_u(c)[p]      block = 4 filter columns (the thirds are padded to multiples of 4 columns so
-//                                                    that a block never straddles one), one instruction per pixel and 64 columns
-//   E[ii][q][co] += XP[ii][q][p]    * dy'[co][p]     block = 4 output channels, one instruction per (pixel, ii)
-// In the pixel-sum phase wave w takes a quarter of the tile's pixels and ALL column groups; the four waves' sums are added
-// through LDS once, at the end of the kernel.
-// ================================================================================================
-template <int TH>
-struct Lw4Cfg {
-    static constexpr int NPIX = TH * 32, PW = NPIX / 64, NH = 4 / PW;       // pixel waves, channel slices
-    static constexpr int TCOLS = 40;
-    static constexpr int XDATA = (TH + 2) * TCOLS / 4;
-    static constexpr int XQ = (XDATA + 1 + 6) / 8 * 8 + 1;
-    static constexpr int XCH = XQ * 4;
-    static constexpr int DCH = NPIX + 4, PL = NPIX + 4;
-    static constexpr int PPW = NPIX / 4;                                    // pixels per wave in the pixel-sum phase
-};
-
-static inline int lw4_lds_floats(int th, int cin, int cout) {
-    const int npix = th * 32;
-    return 2 * (cin * lw_xq(th) * 4 + 64) + cout * (npix + 4) + 2 * LW_ROWS * (npix + 4) + cout * 12 + cin * 48;
-}
-
-__device__ __forceinline__ f32x4 lw_mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
-
-// NGRP: groups of 64 (padded) filter columns; COS: output channels per channel slice
-// (4-row tiles with > 2 column groups hold two x images of 32 channels: one workgroup per CU by LDS, so all 512 registers are its own)
-template <int TH, int NGRP, int COS>
-__global__ __launch_bounds__(256, (TH == 4 && NGRP > 2) ? 1 : 2) void lora_wgrad4_kernel(const LoraWgArgs a) {
-    using C = Lw4Cfg<TH>;
-    constexpr int NPIX = C::NPIX, PW = C::PW, NH = C::NH, TCOLS = C::TCOLS, XQ = C::XQ, XCH = C::XCH, DCH = C::DCH, PL = C::PL, PPW = C::PPW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int cin = a.cin, cout = a.cout;
-    const int xbuf = cin * XCH + 64;                   // one x image
-    float* xs0 = smem;                                 // [2][cin][XCH]: the next tile's image lands while this one is consumed
-    float* ds = xs0 + 2 * xbuf;                        // [cout][DCH]   dy'
-    float* dpl = ds + cout * DCH;                      // [9][PL]       DP planes (m = 3 ii + q)
-    float* xpl = dpl + LW_ROWS * PL;                   // [9][PL]       XP planes
-    float* tb = xpl + LW_ROWS * PL;                    // [cout][12]    lora_B: m = 3 ii + q, entries 9..11 zero
-    float* tq = tb + cout * 12;                        // [cin][4][12]  lora_A of a whole channel: row q (row 3 zero), nine taps + 3 zeros
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t4 = lane & 3;                           // row (A operand) / column (B operand) of this lane inside its block
-    const int H = a.H, W = a.W, HW = H * W;
-    const unsigned plane_bytes = (unsigned)HW * 4u;
-    const int n3 = 3 * cin, P3 = (n3 + 3) & ~3;        // columns of a third, padded to whole blocks
-    const lw_const_f32 la = (lw_const_f32)a.lora_a;
-
-    // ---- tables
-    for (int i = tid; i < cout * 12; i += 256) {
-        const int co = i / 12, m = i - 12 * co;
-        tb[i] = m < LW_ROWS ? a.lora_b[9 * co + m] : 0.f;
-    }
-    for (int i = tid; i < cin * 48; i += 256) {
-        const int ci = i / 48, j = i - 48 * ci, q = j / 12, tp = j - 12 * q;
-        const int ii = (9 * ci) / n3, n = 9 * ci + tp - ii * n3;
-        tq[i] = (q < 3 && tp < 9 && n < n3) ? a.lora_a[q * n3 + n] : 0.f;
-    }
-
-    // ---- x-tile DMA plan (as in the first generation)
-    constexpr int XI_MAX = TH == 4 ? 9 : 11;
-    const int nquads = cin * XQ;
-    int xplan[XI_MAX];                                 // source << 28 | channel in the source << 16 | tile row << 8 | (column + 4); -1: nothing to fetch
-#pragma unroll
-    for (int k = 0; k < XI_MAX; ++k) {
-        const int q = tid + k * 256;
-        const int ch = q / XQ, within = q - ch * XQ;
-        const int row = within / (TCOLS / 4), colp = (within - row * (TCOLS / 4)) * 4;
-        int c = ch, sid = -1;
-        if (q < nquads && within < C::XDATA) {
-#pragma unroll
-            for (int s_ = 0; s_ < YNET_MAX_SRC; ++s_) {
-                if (sid < 0 && s_ < a.nsrc) {
-                    if (c < a.src[s_].c) sid = s_;
-                    else c -= a.src[s_].c;
-                }
-            }
-        }
-        xplan[k] = sid >= 0 ? (sid << 28 | c << 16 | row << 8 | colp) : -1;
-    }
-
-    // ---- projection phase: lane = pixel p of pixel wave pw, channel slice h
-    const int pw = wave % PW;
-    const int h = wave / PW;
-    const int p = pw * 64 + lane;
-    const int prow = p >> 5, pcol = p & 31;
-    const int xoff_p = prow * TCOLS + pcol + 3;
-    const int tboff0 = t4 < 3 ? t4 : 9, tboff1 = t4 < 3 ? 3 + t4 : 10, tboff2 = t4 < 3 ? 6 + t4 : 11;      // lora_B entry of (ii, q = t4); row 3 -> a zero
-    const int tqoff = t4 * 12;                         // lora_A row of q = t4 (row 3: zeros)
-
-    // ---- pixel-sum phase: wave w takes pixels [w * PPW, (w + 1) * PPW) of the tile and every column group
-    const int px0 = wave * PPW;                        // first pixel; PPW = 32 (one tile row) or 16 (half a row)
-    const int prow2 = px0 >> 5, pcol2 = px0 & 31;
-    int gb[NGRP], ga[NGRP];                            // LDS offsets of this lane's B operand (x, column c) / A operand (DP plane) per group
-#pragma unroll
-    for (int g = 0; g < NGRP; ++g) {
-        int c = g * 64 + lane;
-        const int cmax = 3 * P3 - 1;
-        c = c < cmax ? c : cmax;
-        const int ii = c / P3;
-        int n = c - ii * P3;
-        n = n < n3 ? n : n3 - 1;                       // pad columns repeat the third's last one (never written out)
-        const int u = ii * n3 + n, ci = u / 9, tp = u - 9 * ci, ky = tp / 3, kx = tp - 3 * ky;
-        gb[g] = ci * XCH + (prow2 + ky) * TCOLS + pcol2 + kx + 3;
-        // the A operand of a block is DP[ii of the block's columns][q = t4]; the block of this lane starts at column (g * 64 + lane) & ~3
-        int cb = (g * 64 + lane) & ~3;
-        cb = cb < cmax ? cb : cmax;
-        ga[g] = (3 * (cb / P3) + (t4 < 3 ? t4 : 2)) * PL + px0;
-    }
-    int eco = lane < cout ? lane : cout - 1;
-    const int eb = eco * DCH + px0;                    // E: B operand = dy'[co = lane][p]
-    const int ea = (t4 < 3 ? t4 : 2) * PL + px0;       //    A operand = XP[ii][q = t4][p]  (+ 3 ii * PL)
-
-    f32x4 gacc[NGRP], eacc[3];
-#pragma unroll
-    for (int g = 0; g < NGRP; ++g) gacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) eacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // dy / mask of one tile: this lane's pixel, the channels of its slice.  Buffer loads: ONE vector register of address (the
-    // pixel) + the channel as scalar offset (32 global loads with 64-bit addresses would hold 64 registers of pointers)
-    float dyv[COS], mkv[COS];
-    auto fetch_dy = [&](int tile) {
-        int t = tile;
-        const int x0 = (t % a.tiles_x) * 32;
-        t /= a.tiles_x;
-        const int y0 = (t % a.tiles_y) * TH;
-        const int b = t / a.tiles_y;
-        const int gy = y0 + prow, gx = x0 + pcol;
-        const unsigned voff = (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : 0x80000000u;
-        auto rsrc_of = [&](const float* base) {
-            const unsigned long long ub = (unsigned long long)base;
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ub), hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
-            return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, base ? (unsigned)cout * plane_bytes : 0u, 0x00020000);
-        };
-        const __amdgpu_buffer_rsrc_t rd_ = rsrc_of(a.dy + (long long)b * a.dy_bs);
-        const bool has_mask = a.mask != nullptr;
-        const __amdgpu_buffer_rsrc_t rm_ = rsrc_of(has_mask ? a.mask + (long long)b * a.mask_bs : nullptr);
-#pragma unroll
-        for (int k = 0; k < COS; ++k) {
-            const unsigned soff = (unsigned)(h + k * NH) * plane_bytes;      // (channels >= cout fall outside the descriptor: 0)
-            dyv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd_, voff, soff, 0));
-            mkv[k] = has_mask ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm_, voff, soff, 0)) : 1.f;
-        }
-    };
-    auto queue_x = [&](int tile_, int buf_) {
-        int t = tile_;
-        const int x0 = (t % a.tiles_x) * 32;
-        t /= a.tiles_x;
-        const int y0 = (t % a.tiles_y) * TH;
-        const int b = t / a.tiles_y;
-        float* xs = xs0 + buf_ * xbuf;
-        unsigned xo[XI_MAX];
-#pragma unroll
-        for (int k = 0; k < XI_MAX; ++k) {
-            const int gy = y0 + ((xplan[k] >> 8) & 255) - 1, gx = x0 + (xplan[k] & 255) - 4;
-            const bool ok = xplan[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            xo[k] = ok ? (unsigned)((xplan[k] >> 16) & 0xfff) * plane_bytes + (unsigned)(gy * W + gx) * 4u : 0x80000000u;
-        }
-#pragma unroll 1
-        for (int s_ = 0; s_ < a.nsrc; ++s_) {
-            const float* base = a.src[s_].p + (long long)b * a.src[s_].bs;
-            const unsigned long long ub = (unsigned long long)base;
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ub), hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(((unsigned long long)hi << 32) | lo), 0, (unsigned)a.src[s_].c * plane_bytes, 0x00020000);
-#pragma unroll
-            for (int k = 0; k < XI_MAX; ++k) {
-                if (k * 256 < nquads) {
-                    const int with_src = xo[k] == 0x80000000u ? 0 : (xplan[k] >> 28);
-                    if (tid + k * 256 < nquads && with_src == s_) lw_dma16(r, xs + (k * 256 + wave * 64) * 4, xo[k]);
-                }
-            }
-        }
-    };
-    if ((int)blockIdx.x < a.ntiles) {
-        queue_x(blockIdx.x, 0);
-        fetch_dy(blockIdx.x);
-    }
-
-    int cur = 0;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const float* xs = xs0 + cur * xbuf;
-        // -- 1a. dy' and DP: one MFMA per (output channel of the slice, third); the coefficient reads go first (they depend on
-        //        nothing that is in flight)
-        f32x4 dp[3], xp[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) dp[i] = xp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-            // (the three coefficient reads of channel k + 1 are queued before the MFMAs of channel k)
-            float tc0, tc1, tc2;
-            auto rdc = [&](int k, float& c0, float& c1, float& c2) {
-                const int co = h + k * NH;
-                const float* tc = tb + (co < cout ? co : 0) * 12;
-                c0 = tc[tboff0];
-                c1 = tc[tboff1];
-                c2 = tc[tboff2];
-            };
-            rdc(0, tc0, tc1, tc2);
-#pragma unroll
-            for (int k = 0; k < COS; ++k) {
-                const int co = h + k * NH;
-                float n0 = 0.f, n1 = 0.f, n2 = 0.f;
-                if (k + 1 < COS) rdc(k + 1, n0, n1, n2);
-                if (co < cout) {                       // (uniform per slice)
-                    const float d = mkv[k] > 0.f ? dyv[k] : 0.f;
-                    ds[co * DCH + p] = d;
-                    dp[0] = lw_mfma4(tc0, d, dp[0]);
-                    dp[1] = lw_mfma4(tc1, d, dp[1]);
-                    dp[2] = lw_mfma4(tc2, d, dp[2]);
-                }
-                tc0 = n0;
-                tc1 = n1;
-                tc2 = n2;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // this tile's x image landed (queued a whole tile ago), dy' complete
-
-        // -- 1b. XP: whole channels of each third through the MFMA (nine taps: nine instructions), straddling columns one by
-        //        one on the vector ALU (slice 0; the accumulator layout is "lane = pixel, register = q" either way)
-        {
-            const float* xb = xs + xoff_p;
-#pragma unroll
-            for (int ii = 0; ii < 3; ++ii) {
-                const int lo_u = ii * n3, hi_u = lo_u + n3;
-                const int ci_lo = (lo_u + 8) / 9, ci_hi = hi_u / 9;
-                const int head_end = min(9 * ci_lo, hi_u);
-                const int tail_begin = max(9 * ci_hi, head_end);
-                {
-                    // two register sets: the twelve LDS reads of the next whole channel are queued before this channel's MFMAs
-                    f32x4 ca[3], cb_[3];
-                    float xa_[9], xb_[9];
-                    auto rd = [&](int ci, f32x4 (&c)[3], float (&xv)[9]) {
-                        const float* xc = xb + ci * XCH;
-                        const f32x4* cv = reinterpret_cast<const f32x4*>(tq + ci * 48 + tqoff);
-                        c[0] = cv[0];
-                        c[1] = cv[1];
-                        c[2] = cv[2];
-#pragma unroll
-                        for (int tp = 0; tp < 9; ++tp) xv[tp] = xc[(tp / 3) * TCOLS + (tp % 3)];
-                    };
-                    auto mm = [&](const f32x4 (&c)[3], const float (&xv)[9]) {
-#pragma unroll
-                        for (int tp = 0; tp < 9; ++tp) xp[ii] = lw_mfma4(c[tp >> 2][tp & 3], xv[tp], xp[ii]);
-                    };
-                    int ci = ci_lo + h;
-                    if (ci < ci_hi) rd(ci, ca, xa_);
-#pragma unroll 1
-                    for (; ci < ci_hi; ci += 2 * NH) {
-                        if (ci + NH < ci_hi) rd(ci + NH, cb_, xb_);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mm(ca, xa_);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (ci + NH < ci_hi) {
-                            if (ci + 2 * NH < ci_hi) rd(ci + 2 * NH, ca, xa_);
-                            __builtin_amdgcn_sched_barrier(0);
-                            mm(cb_, xb_);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-                if (h == 0) {
-                    auto one = [&](int u) {
-                        const int ci = u / 9, tp = u - 9 * ci, ky = tp / 3, kx = tp - 3 * ky, n = u - lo_u;
-                        const float xv = xb[ci * XCH + ky * TCOLS + kx];
-                        xp[ii][0] = __builtin_fmaf(la[n], xv, xp[ii][0]);
-                        xp[ii][1] = __builtin_fmaf(la[n3 + n], xv, xp[ii][1]);
-                        xp[ii][2] = __builtin_fmaf(la[2 * n3 + n], xv, xp[ii][2]);
-                    };
-#pragma unroll 1
-                    for (int u = lo_u; u < head_end; ++u) one(u);
-#pragma unroll 1
-                    for (int u = tail_begin; u < hi_u; ++u) one(u);
-                }
-            }
-        }
-        // the NH slices add their parts into the planes one after the other (fixed order)
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            if (h == hh) {
-#pragma unroll
-                for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int o = (3 * ii + q) * PL + p;
-                        if (hh == 0) {
-                            dpl[o] = dp[ii][q];
-                            xpl[o] = xp[ii][q];
-                        } else {
-                            dpl[o] += dp[ii][q];
-                            xpl[o] += xp[ii][q];
-                        }
-                    }
-            }
-            __syncthreads();
-        }
-        if (tile + (int)gridDim.x < a.ntiles) {        // the next tile's x image (other buffer) and dy / mask: in flight during the pixel sums
-            queue_x(tile + gridDim.x, cur ^ 1);
-            fetch_dy(tile + gridDim.x);
-        }
-
-        // -- 2. pixel sums.  Per quad of pixels: one 16-byte read of every A operand, four 4-byte reads of every B operand of G;
-        //        the reads of quad qd + 1 are queued before the MFMAs of quad qd, and consecutive MFMAs go to different
-        //        accumulators (pixel-major order).
-        {
-            f32x4 av0[NGRP], av1[NGRP], ev0, ev1, xa0[3], xa1[3];
-            float bv0[NGRP][4], bv1[NGRP][4];
-            auto rd = [&](int qd, f32x4 (&av)[NGRP], float (&bv)[NGRP][4], f32x4& ev, f32x4 (&xa)[3]) {
-                ev = *reinterpret_cast<const f32x4*>(ds + eb + 4 * qd);
-#pragma unroll
-                for (int ii = 0; ii < 3; ++ii) xa[ii] = *reinterpret_cast<const f32x4*>(xpl + ea + 3 * ii * PL + 4 * qd);
-#pragma unroll
-                for (int g = 0; g < NGRP; ++g) {
-                    av[g] = *reinterpret_cast<const f32x4*>(dpl + ga[g] + 4 * qd);
-                    const float* bp = xs + gb[g] + 4 * qd;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[g][e] = bp[e];
-                }
-            };
-            auto mm = [&](const f32x4 (&av)[NGRP], const float (&bv)[NGRP][4], const f32x4& ev, const f32x4 (&xa)[3]) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int g = 0; g < NGRP; ++g) gacc[g] = lw_mfma4(av[g][e], bv[g][e], gacc[g]);
-#pragma unroll
-                    for (int ii = 0; ii < 3; ++ii) eacc[ii] = lw_mfma4(xa[ii][e], ev[e], eacc[ii]);
-                }
-            };
-            constexpr int NQ = PPW / 4;
-            static_assert(NQ % 2 == 0, "quads are processed in pairs");
-            rd(0, av0, bv0, ev0, xa0);
-#pragma unroll
-            for (int qd = 0; qd < NQ; qd += 2) {
-                rd(qd + 1, av1, bv1, ev1, xa1);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(av0, bv0, ev0, xa0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (qd + 2 < NQ) rd(qd + 2, av0, bv0, ev0, xa0);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(av1, bv1, ev1, xa1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();                               // every wave is done with the tile images
-        cur ^= 1;
-    }
-
-    // ---- the four waves' sums (each over its quarter of the pixels) are added through LDS in wave order, wave 0 writes the
-    //      workgroup's partial: G [3][3 P3], then E [9][64]
-    constexpr int NACC = NGRP + 3;
-    float* red = smem;                                 // [3 waves][NACC][4][64]
-    if (wave > 0) {
-        float* w_ = red + (wave - 1) * NACC * 256 + lane;
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w_[(g * 4 + e) * 64] = gacc[g][e];
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w_[((NGRP + ii) * 4 + e) * 64] = eacc[ii][e];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        for (int w = 0; w < 3; ++w) {
-            const float* r_ = red + w * NACC * 256 + lane;
-#pragma unroll
-            for (int g = 0; g < NGRP; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) gacc[g][e] += r_[(g * 4 + e) * 64];
-#pragma unroll
-            for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) eacc[ii][e] += r_[((NGRP + ii) * 4 + e) * 64];
-        }
-        const int ncolp = 3 * P3;
-        float* pg = a.partial + (long long)blockIdx.x * (3 * ncolp + LW_ROWS * 64);
-        float* pe = pg + 3 * ncolp;
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g) {
-            const int c = g * 64 + lane;
-            if (c < ncolp) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) pg[q * ncolp + c] = gacc[g][q];
-            }
-        }
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) pe[(3 * ii + q) * 64 + lane] = eacc[ii][q];
-    }
-}
-
-// dA[q][n] = s * sum_wg sum_ii G_wg[q][ii * P3 + n];  dB[(3 co + ii) * 3 + q] = s * sum_wg E_wg[3 ii + q][co]   (second generation)
-__global__ __launch_bounds__(256) void lora_wgrad4_reduce_kernel(const float* __restrict__ partial, int nwg, int cin, int cout,
-                                                                 float scale, float* __restrict__ d_a, float* __restrict__ d_b) {
-    __shared__ float red[8][32];
-    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int n3 = 3 * cin, P3 = (n3 + 3) & ~3, ncolp = 3 * P3, na = LW_RQ * n3, nb = 9 * cout;
-    const long long stride = 3ll * ncolp + LW_ROWS * 64;
-    for (int base = blockIdx.x * 32; base < na + nb; base += gridDim.x * 32) {
-        const int i = base + o;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        if (i < na) {
-            const int q = i / n3, n = i - q * n3;
-            const float* p0 = partial + q * ncolp + n;
-            int w = g;
-            for (; w + 24 < nwg; w += 32) {
-                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float* pk = p0 + (w + 8 * k) * stride;
-                    t0 += pk[0];
-                    t1 += pk[P3];
-                    t2 += pk[2 * P3];
-                }
-                s0 += t0;
-                s1 += t1;
-                s2 += t2;
-            }
-            for (; w < nwg; w += 8) {
-                const float* pk = p0 + w * stride;
-                s0 += pk[0];
-                s1 += pk[P3];
-                s2 += pk[2 * P3];
-            }
-        } else if (i < na + nb) {
-            const int f = i - na, co = f / 9, m = f - 9 * co;
-            const float* p0 = partial + 3ll * ncolp + m * 64 + co;
-            int w = g;
-            for (; w + 56 < nwg; w += 64) {
-                float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    t0 += p0[(w + 8 * k) * stride];
-                    t1 += p0[(w + 32 + 8 * k) * stride];
-                }
-                s0 += t0;
-                s1 += t1;
-            }
-            for (; w < nwg; w += 8) s0 += p0[w * stride];
-        }
-        red[g][o] = (s0 + s1) + s2;
-        __syncthreads();
-        if (g == 0 && i < na + nb) {
-            float t = red[0][o];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) t += red[k][o];
-            if (i < na) d_a[i] = scale * t;
-            else d_b[i - na] = scale * t;
-        }
-        __syncthreads();
-    }
-}
-
 // dA[q][n] = s * sum_wg sum_ii G_wg[3 ii + q][ii * 3cin + n];  dB[(3 co + ii) * 3 + q] = s * sum_wg E_wg[3 ii + q][co].
 // Thread (o, g) of a block sums the workgroups wg = g mod 8 of output base + o, the eight chains are added in order.
 __global__ __launch_bounds__(256) void lora_wgrad_reduce_kernel(const float* __restrict__ partial, int nwg, int cin, int cout,
@@ -1006,44 +540,6 @@ static int launch_lora_wgrad(const LoraWgArgs& a, int grid, hipStream_t st) {
     return ynet_check_launch("lora_conv2d_wgrad");
 }
 
-template <int TH, int NGRP, int COS>
-static int launch_lora_wgrad4(const LoraWgArgs& a, int grid, hipStream_t st) {
-    static bool attr_dev[YNET_MAX_DEV] = {false};
-    bool& attr_set = attr_dev[ynet_device_slot()];
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lora_wgrad4_kernel<TH, NGRP, COS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    int lds = lw4_lds_floats(TH, a.cin, a.cout) * 4;
-    const int red = 3 * (NGRP + 3) * 256 * 4;          // the final cross-wave sum reuses the image
-    if (lds < red) lds = red;
-    hipLaunchKernelGGL((lora_wgrad4_kernel<TH, NGRP, COS>), dim3(grid), dim3(256), lds, st, a);
-    return ynet_check_launch("lora_conv2d_wgrad");
-}
-
-static int lora_wgrad4(LoraWgArgs& a, float scale, float* d_a, float* d_b, float* workspace, hipStream_t st) {
-    const int cout = a.cout;
-    const int th = (a.cin <= 32 && cout <= 32) ? 4 : 2;
-    a.tiles_x = ceil_div(a.W, 32);
-    a.tiles_y = ceil_div(a.H, th);
-    a.ntiles = a.B * a.tiles_x * a.tiles_y;
-    const int P3 = (3 * a.cin + 3) & ~3, ngrp = ceil_div(3 * P3, 64);
-    YNET_REQUIRE(a.cin * lw_xq(th) <= (th == 4 ? 9 : 11) * 256, "lora_conv2d_wgrad: x tile of %d channels exceeds the DMA plan", a.cin);
-    const int lds = lw4_lds_floats(th, a.cin, cout) * 4;
-    const int grid = lw_grid(a.ntiles, lds);
-    int rc;
-    if (th == 4) {          // cin, cout <= 32: two channel slices of <= 16 output channels, <= 5 column groups
-        rc = ngrp <= 2 ? launch_lora_wgrad4<4, 2, 16>(a, grid, st) : launch_lora_wgrad4<4, 5, 16>(a, grid, st);
-    } else {                // four channel slices of <= 16 output channels
-        YNET_REQUIRE(ngrp <= 5, "lora_conv2d_wgrad: %d column groups exceed the second generation's registers", ngrp);
-        rc = launch_lora_wgrad4<2, 5, 16>(a, grid, st);
-    }
-    if (rc) return rc;
-    const int nout = LW_RQ * 3 * a.cin + 9 * cout;
-    hipLaunchKernelGGL(lora_wgrad4_reduce_kernel, dim3(ceil_div(nout, 32)), dim3(256), 0, st, workspace, grid, a.cin, cout, scale, d_a, d_b);
-    return ynet_check_launch("lora_conv2d_wgrad(reduce)");
-}
-
 extern "C" {
 
 // 1 if ynet_lora_conv2d_wgrad serves this layer (3x3, rank 1, cin / cout <= 64, W % 4 == 0)
@@ -1097,8 +593,6 @@ int ynet_lora_conv2d_wgrad(const float* const* src, const int* src_c, const long
     a.H = H;
     a.W = W;
     a.cout = cout;
-    static const int gen = getenv("YNET_LORA_WGRAD_GEN") ? atoi(getenv("YNET_LORA_WGRAD_GEN")) : 1;      // 1: 16x16x4 tiles + vector-ALU projections; 2: the 4x4x1 experiment (slower, measured)
-    if (gen >= 2 && a.cin <= 32 && cout <= 32) return lora_wgrad4(a, scale, d_a, d_b, workspace, (hipStream_t)stream);      // (<= 5 groups of 64 filter columns: registers)
     a.tiles_x = ceil_div(W, 32);
     a.tiles_y = ceil_div(H, th);
     a.ntiles = B * a.tiles_x * a.tiles_y;
