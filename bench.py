@@ -77,10 +77,10 @@ class ConvTimer:
         self.ops, self.orig, self.rec = ops, ops.conv2d_raw, []
 
     def __enter__(self):
-        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
+        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu)
+            self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of)
             e1.record()
             cin = sum(s[1] for s in srcs)
             dl = list(dsts)
@@ -88,14 +88,15 @@ class ConvTimer:
                 dl.pop()
             cout = sum(d[1] for d in dl)
             flops = 2.0 * B * H * W * cin * cout * K * K
-            byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]))
+            byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]) * (2 if relu_of else 1))
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             if dma:
                 cc = 4
                 x4 = (plan >> 18) & 1
                 fold = 1 << ((plan >> 19) & 3)
-                name = f"conv_dma_kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, {'true' if x4 else 'false'}, {fold}>"
+                name = (f"conv_dma_{'emask_' if relu_of else ''}kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "
+                        f"{'true' if x4 else 'false'}, {fold}>")
             else:
                 name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}, "
                         f"{'true' if m16 else 'false'}>")
@@ -132,12 +133,12 @@ class FlopCounter:
         names = ("conv2d_raw", "conv2d_wgrad_raw", "lora_conv2d_wgrad_raw", "conv2d_shared_term", "pred_bce", "pred_softargmax")
         self.saved = {n: getattr(ops, n) for n in names}
 
-        def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
+        def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, **kw):
             dl = list(dsts)
             while len(dl) > 1 and dl[-1][0] is None:
                 dl.pop()
             me.flops += 2.0 * B * H * W * sum(s_[1] for s_ in srcs) * sum(d[1] for d in dl) * K * K
-            return me.saved["conv2d_raw"](srcs, mask, wp, bias, dsts, B, H, W, K, relu)
+            return me.saved["conv2d_raw"](srcs, mask, wp, bias, dsts, B, H, W, K, relu, **kw)
 
         def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b, *a, **kw):
             cout, cin, k, _ = weight.shape
@@ -582,7 +583,8 @@ def main():
         dist.barrier()
     if rank == 0 and N == 1 and args.config == "C2" and not args.no_c5:
         # ---- BASELINE.json's HBM-bound roofline point (configs[4]: K = 20 goal-decoder sweep, B = 128) in the default run:
-        # one warm-up batch + two timed batches of the evaluation sweep, and its read-out kernel timed in isolation
+        # two warm-up batches (the first ones grow the caching allocator's pools: 150 instead of 121 ms per batch) + four timed
+        # batches of the evaluation sweep, and its read-out kernel timed in isolation
         cfg5, H5, W5, workload5 = make_cfg(O, "C5")
         m5 = ynet.YNet(cfg5.obs_len, cfg5.pred_len, None, encoder_channels=list(cfg5.enc), decoder_channels=list(cfg5.dec),
                        n_waypoints=len(cfg5.waypoints), train_net=cfg5.train_net, position=list(cfg5.position),
@@ -597,14 +599,14 @@ def main():
             traj = O.synthetic_trajectories(cfg5, B5 * n_batches, H5, W5, seed)
             return ev.evaluate(m5, loader_for(traj), img5, dev, "sdd", None, in5, list(cfg5.waypoints), "test", 20, 1,
                                cfg5.obs_len, B5, cfg5.resize_factor, cfg5.temperature)
-        sweep(1, 11)
+        sweep(2, 11)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        a5, f5, _, _ = sweep(2, 12)
+        a5, f5, _, _ = sweep(4, 12)
         torch.cuda.synchronize()
         dt5 = time.perf_counter() - t0
-        out["c5"] = {"workload": workload5, "batch": B5, "batches_timed": 2, "value": 2 * B5 / dt5, "unit": "trajectories/s",
-                     "ms_per_batch": dt5 / 2 * 1e3, "ade": float(a5), "fde": float(f5),
+        out["c5"] = {"workload": workload5, "batch": B5, "batches_timed": 4, "value": 4 * B5 / dt5, "unit": "trajectories/s",
+                     "ms_per_batch": dt5 / 4 * 1e3, "ade": float(a5), "fde": float(f5),
                      "sweep_launch": pkg("utils.evaluate").last_sweep_launch(),
                      "roofline": readout_roofline(ops, ynet, cfg5, B5, H5, W5, dev)}
         del m5

@@ -54,6 +54,17 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                 int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
                 void* stream);
+/* ynet_conv2d as the data gradient of a layer whose INPUT was another layer's post-ReLU output (the conv -> ReLU -> conv chains
+ * of models/ynet.py:192-211,420-451): dx = relu_of > 0 ? conv(dy [kept where mask > 0; mask may be NULL], wp) : 0, i.e. the ReLU
+ * backward of the layer below is applied where its gradient is produced (the activation tile is fetched under the last MFMA
+ * chunk of each output tile), and that layer's own dgrad / wgrad then run without a mask operand.  One source, one destination;
+ * wp packed in mode 1; relu_of [B][dx_c][H][W] with batch stride relu_of_bs, 16-byte aligned.  workspace as for ynet_conv2d.
+ * ynet_conv2d_dgrad_relu_supported: 1 where the mask is applied inside the convolution kernel (3x3, W % 4 == 0, maps large enough
+ * for two-row tiles); elsewhere the call is still correct but costs a pass over dx, and callers keep the consumer-side mask. */
+int ynet_conv2d_dgrad_relu_supported(int B, int H, int W, int dx_c, int K);
+int ynet_conv2d_dgrad_relu(const float* dy, int dy_c, long long dy_bs, const float* mask, long long mask_bs, const float* wp,
+                           float* dx, int dx_c, long long dx_bs, const float* relu_of, long long relu_of_bs,
+                           int B, int H, int W, int K, float* workspace, long long workspace_floats, void* stream);
 /* ynet_conv2d with one destination, no mask, plus a precomputed additive term: y = [relu](conv(cat(src...), wp) + bias +
  * addend[b % addend_bmod]), addend [images][cout][H][W] with batch stride addend_bs (addend_bmod = 0: one image per batch
  * item).  Convolution is linear in its input channels: the part over inputs that REPEAT along the batch -- the encoder
@@ -138,6 +149,9 @@ int ynet_maxpool2_bwd_add(const float* x, const float* dy, const float* add0, co
  * H, W are the LOW-resolution sizes in both directions. */
 int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream);
 int ynet_upsample2x_bwd(const float* dy, float* dx, long long N, int H, int W, void* stream);
+/* ... with the ReLU backward of the up-sampled activation (relu_of [N][H][W], contiguous: the post-ReLU output of the layer in
+ * front of the interpolation, models/ynet.py:463) applied to dx: dx = relu_of > 0 ? dx : 0 */
+int ynet_upsample2x_bwd_relu(const float* dy, float* dx, const float* relu_of, long long N, int H, int W, void* stream);
 /* [x] + [AvgPool2d(2^i)(x) for i = 1..nlev] (utils/train_epoch.py:97-100, utils/evaluate.py:255-257);
  * outs[i-1] receives level i; H, W multiples of 32. */
 int ynet_avgpool_pyramid(const float* x, float* const* outs, int nlev, long long N, int H, int W, void* stream);

@@ -28,6 +28,8 @@ SIGNATURES = {
     "ynet_conv2d_workspace_floats": (c_ll, [c_i, c_i, c_i, c_i]),
     "ynet_conv2d": (c_i, [PP, PI, PLL, PI, c_i, c_fp, c_ll, c_fp, c_fp, PP, PI, PLL, c_i,
                           c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_fp]),
+    "ynet_conv2d_dgrad_relu_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "ynet_conv2d_dgrad_relu": (c_i, [c_fp, c_i, c_ll, c_fp, c_ll, c_fp, c_fp, c_i, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp, c_ll, c_fp]),
     "ynet_conv2d_add_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_add": (c_i, [PP, PI, PLL, PI, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp]),
     "ynet_conv2d_plan": (c_i, [c_i, c_i, c_i, c_i, c_i]),
@@ -48,6 +50,7 @@ SIGNATURES = {
     "ynet_maxpool2_bwd_add": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_fp]),
     "ynet_upsample2x_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_upsample2x_bwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
+    "ynet_upsample2x_bwd_relu": (c_i, [c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_avgpool_pyramid": (c_i, [c_fp, PP, c_i, c_ll, c_i, c_i, c_fp]),
     "ynet_bce_workspace_bytes": (c_ll, []),
     "ynet_bce_logits_fwd": (c_i, [c_fp, c_fp, c_ll, c_fp, c_fp, c_fp]),

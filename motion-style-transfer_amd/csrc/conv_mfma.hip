@@ -45,9 +45,12 @@ struct ConvArgs {
     int ksplit, cps;        // split of the input-channel chunks over workgroups (small maps): chunks per split
     float* partial;         // [ksplit][B][cout][H][W] raw partial sums when ksplit > 1 (NULL: never split)
     long long partial_cap;  // floats available at `partial`
-    const float* addend;    // optional [images][cout][H][W] term added before the ReLU (conv_dma_kernel<..., ADD = true>):
+    const float* addend;    // optional [images][cout][H][W] term added before the ReLU (conv_dma_add_kernel):
     long long addend_bs;    //   y = relu(conv(x) + bias + addend[b % addend_bmod]) -- the part of a convolution over inputs that
     int addend_bmod;        //   repeat along the batch (evaluate()'s K goal samples share the encoder features), computed once
+    const float* emask;     // optional [B][cout][H][W] post-ReLU activation whose backward is applied to the OUTPUT (one destination):
+    long long emask_bs;     //   dst = emask > 0 ? conv(...) : 0 -- a data gradient written for a consumer that then needs no mask
+    int emask_done;         //   (host side) the launched kernels applied it
     int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
     int vec_load;           // 16-byte LDS-DMA of the input tile is legal (W % 4 == 0, aligned sources / mask)
     int tiles_x, tiles_y, cgroups, ntiles, debug;   // debug: timing ablations only (tools/conv_bench.py)
@@ -547,7 +550,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sgpr_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0u, 0x00020000);
 }
 
-template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, bool ADD>
+// EPI: 0 plain epilogue, 1 + the batch-shared additive term (ConvArgs::addend), 2 ReLU backward on the output (ConvArgs::emask)
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, int EPI>
 __device__ __forceinline__ void conv_dma_body() {
     using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
     constexpr int KS = 3, PAD = 1, KK = 9, TH = C::TH, TW = C::TW;
@@ -850,7 +854,7 @@ __device__ __forceinline__ void conv_dma_body() {
             }
         const int ybase = t.y0 + wave * R * FOLD;    // (H % FOLD == 0: a row unit lies wholly inside or outside the image)
         const int c_lo = t.cg * CB;        // first output channel of this tile
-        if constexpr (ADD) {
+        if constexpr (EPI == 1) {
             // + the batch-shared part of the convolution (see ConvArgs::addend): the tile of image b % bmod, read with the
             // addressing of the stores below (lanes past the image / past cout fall outside the descriptor and add 0)
             const int abm = ke->addend_bmod;
@@ -877,6 +881,28 @@ __device__ __forceinline__ void conv_dma_body() {
                     for (int g = 0; g < 2; ++g)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[i][r][g][e] = acc[i][r][g][e] < 0.f ? 0.f : acc[i][r][g][e];
+        }
+        if constexpr (EPI == 2) if (ksplit == 1) {
+            // ReLU backward on the OUTPUT (ConvArgs::emask): the activation values of the tile, read with the addressing of the
+            // stores below (a separate instantiation: the values in flight cost up to 40 registers = one of the four workgroups
+            // resident per CU, which the launches without this mask keep)
+            const __amdgpu_buffer_rsrc_t re = sgpr_rsrc(ke->emask + (long long)t.b * ke->emask_bs, (unsigned)ke->cout * plane_bytes);
+            const unsigned ub = (unsigned)(c_lo * HW + ybase * W) * 4u;
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const unsigned vo = lo[i][g] + ub;
+                    f32x4 em[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        em[r] = (ybase + r * FOLD < H) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(re, vo, (unsigned)(r * FOLD * W) * 4u, 0))
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][r][g][e] = em[r][e] > 0.f ? acc[i][r][g][e] : 0.f;
+                }
         }
         auto store_all = [&](__amdgpu_buffer_rsrc_t rd, unsigned ubase) {
             // ubase = ((c_lo - first channel of the destination) * HW + ybase * W) * 4, modulo 2^32
@@ -980,13 +1006,19 @@ __device__ __forceinline__ void conv_dma_body() {
 
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
-    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, false>();
+    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 0>();
 }
 
 // the same with the batch-shared additive term (ConvArgs::addend) in the epilogue
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
 __global__ __launch_bounds__(256, 2) void conv_dma_add_kernel(const ConvArgs) {
-    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, true>();
+    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 1>();
+}
+
+// the same with the ReLU backward of the layer below applied to the output (ConvArgs::emask)
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
+__global__ __launch_bounds__(256, 2) void conv_dma_emask_kernel(const ConvArgs) {
+    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 2>();
 }
 
 // Split of the input-channel loop over workgroups for launches with fewer work items than CUs.
@@ -1007,6 +1039,8 @@ struct SplitReduceArgs {
     const float* bias;
     YDst dst[YNET_MAX_SRC];
     int ndst, ksplit, B, cout, HW, relu;
+    const float* emask;     // ConvArgs::emask (one destination): out = emask > 0 ? sum : 0
+    long long emask_bs;
 };
 
 __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const SplitReduceArgs a) {
@@ -1028,11 +1062,13 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const SplitReduc
         float* dp = a.dst[d].p;
         if (dp == nullptr) continue;
         dp += (long long)b * a.dst[d].bs + (long long)rel * a.HW + p4 * 4;
+        f32x4 m = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (a.emask) m = *reinterpret_cast<const f32x4*>(a.emask + (long long)b * a.emask_bs + (long long)co * a.HW + p4 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float u = s[e] + bv;
             if (a.relu) u = u < 0.f ? 0.f : u;
-            dp[e] = u;
+            dp[e] = m[e] > 0.f ? u : 0.f;
         }
     }
 }
@@ -1112,11 +1148,13 @@ static int pick_rows(const ConvArgs& a, int cb) {
     return 1;
 }
 
-template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, bool ADD = false>
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, int EPI = 0>
 static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
+    constexpr bool ADD = EPI == 1;
     const auto KERNEL = [] {       // (if constexpr: only the wanted instantiation is compiled)
-        if constexpr (ADD) return &conv_dma_add_kernel<NCB, R, CC, MASK, X4, FOLD>;
+        if constexpr (EPI == 1) return &conv_dma_add_kernel<NCB, R, CC, MASK, X4, FOLD>;
+        else if constexpr (EPI == 2) return &conv_dma_emask_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else return &conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>;
     }();
     a.tiles_x = ceil_div(a.W, C::TW);
@@ -1163,11 +1201,14 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         r.cout = a.cout;
         r.HW = a.H * a.W;
         r.relu = a.relu;
+        r.emask = a.emask;
+        r.emask_bs = a.emask_bs;
         long long n4 = (long long)a.B * a.cout * (r.HW / 4);
         int grid = (int)((n4 + 255) / 256);
         if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL(conv_split_reduce_kernel, dim3(grid), dim3(256), 0, st, r);
     }
+    if (EPI == 2 || a.ksplit > 1) a.emask_done = 1;       // (in the epilogue, or in the reduction of a split channel loop)
     return ynet_check_launch("conv2d");
 }
 
@@ -1185,13 +1226,16 @@ static int small_cc() {
 
 template <int NCB, int R, int FOLD = 1, int CC = 4>
 static int launch_dma(ConvArgs& a, hipStream_t st) {
+    if constexpr (R >= 2 && FOLD == 1) {      // the large-map tiles (ynet_conv2d_dgrad_relu_supported)
+        if (a.emask) return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD, 2>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD, 2>(a, st);
+    }
     return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD>(a, st);
 }
 
 template <int NCB, int R, int FOLD = 1>
 static int launch_dma_small(ConvArgs& a, hipStream_t st) {
     const int cc = small_cc();
-    if (cc >= 16 && !a.mask) return launch_dma_m<NCB, R, 16, false, true, FOLD>(a, st);      // (a masked dgrad holds CC mask quads in registers: 8 at most)
+    if (cc >= 16 && !a.mask && !a.emask) return launch_dma_m<NCB, R, 16, false, true, FOLD>(a, st);      // (a masked dgrad holds CC mask quads in registers: 8 at most)
     if (cc >= 8) return launch_dma<NCB, R, FOLD, 8>(a, st);
     return launch_dma<NCB, R, FOLD, 4>(a, st);
 }
@@ -1347,7 +1391,7 @@ static int narrow_tiles(const ConvArgs& a, int nt16) {
     return n;
 }
 
-static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
+static int conv_dispatch_kernels(ConvArgs& a, int K, hipStream_t st) {
     const bool wide = a.cout > 32;
     const int nt16_full = m16_tiles(K, a.cout);
     const int nt16 = (a.addend == nullptr) ? narrow_tiles(a, nt16_full) : nt16_full;
@@ -1364,8 +1408,8 @@ static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
             ynet_set_error("conv2d_add: shape B=%d %dx%d cout=%d is not served by the additive-term kernels", a.B, a.H, a.W, a.cout);
             return 1;
         }
-        if (nt16 == 2) return rows_a == 4 ? launch_dma_m<2, 4, 4, false, true, 1, true>(a, st) : launch_dma_m<2, 2, 4, false, true, 1, true>(a, st);
-        return launch_dma_m<4, 2, 4, false, true, 1, true>(a, st);
+        if (nt16 == 2) return rows_a == 4 ? launch_dma_m<2, 4, 4, false, true, 1, 1>(a, st) : launch_dma_m<2, 2, 4, false, true, 1, 1>(a, st);
+        return launch_dma_m<4, 2, 4, false, true, 1, 1>(a, st);
     }
     if (nt16 && use_dma && use_x4 && a.vec_store && a.vec_load) {
         const int fold = conv_fold(a.H, a.W);
@@ -1402,6 +1446,27 @@ static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
         case 5: return wide ? launch_conv<5, 2, 4, 4>(a, st) : launch_conv<5, 1, 4, 4>(a, st);
         default: ynet_set_error("conv2d: kernel size %d not supported (1, 3, 5)", K); return 1;
     }
+}
+
+// dst = emask > 0 ? dst : 0 for the kernel families without the output-side mask in their epilogue (register-staged tiles,
+// 1x1 streaming, 5x5): a separate pass, correct everywhere, fast nowhere -- the layers of the hot path take the LDS-DMA kernels.
+__global__ __launch_bounds__(256) void conv_emask_kernel(float* __restrict__ dst, long long dst_bs, const float* __restrict__ emask,
+                                                         long long emask_bs, long long per_image, long long total) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / per_image, o = i - b * per_image;
+        if (!(emask[b * emask_bs + o] > 0.f)) dst[b * dst_bs + o] = 0.f;
+    }
+}
+
+static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
+    a.emask_done = 0;
+    int rc = conv_dispatch_kernels(a, K, st);
+    if (rc || a.emask == nullptr || a.emask_done) return rc;
+    const long long per_image = (long long)a.cout * a.H * a.W, total = per_image * a.B;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(conv_emask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a.dst[0].p, a.dst[0].bs, a.emask, a.emask_bs, per_image, total);
+    return ynet_check_launch("conv2d(output mask)");
 }
 
 // The largest CC used above: the packed filter is zero padded to a multiple of it along cin.
@@ -1489,7 +1554,8 @@ static int conv2d_impl(const float* const* src, const int* src_c, const long lon
                        const float* mask, long long mask_bs, const float* wp, const float* bias,
                        float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                        int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
-                       const float* addend, long long addend_bs, int addend_bmod, void* stream) {
+                       const float* addend, long long addend_bs, int addend_bmod, void* stream,
+                       const float* emask = nullptr, long long emask_bs = 0) {
     YNET_REQUIRE(nsrc >= 1 && nsrc <= YNET_MAX_SRC && ndst >= 1 && ndst <= YNET_MAX_SRC,
                  "conv2d: 1..%d sources/destinations supported (got %d/%d)", YNET_MAX_SRC, nsrc, ndst);
     YNET_REQUIRE(B > 0 && H > 0 && W > 0, "conv2d: empty problem B=%d H=%d W=%d", B, H, W);
@@ -1526,6 +1592,12 @@ static int conv2d_impl(const float* const* src, const int* src_c, const long lon
     a.addend = addend;
     a.addend_bs = addend_bs;
     a.addend_bmod = addend_bmod;
+    a.emask = emask;
+    a.emask_bs = emask_bs;
+    if (emask != nullptr) {
+        YNET_REQUIRE(a.ndst == 1 && a.dst[0].p != nullptr && addend == nullptr, "conv2d: the output-side ReLU mask needs exactly one destination");
+        YNET_REQUIRE((reinterpret_cast<uintptr_t>(emask) & 15) == 0 && (emask_bs & 3) == 0, "conv2d: the output-side ReLU mask must be 16-byte aligned");
+    }
     a.wp = wp;
     a.bias = bias;
     a.B = B;
@@ -1551,6 +1623,39 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
                 void* stream) {
     return conv2d_impl(src, src_c, src_bs, src_bmod, nsrc, mask, mask_bs, wp, bias, dst, dst_c, dst_bs, ndst, B, H, W, K, relu,
                        workspace, workspace_floats, nullptr, 0, 0, stream);
+}
+
+// ynet_conv2d as a data gradient whose result is written THROUGH the ReLU backward of the layer below: dx = relu_of > 0 ?
+// conv(dy [masked where mask <= 0], wp) : 0, relu_of = that layer's post-ReLU output = this convolution's forward input.
+int ynet_conv2d_dgrad_relu(const float* dy, int dy_c, long long dy_bs, const float* mask, long long mask_bs, const float* wp,
+                           float* dx, int dx_c, long long dx_bs, const float* relu_of, long long relu_of_bs,
+                           int B, int H, int W, int K, float* workspace, long long workspace_floats, void* stream) {
+    YNET_REQUIRE(dy != nullptr && dx != nullptr && relu_of != nullptr, "conv2d_dgrad_relu: null pointer");
+    const float* srcs[1] = {dy};
+    const int sc[1] = {dy_c};
+    const long long sb[1] = {dy_bs};
+    float* dsts[1] = {dx};
+    const int dc[1] = {dx_c};
+    const long long db[1] = {dx_bs};
+    return conv2d_impl(srcs, sc, sb, nullptr, 1, mask, mask_bs, wp, nullptr, dsts, dc, db, 1, B, H, W, K, 0, workspace, workspace_floats,
+                       nullptr, 0, 0, stream, relu_of, relu_of_bs);
+}
+
+// 1 if ynet_conv2d_dgrad_relu applies the mask inside the convolution kernel for this problem (3x3 on a map large enough for
+// two-row units); elsewhere it is still correct but adds a pass over dx -- callers keep the consumer-side mask there
+int ynet_conv2d_dgrad_relu_supported(int B, int H, int W, int dx_c, int K) {
+    ConvArgs a{};
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.cout = dx_c;
+    const int nt16 = narrow_tiles(a, m16_tiles(K, dx_c));
+    static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
+    static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
+    if (!(use_dma && use_x4) || K != 3 || (W & 3) || nt16 == 0 || conv_fold(H, W) != 1) return 0;
+    int rows = pick_rows(a, 16 * nt16);
+    if (nt16 >= 3 && rows == 4) rows = 2;
+    return rows >= 2 ? 1 : 0;
 }
 
 // 1 if ynet_conv2d_add serves this problem (3x3, Cout 17..32 or 49..64, W % 4 == 0, a map large enough for two-row units)

@@ -226,8 +226,10 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_rows_kernel(const float* _
 
 // 4 consecutive input-gradient pixels per thread; needs W % 4 == 0.  1-D weights of input i over outputs
 // 2i-1 .. 2i+2 are {.25,.75,.75,.25}, except that output 0 / 2W-1 put their whole weight on input 0 / W-1.
+// relu_of (all three kernels; may be NULL): the post-ReLU activation [N][H][W] that was up-sampled -- its ReLU backward is applied
+// to dx here, where the value is one extra coalesced read, instead of by the masked dgrad / wgrad kernels of its producer.
 __global__ __launch_bounds__(256) void upsample2x_bwd_vec_kernel(const float* __restrict__ dy, float* __restrict__ dx,
-                                                                 long long N, int H, int W) {
+                                                                 const float* __restrict__ relu_of, long long N, int H, int W) {
     const int Ho = 2 * H, Wo = 2 * W, Wq = W >> 2, per_plane = H * Wq;
     for (long long n = blockIdx.y; n < N; n += gridDim.y)
     for (int ip = blockIdx.x * 256 + threadIdx.x; ip < per_plane; ip += gridDim.x * 256) {
@@ -271,6 +273,13 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_vec_kernel(const float* __
             const float w2 = ix < W - 1 ? 0.75f : 1.f, w3 = ix < W - 1 ? 0.25f : 0.f;
             o[e] = (w0 * col[2 * e] + w1 * col[2 * e + 1]) + (w2 * col[2 * e + 2] + w3 * col[2 * e + 3]);
         }
+        if (relu_of) {
+            const float4 a = reinterpret_cast<const float4*>(relu_of)[i];
+            o[0] = a.x > 0.f ? o[0] : 0.f;
+            o[1] = a.y > 0.f ? o[1] : 0.f;
+            o[2] = a.z > 0.f ? o[2] : 0.f;
+            o[3] = a.w > 0.f ? o[3] : 0.f;
+        }
         reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_vec_kernel(const float* __
 // (2*RI + 2) / (2*RI) threads instead of 2.  Needs W even, H % RI == 0, 16-byte aligned dy planes, 8-byte aligned dx.
 template <int RI>
 __global__ __launch_bounds__(256) void upsample2x_bwd_rows_kernel(const float* __restrict__ dy, float* __restrict__ dx,
-                                                                  long long N, int H, int W) {
+                                                                  const float* __restrict__ relu_of, long long N, int H, int W) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     const int Ho = 2 * H, Wo = 2 * W, Wq = W >> 1, per_plane = (H / RI) * Wq;
     for (long long n = blockIdx.y; n < N; n += gridDim.y)
@@ -297,6 +306,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_rows_kernel(const float* _
             wx[e][1] = ix > 0 ? 0.75f : 1.f;
             wx[e][2] = ix < W - 1 ? 0.75f : 1.f;
             wx[e][3] = ix < W - 1 ? 0.25f : 0.f;
+        }
+        f2 act[RI];                     // (queued ahead of the dy rows)
+        if (relu_of) {
+#pragma unroll
+            for (int q = 0; q < RI; ++q) act[q] = *reinterpret_cast<const f2*>(relu_of + (n * H + iy0 + q) * W + 2 * l);
         }
         float h[2 * RI + 2][2];        // horizontally combined dy rows 2*iy0-1 .. 2*iy0+2*RI
 #pragma unroll
@@ -322,13 +336,18 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_rows_kernel(const float* _
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 o[e] = (w0 * h[2 * q][e] + w1 * h[2 * q + 1][e]) + (w2 * h[2 * q + 2][e] + w3 * h[2 * q + 3][e]);
+            if (relu_of) {
+                o[0] = act[q][0] > 0.f ? o[0] : 0.f;
+                o[1] = act[q][1] > 0.f ? o[1] : 0.f;
+            }
             *reinterpret_cast<f2*>(dx + (n * H + iy) * W + 2 * l) = o;
         }
     }
 }
 
 // dx[i][j] = sum over the (at most 4x4) output pixels whose stencil touches (i,j)
-__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long N, int H, int W) {
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, const float* __restrict__ relu_of,
+                                      long long N, int H, int W) {
     const int Ho = 2 * H, Wo = 2 * W;
     const long long total = N * H * W;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -367,7 +386,7 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
             }
             acc += wy[a] * row;
         }
-        dx[i] = acc;
+        dx[i] = (relu_of == nullptr || relu_of[i] > 0.f) ? acc : 0.f;
     }
 }
 
@@ -1267,18 +1286,29 @@ int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, voi
     return ynet_check_launch("upsample2x_fwd");
 }
 
-int ynet_upsample2x_bwd(const float* dy, float* dx, long long N, int H, int W, void* stream) {
+static int upsample2x_bwd_impl(const float* dy, float* dx, const float* relu_of, long long N, int H, int W, void* stream) {
     YNET_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0, "upsample2x_bwd: bad arguments");
-    const bool rows_ok = (W & 1) == 0 && (((uintptr_t)dy) & 15) == 0 && (((uintptr_t)dx) & 7) == 0;
+    const bool act8 = relu_of == nullptr || (((uintptr_t)relu_of) & 7) == 0, act16 = relu_of == nullptr || (((uintptr_t)relu_of) & 15) == 0;
+    const bool rows_ok = (W & 1) == 0 && (((uintptr_t)dy) & 15) == 0 && (((uintptr_t)dx) & 7) == 0 && act8;
     if (rows_ok && (H & 3) == 0 && (long long)H * W >= 64 * 64)
-        hipLaunchKernelGGL(upsample2x_bwd_rows_kernel<4>, plane_grid(N, (long long)(H / 4) * (W / 2)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+        hipLaunchKernelGGL(upsample2x_bwd_rows_kernel<4>, plane_grid(N, (long long)(H / 4) * (W / 2)), dim3(256), 0, (hipStream_t)stream, dy, dx, relu_of, N, H, W);
     else if (rows_ok && (H & 1) == 0)
-        hipLaunchKernelGGL(upsample2x_bwd_rows_kernel<2>, plane_grid(N, (long long)(H / 2) * (W / 2)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
-    else if ((W & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
-        hipLaunchKernelGGL(upsample2x_bwd_vec_kernel, plane_grid(N, (long long)H * (W / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+        hipLaunchKernelGGL(upsample2x_bwd_rows_kernel<2>, plane_grid(N, (long long)(H / 2) * (W / 2)), dim3(256), 0, (hipStream_t)stream, dy, dx, relu_of, N, H, W);
+    else if ((W & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && act16)
+        hipLaunchKernelGGL(upsample2x_bwd_vec_kernel, plane_grid(N, (long long)H * (W / 4)), dim3(256), 0, (hipStream_t)stream, dy, dx, relu_of, N, H, W);
     else
-        hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W);
+        hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, relu_of, N, H, W);
     return ynet_check_launch("upsample2x_bwd");
+}
+
+int ynet_upsample2x_bwd(const float* dy, float* dx, long long N, int H, int W, void* stream) {
+    return upsample2x_bwd_impl(dy, dx, nullptr, N, H, W, stream);
+}
+
+// ... with the ReLU backward of the up-sampled activation applied to dx: dx = relu_of > 0 ? dx : 0 (relu_of [N][H][W], contiguous)
+int ynet_upsample2x_bwd_relu(const float* dy, float* dx, const float* relu_of, long long N, int H, int W, void* stream) {
+    YNET_REQUIRE(relu_of != nullptr, "upsample2x_bwd_relu: the activation is null");
+    return upsample2x_bwd_impl(dy, dx, relu_of, N, H, W, stream);
 }
 
 int ynet_avgpool_pyramid(const float* x, float* const* outs, int nlev, long long N, int H, int W, void* stream) {

@@ -255,9 +255,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
 //     pixels, so nothing is summed across waves when the block is a full 32 x 32; a partial block
 //     (Cin = 14, Cout = 12 ...) hands its spare waves every 2nd / 4th K-step instead and those are
 //     summed through LDS in fixed order;
-//   * K = 4 consecutive pixels per instruction: lane (r16, kq) reads channel r16, pixel 4s + kq; channel
-//     strides are 4 mod 32 floats, so the 64 lanes of an operand read cover every bank exactly twice;
-//   * the mask is applied to the one A operand per K-step (second LDS read + v_cndmask); db is a VALU
+//   * K = 4 pixels per instruction, every second one of an 8-pixel group: lane (r16, kq) reads channel r16,
+//     pixels 8 g + 2 kq + {0, 1} as ONE 8-byte LDS read for the two K-steps of the group; channel strides are 4 mod 32
+//     floats = conflict-free for ds_read_b64 (64 banks per 32 lanes; details at the reads);
+//   * the mask is applied to the A operand of a group (second LDS read + 2 v_cndmask); db is a VALU
 //     sum of that same operand.
 // Needs W % 4 == 0 and 16-byte aligned planes; everything else stays on wgrad_mfma_kernel.
 // ================================================================================================
@@ -290,7 +291,7 @@ struct WgDmaCfg {
     static constexpr int KSTEPS = TH * TW / 4;
     static_assert(XCH % 32 == 4 && DCH % 32 == 4, "bank-conflict-free channel strides");
     static_assert(3 * 37 * 64 <= 2 * BUF, "cross-wave reduction scratch fits");
-    static_assert(KSTEPS % 8 == 0, "a wave runs KSTEPS / rpN K-steps in pairs (rpN <= 4)");
+    static_assert(KSTEPS % 16 == 0, "a wave runs KSTEPS / 2 / rpN groups of two K-steps in pairs (rpN <= 4)");
 };
 
 template <bool MASK, int TH_>
@@ -492,54 +493,92 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     for (int i = 0; i < KK; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
-    const int xoff = (ib * 16 + r16) * XCH + 3 + kq;     // tile column 0 (gx = x0-1) sits at LDS column 3
-    const int doff = (cb * 16 + r16) * DCH + kq;
+    // ---- operand reads.  A K-step takes the pixels 8 g + 2 kq + par of a row (par = 0: the even pixels of an 8-pixel group g,
+    // par = 1: the odd ones), so that one ds_read_b64 of the pair (8 g + 2 kq, + 1) serves lane (r16, kq) in BOTH K-steps of
+    // the group: per group and lane 1 read of dy (+ 1 of the mask) and, per filter row, the three pairs Q0..Q2 at LDS
+    // columns 8 g + 2 kq + 2 .. + 7 (tile column 0 = gx x0 - 1 sits at LDS column 3):
+    //     par 0: taps kx = 0, 1, 2 = Q0.y, Q1.x, Q1.y        par 1: Q1.x, Q1.y, Q2.x
+    // -- 10 (11) 8-byte reads per 18 MFMAs where 4-byte reads took 20 (22).  Banks: ds_read_b64 serves lanes {0-31} = 16
+    // channels x kq {0, 1} in one cycle when their 32 pairs fall on 64 distinct banks: the two kq are neighbours (4
+    // consecutive floats) and the channel strides are 4 mod 32 floats, so they do; a ds_read_b32 (32 banks) of 16 channels
+    // at such a stride was 2-way conflicting whatever the pixel mapping (SQ_LDS_BANK_CONFLICT = half of the LDS cycles).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NGRP = C::KSTEPS / 2;
+    const int xoff = (ib * 16 + r16) * XCH + 2 * kq + 2;
+    const int doff = (cb * 16 + r16) * DCH + 2 * kq;
     auto compute = [&](int buf) {
         const float* xb = xs_of(buf) + xoff;
         const float* ab = ds_of(buf) + doff;
         const float* mb = ms_of(buf) + doff;
-        auto rd_a = [&](int s) {
-            const float v = ab[4 * s];          // rows are 32 pixels = 8 K-steps: 4 s is the pixel offset in the tile
-            if (MASK) return mb[4 * s] > 0.f ? v : 0.f;
-            return v;
+        // (inline asm: hipcc fuses 8-byte reads off one base into ds_read2_b64, which is banked like two 4-byte reads and
+        // takes 8 LDS cycles; the reads are therefore outside the compiler's lgkmcnt tracking and lds_wait() closes them)
+#define WG_LD2(v, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off))
+        auto lds_wait = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+        const unsigned xb_a = (unsigned)(size_t)(wg_lds_ptr_t)xb, ab_a = (unsigned)(size_t)(wg_lds_ptr_t)ab, mb_a = (unsigned)(size_t)(wg_lds_ptr_t)mb;
+        auto rd = [&](int g, f32x2& av, f32x2& mv, f32x2* q) {
+            const unsigned aa = ab_a + 32 * g;  // rows are 32 pixels = 4 groups: 8 g is the pixel offset in the tile
+            WG_LD2(av, aa, 0);
+            if (MASK) {
+                const unsigned ma = mb_a + 32 * g;
+                WG_LD2(mv, ma, 0);
+            }
+            const unsigned pa = xb_a + ((g >> 2) * TCOLS + (g & 3) * 8) * 4;
+            WG_LD2(q[0], pa, 0);
+            WG_LD2(q[1], pa, 8);
+            WG_LD2(q[2], pa, 16);
+            WG_LD2(q[3], pa, TCOLS * 4);
+            WG_LD2(q[4], pa, TCOLS * 4 + 8);
+            WG_LD2(q[5], pa, TCOLS * 4 + 16);
+            WG_LD2(q[6], pa, TCOLS * 8);
+            WG_LD2(q[7], pa, TCOLS * 8 + 8);
+            WG_LD2(q[8], pa, TCOLS * 8 + 16);
         };
-        auto rd_b = [&](int s, float* b) {
-            const float* p = xb + (s >> 3) * TCOLS + (s & 7) * 4;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) b[ky * 3 + kx] = p[ky * TCOLS + kx];
-        };
-        float a_cur, b_cur[KK], a_nxt, b_nxt[KK];
-        int s = rp;
-        a_cur = rd_a(s);
-        rd_b(s, b_cur);
+        f32x2 a_cur, m_cur = f32x2{1.f, 1.f}, q_cur[KK], a_nxt, m_nxt = f32x2{1.f, 1.f}, q_nxt[KK];
+        int g = rp;
+        rd(g, a_cur, m_cur, q_cur);
+        lds_wait();
+        if (MASK) {
+            a_cur.x = m_cur.x > 0.f ? a_cur.x : 0.f;
+            a_cur.y = m_cur.y > 0.f ? a_cur.y : 0.f;
+        }
         // consume the first operands here: with reads still pending at the loop header hipcc waits for ALL LDS
-        // reads (also the prefetch of the next K-step) in front of the second MFMA of every iteration
+        // reads (also the prefetch of the next group) in front of the second MFMA of every iteration
         asm volatile("" : "+v"(a_cur));
 #pragma unroll
-        for (int t = 0; t < KK; ++t) asm volatile("" : "+v"(b_cur[t]));
-        // one K-step: queue the LDS reads of the following step into (a_n, b_n), then the 9 MFMAs of (a_c, b_c)
-        auto step = [&](int sn, float a_c, const float* b_c, float& a_n, float* b_n) {
-            const float v = ab[4 * sn];
-            float m = 1.f;
-            if (MASK) m = mb[4 * sn];
-            rd_b(sn, b_n);
-            __builtin_amdgcn_sched_barrier(0);      // nothing moves across: reads of the next step, THEN the MFMAs of this one
+        for (int t = 0; t < KK; ++t) asm volatile("" : "+v"(q_cur[t]));
+        // one group: queue the LDS reads of the following group into (a_n, q_n), then the 18 MFMAs of (a_c, q_c)
+        auto step = [&](int gn, const f32x2& a_c, const f32x2* q_c, f32x2& a_n, f32x2& m_n, f32x2* q_n) {
+            rd(gn, a_n, m_n, q_n);
+            __builtin_amdgcn_sched_barrier(0);      // nothing moves across: reads of the next group, THEN the MFMAs of this one
 #pragma unroll
-            for (int t = 0; t < KK; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c, b_c[t], acc[t], 0, 0, 0);
+            for (int ky = 0; ky < 3; ++ky) {
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.x, q_c[ky * 3 + 0].y, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.x, q_c[ky * 3 + 1].x, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.x, q_c[ky * 3 + 1].y, acc[ky * 3 + 2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.y, q_c[ky * 3 + 1].x, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.y, q_c[ky * 3 + 1].y, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.y, q_c[ky * 3 + 2].x, acc[ky * 3 + 2], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            a_n = m > 0.f ? v : 0.f;        // VALU work on the fresh reads goes behind the MFMAs (their data has landed by then)
-            bsum += a_c;
+            lds_wait();
+            if (MASK) {      // VALU work on the fresh reads goes behind the MFMAs (their data has landed by then)
+                a_n.x = m_n.x > 0.f ? a_n.x : 0.f;
+                a_n.y = m_n.y > 0.f ? a_n.y : 0.f;
+            }
+            bsum += a_c.x + a_c.y;
             __builtin_amdgcn_sched_barrier(0);
         };
-        // a wave runs KSTEPS / rpN steps (an even number): two per iteration, the register sets swapping roles
-        // (the last step re-reads itself: no branch in the loop body)
+        // a wave runs NGRP / rpN groups (an even number): two per iteration, the register sets swapping roles
+        // (the last group re-reads itself: no branch in the loop body)
 #pragma unroll 1
-        for (; s < C::KSTEPS; s += 2 * rpN) {
-            step(s + rpN, a_cur, b_cur, a_nxt, b_nxt);
-            step(s + 2 * rpN < C::KSTEPS ? s + 2 * rpN : s + rpN, a_nxt, b_nxt, a_cur, b_cur);
+        for (; g < NGRP; g += 2 * rpN) {
+            step(g + rpN, a_cur, q_cur, a_nxt, m_nxt, q_nxt);
+            step(g + 2 * rpN < NGRP ? g + 2 * rpN : g + rpN, a_nxt, q_nxt, a_cur, m_cur, q_cur);
         }
+#undef WG_LD2
     };
 
     // The load cursor walks tiles split, split + nsplit, ...: its (x, y, image) coordinates advance by a fixed

@@ -250,8 +250,9 @@ def side_streams(device, which=None):
     return _side_streams[key][:2] if which is None else _side_streams[key][which]
 
 
-def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
-    """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None."""
+def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None):
+    """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
+    post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
     dp, dc, db = _arrays(dsts)
@@ -263,6 +264,13 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu):
             ws = _conv_ws.get(key)
             if ws is None or ws.numel() < nws:
                 ws = _conv_ws[key] = torch.empty(nws, device=wp.device, dtype=torch.float32)
+    if relu_of is not None:
+        if len(srcs) != 1 or len(dsts) != 1 or bias is not None or relu:
+            raise ValueError("conv2d_raw: relu_of is for a data gradient with one source and one destination")
+        L.check(lib.ynet_conv2d_dgrad_relu(srcs[0][0], srcs[0][1], srcs[0][2], mask[0] if mask else None, mask[1] if mask else 0,
+                                           wp.data_ptr(), dsts[0][0], dsts[0][1], dsts[0][2], relu_of[0], relu_of[1], B, H, W, K,
+                                           ws.data_ptr() if ws is not None else None, nws, _stream()), lib)
+        return
     L.check(lib.ynet_conv2d(sp, sc, sb, _bmods(srcs), len(srcs), mask[0] if mask else None, mask[1] if mask else 0,
                             wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                             dp, dc, db, len(dsts), B, H, W, K, 1 if relu else 0,
@@ -439,10 +447,13 @@ _skip_fold_allowed = _os.environ.get("YNET_SKIP_FOLD", "1") != "0"      # YNET_S
 # ReLU backward applied where a gradient is PRODUCED
 # ------------------------------------------------------------------------------------------------
 # conv + ReLU is one launch here, and the conv's backward zeroes its incoming gradient where the activation y was <= 0 by
-# reading y next to dy (the masked dgrad / wgrad variants: 7-11 % slower, a third tile for the wgrad's DMA stream).  Two
-# producers of such a gradient hold y in registers anyway -- the max-pool backward (y is the pool's input) and the fused
-# predictor + criterion kernel (y is its input x) -- and write the gradient already masked; the conv then runs its
-# unmasked kernels.  Protocol, opt-in like the skip fold (same context manager):
+# reading y next to dy (the masked dgrad / wgrad variants: 7-12 % slower, a third tile for the wgrad's DMA stream).  The
+# producers of such a gradient can apply the mask instead, each where y costs least:
+#   * the max-pool backward (y is the pool's input, in registers anyway) and the fused predictor + criterion kernel (y is its x);
+#   * the bilinear up-sampling backward (y is read at the LOW resolution, a quarter of the gradient it reduces);
+#   * the data gradient of the next conv of a conv -> ReLU -> conv chain (y is that conv's input; its tile is fetched under the
+#     last MFMA chunk of each output tile: ynet_conv2d_dgrad_relu);
+# the conv then runs its unmasked kernels.  Protocol, opt-in like the skip fold (same context manager):
 #   * _Conv2dFn.forward registers the address of every post-ReLU output it produces        (_relu_outputs)
 #   * a producer whose input is such a tensor masks its dx and registers (dx address -> y address, dx version)  (_premasked)
 #   * _Conv2dFn.backward drops its own mask when its dy is registered for ITS y and has not been written since
@@ -463,8 +474,8 @@ def _is_relu_output(t: torch.Tensor) -> bool:
 class fold_skip_gradients:
     """Context manager: inside it (forward AND the full backward of the same graph) the gradients of the encoder
     feature maps that feed a max-pool are added inside the pool's backward kernel instead of by autograd, and the
-    ReLU backward of a conv whose output gradient comes from a max-pool backward or from the fused predictor +
-    criterion is applied by that producer (see `_premasked`)."""
+    ReLU backward of a conv whose output gradient comes from a max-pool / up-sampling backward, from the fused predictor +
+    criterion or from the data gradient of a single-input conv is applied by that producer (see `_premasked`)."""
 
     def __enter__(self):
         global skip_fold, premask
@@ -577,7 +588,17 @@ class _Conv2dFn(torch.autograd.Function):
                     dsts.append((d_srcs[i].data_ptr(), c, c * H * W))
                 else:
                     dsts.append((None, c, 0))
-            conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False)
+            # the single input is itself a post-ReLU conv output that no pool folds: apply THAT layer's ReLU backward to the
+            # gradient produced here (see `_premasked`)
+            s0 = srcs[0]
+            emask = None
+            if (premask and ctx.n_src == 1 and need_src[0] and _is_relu_output(s0) and s0.is_contiguous() and s0.shape[0] == B
+                    and s0.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and not (skip_fold and _skip_entry(s0) is not None)
+                    and _lib().ynet_conv2d_dgrad_relu_supported(B, H, W, int(s0.shape[1]), int(k))):
+                emask = (s0.data_ptr(), s0.shape[1] * H * W)
+            conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_of=emask)
+            if emask is not None:
+                _premasked[d_srcs[0].data_ptr()] = (s0.data_ptr(), d_srcs[0]._version, tuple(d_srcs[0].shape))
             if skip_fold:
                 for i, s in enumerate(srcs):
                     if d_srcs[i] is None:
@@ -734,14 +755,22 @@ class _Upsample2xFn(torch.autograd.Function):
         lib = _lib()
         L.check(lib.ynet_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B * C, H, W, _stream()), lib)
         ctx.shape = (B, C, H, W)
+        # x is a post-ReLU conv output: this backward applies that ReLU's backward to the gradient it produces (`_premasked`)
+        ctx.premask = bool(premask and ctx.needs_input_grad[0] and _is_relu_output(x))
+        ctx.save_for_backward(x if ctx.premask else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         B, C, H, W = ctx.shape
+        (x,) = ctx.saved_tensors
         dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.float32)
         lib = _lib()
-        L.check(lib.ynet_upsample2x_bwd(dy.contiguous().data_ptr(), dx.data_ptr(), B * C, H, W, _stream()), lib)
+        if ctx.premask and premask and x is not None:
+            L.check(lib.ynet_upsample2x_bwd_relu(dy.contiguous().data_ptr(), dx.data_ptr(), x.data_ptr(), B * C, H, W, _stream()), lib)
+            _premasked[dx.data_ptr()] = (x.data_ptr(), dx._version, tuple(dx.shape))
+        else:
+            L.check(lib.ynet_upsample2x_bwd(dy.contiguous().data_ptr(), dx.data_ptr(), B * C, H, W, _stream()), lib)
         return dx
 
 

@@ -448,6 +448,74 @@ def test_relu_backward_applied_by_the_gradient_producers(dev):
     assert not ops._premasked and not ops._relu_outputs
 
 
+# B, H, W, channels of dy (the layer's cout), channels of dx (its cin), dy masked too
+DGRAD_RELU_CASES = [
+    (8, 128, 128, 32, 16, False),       # two-row tiles, one 16-channel tile per workgroup: mask inside the conv kernel
+    (8, 128, 128, 32, 32, True),        # ... with the consumer-side mask of dy on top (masked instantiation)
+    (8, 64, 128, 16, 64, False),        # four 16-channel tiles
+    (4, 64, 64, 64, 48, True),          # three tiles
+    (2, 16, 32, 8, 8, False),           # small map: the fall-back pass
+    (4, 16, 16, 64, 64, False),         # folded tiles, split channel loop: the mask is applied by the reduction
+    (3, 24, 40, 5, 7, True),            # ragged edges, register-staged kernel + fall-back pass
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_RELU_CASES, ids=[str(c) for c in DGRAD_RELU_CASES])
+def test_conv2d_dgrad_relu_writes_through_the_relu_backward_of_the_layer_below(dev, case):
+    """ynet_conv2d_dgrad_relu: dx = relu_of > 0 ? conv(dy [masked], flipped filter) : 0 -- the same values as the plain data
+    gradient with the mask applied afterwards (bit-identical: the arithmetic is the same), on every kernel family."""
+    ops = pkg("ops")
+    B, H, W, cout, cin, masked = case
+    dy, w = rnd(B, cout, H, W, seed=1).to(dev), rnd(cout, cin, 3, 3, seed=2, scale=0.2).to(dev)
+    act = torch.relu(rnd(B, cin, H, W, seed=3)).to(dev)        # the input of the forward conv = post-ReLU output of the layer below
+    y = torch.relu(rnd(B, cout, H, W, seed=4)).to(dev)
+    wp = ops.pack_weight(w, 1)
+    mask = (y.data_ptr(), cout * H * W) if masked else None
+    plain, got = torch.empty(B, cin, H, W, device=dev), torch.full((B, cin, H, W), float("nan"), device=dev)
+    ops.conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp, None, [(plain.data_ptr(), cin, cin * H * W)], B, H, W, 3, False)
+    ops.conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp, None, [(got.data_ptr(), cin, cin * H * W)], B, H, W, 3, False,
+                   relu_of=(act.data_ptr(), cin * H * W))
+    want = torch.where(act > 0, plain, torch.zeros_like(plain))
+    assert torch.equal(got, want), float((got - want).abs().max())
+    ref = F.conv_transpose2d((dy * (y > 0)) if masked else dy, w, padding=1) * (act > 0)
+    close(got, ref, rtol=1e-4, scale_rel=2e-6, msg="dgrad_relu vs torch")
+    # (the first three cases are the ones the conv kernel itself masks; the others take the reduction / the fall-back pass)
+    assert bool(ops._lib().ynet_conv2d_dgrad_relu_supported(B, H, W, cin, 3)) == (case in DGRAD_RELU_CASES[:3])
+
+
+def test_relu_backward_applied_by_upsampling_and_by_the_next_data_gradient(dev):
+    """conv0-ReLU -> conv1-ReLU -> bilinear x2 -> conv2 (no ReLU): conv1's output gradient comes from the up-sampling backward
+    (ynet_upsample2x_bwd_relu), conv0's from conv1's data gradient (ynet_conv2d_dgrad_relu); both then run unmasked dgrad /
+    wgrad kernels.  Same gradients as stock autograd, bit-identical to the consumer-side masks."""
+    ops = pkg("ops")
+    B, H, W = 8, 128, 128          # (large enough for the two-row tiles that mask inside the conv kernel)
+    x = rnd(B, 6, H, W, seed=1)
+    w0, w1, w2 = rnd(16, 6, 3, 3, seed=2, scale=0.2), rnd(16, 16, 3, 3, seed=3, scale=0.2), rnd(4, 16, 3, 3, seed=4, scale=0.2)
+    xc, w0c, w1c = x.clone().requires_grad_(True), w0.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+    g = F.relu(F.conv2d(F.relu(F.conv2d(xc, w0c, padding=1)), w1c, padding=1))
+    F.conv2d(F.interpolate(g, scale_factor=2, mode="bilinear", align_corners=False), w2, padding=1).square().sum().backward()
+    got = {}
+    for on in (True, False):
+        old = ops._premask_allowed
+        ops._premask_allowed = on
+        ops.premask_stats["unmasked_backwards"] = 0
+        try:
+            with ops.fold_skip_gradients():
+                xd, w0d, w1d = x.to(dev).requires_grad_(True), w0.to(dev).requires_grad_(True), w1.to(dev).requires_grad_(True)
+                gd = ops.conv2d(ops.conv2d(xd, w0d, None, True, {}), w1d, None, True, {})
+                ops.conv2d(ops.upsample2x(gd), w2.to(dev), None, False, {}).square().sum().backward()
+        finally:
+            ops._premask_allowed = old
+        assert ops.premask_stats["unmasked_backwards"] == (2 if on else 0)
+        assert not ops._premasked
+        close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx (premask={on})")
+        close(w0d.grad, w0c.grad, rtol=1e-4, scale_rel=1e-5, msg=f"dW0 (premask={on})")
+        close(w1d.grad, w1c.grad, rtol=1e-4, scale_rel=1e-5, msg=f"dW1 (premask={on})")
+        got[on] = (xd.grad.clone(), w0d.grad.clone(), w1d.grad.clone())
+    for a, b in zip(got[True], got[False]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("cin,cout,relu", [(32, 12, False), (12, 32, False), (32, 30, True), (7, 16, True), (32, 33, False)])
 def test_conv1x1_predictor_kernels(dev, cin, cout, relu):
     """The streaming 1x1 kernel (Cout <= 32: 16 x 4-pixel and 32 x 2-pixel variants) and the MFMA path beyond it."""
@@ -477,6 +545,22 @@ def test_upsample2x(dev, shape):
     yd.backward(gy.to(dev))
     close(yd, y, rtol=1e-6, atol=1e-6, msg="up fwd")
     close(xd.grad, xc.grad, rtol=1e-5, atol=1e-5, msg="up bwd")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 16), (1, 4, 5, 3), (2, 16, 32, 32), (1, 2, 3, 6), (1, 3, 7, 12), (1, 2, 64, 64), (1, 1, 68, 62), (1, 2, 6, 10)])
+def test_upsample2x_bwd_relu(dev, shape):
+    """ynet_upsample2x_bwd_relu = ynet_upsample2x_bwd followed by the ReLU backward of the up-sampled activation (every kernel
+    variant: 4-row, 2-row, quad, scalar), bit-identical to masking afterwards."""
+    ops, L = pkg("ops"), pkg("_lib")
+    lib = ops._lib()
+    B, C, H, W = shape
+    gy = rnd(B, C, 2 * H, 2 * W, seed=2).to(dev)
+    act = torch.relu(rnd(B, C, H, W, seed=3)).to(dev)
+    plain, got = torch.empty(B, C, H, W, device=dev), torch.full((B, C, H, W), float("nan"), device=dev)
+    L.check(lib.ynet_upsample2x_bwd(gy.data_ptr(), plain.data_ptr(), B * C, H, W, ops._stream()), lib)
+    L.check(lib.ynet_upsample2x_bwd_relu(gy.data_ptr(), got.data_ptr(), act.data_ptr(), B * C, H, W, ops._stream()), lib)
+    torch.cuda.synchronize()
+    assert torch.equal(got, torch.where(act > 0, plain, torch.zeros_like(plain)))
 
 
 def test_avgpool_pyramid(dev):

@@ -60,6 +60,11 @@ int main() {
     for (int b : {1, 32, 256})
         for (int hw : {8, 32, 64, 256})
             for (int cout : {12, 32, 48, 64}) acc += ynet_conv2d_add_supported(b, hw, hw, cout, 3);
+    EXPECT_REJECT(ynet_conv2d_dgrad_relu(cfp, 4, 64, nullptr, 0, cfp, fp, 4, 64, nullptr, 64, 1, 4, 4, 3, nullptr, 0, nullptr));     // no activation
+    EXPECT_REJECT(ynet_conv2d_dgrad_relu(cfp, 4, 64, nullptr, 0, cfp, fp, 4, 64, cfp + 1, 64, 1, 4, 4, 3, nullptr, 0, nullptr));     // unaligned activation
+    for (int b : {1, 32, 256})
+        for (int hw : {8, 32, 64, 256})
+            for (int c : {12, 32, 48, 64}) acc += ynet_conv2d_dgrad_relu_supported(b, hw, hw, c, 3) + ynet_conv2d_dgrad_relu_supported(b, hw, hw + 2, c, 3);
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 0, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 7, cfp, 4, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_lora_compose(nullptr, cfp, cfp, 1.f, fp, 4, 4, 3, 1, nullptr));
@@ -79,6 +84,7 @@ int main() {
     EXPECT_REJECT(ynet_maxpool2_bwd(cfp, cfp, nullptr, 1, 4, 4, nullptr));
     EXPECT_REJECT(ynet_upsample2x_fwd(cfp, nullptr, 1, 2, 2, nullptr));
     EXPECT_REJECT(ynet_upsample2x_bwd(nullptr, fp, 1, 2, 2, nullptr));
+    EXPECT_REJECT(ynet_upsample2x_bwd_relu(cfp, fp, nullptr, 1, 2, 2, nullptr));
     EXPECT_REJECT(ynet_avgpool_pyramid(cfp, dsts, 9, 1, 32, 32, nullptr));
     EXPECT_REJECT(ynet_bce_logits_fwd(cfp, cfp, 0, fp, fp, nullptr));
     EXPECT_REJECT(ynet_bce_logits_fwd_grad(cfp, nullptr, 4, 1.f, fp, fp, fp, nullptr));

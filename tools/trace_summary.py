@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """On-box summary of a rocprofv3 --kernel-trace run (rocpd SQLite database or kernel_trace CSV):
   <out>_kernel_stats.csv   per-kernel calls / total / average / min / max (the --stats table)
-  <out>_timeline.json      busy time (sum of kernel durations) against the wall time from the first kernel start to the
-                           last kernel end, over the whole run and over its last `--tail-frac` (the timed steps), plus the
-                           gap histogram between consecutive kernels
+  <out>_timeline.json      busy time (sum of kernel durations; > wall when graph branches overlap) and covered time (union of the
+                           kernel intervals) against the wall time from the first kernel start to the last kernel end, over
+                           the whole run and over its last `--tail-frac` (the timed steps), plus the histogram of the gaps
+                           (time with no kernel running)
 usage: trace_summary.py <dir with the rocprofv3 output> <out prefix> [--tail-frac 0.5]"""
 import csv
 import glob
@@ -50,12 +51,20 @@ def main():
     def span(rs):
         busy = sum(b - a for _, a, b in rs)
         wall = max(b for _, _, b in rs) - rs[0][1]
-        gaps = [max(0, rs[i + 1][1] - rs[i][2]) for i in range(len(rs) - 1)]
+        # gaps of the UNION of the kernel intervals (kernels of parallel graph branches overlap: a gap is time with NO kernel running)
+        gaps, covered, reach = [], 0, rs[0][1]
+        for _, a, b in rs:
+            if a > reach:
+                gaps.append(a - reach)
+                covered += 0
+            covered += max(0, b - max(a, reach))
+            reach = max(reach, b)
         hist = {"<1us": 0, "1-2us": 0, "2-5us": 0, "5-10us": 0, "10-50us": 0, ">50us": 0}
         for g in gaps:
             k = "<1us" if g < 1e3 else "1-2us" if g < 2e3 else "2-5us" if g < 5e3 else "5-10us" if g < 1e4 else "10-50us" if g < 5e4 else ">50us"
             hist[k] += 1
         return {"kernels": len(rs), "busy_ms": busy / 1e6, "wall_ms": wall / 1e6, "busy_over_wall": busy / wall,
+                "covered_ms": covered / 1e6, "covered_over_wall": covered / wall,
                 "gap_ms_total": sum(gaps) / 1e6, "gap_us_median": statistics.median(gaps) / 1e3 if gaps else 0, "gap_hist": hist}
     if "--dump" in sys.argv:        # timeline of the last `--dump N` kernels: start offset, duration, concurrency
         k = int(sys.argv[sys.argv.index("--dump") + 1])
