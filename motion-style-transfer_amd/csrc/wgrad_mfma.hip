@@ -19,6 +19,7 @@
 // Both split the pixels over `nsplit` workgroups and reduce the partials with reduce_partials_kernel in a fixed
 // order: bitwise reproducible, no float atomics.
 #include "ynet_common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -33,6 +34,8 @@ struct WgradArgs {
     float* partial_b;         // [nsplit][cout] or NULL
     int B, H, W, cout;
     int tiles_x, tiles_y, ntiles, nsplit, co_blks, ci_blks;
+    int seg, nseg_y, nsegs;   // wgrad_roll_kernel: two-row steps per segment, segments per strip, segments in all
+    int debug;                // timing ablations (YNET_WGRAD_DEBUG; results are wrong): 1 no DMA after a segment's start, 2 no MFMA loop
 #ifdef YNET_WG_PROFILE
     unsigned long long* prof;      // development build: per-phase cycle sums
 #endif
@@ -685,6 +688,461 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs a) {
     }
 }
 
+// ================================================================================================
+// Rolling-row generation of the 3x3 filter gradient (maps of at least a few dozen rows, W % 32 == 0, H % 2 == 0).
+// wgrad_dma_kernel is bound by its DMA instruction stream (a buffer_load ... lds costs the issuing wave 50-130 cycles; 9
+// (12 masked) of them per 144 MFMAs), and two thirds of those fetch the x tile: 4 rows for 2 rows of pixels.  Here a
+// workgroup walks DOWN a 32-column strip of one image, two rows per step, and keeps the x rows it has in LDS: a ring of
+// three row PAIRS (pair m = image rows 2m - 1, 2m; the tile of rows 2j, 2j + 1 needs pairs j and j + 1, pair j + 2 arrives
+// meanwhile) -- one pair = 3 DMA instructions per thread and step instead of 6.  Layout of a pair: [row][channel][44 floats]
+// (10 data quads + 1 pad quad), so that a pair is ONE contiguous LDS range (the DMA writes linearly in the lane index) and
+// the channel stride is 44 = 12 mod 32 floats: the 16 channels x 4 consecutive floats of an 8-byte operand read fall on 64
+// distinct banks.  Strips are cut into segments of `seg` steps (work items for the persistent workgroups); a segment
+// starts with two pairs.  Operand mapping, accumulators, reduction and output as in wgrad_dma_kernel.
+// ================================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (inline asm: hipcc fuses 8-byte reads off one base into ds_read2_b64, which is banked like two 4-byte reads and takes 8 LDS
+// cycles; these reads are outside the compiler's lgkmcnt tracking and an explicit s_waitcnt lgkmcnt(0) closes them)
+template <int OFF>
+__device__ __forceinline__ void wg_ld2(f32x2& v, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+
+template <bool MASK>
+struct WgRollCfg {
+    static constexpr int TW = 32, XCS = 44, XRS = 32 * XCS, XPS = 2 * XRS, XRING = 3 * XPS;
+    static constexpr int PQ = 2 * 32 * 11;                    // quads of a pair image
+    static constexpr int XI = (PQ + 255) / 256;               // = 3 (the third by 192 threads)
+    static constexpr int DDATA = 2 * TW / 4, DQ = (DDATA + 1 + 6) / 8 * 8 + 1, DCH = DQ * 4;
+    static constexpr int DS = 32 * DCH + 128, DBUF = DS * (MASK ? 2 : 1);
+    static constexpr int DI = (32 * DQ + 255) / 256;
+    static constexpr int LDS_FLOATS = XRING + 2 * DBUF, LDS_BYTES = LDS_FLOATS * 4;
+    static constexpr int NGRP = 8;
+    static_assert(DCH % 32 == 4 && (XCS * 4) % 16 == 0, "operand strides");
+    static_assert(3 * 37 * 64 <= LDS_FLOATS, "cross-wave reduction scratch fits");
+};
+
+template <bool MASK>
+__global__ __launch_bounds__(256, MASK ? 2 : 3) void wgrad_roll_kernel(const WgradArgs a) {
+    using C = WgRollCfg<MASK>;
+    constexpr int TW = C::TW, XCS = C::XCS, XRS = C::XRS, XPS = C::XPS, DQ = C::DQ, DCH = C::DCH, XI = C::XI, DI = C::DI, KK = 9;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto ds_of = [&](int b) { return smem + C::XRING + b * C::DBUF; };
+    auto ms_of = [&](int b) { return smem + C::XRING + b * C::DBUF + C::DS; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    int bid = blockIdx.x;
+    const int cib = bid % a.ci_blks;
+    bid /= a.ci_blks;
+    const int cob = bid % a.co_blks;
+    const int split = bid / a.co_blks;
+    const int H = a.H, W = a.W;
+    const int HW = __builtin_amdgcn_readfirstlane(H * W);
+    const unsigned plane_bytes = (unsigned)HW * 4u;
+    const int ci0 = cib * 32, co0 = cob * 32;
+    const int ncib = min(32, a.cin - ci0), nco = min(32, a.cout - co0);
+    const bool want_bias = (a.partial_b != nullptr) && cib == 0;
+    const int cbN = nco > 16 ? 2 : 1, ibN = ncib > 16 ? 2 : 1, rpN = 4 / (cbN * ibN);
+    const int cb = wave % cbN, ib = (wave / cbN) % ibN, rp = wave / (cbN * ibN);
+
+    // ---- x pair DMA: LDS quad q = tid + 256 k  ->  (row q / 352, channel (q % 352) / 11, quad q % 11)
+    int xsrc[XI], xrow[XI], xcol[XI];   // source of the quad's channel (-1: pad quad / no channel), pair row, first column relative to x0
+    unsigned xcoff[XI];                 // byte offset of the channel's plane inside that source's image
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const int q = tid + k * 256;
+        const int row = q / 352, within = q - row * 352, ch = within / 11, u = within - ch * 11;
+        xrow[k] = row;
+        xcol[k] = 4 * u - 4;
+        int c = ci0 + ch, sid = -1;
+        unsigned off = 0;
+        if (q < C::PQ && u < 10 && ch < ncib) {
+#pragma unroll
+            for (int s = 0; s < YNET_MAX_SRC; ++s) {
+                if (sid < 0 && s < a.nsrc) {
+                    if (c < a.src[s].c) {
+                        sid = s;
+                        off = (unsigned)c * plane_bytes;
+                    } else {
+                        c -= a.src[s].c;
+                    }
+                }
+            }
+        }
+        xsrc[k] = sid;
+        xcoff[k] = off;
+    }
+    // static per-lane offsets relative to (first row of the pair, x0 - 4): interior / first / last / only tile column
+    unsigned xs_in[XI], xs_l[XI], xs_r[XI], xs_lr[XI];
+#pragma unroll
+    for (int k = 0; k < XI; ++k) {
+        const bool ok = xsrc[k] >= 0;
+        const unsigned in = ok ? xcoff[k] + (unsigned)(xrow[k] * W + xcol[k] + 4) * 4u : 0x80000000u;
+        const bool lh = xcol[k] < 0, rh = xcol[k] >= TW;
+        xs_in[k] = in;
+        xs_l[k] = lh ? 0x80000000u : in;
+        xs_r[k] = rh ? 0x80000000u : in;
+        xs_lr[k] = (lh || rh) ? 0x80000000u : in;
+    }
+    unsigned dstat[DI];                 // dy / mask tile: as in wgrad_dma_kernel (2 rows x 32 pixels per channel, stride DCH)
+#pragma unroll
+    for (int k = 0; k < DI; ++k) {
+        const int q = tid + k * 256;
+        const int ch = q / DQ, within = q - ch * DQ;
+        const bool ok = q < 32 * DQ && within < C::DDATA;
+        dstat[k] = ok ? (unsigned)ch * plane_bytes + (unsigned)((within / (TW / 4)) * W + (within % (TW / 4)) * 4) * 4u : 0x80000000u;
+    }
+
+    typedef const __attribute__((address_space(4))) WgradArgs* wg_kargs_t;
+    // rows 2 m - 1, 2 m of image b, columns x0 - 4 .. x0 + 35 -> ring slot `slot`
+    auto issue_pair = [&](int b, int x0, int m, int slot) {
+        wg_kargs_t ka = (wg_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        float* xs = smem + slot * XPS;
+        const int y0 = 2 * m - 1;
+        const bool at_left = x0 == 0, at_right = x0 + TW >= W;
+        unsigned xo[XI], xso;
+        if (y0 >= 0 && y0 + 1 < H && y0 * W + x0 - 4 >= 0) {          // both rows inside the image: static offsets + a scalar offset
+            xso = (unsigned)(y0 * W + x0 - 4) * 4u;
+            if (!at_left && !at_right) {
+#pragma unroll
+                for (int k = 0; k < XI; ++k) xo[k] = xs_in[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < XI; ++k) {
+                    const unsigned l = at_right ? xs_lr[k] : xs_l[k];
+                    xo[k] = at_left ? l : xs_r[k];
+                }
+            }
+        } else {                                                       // first / last pair of the image (a row outside)
+            xso = 0u;
+#pragma unroll
+            for (int k = 0; k < XI; ++k) {
+                const int gy = y0 + xrow[k], gx = x0 + xcol[k];
+                const bool ok = xsrc[k] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                xo[k] = ok ? xcoff[k] + (unsigned)(gy * W + gx) * 4u : 0x80000000u;
+            }
+        }
+        const int nsrc = ka->nsrc;
+        if (nsrc == 1) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(ka->src[0].p + (long long)b * ka->src[0].bs), 0, (unsigned)ka->src[0].c * plane_bytes, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < XI - 1; ++k) wg_dma16s(r, xs + (k * 256 + wave * 64) * 4, xo[k], xso);
+            if (wave < 3) wg_dma16s(r, xs + ((XI - 1) * 256 + wave * 64) * 4, xo[XI - 1], xso);      // quads 512 .. 703
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < nsrc; ++s) {
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(ka->src[s].p + (long long)b * ka->src[s].bs), 0, (unsigned)ka->src[s].c * plane_bytes, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < XI; ++k)
+                    if (xsrc[k] == s) wg_dma16s(r, xs + (k * 256 + wave * 64) * 4, xo[k], xso);
+            }
+        }
+    };
+    // rows 2 j, 2 j + 1 of dy (and of the activation) -> buffer `buf`
+    auto issue_dy = [&](int b, int x0, int j, int buf) {
+        wg_kargs_t ka = (wg_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        constexpr int DFULL = 32 * DQ / 256;
+        static_assert(32 * DQ - DFULL * 256 <= 64, "the partial instruction fits one wave");
+        const unsigned dso = (unsigned)(2 * j * W + x0) * 4u;
+        {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(ka->dy + (long long)b * ka->dy_bs + (long long)co0 * HW), 0, (unsigned)nco * plane_bytes, 0x00020000);
+            float* ds = ds_of(buf);
+#pragma unroll
+            for (int k = 0; k < DFULL; ++k) wg_dma16s(r, ds + (k * 256 + wave * 64) * 4, dstat[k], dso);
+            if (DI > DFULL && wave == 0) wg_dma16s(r, ds + (DFULL * 256) * 4, dstat[DI - 1], dso);
+        }
+        if (MASK) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(ka->mask + (long long)b * ka->mask_bs + (long long)co0 * HW), 0, (unsigned)nco * plane_bytes, 0x00020000);
+            float* ms = ms_of(buf);
+#pragma unroll
+            for (int k = 0; k < DFULL; ++k) wg_dma16s(r, ms + (k * 256 + wave * 64) * 4, dstat[k], dso);
+            if (DI > DFULL && wave == 0) wg_dma16s(r, ms + (DFULL * 256) * 4, dstat[DI - 1], dso);
+        }
+    };
+
+    f32x4 acc[KK];
+#pragma unroll
+    for (int i = 0; i < KK; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // The K-step groups of a tile are unrolled with every LDS offset an immediate (group column, filter row, pair Q0..Q2): the
+    // loop then holds 18 MFMAs + 10 (11) reads + ONE vector-ALU instruction (the packed bias sum) per group.  A vector-ALU
+    // instruction of a wave whose SIMD neighbour streams MFMAs takes 40-70 cycles (tools/valu_under_mfma.hip); the rolled
+    // loop's 9 per group (addresses of a run-time group index, scalar-style sums) held it at 0.73 of the MFMA rate with no
+    // DMA in flight at all (YNET_WGRAD_DEBUG=1).  Per tile: 4 row addresses + 1 dy address.
+    // A wave takes the groups rp, rp + RPN, ...: rp only shifts the column (32 bytes), which goes into the address registers.
+    const unsigned x_lane = (unsigned)(size_t)(wg_lds_ptr_t)(smem + (ib * 16 + r16) * XCS + 2 * kq + 2) + 32u * rp;
+    const unsigned d_lane = (unsigned)(size_t)(wg_lds_ptr_t)(smem + C::XRING + (cb * 16 + r16) * DCH + 2 * kq) + 32u * rp;
+    f32x2 bsum2 = f32x2{0.f, 0.f};
+    // tile of rows 2 j, 2 j + 1: x rows 2 j - 1 .. 2 j + 2 = rows 0, 1 of pair slot sa and of pair slot sb (byte offsets)
+    auto compute = [&](auto rpn_tag, int buf, unsigned sa, unsigned sb) {
+        constexpr int RPN = decltype(rpn_tag)::value, NG = C::NGRP / RPN;
+        const unsigned ab = d_lane + (unsigned)(buf * C::DBUF * 4), mb = ab + C::DS * 4;
+        unsigned pa[4];
+        pa[0] = x_lane + sa;
+        pa[1] = x_lane + sa + XRS * 4;
+        pa[2] = x_lane + sb;
+        pa[3] = x_lane + sb + XRS * 4;
+        f32x2 av[2], mv[2], q[2][KK];
+        mv[0] = mv[1] = f32x2{1.f, 1.f};
+        auto rd = [&](auto g_tag, f32x2& a_, f32x2& m_, f32x2* q_) {
+            constexpr int G = decltype(g_tag)::value, r = G >> 2, col = (G & 3) * 32;
+            wg_ld2<32 * G>(a_, ab);
+            if (MASK) wg_ld2<32 * G>(m_, mb);
+            wg_ld2<col>(q_[0], pa[r]);
+            wg_ld2<col + 8>(q_[1], pa[r]);
+            wg_ld2<col + 16>(q_[2], pa[r]);
+            wg_ld2<col>(q_[3], pa[r + 1]);
+            wg_ld2<col + 8>(q_[4], pa[r + 1]);
+            wg_ld2<col + 16>(q_[5], pa[r + 1]);
+            wg_ld2<col>(q_[6], pa[r + 2]);
+            wg_ld2<col + 8>(q_[7], pa[r + 2]);
+            wg_ld2<col + 16>(q_[8], pa[r + 2]);
+        };
+        auto lds_wait = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+        auto select = [&](f32x2& a_, const f32x2& m_) {
+            if (MASK) {
+                a_.x = m_.x > 0.f ? a_.x : 0.f;
+                a_.y = m_.y > 0.f ? a_.y : 0.f;
+            }
+        };
+        auto mfmas = [&](const f32x2& a_c, const f32x2* q_c) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.x, q_c[ky * 3 + 0].y, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.x, q_c[ky * 3 + 1].x, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.x, q_c[ky * 3 + 1].y, acc[ky * 3 + 2], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.y, q_c[ky * 3 + 1].x, acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.y, q_c[ky * 3 + 1].y, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_c.y, q_c[ky * 3 + 2].x, acc[ky * 3 + 2], 0, 0, 0);
+            }
+        };
+        rd(std::integral_constant<int, 0>{}, av[0], mv[0], q[0]);
+        lds_wait();
+        select(av[0], mv[0]);
+        // group i: queue the reads of group i + 1 into the other register set, then the 18 MFMAs of group i
+        auto groups = [&](auto self, auto i_tag) -> void {
+            constexpr int I = decltype(i_tag)::value, cur = I & 1, nxt = cur ^ 1;
+            if constexpr (I + 1 < NG) rd(std::integral_constant<int, (I + 1) * RPN>{}, av[nxt], mv[nxt], q[nxt]);
+            __builtin_amdgcn_sched_barrier(0);      // nothing moves across: reads of the next group, THEN the MFMAs of this one
+            mfmas(av[cur], q[cur]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I + 1 < NG) {
+                lds_wait();
+                select(av[nxt], mv[nxt]);           // VALU work on the fresh reads goes behind the MFMAs
+            }
+            bsum2 += av[cur];                        // (v_pk_add_f32)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I + 1 < NG) self(self, std::integral_constant<int, I + 1>{});
+        };
+        groups(groups, std::integral_constant<int, 0>{});
+    };
+
+    // ---- segments split, split + nsplit, ...: (image, strip, run of `seg` two-row steps)
+    const int seg = a.seg, nseg_y = a.nseg_y, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
+    bool first = true;
+    for (int sidx = split; sidx < a.nsegs; sidx += a.nsplit) {
+        const int xt = sidx % tiles_x, t2 = sidx / tiles_x;
+        const int ys = t2 % nseg_y, b = t2 / nseg_y;
+        const int x0 = xt * TW, j0 = ys * seg, j1 = min(j0 + seg, tiles_y);
+        if (!first) __syncthreads();       // every wave is done with the previous segment's rows and dy tiles
+        first = false;
+        issue_pair(b, x0, j0, 0);
+        issue_pair(b, x0, j0 + 1, 1);
+        issue_dy(b, x0, j0, 0);
+        int sj = 0, buf = 0;
+        for (int j = j0; j < j1; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int s1 = sj == 2 ? 0 : sj + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+            if (j + 1 < j1 && !(a.debug & 1)) {
+                issue_pair(b, x0, j + 2, s2);
+                issue_dy(b, x0, j + 1, buf ^ 1);
+            }
+            if (!(a.debug & 2)) {
+                const unsigned sa = (unsigned)(sj * XPS * 4), sb = (unsigned)(s1 * XPS * 4);
+                if (rpN == 1) compute(std::integral_constant<int, 1>{}, buf, sa, sb);
+                else if (rpN == 2) compute(std::integral_constant<int, 2>{}, buf, sa, sb);
+                else compute(std::integral_constant<int, 4>{}, buf, sa, sb);
+            }
+            buf ^= 1;
+            sj = s1;
+        }
+    }
+
+    // ---- K-step residues of a partial block: waves rp = 1.. hand their sums to wave rp = 0 (fixed order)
+    float bsum = bsum2.x + bsum2.y;
+    if (rpN > 1) {
+        float* red = smem;
+        __syncthreads();
+        if (rp > 0) {
+            float* w = red + (wave - cbN * ibN) * 37 * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < KK; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[(t * 4 + e) * 64] = acc[t][e];
+            w[36 * 64] = bsum2.x + bsum2.y;
+        }
+        __syncthreads();
+        if (rp == 0) {
+            for (int q = 1; q < rpN; ++q) {
+                const float* w = red + (cb + cbN * (ib + ibN * q) - cbN * ibN) * 37 * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < KK; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][e] += w[(t * 4 + e) * 64];
+                bsum += w[36 * 64];
+            }
+        }
+    }
+    if (rp == 0) {
+        float* pw = a.partial_w + (long long)split * a.cout * a.cin * KK;
+        const int ci = ib * 16 + r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = cb * 16 + 4 * kq + e;
+            if (co < nco && ci < ncib) {
+#pragma unroll
+                for (int t = 0; t < KK; ++t) pw[((long long)(co0 + co) * a.cin + ci0 + ci) * KK + t] = acc[t][e];
+            }
+        }
+        if (want_bias && ib == 0) {
+            float v = bsum;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int co = cb * 16 + r16;
+            if (kq == 0 && co < nco) a.partial_b[(long long)split * a.cout + co0 + co] = v;
+        }
+    }
+}
+
+// ================================================================================================
+// Filter / bias gradient of the 1x1 predictors (32 -> pred_len; models/ynet.py:469): 0.75 .. 1.9 FLOP per byte, HBM-bound.
+// A wave walks 16-pixel chunks: lane (r16, kq) reads ONE 16-byte quad per operand row -- pixels 4 kq .. 4 kq + 3 of the chunk
+// for channel r16 (dy) / r16, r16 + 16 (x) -- and element e of the three quads is K-step e of v_mfma_f32_16x16x4_f32 (K-slot kq
+// = pixel 4 kq + e for both operands), so nothing goes through LDS and every byte is read once; the next chunk's quads are in
+// flight under the 8 (16) MFMAs of this one.  The four waves of a workgroup take consecutive chunks (256 contiguous bytes
+// per channel row) and add their tiles through LDS in wave order; workgroup partials -> reduce_partials_kernel.
+// (wgrad_mfma_kernel<1>, which stages tiles through LDS like the 5x5 case, ran at 1.9 TB/s.)
+// ================================================================================================
+struct Wg1x1Args {
+    const float* x;
+    long long x_bs;
+    const float* dy;
+    long long dy_bs;
+    float* partial_w;      // [gridDim.x][cout * 32]
+    float* partial_b;      // [gridDim.x][cout] or NULL
+    int B, cout, HW, hw16;
+    long long chunks;      // B * HW / 16
+};
+
+template <int CT>
+__global__ __launch_bounds__(256) void wgrad1x1_stream_kernel(const Wg1x1Args a) {
+    __shared__ float red[3][CT * 2 * 4 + CT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
+    f32x4 acc[CT][2];
+    float bs[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bs[t] = 0.f;
+    }
+    const long long stride = (long long)gridDim.x * 4;
+    long long c = (long long)blockIdx.x * 4 + wave;
+    int b = (int)(c / a.hw16), pc = (int)(c - (long long)b * a.hw16);      // image, chunk inside the image
+    const int sb = (int)(stride / a.hw16), sp = (int)(stride - (long long)sb * a.hw16);
+    const long long HW = a.HW;
+    auto load = [&](int bb, int pp, f32x4& xa, f32x4& xb, f32x4* d) {
+        const float* xp = a.x + (long long)bb * a.x_bs + (long long)r16 * HW + pp * 16 + 4 * kq;
+        xa = *reinterpret_cast<const f32x4*>(xp);
+        xb = *reinterpret_cast<const f32x4*>(xp + 16 * HW);
+        const float* dp = a.dy + (long long)bb * a.dy_bs + (long long)r16 * HW + pp * 16 + 4 * kq;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+            d[t] = (t * 16 + r16 < a.cout) ? *reinterpret_cast<const f32x4*>(dp + (long long)t * 16 * HW) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 xa, xb, d[CT], nxa, nxb, nd[CT];
+    if (c < a.chunks) load(b, pc, xa, xb, d);
+    while (c < a.chunks) {
+        const long long cn = c + stride;
+        int bn = b + sb, pn = pc + sp;
+        if (pn >= a.hw16) {
+            pn -= a.hw16;
+            ++bn;
+        }
+        if (cn < a.chunks) load(bn, pn, nxa, nxb, nd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[t][e], xa[e], acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[t][e], xb[e], acc[t][1], 0, 0, 0);
+                bs[t] += d[t][e];
+            }
+        xa = nxa;
+        xb = nxb;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) d[t] = nd[t];
+        c = cn;
+        b = bn;
+        pc = pn;
+    }
+    // waves 1..3 -> wave 0, in order
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave - 1][(t * 2 + h) * 4 + e][lane] = acc[t][h][e];
+            red[wave - 1][CT * 8 + t][lane] = bs[t];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < 3; ++w) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][h][e] += red[w][(t * 2 + h) * 4 + e][lane];
+                bs[t] += red[w][CT * 8 + t][lane];
+            }
+        }
+        float* pw = a.partial_w + (long long)blockIdx.x * a.cout * 32;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = t * 16 + 4 * kq + e;      // D[i][j]: row i = 4 kq + e in register e of lane (j = r16, kq)
+                if (co < a.cout) {
+                    pw[co * 32 + r16] = acc[t][0][e];
+                    pw[co * 32 + 16 + r16] = acc[t][1][e];
+                }
+            }
+        if (a.partial_b != nullptr) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                float v = bs[t];                         // lane (r16, kq) summed the pixels 4 kq .. 4 kq + 3 of channel 16 t + r16
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (kq == 0 && t * 16 + r16 < a.cout) a.partial_b[(long long)blockIdx.x * a.cout + t * 16 + r16] = v;
+            }
+        }
+    }
+}
+
 // out[i] = sum_s partial[s][i] in a fixed order: thread (o, g) of a block sums the splits s = g mod 8 of output
 // base + o (four independent chains, 128-byte coalesced rows), the eight g are then added in order through LDS.
 __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ partial, float* __restrict__ out, long long n,
@@ -810,6 +1268,109 @@ static int launch_wgrad_dma(WgradArgs& a, float* dw, float* db, hipStream_t st) 
     return ynet_check_launch("conv2d_wgrad(reduce)");
 }
 
+// 1x1, one 32-channel source, <= 32 output channels, no mask, whole 16-pixel chunks, 16-byte aligned planes
+static const int WG1X1_BLOCKS = 512;
+static bool wgrad1x1_stream_ok(const WgradArgs& a, int K) {
+    static const int on = getenv("YNET_WGRAD_1X1_STREAM") ? atoi(getenv("YNET_WGRAD_1X1_STREAM")) : 1;
+    return on && K == 1 && a.nsrc == 1 && a.cin == 32 && a.cout <= 32 && a.mask == nullptr && ((long long)a.H * a.W) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(a.src[0].p) & 15) == 0 && (a.src[0].bs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0 && (a.dy_bs & 3) == 0;
+}
+
+static int launch_wgrad1x1_stream(WgradArgs& a, float* dw, float* db, float* workspace, hipStream_t st) {
+    Wg1x1Args k{};
+    k.x = a.src[0].p;
+    k.x_bs = a.src[0].bs;
+    k.dy = a.dy;
+    k.dy_bs = a.dy_bs;
+    k.B = a.B;
+    k.cout = a.cout;
+    k.HW = a.H * a.W;
+    k.hw16 = k.HW / 16;
+    k.chunks = (long long)a.B * k.hw16;
+    int grid = WG1X1_BLOCKS;
+    if ((long long)grid * 4 > k.chunks) grid = (int)((k.chunks + 3) / 4);
+    a.nsplit = grid;
+    a.partial_w = k.partial_w = workspace;
+    a.partial_b = k.partial_b = db ? workspace + (long long)grid * a.cout * 32 : nullptr;
+    if (a.cout <= 16) hipLaunchKernelGGL(wgrad1x1_stream_kernel<1>, dim3(grid), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(wgrad1x1_stream_kernel<2>, dim3(grid), dim3(256), 0, st, k);
+    int rc = ynet_check_launch("conv2d_wgrad(1x1)");
+    if (rc) return rc;
+    launch_reduce_partials(a, dw, db, (long long)a.cout * 32, st);
+    return ynet_check_launch("conv2d_wgrad(reduce)");
+}
+
+template <bool MASK>
+static int launch_wgrad_roll(WgradArgs& a, float* dw, float* db, hipStream_t st) {
+    using C = WgRollCfg<MASK>;
+    static bool attr_dev[YNET_MAX_DEV] = {false};
+    bool& attr_set = attr_dev[ynet_device_slot()];
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_roll_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+        if (getenv("YNET_DEBUG_OCC")) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_roll_kernel<MASK>, 256, C::LDS_BYTES);
+            fprintf(stderr, "wgrad_roll_kernel<%d>: %d bytes of LDS, %d workgroups per CU\n", (int)MASK, C::LDS_BYTES, per_cu);
+        }
+    }
+    const long long nblk = (long long)a.nsplit * a.co_blks * a.ci_blks;
+    static const bool timing = getenv("YNET_WGRAD_TIME") != nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, st);
+    }
+    hipLaunchKernelGGL((wgrad_roll_kernel<MASK>), dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, st, a);
+    if (timing) {
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "wgrad_roll_kernel<%d> B %d %dx%d cin %d cout %d nsplit %d segments %d x %d steps, blocks %lld: %.1f us  %.1f TFLOP/s\n", (int)MASK, a.B,
+                a.H, a.W, a.cin, a.cout, a.nsplit, a.nsegs, a.seg, nblk, ms * 1e3f, 2.0 * a.B * a.H * a.W * (double)a.cin * a.cout * 9 / (ms * 1e9));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    int rc = ynet_check_launch("conv2d_wgrad");
+    if (rc) return rc;
+    launch_reduce_partials(a, dw, db, (long long)a.cout * a.cin * 9, st);
+    return ynet_check_launch("conv2d_wgrad(reduce)");
+}
+
+// Rolling-row kernel: W % 32 == 0, H even, and enough strip segments of >= 4 two-row steps for the persistent workgroups
+// (16 / 8 / 4 steps: the longest that still gives three segments per workgroup; a segment start costs one extra row pair)
+static bool wgrad_roll_plan(WgradArgs& a) {
+    static const int on = getenv("YNET_WGRAD_ROLL") ? atoi(getenv("YNET_WGRAD_ROLL")) : 1;
+    static const int forced = getenv("YNET_WGRAD_SEG") ? atoi(getenv("YNET_WGRAD_SEG")) : 0;
+    if (!on || (a.W % 32) != 0 || (a.H & 1) != 0) return false;
+    const int tiles_y = a.H / 2, strips = a.B * (a.W / 32);
+    // without the mask tile three workgroups fit a CU (51 KB each): with two, 27 % of the MFMA slots stay empty even when no DMA
+    // is issued at all (YNET_WGRAD_DEBUG=1) -- the waves of a workgroup meet at a barrier every 144 MFMAs
+    static const int wg3 = getenv("YNET_WGRAD_WG3") ? atoi(getenv("YNET_WGRAD_WG3")) : 1;
+    if (a.mask == nullptr && wg3) {
+        const int blocks = a.co_blks * ceil_div(a.cin, 32);
+        int n = 768 / blocks;
+        if (n < 1) n = 1;
+        if (n > a.ntiles) n = a.ntiles;
+        a.nsplit = n;
+    }
+    int seg = 0;
+    for (int s : {16, 8, 4})
+        if (seg == 0 && (long long)strips * ceil_div(tiles_y, s) >= 3ll * a.nsplit) seg = s;
+    if (seg == 0 && (long long)strips * ceil_div(tiles_y, 4) >= a.nsplit) seg = 4;
+    if (forced > 0) seg = forced;
+    if (seg == 0 || tiles_y < 2) return false;
+    static const int debug = getenv("YNET_WGRAD_DEBUG") ? atoi(getenv("YNET_WGRAD_DEBUG")) : 0;
+    a.debug = debug;
+    a.seg = seg;
+    a.nseg_y = ceil_div(tiles_y, seg);
+    a.nsegs = strips * a.nseg_y;
+    if (a.nsplit > a.nsegs) a.nsplit = a.nsegs;
+    return true;
+}
+
 template <int KS>
 static int launch_wgrad(WgradArgs& a, float* dw, float* db, hipStream_t st) {
     a.ci_blks = ceil_div(a.cin, WgCfg<KS>::CIB);
@@ -844,7 +1405,8 @@ long long ynet_conv2d_wgrad_workspace_floats(int B, int H, int W, int cout, int 
     wgrad_plan(B, H, W, cout, cin, K, 1, &n1);
     wgrad_plan(B, H, W, cout, cin, K, 2, &n2);
     wgrad_plan(B, H, W, cout, cin, K, 4, &n4);
-    const int n = n1 > n2 ? (n1 > n4 ? n1 : n4) : (n2 > n4 ? n2 : n4);
+    int n = n1 > n2 ? (n1 > n4 ? n1 : n4) : (n2 > n4 ? n2 : n4);
+    if (K == 1 && n < WG1X1_BLOCKS) n = WG1X1_BLOCKS;      // (the streaming 1x1 kernel: one partial per workgroup)
     return (long long)n * ((long long)cout * cin * K * K + cout);
 }
 
@@ -883,12 +1445,18 @@ int ynet_conv2d_wgrad(const float* const* src, const int* src_c, const long long
     a.ntiles = wgrad_plan(B, H, W, cout, a.cin, K, th, &a.nsplit);
     a.co_blks = ceil_div(cout, 32);
     a.partial_w = workspace;
-    a.partial_b = db ? workspace + (long long)a.nsplit * cout * a.cin * K * K : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (dma) {
         a.ci_blks = ceil_div(a.cin, 32);
+        const int nsplit_dma = a.nsplit;
+        const bool roll = wgrad_roll_plan(a);      // (may change nsplit: up to the 768 resident workgroups the workspace is sized for)
+        if (!roll) a.nsplit = nsplit_dma;
+        a.partial_b = db ? workspace + (long long)a.nsplit * cout * a.cin * K * K : nullptr;
+        if (roll) return mask ? launch_wgrad_roll<true>(a, dw, db, st) : launch_wgrad_roll<false>(a, dw, db, st);
         return mask ? launch_wgrad_dma<true, 2>(a, dw, db, st) : launch_wgrad_dma<false, 2>(a, dw, db, st);
     }
+    a.partial_b = db ? workspace + (long long)a.nsplit * cout * a.cin * K * K : nullptr;
+    if (wgrad1x1_stream_ok(a, K)) return launch_wgrad1x1_stream(a, dw, db, workspace, st);
     switch (K) {
         case 1: return launch_wgrad<1>(a, dw, db, st);
         case 3: return launch_wgrad<3>(a, dw, db, st);

@@ -202,6 +202,62 @@ def test_lora_compose_and_grad(dev, cout, cin, r):
     close(d_b, bc.grad, rtol=1e-4, scale_rel=2e-6, msg="dB")
 
 
+ROLL_WGRAD_CASES = [
+    # B, H, W, [source channels], cout, ReLU mask, bias -- maps with enough 32-column strips for the rolling-row kernel
+    (4, 128, 256, [6, 8], 32, True, True),      # encoder.stages.0.0: two sources, 14 channels (spare waves take K-step residues)
+    (8, 64, 128, [32, 16], 32, True, False),    # 48 input channels = a full and a half channel block, segments of 4 steps
+    (8, 64, 64, [64], 64, False, True),         # 2 x 2 blocks, first and last tile column only
+    (4, 256, 128, [32], 16, True, True),        # half an output block
+    (2, 256, 256, [32], 32, False, False),      # segments of 16 steps; interior tile columns
+]
+
+
+@pytest.mark.parametrize("B,H,W,cs,cout,relu,bias", ROLL_WGRAD_CASES)
+def test_conv2d_wgrad_rolling_rows(dev, B, H, W, cs, cout, relu, bias):
+    """wgrad_roll_kernel (x rows kept in an LDS ring while a workgroup walks down a strip): dW / db against stock autograd at
+    shapes that take it (image top / bottom pairs, first / last tile columns, segment starts), bitwise reproducible."""
+    ops = pkg("ops")
+    cin = sum(cs)
+    xs = [rnd(B, c, H, W, seed=i + 1) for i, c in enumerate(cs)]
+    w = rnd(cout, cin, 3, 3, seed=10, scale=1.0 / (cin * 9) ** 0.5)
+    b = rnd(cout, seed=11, scale=0.1)
+    gy = rnd(B, cout, H, W, seed=12)
+    wc, bc = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(torch.cat(xs, 1), wc, bc, padding=1)
+    y = F.relu(y) if relu else y
+    y.backward(gy)
+    xd, yd, gyd = [x.to(dev) for x in xs], y.detach().to(dev), gy.to(dev)
+    mask = (yd.data_ptr(), cout * H * W) if relu else None
+    dw, db = ops.conv2d_wgrad_raw(xd, gyd, mask, w.to(dev), bias)
+    close(dw, wc.grad, rtol=1e-4, scale_rel=1e-5, msg="dW")
+    if bias:
+        close(db, bc.grad, rtol=1e-4, scale_rel=1e-5, msg="db")
+    dw2, db2 = ops.conv2d_wgrad_raw(xd, gyd, mask, w.to(dev), bias)
+    assert torch.equal(dw, dw2) and (not bias or torch.equal(db, db2))
+
+
+@pytest.mark.parametrize("B,H,W,cout,bias", [(3, 16, 24, 12, True), (2, 64, 64, 30, True), (5, 8, 8, 32, False), (1, 4, 4, 7, True), (33, 32, 32, 12, True)])
+def test_conv1x1_wgrad_streaming_kernel(dev, B, H, W, cout, bias):
+    """wgrad1x1_stream_kernel (the predictors' filter / bias gradient, 32 -> pred_len): against stock autograd, for one and
+    two output-channel tiles, maps smaller than the grid and chunk walks that cross image borders; reproducible."""
+    ops = pkg("ops")
+    x, w, b = rnd(B, 32, H, W, seed=1), rnd(cout, 32, 1, 1, seed=2, scale=0.3), rnd(cout, seed=3, scale=0.1)
+    gy = rnd(B, cout, H, W, seed=4)
+    wc, bc = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.conv2d(x, wc, bc).backward(gy)
+    dw, db = ops.conv2d_wgrad_raw([x.to(dev)], gy.to(dev), None, w.to(dev), bias)
+    close(dw, wc.grad, rtol=1e-4, scale_rel=1e-5, msg="dW 1x1")
+    if bias:
+        close(db, bc.grad, rtol=1e-4, scale_rel=1e-5, msg="db 1x1")
+    dw2, _ = ops.conv2d_wgrad_raw([x.to(dev)], gy.to(dev), None, w.to(dev), bias)
+    assert torch.equal(dw, dw2)
+    # a batch-strided view of a wider tensor as the source (the decoder's last activation inside a larger buffer)
+    big = rnd(B, 40, H, W, seed=5).to(dev)
+    dw3, _ = ops.conv2d_wgrad_raw([big[:, 8:40]], gy.to(dev), None, w.to(dev), False)
+    F.conv2d(big[:, 8:40].cpu(), wc2 := w.clone().requires_grad_(True)).backward(gy)
+    close(dw3, wc2.grad, rtol=1e-4, scale_rel=1e-5, msg="dW 1x1 strided")
+
+
 LORA_WGRAD_CASES = [
     # B, H, W, [source channels], cout, ReLU mask
     (2, 16, 32, [14], 32, True),            # tiny; W = one tile
