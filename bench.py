@@ -531,9 +531,9 @@ def main():
                 traffic = entry["hbm_bytes_per_launch_fetch_x2" if name.startswith("conv_dma") else "hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                           "profile": "profiles/r02_bench_C2_serial_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command "
+                           "profile": "profiles/r03_bench_C2_serial_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command "
                                       "with YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1: the same isolated launches); "
-                                      "profiles/r02_bench_C2_kernel_stats.csv is the default command (captured step, concurrent branches)",
+                                      "profiles/r03_bench_C2_kernel_stats.csv is the default command (captured step, concurrent branches)",
                            "traffic_source": None if traffic is None else
                            "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
                            "earlier run of the same build; NOT measured in this run)",
@@ -543,12 +543,12 @@ def main():
                            "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
                            "note": "per-kernel HIP-event timing of 3 instrumented EAGER steps on one stream, run before the "
                                    "warm-up of the timed region (YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1 reproduces the condition under "
-                                   "rocprofv3: profiles/r02_bench_C2_serial_kernel_stats.csv; a HIP-event pair also reads the marker / dispatch "
+                                   "rocprofv3: profiles/r03_bench_C2_serial_kernel_stats.csv; a HIP-event pair also reads the marker / dispatch "
                                    "latency around the kernel -- `event_pair_floor_us` is what it reads around a 1-element fill -- so "
                                    "`avg_launch_us` sits that much above rocprofv3's kernel-only average and `frac` below "
                                    "the fraction computed from the profile).  The timed region itself "
                                    "replays the captured step, whose decoder branches run CONCURRENTLY: per-kernel durations "
-                                   "inside it are inflated by sharing the GPU (profiles/r02_bench_C2_kernel_stats.csv) and "
+                                   "inside it are inflated by sharing the GPU (profiles/r03_bench_C2_kernel_stats.csv) and "
                                    "are not a kernel-quality measure; `value` and `step_roofline` are."}
         out["conv_kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}

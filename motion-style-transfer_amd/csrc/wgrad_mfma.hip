@@ -933,7 +933,11 @@ __global__ __launch_bounds__(256, MASK ? 2 : 3) void wgrad_roll_kernel(const Wgr
         // group i: queue the reads of group i + 1 into the other register set, then the 18 MFMAs of group i
         auto groups = [&](auto self, auto i_tag) -> void {
             constexpr int I = decltype(i_tag)::value, cur = I & 1, nxt = cur ^ 1;
+#ifdef YNET_WG_EXPERIMENT      // (development: YNET_WGRAD_DEBUG & 4 = the MFMA loop without its LDS reads, stale operands)
+            if constexpr (I + 1 < NG) if (!(a.debug & 4)) rd(std::integral_constant<int, (I + 1) * RPN>{}, av[nxt], mv[nxt], q[nxt]);
+#else
             if constexpr (I + 1 < NG) rd(std::integral_constant<int, (I + 1) * RPN>{}, av[nxt], mv[nxt], q[nxt]);
+#endif
             __builtin_amdgcn_sched_barrier(0);      // nothing moves across: reads of the next group, THEN the MFMAs of this one
             mfmas(av[cur], q[cur]);
             __builtin_amdgcn_sched_barrier(0);

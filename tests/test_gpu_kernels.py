@@ -542,7 +542,7 @@ def test_conv2d_dgrad_relu_writes_through_the_relu_backward_of_the_layer_below(d
 def test_relu_backward_applied_by_upsampling_and_by_the_next_data_gradient(dev):
     """conv0-ReLU -> conv1-ReLU -> bilinear x2 -> conv2 (no ReLU): conv1's output gradient comes from the up-sampling backward
     (ynet_upsample2x_bwd_relu), conv0's from conv1's data gradient (ynet_conv2d_dgrad_relu); both then run unmasked dgrad /
-    wgrad kernels.  Same gradients as stock autograd, bit-identical to the consumer-side masks."""
+    wgrad kernels.  Same gradients as stock autograd; the data gradient bit-identical to the consumer-side masks."""
     ops = pkg("ops")
     B, H, W = 8, 128, 128          # (large enough for the two-row tiles that mask inside the conv kernel)
     x = rnd(B, 6, H, W, seed=1)
@@ -568,8 +568,11 @@ def test_relu_backward_applied_by_upsampling_and_by_the_next_data_gradient(dev):
         close(w0d.grad, w0c.grad, rtol=1e-4, scale_rel=1e-5, msg=f"dW0 (premask={on})")
         close(w1d.grad, w1c.grad, rtol=1e-4, scale_rel=1e-5, msg=f"dW1 (premask={on})")
         got[on] = (xd.grad.clone(), w0d.grad.clone(), w1d.grad.clone())
-    for a, b in zip(got[True], got[False]):
-        assert torch.equal(a, b)
+    # the data gradient is bit-identical (the mask is an exact zeroing wherever it is applied); the filter gradients of a map this
+    # large come from differently split pixel sums (unmasked rolling-row kernel: 3 workgroups per CU, masked: 2) -> rounding only
+    assert torch.equal(got[True][0], got[False][0])
+    for a, b in zip(got[True][1:], got[False][1:]):
+        close(a, b, rtol=1e-5, scale_rel=2e-6, msg="dW, masks at the producer vs at the consumer")
 
 
 @pytest.mark.parametrize("cin,cout,relu", [(32, 12, False), (12, 32, False), (32, 30, True), (7, 16, True), (32, 33, False)])

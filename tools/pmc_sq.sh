@@ -22,10 +22,18 @@ res = {}
 for db in glob.glob(os.path.join(out, "p*", "*.db")):
     con = sqlite3.connect(db)
     for name, counter, value in con.execute("select name, counter_name, counter_value from pmc_events"):
-        if "conv_dma_kernel<2, 4, 4" in name or "wgrad_dma" in name or "conv_dma_kernel<4, 2, 4" in name or "lora_wgrad" in name or "conv_dma_kernel<3, 2, 4" in name or "conv_dma_kernel<2, 2, 4" in name:
+        if any(k in name for k in ("kernel<2, 4, 4", "kernel<4, 2, 4", "kernel<3, 2, 4", "kernel<2, 2, 4", "wgrad_dma", "wgrad_roll", "lora_wgrad_kernel")):
             d = res.setdefault(name[:60], {}).setdefault(counter, [0.0, 0])
             d[0] += float(value); d[1] += 1
     con.close()
     os.remove(db)
-json.dump({k: {c: v[0] / v[1] for c, v in d.items()} for k, d in res.items()}, open(os.path.join(out, "summary.json"), "w"), indent=1)
+summary = {}
+for k, d in res.items():
+    e = {c: v[0] / v[1] for c, v in d.items()}
+    busy, mfma, act, conf = e.get("SQ_BUSY_CU_CYCLES"), e.get("SQ_VALU_MFMA_BUSY_CYCLES"), e.get("SQ_LDS_IDX_ACTIVE"), e.get("SQ_LDS_BANK_CONFLICT")
+    e["derived"] = {"mfma_busy_frac": mfma / (4 * busy) if busy and mfma is not None else None,          # 4 SIMDs per CU
+                    "lds_bank_conflict_per_lds_active": conf / act if act else None,
+                    "lds_active_per_busy_cu_cycle": act / busy if busy and act is not None else None}
+    summary[k] = e
+json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 PY
