@@ -250,6 +250,32 @@ def side_streams(device, which=None):
     return _side_streams[key][:2] if which is None else _side_streams[key][which]
 
 
+# Adapter gradients beside the data-gradient chain (mosa_*: only lora_A / lora_B train).  The encoder's backward is a strict chain
+# [pool backward -> dgrad -> dgrad -> ...] of small-map launches that leave most of the chip idle, and nothing on that chain waits for
+# a layer's adapter gradient: inside fold_skip_gradients() it is computed on a fourth stream (a branch of the captured step) and
+# written straight to lora_A.grad / lora_B.grad; the context's exit joins the branch.  (Opt-in with the context like the skip fold;
+# outside it -- torch.autograd.grad, hooks, accumulation into an existing .grad -- the gradients flow through autograd as before.)
+wgrad_branch = False
+_wgrad_branch_allowed = _os.environ.get("YNET_WGRAD_BRANCH", "1") != "0"
+_wgrad_streams = {}
+_wgrad_pending = {}
+
+
+def _wgrad_stream(device):
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _wgrad_streams:
+        _wgrad_streams[key] = torch.cuda.Stream(device=dev)
+    return key, _wgrad_streams[key]
+
+
+def join_wgrad_branch():
+    """The current stream of every device with adapter gradients in flight waits for them."""
+    for key, side in list(_wgrad_pending.items()):
+        torch.cuda.current_stream(torch.device(key[0], key[1])).wait_stream(side)
+    _wgrad_pending.clear()
+
+
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None."""
@@ -478,17 +504,19 @@ class fold_skip_gradients:
     criterion or from the data gradient of a single-input conv is applied by that producer (see `_premasked`)."""
 
     def __enter__(self):
-        global skip_fold, premask
-        self._prev = (skip_fold, premask)
+        global skip_fold, premask, wgrad_branch
+        self._prev = (skip_fold, premask, wgrad_branch)
         skip_fold = _skip_fold_allowed
         premask = _premask_allowed
+        wgrad_branch = _wgrad_branch_allowed and overlap_decoders
         _relu_outputs.clear()
         _premasked.clear()
         return self
 
     def __exit__(self, *exc):
-        global skip_fold, premask
-        skip_fold, premask = self._prev
+        global skip_fold, premask, wgrad_branch
+        skip_fold, premask, wgrad_branch = self._prev
+        join_wgrad_branch()
         _relu_outputs.clear()
         _premasked.clear()
         # gradients handed over to a pool whose backward never ran (an exception, a pruned graph) must not linger
@@ -574,6 +602,13 @@ class _Conv2dFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         need_src = list(need[5:5 + ctx.n_src])
         d_srcs = [None] * ctx.n_src
+        branch = None
+        if (wgrad_branch and ctx.has_lora and dy.is_cuda and not need[1] and not (ctx.has_bias and need[2]) and (need[3] or need[4])
+                and lora_a.is_leaf and lora_b.is_leaf and not lora_a._backward_hooks and not lora_b._backward_hooks):
+            # fork BEFORE the data gradient is queued: the adapter gradients (below) run beside it (see `wgrad_branch`)
+            cur = torch.cuda.current_stream(dy.device)
+            bkey, branch = _wgrad_stream(dy.device)
+            branch.wait_stream(cur)
         if any(need_src):
             if ctx.w_key != _weight_key(weight, lora_a, lora_b):
                 raise RuntimeError("conv2d backward: a parameter was modified in place between forward and backward")
@@ -612,7 +647,28 @@ class _Conv2dFn(torch.autograd.Function):
         d_w = d_b = d_a = d_bm = None
         want_w = need[1] or (ctx.has_lora and (need[3] or need[4]))
         want_b = ctx.has_bias and need[2]
-        if want_w or want_b:
+        if branch is not None:
+            for t in (dy, y, weight, lora_a, lora_b, *srcs):
+                if t is not None:
+                    t.record_stream(branch)
+            with torch.cuda.stream(branch):
+                if lora_conv2d_wgrad_supported(srcs, dy, weight, lora_a, preferred=True):
+                    d_a, d_bm = lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a.detach(), lora_b.detach(), scale)
+                else:
+                    dw, _ = conv2d_wgrad_raw(srcs, dy, mask, weight, False)
+                    d_a, d_bm = lora_grad(dw, lora_a.detach(), lora_b.detach(), scale)
+                # (an existing .grad -- the data-parallel flat buffer's view, an accumulation -- is added to in place, on the branch:
+                # this backward is the only writer of these two parameters' gradients)
+                for p_, g_, want in ((lora_a, d_a, need[3]), (lora_b, d_bm, need[4])):
+                    if want and p_.grad is not None:
+                        p_.grad.add_(g_.view_as(p_.grad))
+            for p_, g_, want in ((lora_a, d_a, need[3]), (lora_b, d_bm, need[4])):
+                g_.record_stream(cur)         # read by the optimizer (and a data-parallel stage) on the step's stream, after the join
+                if want and p_.grad is None:
+                    p_.grad = g_.view_as(p_)
+            d_a = d_bm = None
+            _wgrad_pending[bkey] = branch
+        elif want_w or want_b:
             if ctx.has_lora and not need[1] and not want_b and lora_conv2d_wgrad_supported(srcs, dy, weight, lora_a, preferred=True):
                 # only the adapter trains (mosa_*): dA / dB straight from projected planes, no dW (ynet_lora_conv2d_wgrad)
                 d_a, d_bm = lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a.detach(), lora_b.detach(), scale)
@@ -882,12 +938,17 @@ class _PredBCEFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight)
         ctx.mark_non_differentiable(y)
+        # (the logits are an output without a gradient: left to its default, autograd materialises a ZERO tensor of their size
+        # for backward -- a 100 MB fill per decoder, 2 x 32 us on the step's critical path in the trace)
+        ctx.set_materialize_grads(False)
         return y, loss
 
     @staticmethod
     def backward(ctx, _gy, g):
         x, weight = ctx.saved_tensors
         lib = _lib()
+        if g is None:      # (the loss did not take part in the differentiated graph)
+            return None, None, None, None, None, None
         g = g.contiguous().float()
         dx, dy, ctx.dx, ctx.dy = ctx.dx, ctx.dy, None, None
         if (ctx.needs_input_grad[0] and dx is None) or ((ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and dy is None):
