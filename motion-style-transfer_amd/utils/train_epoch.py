@@ -133,8 +133,9 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
                 t.record_stream(s_m)
             with torch.cuda.stream(s_m), torch.no_grad():
                 early = _step_metrics(model, pred_goal_map, pred_traj_map, gt_future, resize_factor)
-        # (filter gradients on a fourth branch beside the dgrad chain were measured: no gain at C2, 5 % slower at C1 --
-        # both are MFMA-bound and compete for the same CUs)
+        # (adapter gradients of the mosa_* modes run on a fourth branch beside the encoder's dgrad chain: ops.wgrad_branch.  FULL filter
+        # gradients there were measured twice: every one of them in round 2 -- 5 % slower at C1 -- and those of the <= 32^2 / 64^2 / 128^2
+        # maps only in round 3 -- 14.09 -> 14.34 / 14.29 / 14.43 ms: one more branch couples the two decoders' backward streams)
         loss.backward()
         if early is not None:
             cur = torch.cuda.current_stream(device)
