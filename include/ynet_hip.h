@@ -54,6 +54,15 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                 int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
                 void* stream);
+/* ynet_conv2d with ONE destination plus its 2 x 2 max-pooled copy written by the same epilogue: the last convolution of an encoder
+ * stage and the nn.MaxPool2d(2, 2) that opens the next one (models/ynet.py:202,215) without the stand-alone pass over y.
+ * pooled [B][cout][H/2][W/2] (batch stride pooled_bs), the first-maximum / NaN rule of ynet_maxpool2_fwd; H, W even.
+ * ynet_conv2d_pool_supported: 1 for the shapes that take it (3x3, W % 4 == 0, maps large enough for two-row tiles); the call fails
+ * elsewhere, callers then run ynet_conv2d + ynet_maxpool2_fwd. */
+int ynet_conv2d_pool_supported(int B, int H, int W, int cout, int K);
+int ynet_conv2d_pool(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* wp, const float* bias,
+                     float* dst, int cout, long long dst_bs, float* pooled, long long pooled_bs,
+                     int B, int H, int W, int K, int relu, void* stream);
 /* ynet_conv2d as the data gradient of a layer whose INPUT was another layer's post-ReLU output (the conv -> ReLU -> conv chains
  * of models/ynet.py:192-211,420-451): dx = relu_of > 0 ? conv(dy [kept where mask > 0; mask may be NULL], wp) : 0, i.e. the ReLU
  * backward of the layer below is applied where its gradient is produced (the activation tile is fetched under the last MFMA

@@ -50,7 +50,9 @@ struct ConvArgs {
     int addend_bmod;        //   repeat along the batch (evaluate()'s K goal samples share the encoder features), computed once
     const float* emask;     // optional [B][cout][H][W] post-ReLU activation whose backward is applied to the OUTPUT (one destination):
     long long emask_bs;     //   dst = emask > 0 ? conv(...) : 0 -- a data gradient written for a consumer that then needs no mask
-    int emask_done;         //   (host side) the launched kernels applied it
+    int emask_done, pool_done;      //   (host side) the launched kernels applied it / wrote the pooled copy
+    float* pool;            // optional second output [B][cout][H/2][W/2] = MaxPool2d(2, 2) of the (post-ReLU) first one, written by
+    long long pool_bs;      //   the epilogue (conv_dma_pool_kernel): models/ynet.py:202,215 without the stand-alone pass over y
     int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
     int vec_load;           // 16-byte LDS-DMA of the input tile is legal (W % 4 == 0, aligned sources / mask)
     int tiles_x, tiles_y, cgroups, ntiles, debug;   // debug: timing ablations only (tools/conv_bench.py)
@@ -550,7 +552,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sgpr_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0u, 0x00020000);
 }
 
-// EPI: 0 plain epilogue, 1 + the batch-shared additive term (ConvArgs::addend), 2 ReLU backward on the output (ConvArgs::emask)
+// EPI: 0 plain epilogue, 1 + the batch-shared additive term (ConvArgs::addend), 2 ReLU backward on the output (ConvArgs::emask),
+//      3 + the 2 x 2 max-pooled copy of the output (ConvArgs::pool)
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, int EPI>
 __device__ __forceinline__ void conv_dma_body() {
     using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
@@ -904,6 +907,41 @@ __device__ __forceinline__ void conv_dma_body() {
                         for (int e = 0; e < 4; ++e) acc[i][r][g][e] = em[r][e] > 0.f ? acc[i][r][g][e] : 0.f;
                 }
         }
+        if constexpr (EPI == 3) {
+            // MaxPool2d(2, 2) of the tile: a lane holds 4 consecutive pixels of R rows per channel -- two pooled pixels per row pair,
+            // one 8-byte store (the same first-maximum / NaN rule as maxpool2_fwd_kernel).  R and the tile origin are even.
+            static_assert(R % 2 == 0 && FOLD == 1, "pooled epilogue: row pairs inside a wave's rows");
+            typedef float f32x2e __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x2e __attribute__((ext_vector_type(2)));
+            float* pp = ke->pool;
+            const int Wo = W >> 1, HWo = (H >> 1) * Wo;
+            const __amdgpu_buffer_rsrc_t rp = sgpr_rsrc(pp + (long long)t.b * ke->pool_bs, (unsigned)ke->cout * (unsigned)HWo * 4u);
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int q0 = 16 * g + 4 * kq, gx = t.x0 + q0;
+                    const unsigned vo = gx < W ? (unsigned)((c_lo + i * 16 + r16) * HWo + (gx >> 1)) * 4u : 0x80000000u;
+#pragma unroll
+                    for (int r = 0; r < R; r += 2) {
+                        if (ybase + r < H) {
+                            const f32x4 a = acc[i][r][g], b = acc[i][r + 1][g];
+                            f32x2e o;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                float m = a[2 * h], v = a[2 * h + 1];
+                                m = (v > m || v != v) ? v : m;
+                                v = b[2 * h];
+                                m = (v > m || v != v) ? v : m;
+                                v = b[2 * h + 1];
+                                m = (v > m || v != v) ? v : m;
+                                o[h] = m;
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2e, o), rp, vo, (unsigned)(((ybase + r) >> 1) * Wo) * 4u, 0);
+                        }
+                    }
+                }
+        }
         auto store_all = [&](__amdgpu_buffer_rsrc_t rd, unsigned ubase) {
             // ubase = ((c_lo - first channel of the destination) * HW + ybase * W) * 4, modulo 2^32
 #pragma unroll
@@ -1013,6 +1051,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs) {
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
 __global__ __launch_bounds__(256, 2) void conv_dma_add_kernel(const ConvArgs) {
     conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 1>();
+}
+
+// the same with the 2 x 2 max-pooled copy of the output as a second destination (ConvArgs::pool)
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
+__global__ __launch_bounds__(256, 2) void conv_dma_pool_kernel(const ConvArgs) {
+    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 3>();
 }
 
 // the same with the ReLU backward of the layer below applied to the output (ConvArgs::emask)
@@ -1155,6 +1199,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     const auto KERNEL = [] {       // (if constexpr: only the wanted instantiation is compiled)
         if constexpr (EPI == 1) return &conv_dma_add_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else if constexpr (EPI == 2) return &conv_dma_emask_kernel<NCB, R, CC, MASK, X4, FOLD>;
+        else if constexpr (EPI == 3) return &conv_dma_pool_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else return &conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>;
     }();
     a.tiles_x = ceil_div(a.W, C::TW);
@@ -1165,7 +1210,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         int nchunks = 0;
         for (int i = 0; i < a.nsrc; ++i) nchunks += ceil_div(a.src[i].c, CC);
         a.ksplit = 1;
-        if (a.partial != nullptr && !ADD) a.ksplit = conv_ksplit(nt, nchunks);
+        if (a.partial != nullptr && !ADD && EPI != 3) a.ksplit = conv_ksplit(nt, nchunks);
         while (a.ksplit > 1 && (long long)a.ksplit * a.B * a.cout * a.H * a.W > a.partial_cap) --a.ksplit;
         a.cps = ceil_div(nchunks, a.ksplit);
         a.ksplit = ceil_div(nchunks, a.cps);
@@ -1209,6 +1254,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(conv_split_reduce_kernel, dim3(grid), dim3(256), 0, st, r);
     }
     if (EPI == 2 || a.ksplit > 1) a.emask_done = 1;       // (in the epilogue, or in the reduction of a split channel loop)
+    if (EPI == 3) a.pool_done = 1;
     return ynet_check_launch("conv2d");
 }
 
@@ -1228,6 +1274,7 @@ template <int NCB, int R, int FOLD = 1, int CC = 4>
 static int launch_dma(ConvArgs& a, hipStream_t st) {
     if constexpr (R >= 2 && FOLD == 1) {      // the large-map tiles (ynet_conv2d_dgrad_relu_supported)
         if (a.emask) return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD, 2>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD, 2>(a, st);
+        if (a.pool && !a.mask) return launch_dma_m<NCB, R, CC, false, true, FOLD, 3>(a, st);
     }
     return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD>(a, st);
 }
@@ -1235,7 +1282,7 @@ static int launch_dma(ConvArgs& a, hipStream_t st) {
 template <int NCB, int R, int FOLD = 1>
 static int launch_dma_small(ConvArgs& a, hipStream_t st) {
     const int cc = small_cc();
-    if (cc >= 16 && !a.mask && !a.emask) return launch_dma_m<NCB, R, 16, false, true, FOLD>(a, st);      // (a masked dgrad holds CC mask quads in registers: 8 at most)
+    if (cc >= 16 && !a.mask && !a.emask && !a.pool) return launch_dma_m<NCB, R, 16, false, true, FOLD>(a, st);      // (a masked dgrad holds CC mask quads in registers: 8 at most)
     if (cc >= 8) return launch_dma<NCB, R, FOLD, 8>(a, st);
     return launch_dma<NCB, R, FOLD, 4>(a, st);
 }
@@ -1460,7 +1507,12 @@ __global__ __launch_bounds__(256) void conv_emask_kernel(float* __restrict__ dst
 
 static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
     a.emask_done = 0;
+    a.pool_done = 0;
     int rc = conv_dispatch_kernels(a, K, st);
+    if (!rc && a.pool != nullptr && !a.pool_done) {
+        ynet_set_error("conv2d_pool: shape B=%d %dx%d cout=%d is not served by the pooling epilogue (ask ynet_conv2d_pool_supported)", a.B, a.H, a.W, a.cout);
+        return 1;
+    }
     if (rc || a.emask == nullptr || a.emask_done) return rc;
     const long long per_image = (long long)a.cout * a.H * a.W, total = per_image * a.B;
     long long blocks = (total + 255) / 256;
@@ -1555,7 +1607,7 @@ static int conv2d_impl(const float* const* src, const int* src_c, const long lon
                        float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                        int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
                        const float* addend, long long addend_bs, int addend_bmod, void* stream,
-                       const float* emask = nullptr, long long emask_bs = 0) {
+                       const float* emask = nullptr, long long emask_bs = 0, float* pool = nullptr, long long pool_bs = 0) {
     YNET_REQUIRE(nsrc >= 1 && nsrc <= YNET_MAX_SRC && ndst >= 1 && ndst <= YNET_MAX_SRC,
                  "conv2d: 1..%d sources/destinations supported (got %d/%d)", YNET_MAX_SRC, nsrc, ndst);
     YNET_REQUIRE(B > 0 && H > 0 && W > 0, "conv2d: empty problem B=%d H=%d W=%d", B, H, W);
@@ -1592,6 +1644,12 @@ static int conv2d_impl(const float* const* src, const int* src_c, const long lon
     a.addend = addend;
     a.addend_bs = addend_bs;
     a.addend_bmod = addend_bmod;
+    a.pool = pool;
+    a.pool_bs = pool_bs;
+    if (pool != nullptr) {
+        YNET_REQUIRE(a.ndst == 1 && a.dst[0].p != nullptr && mask == nullptr && addend == nullptr && emask == nullptr, "conv2d_pool: one destination, no mask / additive term");
+        YNET_REQUIRE((H & 1) == 0 && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(pool) & 7) == 0 && (pool_bs & 1) == 0, "conv2d_pool: even H, W and an 8-byte aligned pooled output");
+    }
     a.emask = emask;
     a.emask_bs = emask_bs;
     if (emask != nullptr) {
@@ -1639,6 +1697,39 @@ int ynet_conv2d_dgrad_relu(const float* dy, int dy_c, long long dy_bs, const flo
     const long long db[1] = {dx_bs};
     return conv2d_impl(srcs, sc, sb, nullptr, 1, mask, mask_bs, wp, nullptr, dsts, dc, db, 1, B, H, W, K, 0, workspace, workspace_floats,
                        nullptr, 0, 0, stream, relu_of, relu_of_bs);
+}
+
+// ynet_conv2d with one destination + its 2 x 2 max-pooled copy (MaxPool2d(2, 2) of the next encoder stage, models/ynet.py:202,215)
+// written by the same epilogue.  ynet_conv2d_pool_supported: the shapes that take it (3x3, two-row tiles: the large maps, where the
+// stand-alone pool is a 60 us pass on the forward's critical path).
+static int conv_rows_tiles_ok(int B, int H, int W, int cout, int K) {
+    ConvArgs a{};
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.cout = cout;
+    const int nt16 = narrow_tiles(a, m16_tiles(K, cout));
+    static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
+    static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
+    if (!(use_dma && use_x4) || K != 3 || (W & 3) || nt16 == 0 || conv_fold(H, W) != 1) return 0;
+    int rows = pick_rows(a, 16 * nt16);
+    if (nt16 >= 3 && rows == 4) rows = 2;
+    return rows >= 2 ? 1 : 0;
+}
+
+int ynet_conv2d_pool_supported(int B, int H, int W, int cout, int K) {
+    return ((H | W) & 1) == 0 && conv_rows_tiles_ok(B, H, W, cout, K);
+}
+
+int ynet_conv2d_pool(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* wp, const float* bias,
+                     float* dst, int cout, long long dst_bs, float* pooled, long long pooled_bs,
+                     int B, int H, int W, int K, int relu, void* stream) {
+    YNET_REQUIRE(dst != nullptr && pooled != nullptr, "conv2d_pool: null destination");
+    float* dsts[1] = {dst};
+    const int dc[1] = {cout};
+    const long long db[1] = {dst_bs};
+    return conv2d_impl(src, src_c, src_bs, nullptr, nsrc, nullptr, 0, wp, bias, dsts, dc, db, 1, B, H, W, K, relu, nullptr, 0,
+                       nullptr, 0, 0, stream, nullptr, 0, pooled, pooled_bs);
 }
 
 // 1 if ynet_conv2d_dgrad_relu applies the mask inside the convolution kernel for this problem (3x3 on a map large enough for

@@ -51,8 +51,8 @@ class HipConv2d(nn.Conv2d):
         super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
         self._packed = {}
 
-    def forward(self, x, relu=False):
-        return ops.conv2d(x, self.weight, self.bias, relu, self._packed)
+    def forward(self, x, relu=False, pool=False):
+        return ops.conv2d(x, self.weight, self.bias, relu, self._packed, pool=pool)
 
 
 class LoRAConv2d(HipConv2d):
@@ -80,10 +80,10 @@ class LoRAConv2d(HipConv2d):
             nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
             nn.init.zeros_(self.lora_B)
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, pool=False):
         if self.r > 0:
-            return ops.conv2d(x, self.weight, self.bias, relu, self._packed, self.lora_A, self.lora_B, self.scaling)
-        return ops.conv2d(x, self.weight, self.bias, relu, self._packed)
+            return ops.conv2d(x, self.weight, self.bias, relu, self._packed, self.lora_A, self.lora_B, self.scaling, pool=pool)
+        return ops.conv2d(x, self.weight, self.bias, relu, self._packed, pool=pool)
 
 
 class HipMaxPool2d(nn.MaxPool2d):
@@ -176,14 +176,17 @@ class AdapterLayer(HipConv2d, _AdapterMixin):
 class FusedSequential(nn.Sequential):
     """nn.Sequential with the reference's child indices, executing Conv2d+ReLU pairs as one launch."""
 
-    def forward(self, x):
+    def forward(self, x, pool_next=False):
+        """pool_next: the caller feeds the result to a MaxPool2d(2, 2) next (the following encoder stage opens with one): the last
+        conv + ReLU of this sequence is asked to write the pooled copy too (ops.conv2d(pool=True))."""
         mods = list(self)
         i = 0
         while i < len(mods):
             m = mods[i]
             if isinstance(m, HipConv2d):
                 fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = m(x, relu=fuse)
+                last = i + (2 if fuse else 1) >= len(mods)
+                x = m(x, relu=fuse, pool=True) if (pool_next and last and type(m) in (HipConv2d, LoRAConv2d)) else m(x, relu=fuse)
                 i += 2 if fuse else 1
             else:
                 if isinstance(m, nn.ReLU):
@@ -240,8 +243,9 @@ class YNetEncoder(nn.Module):
 
     def forward(self, x):
         features = []
-        for stage in self.stages:
-            x = stage(x)
+        for i, stage in enumerate(self.stages):
+            nxt = self.stages[i + 1] if i + 1 < len(self.stages) else None
+            x = stage(x, pool_next=nxt is not None and isinstance(nxt[0], HipMaxPool2d))
             features.append(x)
         return features
 
@@ -337,19 +341,26 @@ class YNetEncoderFusion(nn.Module):
         B = scene_map.shape[0]
         once = SHARED_SCENE_BRANCH and torch.is_tensor(scene_map) and B > 1 and scene_map.stride(0) == 0
         x = scene_map[:1] if once else scene_map
-        for stage in self.scene_stages:
-            x = stage(x)
-            scene.append(x)
+        def walk(stages, x, out, tail_pooled):
+            # (every stage but a branch's last is followed by a stage that opens with MaxPool2d; the branch's last output is pooled by
+            # the first fused stage -- as part of a concatenation, so each part is pooled on its own there)
+            for i, stage in enumerate(stages):
+                nxt = stages[i + 1] if i + 1 < len(stages) else None
+                x = stage(x, pool_next=(isinstance(nxt[0], HipMaxPool2d) if nxt is not None else tail_pooled))
+                out.append(x)
+            return x
+
+        tail = len(self.fusion_stages) > 0 and isinstance(self.fusion_stages[0][0], HipMaxPool2d)
+        walk(self.scene_stages, x, scene, tail)
         last_scene = scene[-1]
         if once:
             scene = [t.expand(B, -1, -1, -1) for t in scene]
-        x = motion_map
-        for stage in self.motion_stages:
-            x = stage(x)
-            motion.append(x)
+        walk(self.motion_stages, motion_map, motion, tail)
         features = [ops.lazy_cat([s, m]) for s, m in zip(scene, motion)]
         x = features[-1]
         for i, stage in enumerate(self.fusion_stages):
+            nxt = self.fusion_stages[i + 1] if i + 1 < len(self.fusion_stages) else None
+            pool_next = nxt is not None and isinstance(nxt[0], HipMaxPool2d)
             if i == 0:
                 # first fused stage starts with a max-pool of the concatenation = concat of the pools
                 mods = list(stage)
@@ -361,12 +372,13 @@ class YNetEncoderFusion(nn.Module):
                 j = 1
                 while j < len(mods):
                     fuse = j + 1 < len(mods) and isinstance(mods[j + 1], nn.ReLU)
-                    x = mods[j](x, relu=fuse)
+                    last = j + (2 if fuse else 1) >= len(mods)
+                    x = mods[j](x, relu=fuse, pool=True) if (pool_next and last and type(mods[j]) in (HipConv2d, LoRAConv2d)) else mods[j](x, relu=fuse)
                     j += 2 if fuse else 1
                 if isinstance(x, ops.LazyCat):      # n_fusion == 0: only the final pool
                     x = x.materialize()
             else:
-                x = stage(x)
+                x = stage(x, pool_next=pool_next)
             features.append(x)
         return features
 

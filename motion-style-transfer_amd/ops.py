@@ -276,11 +276,18 @@ def join_wgrad_branch():
     _wgrad_pending.clear()
 
 
-def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None):
+def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
-    post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None."""
+    post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None.  pooled: (ptr,
+    batch_stride) of a second output, the 2 x 2 max-pooled copy of the single destination (ynet_conv2d_pool), or None."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
+    if pooled is not None:
+        if len(dsts) != 1 or mask is not None or relu_of is not None or _bmods(srcs) is not None:
+            raise ValueError("conv2d_raw: pooled is for a forward convolution with one destination")
+        L.check(lib.ynet_conv2d_pool(sp, sc, sb, len(srcs), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                     dsts[0][0], dsts[0][1], dsts[0][2], pooled[0], pooled[1], B, H, W, K, 1 if relu else 0, _stream()), lib)
+        return
     dp, dc, db = _arrays(dsts)
     nws, ws = 0, None
     if B * H * W <= 65536:                                       # small maps only (see ynet_conv2d_workspace_floats)
@@ -574,7 +581,17 @@ class _Conv2dFn(torch.autograd.Function):
         wp = _cached(cache, weight, lora_a, lora_b, scale, "fwd")
         y = torch.empty((B, cout, H, W), device=weight.device, dtype=torch.float32)
         b = bias.detach() if bias is not None else None
-        conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu)
+        pooled = None
+        if (meta.get("pool") and _pool_epilogue_allowed and not meta.get("repeat") and H % 2 == 0 and W % 2 == 0
+                and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs) and _lib().ynet_conv2d_pool_supported(B, H, W, cout, k)):
+            # the next module is MaxPool2d(2, 2): its output comes out of this launch's epilogue (see _MaxPool2Fn.forward)
+            pooled = torch.empty((B, cout, H // 2, W // 2), device=weight.device, dtype=torch.float32)
+        conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu,
+                   pooled=None if pooled is None else (pooled.data_ptr(), cout * (H // 2) * (W // 2)))
+        if pooled is not None:
+            for k_ in [k_ for k_, e_ in _pooled_outputs.items() if e_[0]() is None]:      # (a pool that never followed)
+                del _pooled_outputs[k_]
+            _pooled_outputs[y.data_ptr()] = (weakref.ref(y), tuple(y.shape), pooled)
         ctx.meta = meta
         ctx.n_src = len(srcs)
         ctx.has_bias = bias is not None
@@ -735,10 +752,11 @@ def lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a, lora_b, scale):
     return d_a, d_b
 
 
-def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0):
-    """[ReLU](conv(cat(x), W_eff) + bias); x is a tensor or a LazyCat."""
+def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0, pool: bool = False):
+    """[ReLU](conv(cat(x), W_eff) + bias); x is a tensor or a LazyCat.  pool: the caller applies max_pool2 to the result next --
+    where the kernel can, the pooled copy is written by this launch and that max_pool2 call finds it (no kernel)."""
     parts = _parts(x)
-    meta = {"relu": bool(relu), "scale": float(scale), "cache": cache}
+    meta = {"relu": bool(relu), "scale": float(scale), "cache": cache, "pool": bool(pool)}
     if any(isinstance(p, BatchRepeat) for p in parts):
         if torch.is_grad_enabled() and any(t.requires_grad for t in (weight, bias, lora_a, lora_b) if t is not None):
             raise NotImplementedError("conv2d: batch-repeated inputs are for inference (torch.no_grad) only")
@@ -750,15 +768,25 @@ def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, s
 # ------------------------------------------------------------------------------------------------
 # pooling / resampling
 # ------------------------------------------------------------------------------------------------
+# conv outputs whose 2 x 2 max-pooled copy was written by the conv's own epilogue (ops.conv2d(..., pool=True)):
+# address of y -> (weak reference to y, its shape, the pooled tensor); consumed by the max_pool2 call that follows
+_pooled_outputs = {}
+_pool_epilogue_allowed = _os.environ.get("YNET_POOL_EPILOGUE", "1") != "0"
+
+
 class _MaxPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         _need_gpu(x, "max_pool2d")
         x = x.contiguous()
         B, C, H, W = x.shape
-        y = torch.empty((B, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
-        lib = _lib()
-        L.check(lib.ynet_maxpool2_fwd(x.data_ptr(), y.data_ptr(), B * C, H, W, _stream()), lib)
+        e = _pooled_outputs.pop(x.data_ptr(), None) if _pooled_outputs else None
+        if e is not None and e[0]() is x and e[1] == tuple(x.shape) and x._version == 0:
+            y = e[2]                 # written by the producing conv's epilogue: no pass over x here
+        else:
+            y = torch.empty((B, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+            lib = _lib()
+            L.check(lib.ynet_maxpool2_fwd(x.data_ptr(), y.data_ptr(), B * C, H, W, _stream()), lib)
         ctx.save_for_backward(x)
         ctx.folds = bool(skip_fold and ctx.needs_input_grad[0] and H % 2 == 0 and W % 2 == 0)
         if ctx.folds:

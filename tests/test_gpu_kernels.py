@@ -504,6 +504,58 @@ def test_relu_backward_applied_by_the_gradient_producers(dev):
     assert not ops._premasked and not ops._relu_outputs
 
 
+@pytest.mark.parametrize("B,H,W,cs,cout", [(8, 128, 128, [6, 8], 32), (8, 64, 128, [32], 64), (4, 128, 256, [32], 16), (2, 256, 256, [16, 16], 48)])
+def test_conv2d_pool_epilogue(dev, B, H, W, cs, cout):
+    """ynet_conv2d_pool: conv + bias + ReLU with the 2 x 2 max-pooled copy written by the same epilogue -- both outputs bit-identical
+    to ynet_conv2d followed by ynet_maxpool2_fwd, NaN propagation included; through ops.conv2d(pool=True) + ops.max_pool2 the pool
+    kernel is not launched and the gradients equal stock autograd."""
+    ops, L = pkg("ops"), pkg("_lib")
+    lib = ops._lib()
+    cin = sum(cs)
+    xs = [rnd(B, c, H, W, seed=i + 1).to(dev) for i, c in enumerate(cs)]
+    xs[0][0, 0, 5, 7] = float("nan")
+    w, b = rnd(cout, cin, 3, 3, seed=10, scale=1.0 / (cin * 9) ** 0.5).to(dev), rnd(cout, seed=11, scale=0.1).to(dev)
+    assert lib.ynet_conv2d_pool_supported(B, H, W, cout, 3)
+    wp = ops.pack_weight(w, 0)
+    descs = [(x.data_ptr(), x.shape[1], x.shape[1] * H * W) for x in xs]
+    y0, y1 = torch.empty(B, cout, H, W, device=dev), torch.empty(B, cout, H, W, device=dev)
+    p0, p1 = torch.empty(B, cout, H // 2, W // 2, device=dev), torch.full((B, cout, H // 2, W // 2), 7.0, device=dev)
+    ops.conv2d_raw(descs, None, wp, b, [(y0.data_ptr(), cout, cout * H * W)], B, H, W, 3, True)
+    L.check(lib.ynet_maxpool2_fwd(y0.data_ptr(), p0.data_ptr(), B * cout, H, W, ops._stream()), lib)
+    ops.conv2d_raw(descs, None, wp, b, [(y1.data_ptr(), cout, cout * H * W)], B, H, W, 3, True, pooled=(p1.data_ptr(), cout * (H // 2) * (W // 2)))
+    assert torch.equal(torch.nan_to_num(y0, nan=-1.0), torch.nan_to_num(y1, nan=-1.0))
+    assert bool(torch.isnan(p0).any()) and torch.equal(torch.isnan(p0), torch.isnan(p1))
+    assert torch.equal(torch.nan_to_num(p0, nan=-1.0), torch.nan_to_num(p1, nan=-1.0))
+    # autograd path: conv2d(pool=True) -> max_pool2 (no pool kernel) against stock torch
+    xs = [rnd(B, c, H, W, seed=i + 1) for i, c in enumerate(cs)]
+    xc = [x.clone().requires_grad_(True) for x in xs]
+    wc = w.cpu().clone().requires_grad_(True)
+    F.max_pool2d(F.relu(F.conv2d(torch.cat(xc, 1), wc, b.cpu(), padding=1)), 2, 2).square().sum().backward()
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    wd = w.clone().requires_grad_(True)
+    yd = ops.conv2d(ops.lazy_cat(xd) if len(xd) > 1 else xd[0], wd, b, True, {}, pool=True)
+    assert yd.data_ptr() in ops._pooled_outputs
+    ops.max_pool2(yd).square().sum().backward()
+    assert not ops._pooled_outputs
+    close(wd.grad, wc.grad, rtol=1e-4, scale_rel=1e-5, msg="dW through the pooled epilogue")
+    for a, c in zip(xd, xc):
+        close(a.grad, c.grad, rtol=1e-4, scale_rel=2e-6, msg="dx through the pooled epilogue")
+
+
+def test_conv2d_pool_rejects_shapes_without_the_epilogue(dev):
+    ops = pkg("ops")
+    lib = ops._lib()
+    assert not lib.ynet_conv2d_pool_supported(2, 16, 16, 32, 3) and not lib.ynet_conv2d_pool_supported(8, 128, 128, 32, 1)
+    x, w = rnd(2, 8, 16, 16, seed=1).to(dev), rnd(32, 8, 3, 3, seed=2).to(dev)
+    y, p = torch.empty(2, 32, 16, 16, device=dev), torch.empty(2, 32, 8, 8, device=dev)
+    with pytest.raises(RuntimeError, match="pooling epilogue"):
+        ops.conv2d_raw([(x.data_ptr(), 8, 8 * 256)], None, ops.pack_weight(w, 0), None, [(y.data_ptr(), 32, 32 * 256)], 2, 16, 16, 3, True,
+                       pooled=(p.data_ptr(), 32 * 64))
+    # ... and ops.conv2d(pool=True) simply does not use it there
+    yd = ops.conv2d(x, w, None, True, {}, pool=True)
+    assert yd.data_ptr() not in ops._pooled_outputs
+
+
 # B, H, W, channels of dy (the layer's cout), channels of dx (its cin), dy masked too
 DGRAD_RELU_CASES = [
     (8, 128, 128, 32, 16, False),       # two-row tiles, one 16-channel tile per workgroup: mask inside the conv kernel

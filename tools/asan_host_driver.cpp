@@ -60,6 +60,11 @@ int main() {
     for (int b : {1, 32, 256})
         for (int hw : {8, 32, 64, 256})
             for (int cout : {12, 32, 48, 64}) acc += ynet_conv2d_add_supported(b, hw, hw, cout, 3);
+    EXPECT_REJECT(ynet_conv2d_pool(srcs, &one, &bs, 1, cfp, nullptr, fp, 4, 64, nullptr, 16, 1, 4, 4, 3, 1, nullptr));               // no pooled output
+    EXPECT_REJECT(ynet_conv2d_pool(srcs, &one, &bs, 1, cfp, nullptr, fp, 4, 64, fp, 16, 1, 5, 4, 3, 1, nullptr));                    // odd H
+    for (int b : {1, 32, 256})
+        for (int hw : {8, 32, 64, 256})
+            for (int c : {12, 32, 48, 64}) acc += ynet_conv2d_pool_supported(b, hw, hw, c, 3) + ynet_conv2d_pool_supported(b, hw + 1, hw, c, 3);
     EXPECT_REJECT(ynet_conv2d_dgrad_relu(cfp, 4, 64, nullptr, 0, cfp, fp, 4, 64, nullptr, 64, 1, 4, 4, 3, nullptr, 0, nullptr));     // no activation
     EXPECT_REJECT(ynet_conv2d_dgrad_relu(cfp, 4, 64, nullptr, 0, cfp, fp, 4, 64, cfp + 1, 64, 1, 4, 4, 3, nullptr, 0, nullptr));     // unaligned activation
     for (int b : {1, 32, 256})
