@@ -284,6 +284,15 @@ int ynet_pad2d(const float* x, float* y, long long N, int H, int W, int Hp, int 
  * [H][W] -> `classes` one-hot fp32 planes [classes][Hp][Wp]; the border is padded BEFORE the encoding, i.e. it is class 0. */
 int ynet_seg_onehot_pad(const int* labels, float* y, int H, int W, int Hp, int Wp, int classes, void* stream);
 
+/* ---- optimizer step --------------------------------------------------------------------------- */
+/* torch.optim.Adam / AdamW (models/trainer.py:182: Adam(lr)) for ALL parameters in two launches -- used inside captured training
+ * steps, where torch's fused multi-tensor form costs 6 launches (0.18 ms alone on the GPU for a fully trainable Y-Net).  Same update
+ * rule and precision choices as torch's fused kernel (no amsgrad / maximize); state stays optimizer.state's own tensors.
+ *   table [6][ntensors] 64-bit: pointers to param, grad, exp_avg, exp_avg_sq (fp32, contiguous), step (ONE fp32, incremented here), numel
+ *   chunk c = 1024 consecutive elements of tensor chunk_tensor[c] starting at element chunk_first[c]; all arrays on the device. */
+int ynet_adam_step(const long long* table, const int* chunk_tensor, const long long* chunk_first, int ntensors, int nchunks,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, void* stream);
+
 /* ---- data-parallel exchange (new: the reference is single-process) --------------- */
 /* One-shot all-reduce(SUM) of the flat trainable-gradient buffer among the GPUs of ONE node: every rank publishes its
  * buffer in a mailbox the other ranks map through HIP IPC (peer access over xGMI) and reads the N - 1 peers directly --

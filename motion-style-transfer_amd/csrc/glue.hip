@@ -1311,6 +1311,67 @@ int ynet_upsample2x_bwd_relu(const float* dy, float* dx, const float* relu_of, l
     return upsample2x_bwd_impl(dy, dx, relu_of, N, H, W, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// torch.optim.Adam / AdamW step (models/trainer.py:182) for a captured training step, all parameters in TWO launches: torch's
+// fused multi-tensor form takes 6 launches = 0.18 ms for the 110 tensors of a fully trainable Y-Net (C1), alone on the GPU at the end
+// of every step.  Same update rule and the same precision choices as torch's fused kernel (fused_adam_utils.cuh): bias corrections
+// and the second-moment update in double, everything else in fp32; `step` counters stay the per-parameter fp32 device tensors of
+// optimizer.state (incremented by the first launch), so optimizer.state_dict() and torch's own step() see a consistent state.
+//   table [6][ntensors] of 64-bit values: param, grad, exp_avg, exp_avg_sq, step (pointers), numel
+//   chunk c (1024 elements): tensor chunk_tensor[c], first element chunk_first[c]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_steps_kernel(const long long* __restrict__ table, int ntensors) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < ntensors) {
+        float* st = reinterpret_cast<float*>(table[4ll * ntensors + i]);
+        *st += 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_update_kernel(const long long* __restrict__ table, const int* __restrict__ chunk_tensor,
+                                                          const long long* __restrict__ chunk_first, int ntensors, double lr, double beta1,
+                                                          double beta2, double eps, double weight_decay, int adamw) {
+    const int t = chunk_tensor[blockIdx.x];
+    float* __restrict__ p = reinterpret_cast<float*>(table[t]);
+    const float* __restrict__ g = reinterpret_cast<const float*>(table[1ll * ntensors + t]);
+    float* __restrict__ m = reinterpret_cast<float*>(table[2ll * ntensors + t]);
+    float* __restrict__ v = reinterpret_cast<float*>(table[3ll * ntensors + t]);
+    const double step = (double)*reinterpret_cast<const float*>(table[4ll * ntensors + t]);
+    const long long n = table[5ll * ntensors + t];
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - beta1);
+    const long long i0 = chunk_first[blockIdx.x] + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = i0 + k * 256;
+        if (i < n) {
+            float pv = p[i], gv = g[i], mv = m[i], vv = v[i];
+            if (weight_decay != 0.0) {
+                if (adamw) pv -= (float)(lr * weight_decay) * pv;
+                else gv += (float)((double)pv * weight_decay);
+            }
+            mv = mv + w1 * (gv - mv);                                            // lerp(exp_avg, grad, 1 - beta1), weight < 0.5
+            vv = (float)(beta2 * (double)vv + (1.0 - beta2) * (double)gv * (double)gv);
+            const float denom = (float)((double)(sqrtf(vv) / bc2_sqrt) + eps);
+            pv -= step_size * mv / denom;
+            p[i] = pv;
+            m[i] = mv;
+            v[i] = vv;
+        }
+    }
+}
+
+int ynet_adam_step(const long long* table, const int* chunk_tensor, const long long* chunk_first, int ntensors, int nchunks,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, int adamw, void* stream) {
+    YNET_REQUIRE(table && chunk_tensor && chunk_first && ntensors > 0 && nchunks > 0, "adam_step: bad arguments");
+    YNET_REQUIRE(lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "adam_step: bad hyper-parameters");
+    hipLaunchKernelGGL(adam_steps_kernel, dim3((ntensors + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, ntensors);
+    hipLaunchKernelGGL(adam_update_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor, chunk_first, ntensors, lr,
+                       beta1, beta2, eps, weight_decay, adamw);
+    return ynet_check_launch("adam_step");
+}
+
 int ynet_avgpool_pyramid(const float* x, float* const* outs, int nlev, long long N, int H, int W, void* stream) {
     YNET_REQUIRE(x && outs && nlev >= 1 && nlev <= 5, "avgpool_pyramid: 1..5 levels supported (got %d)", nlev);
     YNET_REQUIRE(N > 0 && H % 32 == 0 && W % 32 == 0 && H > 0 && W > 0,

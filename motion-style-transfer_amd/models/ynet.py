@@ -303,7 +303,8 @@ class YNetEncoderB(YNetEncoder):
                         j += 1
                     x = y
             else:
-                x = stage(x)
+                nxt = self.stages[i + 1] if i + 1 < len(self.stages) else None
+                x = stage(x, pool_next=nxt is not None and isinstance(nxt[0], HipMaxPool2d))
             features.append(x)
         return features
 

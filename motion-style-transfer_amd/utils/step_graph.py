@@ -146,6 +146,81 @@ def _make_capturable(optimizer, fused: bool = True) -> bool:
     return isinstance(optimizer, torch.optim.SGD)
 
 
+ADAM_KERNEL = os.environ.get("YNET_ADAM_KERNEL", "1") != "0"      # 0: captured steps call torch's (fused) optimizer.step()
+
+
+class _AdamTables:
+    """Device tables for ynet_adam_step.  prepare() runs BEFORE the capture (allocations and host-to-device copies are not capturable):
+    it allocates the tables and fills what depends on sizes only; the launches are recorded with the tables' addresses; fill() runs
+    AFTER the capture, when the addresses of the gradients the captured backward pass writes are known, and stores the pointers.
+    None when the optimizer is not a plain Adam / AdamW on contiguous fp32 device tensors whose state torch has already created (the
+    eager step that precedes every capture does that)."""
+
+    @staticmethod
+    def prepare(optimizer):
+        if not ADAM_KERNEL or type(optimizer) not in (torch.optim.Adam, torch.optim.AdamW):
+            return None
+        groups = []
+        for g in optimizer.param_groups:
+            if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or torch.is_tensor(g["lr"]):
+                return None
+            params = [p for p in g["params"] if p.requires_grad]
+            if not params:
+                continue
+            for p in params:
+                st = optimizer.state.get(p)
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    return None
+                if st and not all(k in st for k in ("step", "exp_avg", "exp_avg_sq")):
+                    return None
+            dev = params[0].device
+            ct, cf = [], []
+            for i, p in enumerate(params):
+                for first in range(0, p.numel(), 1024):
+                    ct.append(i)
+                    cf.append(first)
+            groups.append({"params": params, "table": torch.zeros((6, len(params)), dtype=torch.int64, device=dev),
+                           "dummy_step": torch.zeros(1, dtype=torch.float32, device=dev),
+                           "chunk_tensor": torch.tensor(ct, dtype=torch.int32).to(dev), "chunk_first": torch.tensor(cf, dtype=torch.int64).to(dev),
+                           "chunks": len(ct), "lr": float(g["lr"]), "betas": (float(g["betas"][0]), float(g["betas"][1])),
+                           "eps": float(g["eps"]), "wd": float(g.get("weight_decay", 0.0)),
+                           "adamw": 1 if type(optimizer) is torch.optim.AdamW else 0})
+        return groups or None
+
+    @staticmethod
+    def step(groups):
+        from .. import _lib as L
+        from .. import ops
+        lib = ops._lib()
+        for g in groups:
+            L.check(lib.ynet_adam_step(g["table"].data_ptr(), g["chunk_tensor"].data_ptr(), g["chunk_first"].data_ptr(), len(g["params"]),
+                                       g["chunks"], g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["wd"], g["adamw"], ops._stream()), lib)
+
+    @staticmethod
+    def fill(groups, optimizer):
+        """Pointers of (param, grad, exp_avg, exp_avg_sq, step) and the element count per parameter; a parameter without a gradient
+        in the captured step gets count 0 and a dummy step counter (torch skips it too).  Raises when a tensor is not what the kernel
+        expects -- the caller then captures again with torch's optimizer.step()."""
+        for g in groups:
+            rows, keep = [], []
+            for p in g["params"]:
+                st = optimizer.state.get(p)
+                if p.grad is None:
+                    rows.append([p.data_ptr(), 0, 0, 0, g["dummy_step"].data_ptr(), 0])
+                    continue
+                if not st:
+                    raise RuntimeError("optimizer state missing for a parameter with a gradient")
+                ts = (p, p.grad, st["exp_avg"], st["exp_avg_sq"])
+                sp = st["step"]
+                if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() for t in ts) or \
+                        not (torch.is_tensor(sp) and sp.is_cuda and sp.dtype == torch.float32 and sp.numel() == 1):
+                    raise RuntimeError("a tensor of the Adam step is not a contiguous fp32 device tensor")
+                rows.append([t.data_ptr() for t in ts] + [sp.data_ptr(), p.numel()])
+                keep.append(ts + (sp,))
+            g["keep"] = keep
+            g["table"].copy_(torch.tensor(rows, dtype=torch.int64).t().contiguous())
+
+
 class GraphCache:
     MAX_ENTRIES = 64
 
@@ -156,6 +231,7 @@ class GraphCache:
         self.last = None
         self.token = None
         self.fused_ok = os.environ.get("YNET_FUSED_ADAM", "1") != "0"
+        self.adam_ok = ADAM_KERNEL
 
     def lookup(self, key):
         """Least-recently-used cache of captured steps (a hit moves the entry to the young end: a dataset that cycles through
@@ -190,13 +266,20 @@ class CapturedStep:
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
-            for fused in ((True, False) if self.cache.fused_ok else (False,)):
+            for _ in range(3):      # ynet_adam_step -> torch's fused multi-tensor Adam -> its capturable foreach form
+                fused = self.cache.fused_ok
                 self.failed = False
+                self.adam_kernel = False
                 self._capture(batch, scene_image, forward_backward, optimizer, dp, finish, dev, fused)
                 if self.ready:
                     break
-                self.cache.fused_ok = False      # (a build without the fused kernel: capturable foreach from now on)
                 self.cache.pool = None           # a failed capture leaves its memory pool unusable: start a fresh one
+                if self.adam_kernel:
+                    self.cache.adam_ok = False   # (next attempt: torch's optimizer.step() inside the capture)
+                elif fused:
+                    self.cache.fused_ok = False  # (a build without the fused kernel: capturable foreach from now on)
+                else:
+                    break
         finally:
             if gc_was_enabled:
                 gc.enable()
@@ -221,6 +304,14 @@ class CapturedStep:
             # only the capturing thread is held to capture-safe calls then.
             pg = dist.is_available() and dist.is_initialized()
             mode = "thread_local" if (self.split or pg) else "global"
+            adam = _AdamTables.prepare(optimizer) if (fused and self.cache.adam_ok) else None
+            self.adam_kernel = adam is not None
+
+            def opt_step():
+                if adam is not None:
+                    _AdamTables.step(adam)
+                else:
+                    optimizer.step()
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, pool=self.cache.pool, stream=stream, capture_error_mode=mode):
                 fb = forward_backward(self.coords, self.scene, OVERLAP_DECODERS)
@@ -230,17 +321,20 @@ class CapturedStep:
                 if not self.split:
                     if dp is not None:
                         loss = dp.loss_value()
-                    optimizer.step()
+                    opt_step()
                     ade, fde = finish(fb)
             self.graphs = [g1]
             if self.split:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, pool=self.cache.pool, stream=stream, capture_error_mode=mode):
                     loss = dp.loss_value()
-                    optimizer.step()
+                    opt_step()
                     ade, fde = finish(fb)
                 self.graphs.append(g2)
             self.keep = fb                       # activations the second graph / the read-out consume
+            if adam is not None:
+                _AdamTables.fill(adam, optimizer)          # (the gradients' addresses exist now; raises -> captured again without it)
+                self.adam = adam
             self.grads = [p.grad for p in self.params]
             self.loss, self.ade, self.fde = loss, ade, fde
             self.ready = True

@@ -674,6 +674,38 @@ def test_upsample2x_bwd_relu(dev, shape):
     assert torch.equal(got, torch.where(act > 0, plain, torch.zeros_like(plain)))
 
 
+@pytest.mark.parametrize("cls,wd", [("Adam", 0.0), ("Adam", 0.01), ("AdamW", 0.05)])
+def test_adam_step_kernel_matches_torch(dev, cls, wd):
+    """ynet_adam_step (what a captured step launches instead of torch's fused multi-tensor Adam) against torch.optim.Adam / AdamW on the
+    device: five steps over tensors of 1 .. 70,000 elements, one of them without a gradient; the step counters advance as torch's do."""
+    sg = pkg("utils.step_graph")
+    shapes = [(1,), (7, 3), (1025,), (64, 64, 3, 3), (70000,), (5,)]
+    ps = [torch.nn.Parameter(rnd(*sh, seed=i).to(dev)) for i, sh in enumerate(shapes)]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    make = getattr(torch.optim, cls)
+    ref, mine = make(ps, lr=1e-3, weight_decay=wd), make(qs, lr=1e-3, weight_decay=wd, capturable=True, fused=True)
+    for step in range(5):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            g = None if i == 5 else rnd(*shapes[i], seed=100 + 10 * step + i).to(dev) * (10.0 if i == 2 else 1.0)
+            p.grad, q.grad = g, (None if g is None else g.clone())
+        ref.step()
+        if step == 0:
+            mine.step()                      # (torch creates the state; from then on the kernel advances it)
+            tabs = sg._AdamTables.prepare(mine)
+            assert tabs is not None
+        else:
+            sg._AdamTables.fill(tabs, mine)  # (new gradient tensors every step here: refresh the pointers)
+            sg._AdamTables.step(tabs)
+    torch.cuda.synchronize()
+    for i, (p, q) in enumerate(zip(ps, qs)):
+        close(q, p, rtol=1e-5, scale_rel=1e-6, msg=f"param {i}")
+        if i != 5:
+            close(mine.state[q]["exp_avg"], ref.state[p]["exp_avg"], rtol=1e-5, scale_rel=1e-6, msg="exp_avg")      # (torch's default foreach path rounds its lerp differently by an ulp)
+            close(mine.state[q]["exp_avg_sq"], ref.state[p]["exp_avg_sq"], rtol=1e-5, scale_rel=1e-6, msg="exp_avg_sq")
+            assert float(mine.state[q]["step"]) == 5.0
+    assert torch.equal(qs[5], ps[5]) and qs[5] not in mine.state or "step" not in mine.state.get(qs[5], {})
+
+
 def test_avgpool_pyramid(dev):
     ops = pkg("ops")
     x = rnd(3, 2, 64, 96, seed=1).abs()

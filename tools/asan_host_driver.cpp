@@ -85,6 +85,8 @@ int main() {
     EXPECT_REJECT(ynet_lora_conv2d_wgrad(srcs, &one, &bs, 1, cfp, 4, nullptr, 0, cfp, cfp, 1.f, fp, fp, fp, 1, 4, 6, 4, 3, 1, nullptr));       // W % 4
     EXPECT_REJECT(ynet_lora_compose_pack_multi(0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
     EXPECT_REJECT(ynet_lora_compose_pack_multi(99, srcs, srcs, srcs, cfp, dsts, dsts, &one, &one, &one, &one, nullptr));
+    EXPECT_REJECT(ynet_adam_step(nullptr, &one, (const long long*)dummy, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, nullptr));     // no table
+    EXPECT_REJECT(ynet_adam_step((const long long*)dummy, &one, (const long long*)dummy, 1, 1, 1e-3, 1.5, 0.999, 1e-8, 0.0, 0, nullptr));   // beta1 >= 1
     EXPECT_REJECT(ynet_maxpool2_fwd(nullptr, fp, 1, 4, 4, nullptr));
     EXPECT_REJECT(ynet_maxpool2_bwd(cfp, cfp, nullptr, 1, 4, 4, nullptr));
     EXPECT_REJECT(ynet_upsample2x_fwd(cfp, nullptr, 1, 2, 2, nullptr));
