@@ -77,10 +77,10 @@ class ConvTimer:
         self.ops, self.orig, self.rec = ops, ops.conv2d_raw, []
 
     def __enter__(self):
-        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None):
+        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of)
+            self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled)
             e1.record()
             cin = sum(s[1] for s in srcs)
             dl = list(dsts)
@@ -88,14 +88,14 @@ class ConvTimer:
                 dl.pop()
             cout = sum(d[1] for d in dl)
             flops = 2.0 * B * H * W * cin * cout * K * K
-            byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]) * (2 if relu_of else 1))
+            byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]) * (2 if relu_of else (1.25 if pooled else 1)))
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             if dma:
                 cc = 4
                 x4 = (plan >> 18) & 1
                 fold = 1 << ((plan >> 19) & 3)
-                name = (f"conv_dma_{'emask_' if relu_of else ''}kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "
+                name = (f"conv_dma_{'emask_' if relu_of else ('pool_' if pooled else '')}kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "
                         f"{'true' if x4 else 'false'}, {fold}>")
             else:
                 name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}, "
