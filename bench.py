@@ -402,7 +402,7 @@ def main():
     # FLOPs the product really launches per step (one counted step; all ranks run it: collectives inside)
     with FlopCounter(ops) as fc:
         run(1, 4, graph=False)
-    executed_gflop_per_traj = fc.flops / (B * N) / 1e9 * (1 if args.config != "C5" else 1)
+    executed_gflop_per_traj = fc.flops / B / 1e9      # (this rank's launches over this rank's B trajectories)
     ct, n_inst = None, 3
     if not args.no_roofline and args.config != "C5":
         ops.overlap_decoders = False      # kernels are timed in isolation: the two decoder streams run back to back
