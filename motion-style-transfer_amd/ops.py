@@ -621,7 +621,8 @@ class _Conv2dFn(torch.autograd.Function):
         d_srcs = [None] * ctx.n_src
         branch = None
         if (wgrad_branch and ctx.has_lora and dy.is_cuda and not need[1] and not (ctx.has_bias and need[2]) and (need[3] or need[4])
-                and lora_a.is_leaf and lora_b.is_leaf and not lora_a._backward_hooks and not lora_b._backward_hooks):
+                and lora_a.is_leaf and lora_b.is_leaf and not lora_a._backward_hooks and not lora_b._backward_hooks
+                and not getattr(lora_a, "_post_accumulate_grad_hooks", None) and not getattr(lora_b, "_post_accumulate_grad_hooks", None)):
             # fork BEFORE the data gradient is queued: the adapter gradients (below) run beside it (see `wgrad_branch`)
             cur = torch.cuda.current_stream(dy.device)
             bkey, branch = _wgrad_stream(dy.device)

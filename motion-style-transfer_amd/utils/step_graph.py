@@ -160,6 +160,8 @@ class _AdamTables:
     def prepare(optimizer):
         if not ADAM_KERNEL or type(optimizer) not in (torch.optim.Adam, torch.optim.AdamW):
             return None
+        if getattr(optimizer, "_optimizer_step_pre_hooks", None) or getattr(optimizer, "_optimizer_step_post_hooks", None):
+            return None          # (step hooks run inside optimizer.step(): keep it)
         groups = []
         for g in optimizer.param_groups:
             if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or torch.is_tensor(g["lr"]):

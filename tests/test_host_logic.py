@@ -258,3 +258,29 @@ def test_pad_numpy_branch_matches_copy_make_border_semantics():
     assert images["a"].shape == (32, 32, 3) and np.array_equal(images["a"][:5, :7], rgb)
     assert images["a"][5:].sum() == 0 and images["a"][:, 7:].sum() == 0 and images["a"].dtype == np.uint8
     assert images["b"].shape == (64, 32) and images["b"].sum() == 64 * 32
+
+
+def test_adam_kernel_tables_refuse_what_the_kernel_does_not_cover():
+    """utils/step_graph._AdamTables.prepare: only a plain Adam / AdamW over contiguous fp32 DEVICE parameters without step hooks is
+    taken over by ynet_adam_step inside a captured step; everything else keeps optimizer.step()."""
+    sg = pkg("utils.step_graph")
+    p = torch.nn.Parameter(torch.zeros(4))
+    assert sg._AdamTables.prepare(torch.optim.SGD([p], lr=0.1)) is None
+    assert sg._AdamTables.prepare(torch.optim.Adam([p], lr=0.1)) is None                      # host parameter
+    assert sg._AdamTables.prepare(torch.optim.Adam([p], lr=0.1, amsgrad=True)) is None
+    opt = torch.optim.Adam([p], lr=0.1)
+    opt.register_step_post_hook(lambda *a, **k: None)
+    assert sg._AdamTables.prepare(opt) is None
+
+    class MyAdam(torch.optim.Adam):
+        pass
+    assert sg._AdamTables.prepare(MyAdam([p], lr=0.1)) is None                               # a subclass may change the rule
+
+
+def test_fold_context_switches_the_gradient_branch_on_and_off():
+    ops = pkg("ops")
+    assert ops.wgrad_branch is False and ops.premask is False and ops.skip_fold is False
+    with ops.fold_skip_gradients():
+        assert ops.wgrad_branch == (ops._wgrad_branch_allowed and ops.overlap_decoders)
+        assert ops.premask == ops._premask_allowed
+    assert ops.wgrad_branch is False and ops.premask is False and not ops._wgrad_pending
