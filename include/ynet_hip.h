@@ -54,19 +54,6 @@ int ynet_conv2d(const float* const* src, const int* src_c, const long long* src_
                 float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                 int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
                 void* stream);
-/* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) followed by a 3x3 convolution (the decoder's
- * `x = F.interpolate(x, ...); x = self.upsample_conv[i](x)`, models/ynet.py:463-464) as ONE convolution over the LOW-resolution map:
- * output pixel (2y + a, 2x + b) is a 3x3 filter W_ab over x[y-1..y+1][x-1..x+1] (W_ab = the conv's filter composed with the two
- * interpolation rows / columns of phase (a, b)) -- the same FLOPs on a quarter of the input, and the up-sampled tensor is neither
- * written nor read.  The 2-pixel border ring (edge clamping vs zero padding) is recomputed from the definition by a second launch.
- *   ynet_upconv2x_pack:  w [cout][cin][3][3] (+ bias or NULL) -> wp, ynet_upconv2x_packed_floats(cout, cin) floats
- *   ynet_upconv2x:       x [B][cin][H][W] (batch stride x_bs) -> y [B][cout][2H][2W] (batch stride y_bs); w / bias again for the ring
- *   ynet_upconv2x_supported: W % 4 == 0, H >= 8, W > 16, enough tiles to fill the chip; elsewhere ynet_upsample2x_fwd + ynet_conv2d. */
-long long ynet_upconv2x_packed_floats(int cout, int cin);
-int ynet_upconv2x_pack(const float* w, const float* bias, float* wp, int cout, int cin, void* stream);
-int ynet_upconv2x_supported(int B, int H, int W, int cout, int cin);
-int ynet_upconv2x(const float* x, long long x_bs, int cin, const float* wp, const float* w, const float* bias, float* y, long long y_bs,
-                  int cout, int B, int H, int W, int relu, void* stream);
 /* ynet_conv2d with ONE destination plus its 2 x 2 max-pooled copy written by the same epilogue: the last convolution of an encoder
  * stage and the nn.MaxPool2d(2, 2) that opens the next one (models/ynet.py:202,215) without the stand-alone pass over y.
  * pooled [B][cout][H/2][W/2] (batch stride pooled_bs), the first-maximum / NaN rule of ynet_maxpool2_fwd; H, W even.

@@ -28,10 +28,6 @@ SIGNATURES = {
     "ynet_conv2d_workspace_floats": (c_ll, [c_i, c_i, c_i, c_i]),
     "ynet_conv2d": (c_i, [PP, PI, PLL, PI, c_i, c_fp, c_ll, c_fp, c_fp, PP, PI, PLL, c_i,
                           c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_fp]),
-    "ynet_upconv2x_packed_floats": (c_ll, [c_i, c_i]),
-    "ynet_upconv2x_pack": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
-    "ynet_upconv2x_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
-    "ynet_upconv2x": (c_i, [c_fp, c_ll, c_i, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_pool_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_pool": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_dgrad_relu_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),

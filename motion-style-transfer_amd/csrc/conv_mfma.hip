@@ -51,8 +51,6 @@ struct ConvArgs {
     const float* emask;     // optional [B][cout][H][W] post-ReLU activation whose backward is applied to the OUTPUT (one destination):
     long long emask_bs;     //   dst = emask > 0 ? conv(...) : 0 -- a data gradient written for a consumer that then needs no mask
     int emask_done, pool_done;      //   (host side) the launched kernels applied it / wrote the pooled copy
-    int up_cout;            // conv_dma_up_kernel (bilinear x2 + conv as four phase filters on the low-resolution map, see ynet_upconv2x):
-                            //   real output channels; `cout` is then 4 x 16 virtual channels per group of 16 real ones
     float* pool;            // optional second output [B][cout][H/2][W/2] = MaxPool2d(2, 2) of the (post-ReLU) first one, written by
     long long pool_bs;      //   the epilogue (conv_dma_pool_kernel): models/ynet.py:202,215 without the stand-alone pass over y
     int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
@@ -556,7 +554,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sgpr_rsrc(const void* p, unsig
 
 // EPI: 0 plain epilogue, 1 + the batch-shared additive term (ConvArgs::addend), 2 ReLU backward on the output (ConvArgs::emask),
 //      3 + the 2 x 2 max-pooled copy of the output (ConvArgs::pool)
-//      4 the four 16-channel tiles are the phases (2a + b) of a x2 up-sampled output: interleaved into the high-resolution image
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, int EPI>
 __device__ __forceinline__ void conv_dma_body() {
     using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
@@ -945,35 +942,6 @@ __device__ __forceinline__ void conv_dma_body() {
                     }
                 }
         }
-        if constexpr (EPI == 4) {
-            // Tile i = phase 2 a + b of the SAME 16 real output channels (ynet_upconv2x): output pixel (2 y + a, 2 x + b).  A lane's 4
-            // consecutive low-resolution pixels of the phases b = 0, 1 interleave into 8 consecutive high-resolution pixels of row
-            // 2 y + a: two 16-byte stores.  (The 2-pixel border ring is rewritten by upconv_border_kernel.)
-            static_assert(NCB == 4 && FOLD == 1, "phase epilogue: four 16-channel tiles");
-            const int Wh = 2 * W, HWh = 4 * HW;
-            float* dp = ke->dst[0].p + (long long)t.b * ke->dst[0].bs;
-            const __amdgpu_buffer_rsrc_t rd = sgpr_rsrc(dp, (unsigned)ke->up_cout * (unsigned)HWh * 4u);
-            const int c_real = t.cg * 16 + r16;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int gx = t.x0 + 16 * g + 4 * kq;
-                const unsigned vo = gx < W ? (unsigned)(c_real * HWh + 2 * gx) * 4u : 0x80000000u;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (ybase + r < H) {
-#pragma unroll
-                        for (int a2 = 0; a2 < 2; ++a2) {
-                            const f32x4 p0 = acc[2 * a2][r][g], p1 = acc[2 * a2 + 1][r][g];
-                            const f32x4 lo4 = f32x4{p0[0], p1[0], p0[1], p1[1]}, hi4 = f32x4{p0[2], p1[2], p0[3], p1[3]};
-                            const unsigned so = (unsigned)((2 * (ybase + r) + a2) * Wh) * 4u;
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo4), rd, vo, so, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi4), rd, vo + 16u, so, 0);
-                        }
-                    }
-                }
-            }
-            return;
-        }
         auto store_all = [&](__amdgpu_buffer_rsrc_t rd, unsigned ubase) {
             // ubase = ((c_lo - first channel of the destination) * HW + ybase * W) * 4, modulo 2^32
 #pragma unroll
@@ -1089,12 +1057,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_add_kernel(const ConvArgs) {
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
 __global__ __launch_bounds__(256, 2) void conv_dma_pool_kernel(const ConvArgs) {
     conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 3>();
-}
-
-// the same with the four tiles written as the phases of a x2 up-sampled output (ynet_upconv2x)
-template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
-__global__ __launch_bounds__(256, 2) void conv_dma_up_kernel(const ConvArgs) {
-    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 4>();
 }
 
 // the same with the ReLU backward of the layer below applied to the output (ConvArgs::emask)
@@ -1238,7 +1200,6 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         if constexpr (EPI == 1) return &conv_dma_add_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else if constexpr (EPI == 2) return &conv_dma_emask_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else if constexpr (EPI == 3) return &conv_dma_pool_kernel<NCB, R, CC, MASK, X4, FOLD>;
-        else if constexpr (EPI == 4) return &conv_dma_up_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else return &conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>;
     }();
     a.tiles_x = ceil_div(a.W, C::TW);
@@ -1249,7 +1210,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         int nchunks = 0;
         for (int i = 0; i < a.nsrc; ++i) nchunks += ceil_div(a.src[i].c, CC);
         a.ksplit = 1;
-        if (a.partial != nullptr && !ADD && EPI < 3) a.ksplit = conv_ksplit(nt, nchunks);
+        if (a.partial != nullptr && !ADD && EPI != 3) a.ksplit = conv_ksplit(nt, nchunks);
         while (a.ksplit > 1 && (long long)a.ksplit * a.B * a.cout * a.H * a.W > a.partial_cap) --a.ksplit;
         a.cps = ceil_div(nchunks, a.ksplit);
         a.ksplit = ceil_div(nchunks, a.cps);
@@ -1586,114 +1547,6 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// bilinear x2 (align_corners = False) followed by a 3x3 convolution (models/ynet.py:463-464: F.interpolate + upsample_conv) as ONE
-// convolution over the LOW-resolution map.  Output pixel (2 y + a, 2 x + b) depends on the low-resolution pixels (y - 1 .. y + 1,
-// x - 1 .. x + 1) only: the conv's tap ky reads up-sampled row 2 y + a + ky - 1 = a fixed blend of two neighbouring low-resolution rows,
-//     a = 0:  ky 0 -> .75 x[y-1] + .25 x[y]    ky 1 -> .25 x[y-1] + .75 x[y]    ky 2 -> .75 x[y] + .25 x[y+1]
-//     a = 1:  ky 0 -> .25 x[y-1] + .75 x[y]    ky 1 -> .75 x[y] + .25 x[y+1]    ky 2 -> .25 x[y] + .75 x[y+1]
-// so  W_ab[co][ci][u][v] = sum_ky sum_kx W[co][ci][ky][kx] Ry_a[ky][u] Rx_b[kx][v]  is a 3x3 filter per phase (a, b): the same FLOPs as the
-// convolution of the up-sampled map, on a quarter of the input, and the up-sampled tensor (4 x the input) is neither written nor read.
-// The four phases of 16 real output channels are the four 16-channel tiles of conv_dma_up_kernel<4, R, ...>, whose epilogue interleaves
-// them into the high-resolution image.  The identity does not hold on the 2-pixel border ring (the interpolation clamps at the edge, the
-// convolution pads the up-sampled map with zeros, the low-resolution tile is zero padded): upconv_border_kernel recomputes that ring
-// (1.6-6 % of the pixels) from the definition.
-//   packed: [cin_pad][9][cout_v_pad] composed filters, cout_v = 64 * ceil(cout / 16) (virtual channel = 64 grp + 16 phase + c), followed
-//   by cout_v_pad floats of bias per virtual channel.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float up2_blend(int a, int k, int u) {      // coefficient of x[y + u - 1] in up-sampled row 2 y + a + k - 1
-    const int hr = a + k - 1;                    // relative up-sampled row: -1 .. 2
-    // row 2 m + s: s = 0 -> .25 x[m-1] + .75 x[m];  s = 1 -> .75 x[m] + .25 x[m+1]   (m relative to y)
-    const int m = hr >= 0 ? hr / 2 : -1, sft = hr - 2 * m;
-    const int lo_idx = sft == 0 ? m - 1 : m, hi_idx = lo_idx + 1;      // the two rows blended, relative to y
-    const float wl = sft == 0 ? 0.25f : 0.75f, wh = 1.f - wl;
-    const int r = u - 1;
-    return (r == lo_idx ? wl : 0.f) + (r == hi_idx ? wh : 0.f);
-}
-
-__global__ void upconv_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wp, int cout, int cin,
-                                   int cin_pad, int cout_v_pad) {
-    const long long nw = (long long)cin_pad * 9 * cout_v_pad;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nw + cout_v_pad; i += (long long)gridDim.x * blockDim.x) {
-        const int v = (int)(i % cout_v_pad);
-        const int co = (v / 64) * 16 + (v % 16), ph = (v / 16) % 4, a = ph >> 1, b = ph & 1;
-        float out = 0.f;
-        if (i >= nw) {                                  // bias per virtual channel
-            out = (bias != nullptr && co < cout) ? bias[co] : 0.f;
-        } else {
-            const int t = (int)((i / cout_v_pad) % 9), ci = (int)(i / ((long long)cout_v_pad * 9));
-            const int u = t / 3, vv = t % 3;
-            if (co < cout && ci < cin) {
-                const float* wk = w + ((long long)co * cin + ci) * 9;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) out += wk[ky * 3 + kx] * up2_blend(a, ky, u) * up2_blend(b, kx, vv);
-            }
-        }
-        wp[i] = out;
-    }
-}
-
-// source rows / columns and weights of up-sampled index o (F.interpolate(scale_factor=2, mode='bilinear', align_corners=False); as glue.hip)
-__device__ __forceinline__ void up2_src(int o, int in, int& i0, int& i1, float& l0, float& l1) {
-    float s = 0.5f * ((float)o + 0.5f) - 0.5f;
-    s = s < 0.f ? 0.f : s;
-    i0 = (int)s;
-    i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    l1 = s - (float)i0;
-    l0 = 1.f - l1;
-}
-
-// y[b][co][Y][X] for the pixels of the 2-pixel border ring of the high-resolution image, from the definition:
-// bias + sum_ci sum_ky,kx w[co][ci][ky][kx] * UP(ci, Y + ky - 1, X + kx - 1), UP = 0 outside the image, bilinear with edge clamping inside.
-__global__ __launch_bounds__(256) void upconv_border_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int B,
-                                                            int cin, int cout, int H, int W, int relu) {
-    const int Hh = 2 * H, Wh = 2 * W;
-    const int ring = 4 * Wh + 4 * (Hh - 4);            // rows 0, 1, Hh-2, Hh-1 in full; columns 0, 1, Wh-2, Wh-1 of the others
-    const long long total = (long long)B * cout * ring;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int p = (int)(i % ring), co = (int)((i / ring) % cout), b = (int)(i / ((long long)ring * cout));
-        int Y, X;
-        if (p < 4 * Wh) {
-            const int rr = p / Wh;
-            Y = rr < 2 ? rr : Hh - 4 + rr;
-            X = p - rr * Wh;
-        } else {
-            const int q = p - 4 * Wh, rr = q / 4, cc = q % 4;
-            Y = 2 + rr;
-            X = cc < 2 ? cc : Wh - 4 + cc;
-        }
-        float acc = bias ? bias[co] : 0.f;
-        const float* xb = x + (long long)b * x_bs;
-        for (int ci = 0; ci < cin; ++ci) {
-            const float* xp = xb + (long long)ci * H * W;
-            const float* wk = w + ((long long)co * cin + ci) * 9;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = Y + ky - 1;
-                if (yy < 0 || yy >= Hh) continue;
-                int y0, y1;
-                float ly0, ly1;
-                up2_src(yy, H, y0, y1, ly0, ly1);
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = X + kx - 1;
-                    if (xx < 0 || xx >= Wh) continue;
-                    int x0, x1;
-                    float lx0, lx1;
-                    up2_src(xx, W, x0, x1, lx0, lx1);
-                    const float v = ly0 * (lx0 * xp[y0 * W + x0] + lx1 * xp[y0 * W + x1]) + ly1 * (lx0 * xp[y1 * W + x0] + lx1 * xp[y1 * W + x1]);
-                    acc = __builtin_fmaf(wk[ky * 3 + kx], v, acc);
-                }
-            }
-        }
-        if (relu) acc = acc < 0.f ? 0.f : acc;
-        y[(long long)b * y_bs + ((long long)co * Hh + Y) * Wh + X] = acc;
-    }
-}
-
 extern "C" {
 
 // The kernel instantiation the dispatcher picks for this problem, for naming it in profiles:
@@ -1877,66 +1730,6 @@ int ynet_conv2d_pool(const float* const* src, const int* src_c, const long long*
     const long long db[1] = {dst_bs};
     return conv2d_impl(src, src_c, src_bs, nullptr, nsrc, nullptr, 0, wp, bias, dsts, dc, db, 1, B, H, W, K, relu, nullptr, 0,
                        nullptr, 0, 0, stream, nullptr, 0, pooled, pooled_bs);
-}
-
-// ---- bilinear x2 + 3x3 convolution as one launch over the low-resolution map (+ the border ring) ----
-static int upconv_cin_pad(int cin) { return ceil_div(cin, YNET_CIN_PAD) * YNET_CIN_PAD; }
-static int upconv_cout_v(int cout) { return 64 * ceil_div(cout, 16); }
-
-long long ynet_upconv2x_packed_floats(int cout, int cin) {
-    return (long long)upconv_cin_pad(cin) * 9 * upconv_cout_v(cout) + upconv_cout_v(cout);
-}
-
-int ynet_upconv2x_pack(const float* w, const float* bias, float* wp, int cout, int cin, void* stream) {
-    YNET_REQUIRE(w != nullptr && wp != nullptr && cout > 0 && cin > 0, "upconv2x_pack: bad arguments");
-    const long long n = ynet_upconv2x_packed_floats(cout, cin);
-    int grid = (int)((n + 255) / 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(upconv_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, bias, wp, cout, cin, upconv_cin_pad(cin), upconv_cout_v(cout));
-    return ynet_check_launch("upconv2x_pack");
-}
-
-// the shapes the fused form serves: low-resolution maps wide enough for unfolded 32-pixel row units and with enough two-row tiles to fill
-// the chip (elsewhere: ynet_upsample2x_fwd + ynet_conv2d)
-int ynet_upconv2x_supported(int B, int H, int W, int cout, int cin) {
-    static const int on = getenv("YNET_UPCONV") ? atoi(getenv("YNET_UPCONV")) : 1;
-    static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
-    if (!on || !use_dma || B <= 0 || H < 8 || (W & 3) || cout <= 0 || cin <= 0 || conv_fold(H, W) != 1) return 0;
-    const long long tiles = (long long)ceil_div(W, 32) * ceil_div(H, 8) * ceil_div(cout, 16) * B;
-    return tiles >= 512 ? 1 : 0;
-}
-
-int ynet_upconv2x(const float* x, long long x_bs, int cin, const float* wp, const float* w, const float* bias, float* y, long long y_bs,
-                  int cout, int B, int H, int W, int relu, void* stream) {
-    YNET_REQUIRE(x && wp && w && y && cin > 0 && cout > 0 && B > 0, "upconv2x: bad arguments");
-    YNET_REQUIRE(ynet_upconv2x_supported(B, H, W, cout, cin), "upconv2x: shape B=%d %dx%d cin=%d cout=%d is not served (ask ynet_upconv2x_supported)", B, H, W, cin, cout);
-    YNET_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (x_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_bs & 3) == 0,
-                 "upconv2x: 16-byte aligned planes required");
-    hipStream_t st = (hipStream_t)stream;
-    ConvArgs a{};
-    a.nsrc = 1;
-    a.cin = cin;
-    a.src[0] = YSrc{x, cin, x_bs, 0};
-    a.ndst = 1;
-    a.cout = upconv_cout_v(cout);
-    a.cout_pad = a.cout;
-    a.up_cout = cout;
-    a.dst[0] = YDst{y, a.cout, y_bs};
-    a.wp = wp;
-    a.bias = wp + (long long)upconv_cin_pad(cin) * 9 * a.cout;
-    a.B = B;
-    a.H = H;
-    a.W = W;
-    a.relu = relu;
-    a.vec_store = 1;
-    a.vec_load = 1;
-    int rc = launch_dma_m<4, 2, 4, false, true, 1, 4>(a, st);
-    if (rc) return rc;
-    const long long ring = (long long)B * cout * (8ll * W + 4ll * (2 * H - 4));
-    long long blocks = (ring + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(upconv_border_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, B, cin, cout, H, W, relu);
-    return ynet_check_launch("upconv2x(border)");
 }
 
 // 1 if ynet_conv2d_dgrad_relu applies the mask inside the convolution kernel for this problem (3x3 on a map large enough for

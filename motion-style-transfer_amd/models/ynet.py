@@ -429,11 +429,8 @@ class YNetDecoder(nn.Module):
         features = features[::-1]
         x = self.center(features[0])
         for lvl, (f, d, up) in enumerate(zip(features[1:], self.decoder, self.upsample_conv)):
-            if type(up) is HipConv2d and ops.upconv_supported(x, up.weight, up.bias):
-                x = ops.upsample_conv2d(x, up.weight, up.bias, up._packed)      # bilinear x2 + conv: one launch over the low-res map
-            else:
-                x = ops.upsample2x(x)
-                x = up(x)
+            x = ops.upsample2x(x)
+            x = up(x)
             y = self._first_conv_shared(lvl, d, x, f)
             x = d[2](y, relu=True) if y is not None else d(ops.lazy_cat([x, f]))
         if readout:

@@ -859,75 +859,6 @@ class _Upsample2xFn(torch.autograd.Function):
         return dx
 
 
-_upconv_allowed = _os.environ.get("YNET_UPCONV", "1") != "0"
-
-
-def upconv_supported(x, weight, bias) -> bool:
-    """Can bilinear x2 + this 3x3 conv run as one launch over the low-resolution map (ynet_upconv2x)?  Frozen filters only: the filter
-    gradient would need the up-sampled input that the fused form never writes."""
-    if not (_upconv_allowed and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()):
-        return False
-    if tuple(weight.shape[2:]) != (3, 3) or weight.requires_grad or (bias is not None and bias.requires_grad) or x.data_ptr() % 16:
-        return False
-    B, cin, H, W = x.shape
-    return cin == weight.shape[1] and bool(_lib().ynet_upconv2x_supported(B, H, W, int(weight.shape[0]), cin))
-
-
-class _UpConvFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, cache):
-        B, cin, H, W = x.shape
-        cout = weight.shape[0]
-        lib = _lib()
-        key = _weight_key(weight, None, None)
-        if cache.get("key") != key:
-            cache.clear()
-            cache["key"] = key
-        bkey = None if bias is None else (bias.data_ptr(), bias._version)
-        e = cache.get("upconv")
-        if e is None or e[0] != bkey:
-            w = weight.detach().contiguous()
-            wp = torch.empty(lib.ynet_upconv2x_packed_floats(cout, cin), device=x.device, dtype=torch.float32)
-            L.check(lib.ynet_upconv2x_pack(w.data_ptr(), bias.detach().data_ptr() if bias is not None else None, wp.data_ptr(), cout, cin,
-                                           _stream()), lib)
-            e = cache["upconv"] = (bkey, wp, w)
-        _, wp, w = e
-        y = torch.empty((B, cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
-        L.check(lib.ynet_upconv2x(x.data_ptr(), cin * H * W, cin, wp.data_ptr(), w.data_ptr(),
-                                  bias.detach().data_ptr() if bias is not None else None, y.data_ptr(), cout * 4 * H * W, cout, B, H, W, 0,
-                                  _stream()), lib)
-        ctx.cache, ctx.shape = cache, (B, cin, H, W)
-        # x is a post-ReLU conv output: the backward below applies that ReLU's backward to the gradient it produces (`_premasked`)
-        ctx.premask = bool(premask and ctx.needs_input_grad[0] and _is_relu_output(x))
-        ctx.save_for_backward(weight, x if ctx.premask else None)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        weight, x = ctx.saved_tensors
-        B, cin, H, W = ctx.shape
-        cout = weight.shape[0]
-        lib = _lib()
-        dy = dy.contiguous()
-        # data gradient of the 3x3 conv on the high-resolution grid, then the bilinear backward: the two launches of the unfused path
-        wp_d = _cached(ctx.cache, weight, None, None, 1.0, "dgrad")
-        d_up = torch.empty((B, cin, 2 * H, 2 * W), device=dy.device, dtype=torch.float32)
-        conv2d_raw([(dy.data_ptr(), cout, cout * 4 * H * W)], None, wp_d, None, [(d_up.data_ptr(), cin, cin * 4 * H * W)], B, 2 * H, 2 * W, 3, False)
-        dx = torch.empty((B, cin, H, W), device=dy.device, dtype=torch.float32)
-        if ctx.premask and premask and x is not None:
-            L.check(lib.ynet_upsample2x_bwd_relu(d_up.data_ptr(), dx.data_ptr(), x.data_ptr(), B * cin, H, W, _stream()), lib)
-            _premasked[dx.data_ptr()] = (x.data_ptr(), dx._version, tuple(dx.shape))
-        else:
-            L.check(lib.ynet_upsample2x_bwd(d_up.data_ptr(), dx.data_ptr(), B * cin, H, W, _stream()), lib)
-        return dx, None, None, None
-
-
-def upsample_conv2d(x, weight, bias, cache: dict):
-    """conv3x3(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False), weight) + bias as one launch over x (see
-    ynet_upconv2x); callers check `upconv_supported` first."""
-    return _UpConvFn.apply(x, weight, bias, cache)
-
-
 def upsample2x(x):
     return _Upsample2xFn.apply(x)
 

@@ -706,30 +706,6 @@ def test_adam_step_kernel_matches_torch(dev, cls, wd):
     assert torch.equal(qs[5], ps[5]) and qs[5] not in mine.state or "step" not in mine.state.get(qs[5], {})
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout,bias", [(8, 128, 128, 32, 16, True), (8, 64, 128, 64, 32, True), (32, 32, 64, 64, 32, False),
-                                                 (4, 256, 256, 32, 16, True), (18, 44, 72, 16, 24, True)])
-def test_upsample_conv_as_one_launch(dev, B, H, W, cin, cout, bias):
-    """ynet_upconv2x: conv3x3(bilinear x2 (x)) as four phase filters over the low-resolution map + the recomputed border ring, against
-    F.conv2d(F.interpolate(...)) -- interior, ring and corners --, and its backward (conv dgrad + bilinear backward) against autograd."""
-    ops = pkg("ops")
-    x, w = rnd(B, cin, H, W, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=1.0 / (cin * 9) ** 0.5)
-    b = rnd(cout, seed=3, scale=0.1) if bias else None
-    xc = x.clone().requires_grad_(True)
-    y = F.conv2d(F.interpolate(xc, scale_factor=2, mode="bilinear", align_corners=False), w, b, padding=1)
-    gy = rnd(*y.shape, seed=4)
-    y.backward(gy)
-    xd, wd = x.to(dev).requires_grad_(True), w.to(dev)
-    bd = b.to(dev) if bias else None
-    assert ops.upconv_supported(xd, wd, bd)
-    yd = ops.upsample_conv2d(xd, wd, bd, {})
-    close(yd, y, rtol=1e-4, scale_rel=2e-6, msg="fused up-conv")
-    yd.backward(gy.to(dev))
-    close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg="dx of the fused up-conv")
-    # a trainable filter keeps the two-launch path (its gradient needs the up-sampled input)
-    assert not ops.upconv_supported(xd, wd.clone().requires_grad_(True), bd)
-    assert not ops.upconv_supported(x.to(dev)[:, :, :4, :8].contiguous(), wd, bd)
-
-
 def test_avgpool_pyramid(dev):
     ops = pkg("ops")
     x = rnd(3, 2, 64, 96, seed=1).abs()

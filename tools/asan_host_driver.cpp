@@ -60,11 +60,6 @@ int main() {
     for (int b : {1, 32, 256})
         for (int hw : {8, 32, 64, 256})
             for (int cout : {12, 32, 48, 64}) acc += ynet_conv2d_add_supported(b, hw, hw, cout, 3);
-    EXPECT_REJECT(ynet_upconv2x_pack(nullptr, nullptr, fp, 4, 4, nullptr));
-    EXPECT_REJECT(ynet_upconv2x(cfp, 64, 4, cfp, cfp, nullptr, fp, 256, 4, 1, 4, 4, 0, nullptr));                                   // a map the fused form does not serve
-    for (int b : {1, 32, 256})
-        for (int hw : {8, 32, 64, 128})
-            for (int c : {16, 32, 64}) acc += ynet_upconv2x_supported(b, hw, hw, c, 2 * c) + ynet_upconv2x_packed_floats(c, 2 * c) + ynet_upconv2x_supported(b, hw, hw + 2, c, c);
     EXPECT_REJECT(ynet_conv2d_pool(srcs, &one, &bs, 1, cfp, nullptr, fp, 4, 64, nullptr, 16, 1, 4, 4, 3, 1, nullptr));               // no pooled output
     EXPECT_REJECT(ynet_conv2d_pool(srcs, &one, &bs, 1, cfp, nullptr, fp, 4, 64, fp, 16, 1, 5, 4, 3, 1, nullptr));                    // odd H
     for (int b : {1, 32, 256})
