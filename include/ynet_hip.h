@@ -284,6 +284,11 @@ int ynet_pad2d(const float* x, float* y, long long N, int H, int W, int Hp, int 
  * [H][W] -> `classes` one-hot fp32 planes [classes][Hp][Wp]; the border is padded BEFORE the encoding, i.e. it is class 0. */
 int ynet_seg_onehot_pad(const int* labels, float* y, int H, int W, int Hp, int Wp, int classes, void* stream);
 
+/* y[i] = sum over b of x[b * batch_stride + i], i < n, in batch order (bitwise reproducible): the backward of `semantic_img.expand(B, ...)`
+ * (utils/train_epoch.py:87) and of the batch-broadcast scene features of Y-Net-Mod -- the gradient of a one-image tensor that every
+ * trajectory of the batch read.  n and batch_stride multiples of 4, 16-byte aligned. */
+int ynet_batch_sum(const float* x, float* y, int B, long long n, long long batch_stride, void* stream);
+
 /* ---- optimizer step --------------------------------------------------------------------------- */
 /* torch.optim.Adam / AdamW (models/trainer.py:182: Adam(lr)) for ALL parameters in two launches -- used inside captured training
  * steps, where torch's fused multi-tensor form costs 6 launches (0.18 ms alone on the GPU for a fully trainable Y-Net).  Same update

@@ -47,6 +47,7 @@ SIGNATURES = {
                                      c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_compose_pack": (c_i, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_lora_compose_pack_multi": (c_i, [c_i, PP, PP, PP, ctypes.POINTER(c_f), PP, PP, PI, PI, PI, PI, c_fp]),
+    "ynet_batch_sum": (c_i, [c_fp, c_fp, c_i, c_ll, c_ll, c_fp]),
     "ynet_adam_step": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                              c_i, c_fp]),
     "ynet_maxpool2_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),

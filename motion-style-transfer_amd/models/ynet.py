@@ -355,7 +355,9 @@ class YNetEncoderFusion(nn.Module):
         walk(self.scene_stages, x, scene, tail)
         last_scene = scene[-1]
         if once:
-            scene = [t.expand(B, -1, -1, -1) for t in scene]
+            # (training: every conv that reads a scene feature expands it itself, ops.BatchExpand -- the two decoders' gradients are
+            # then summed over the batch BEFORE they are added)
+            scene = [ops.BatchExpand(t, B) if (torch.is_grad_enabled() and t.requires_grad) else t.expand(B, -1, -1, -1) for t in scene]
         walk(self.motion_stages, motion_map, motion, tail)
         features = [ops.lazy_cat([s, m]) for s, m in zip(scene, motion)]
         x = features[-1]

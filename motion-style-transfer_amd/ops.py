@@ -77,8 +77,8 @@ class LazyCat:
         return self.parts[0].dtype
 
     def materialize(self) -> torch.Tensor:
-        return torch.cat([(p.tensor.repeat(p.times, 1, 1, 1) if isinstance(p, BatchRepeat) else p).contiguous()
-                          for p in self.parts], dim=1)
+        return torch.cat([(p.tensor.repeat(p.times, 1, 1, 1) if isinstance(p, BatchRepeat) else
+                           (p.expand() if isinstance(p, BatchExpand) else p)).contiguous() for p in self.parts], dim=1)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -123,6 +123,61 @@ class BatchRepeat:
     @property
     def dtype(self):
         return self.tensor.dtype
+
+
+class _BatchExpandFn(torch.autograd.Function):
+    """x [1,C,H,W] -> its stride-0 expansion to B images; backward: the sum of the B per-image gradients by ynet_batch_sum."""
+
+    @staticmethod
+    def forward(ctx, x, batch):
+        ctx.batch = int(batch)
+        return x.expand(ctx.batch, -1, -1, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B = ctx.batch
+        n = g[0].numel()
+        if not (g.is_cuda and g.dtype == torch.float32 and n % 4 == 0):
+            return g.sum(dim=0, keepdim=True), None
+        g = g.contiguous()
+        out = torch.empty((1,) + tuple(g.shape[1:]), device=g.device, dtype=torch.float32)
+        lib = _lib()
+        L.check(lib.ynet_batch_sum(g.data_ptr(), out.data_ptr(), B, n, n, _stream()), lib)
+        return out, None
+
+
+class BatchExpand:
+    """``tensor.expand(B, -1, -1, -1)`` of a one-image tensor, expanded anew by EVERY convolution that reads it (ops.conv2d): each
+    consumer then has its own expand node in the autograd graph, whose backward sums that consumer's per-image gradient over the batch
+    -- the sums of two consumers are added as ONE-image tensors.  With a single expanded tensor shared by the two decoders autograd adds
+    their full per-image gradients first (a B x C x H x W add: 0.43 ms at the top level of C4) and sums over the batch afterwards."""
+
+    def __init__(self, tensor: torch.Tensor, batch: int):
+        if tensor.dim() != 4 or tensor.shape[0] != 1 or batch < 1:
+            raise ValueError("BatchExpand: expected a 1xCxHxW tensor and a batch size >= 1")
+        self.tensor, self.batch = tensor, int(batch)
+
+    @property
+    def shape(self):
+        t = self.tensor
+        return torch.Size((self.batch, t.shape[1], t.shape[2], t.shape[3]))
+
+    def dim(self):
+        return 4
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @property
+    def dtype(self):
+        return self.tensor.dtype
+
+    def expand(self):
+        return _BatchExpandFn.apply(self.tensor, self.batch)
+
+    def record_stream(self, stream):
+        self.tensor.record_stream(stream)
 
 
 def batch_repeat(x, times: int):
@@ -756,7 +811,7 @@ def lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a, lora_b, scale):
 def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0, pool: bool = False):
     """[ReLU](conv(cat(x), W_eff) + bias); x is a tensor or a LazyCat.  pool: the caller applies max_pool2 to the result next --
     where the kernel can, the pooled copy is written by this launch and that max_pool2 call finds it (no kernel)."""
-    parts = _parts(x)
+    parts = [p.expand() if isinstance(p, BatchExpand) else p for p in _parts(x)]      # (a fresh expand node per consumer)
     meta = {"relu": bool(relu), "scale": float(scale), "cache": cache, "pool": bool(pool)}
     if any(isinstance(p, BatchRepeat) for p in parts):
         if torch.is_grad_enabled() and any(t.requires_grad for t in (weight, bias, lora_a, lora_b) if t is not None):

@@ -706,6 +706,26 @@ def test_adam_step_kernel_matches_torch(dev, cls, wd):
     assert torch.equal(qs[5], ps[5]) and qs[5] not in mine.state or "step" not in mine.state.get(qs[5], {})
 
 
+def test_batch_expand_gives_every_consumer_its_own_batch_sum(dev):
+    """ops.BatchExpand: a one-image tensor read by two convolutions as a batch-broadcast source -- each conv expands it itself
+    (_BatchExpandFn), so its gradient is two ynet_batch_sum launches + a one-image add; same gradient as stock autograd."""
+    ops = pkg("ops")
+    B, C, H, W = 6, 8, 16, 32
+    x, w1, w2 = rnd(1, C, H, W, seed=1), rnd(12, C, 3, 3, seed=2, scale=0.2), rnd(4, C + 3, 3, 3, seed=3, scale=0.2)
+    other = rnd(B, 3, H, W, seed=4)
+    xc = x.clone().requires_grad_(True)
+    xe = xc.expand(B, -1, -1, -1)
+    (F.conv2d(xe, w1, padding=1).square().sum() + F.conv2d(torch.cat([xe, other], 1), w2, padding=1).sum() * 3.0).backward()
+    xd = x.to(dev).requires_grad_(True)
+    be = ops.BatchExpand(xd, B)
+    total = ops.conv2d(be, w1.to(dev), None, False, {}).square().sum() \
+        + ops.conv2d(ops.lazy_cat([be, other.to(dev)]), w2.to(dev), None, False, {}).sum() * 3.0
+    total.backward()
+    close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg="gradient of the broadcast image")
+    got = ops.lazy_cat([be, other.to(dev)]).materialize()
+    assert torch.equal(got.cpu(), torch.cat([x.expand(B, -1, -1, -1), other], 1))
+
+
 def test_avgpool_pyramid(dev):
     ops = pkg("ops")
     x = rnd(3, 2, 64, 96, seed=1).abs()

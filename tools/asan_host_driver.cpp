@@ -87,6 +87,8 @@ int main() {
     EXPECT_REJECT(ynet_lora_compose_pack_multi(99, srcs, srcs, srcs, cfp, dsts, dsts, &one, &one, &one, &one, nullptr));
     EXPECT_REJECT(ynet_adam_step(nullptr, &one, (const long long*)dummy, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, nullptr));     // no table
     EXPECT_REJECT(ynet_adam_step((const long long*)dummy, &one, (const long long*)dummy, 1, 1, 1e-3, 1.5, 0.999, 1e-8, 0.0, 0, nullptr));   // beta1 >= 1
+    EXPECT_REJECT(ynet_batch_sum(cfp, fp, 2, 6, 6, nullptr));           // n % 4
+    EXPECT_REJECT(ynet_batch_sum(nullptr, fp, 2, 8, 8, nullptr));
     EXPECT_REJECT(ynet_maxpool2_fwd(nullptr, fp, 1, 4, 4, nullptr));
     EXPECT_REJECT(ynet_maxpool2_bwd(cfp, cfp, nullptr, 1, 4, 4, nullptr));
     EXPECT_REJECT(ynet_upsample2x_fwd(cfp, nullptr, 1, 2, 2, nullptr));
