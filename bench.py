@@ -24,6 +24,7 @@ import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -48,22 +49,98 @@ def pkg(sub):
     return importlib.import_module(PKG + "." + sub)
 
 
-def make_cfg(O, name):
+class WorkCfg(SimpleNamespace):
+    """The workload's hyper-parameters; `oracle_cfg` turns it into the oracle's Cfg for the CPU legs."""
+
+    @property
+    def template_size(self):
+        return int(4200 * self.resize_factor)      # models/trainer.py:61
+
+
+def _cfg(obs_len, pred_len, waypoints, resize_factor, temperature, **kw):
+    base = dict(obs_len=obs_len, pred_len=pred_len, waypoints=tuple(waypoints), resize_factor=resize_factor, temperature=temperature,
+                n_classes=6, enc=(32, 32, 64, 64, 64), dec=(64, 64, 64, 32, 32), network="original", n_fusion=None,
+                train_net="train", position=[], loss_scale=1000.0, kernlen=31, nsig=4.0)
+    base.update(kw)
+    return WorkCfg(**base)
+
+
+def sdd_short(**kw):
+    return _cfg(8, 12, (11,), 0.25, 1.0, **kw)
+
+
+def sdd_long(**kw):
+    return _cfg(5, 30, (14, 29), 0.25, 1.8, **kw)
+
+
+def ind_long(**kw):
+    return _cfg(5, 30, (14, 29), 0.33, 1.8, **kw)
+
+
+def oracle_cfg(O, c):
+    return O.Cfg(**{k: v for k, v in vars(c).items()})
+
+
+def make_cfg(name):
     pos5 = ["0", "1", "2", "3", "4"]
     if name == "C2":
-        return O.sdd_short(train_net="mosa_1", position=pos5), 256, 256, \
+        return sdd_short(train_net="mosa_1", position=pos5), 256, 256, \
             "C2: SDD shortterm Y-Net + LoRA rank=1 on encoder[0-4], 256x256 raster, obs=8 pred=12"
     if name == "C1":
-        return O.sdd_short(train_net="train"), 256, 256, "C1: SDD shortterm Y-Net, all weights trainable, 256x256"
+        return sdd_short(train_net="train"), 256, 256, "C1: SDD shortterm Y-Net, all weights trainable, 256x256"
     if name == "C3":
-        return O.sdd_short(train_net="mosa_4", position=pos5), 256, 256, "C3: SDD ped->biker MoSA, LoRA rank=4, 256x256"
+        return sdd_short(train_net="mosa_4", position=pos5), 256, 256, "C3: SDD ped->biker MoSA, LoRA rank=4, 256x256"
     if name == "C4":
-        return O.ind_long(network="fusion", n_fusion=2, train_net="mosa_3", position=["scene"]), 512, 512, \
+        return ind_long(network="fusion", n_fusion=2, train_net="mosa_3", position=["scene"]), 512, 512, \
             "C4: inD longterm Y-Net-Mod, scene adapter only (LoRA r=3), 512x512, obs=5 pred=30"
     if name == "C5":
-        return O.sdd_long(train_net="train"), 256, 256, \
+        return sdd_long(train_net="train"), 256, 256, \
             "C5: SDD longterm eval sweep, K=20 goal samples, obs=5 pred=30 waypoints [14,29], 256x256"
     raise SystemExit(f"unknown config {name}")
+
+
+# Synthetic inputs of BASELINE.md section 3 (the product's own generators: the oracle is imported by the cpu_baseline /
+# parity_check legs only): semantic map softmax(randn(6, H, W), 0) shared by the batch; trajectories start ~ U(0.3 W, 0.7 W)^2,
+# steps ~ N(0, 2 px) cumulative, fp32 [n, obs + pred, 2].
+def synthetic_scene(cfg, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.softmax(torch.randn(cfg.n_classes, H, W, generator=g), dim=0).unsqueeze(0)
+
+
+def synthetic_trajectories(cfg, n, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed + 1)
+    start = torch.rand(n, 1, 2, generator=g) * torch.tensor([0.4 * W, 0.4 * H]) + torch.tensor([0.3 * W, 0.3 * H])
+    steps = torch.randn(n, cfg.obs_len + cfg.pred_len, 2, generator=g) * 2.0
+    steps[:, 0] = 0
+    return (start + steps.cumsum(dim=1)).float()
+
+
+def build_model(cfg, dev, seed=0, lora_b_std=0.05, state_dict=None):
+    """Random-init Y-Net of the config (torch's default initialisation under a fixed seed; LoRA runs set lora_B ~ N(0, 0.05):
+    BASELINE.md section 3) with the freeze policy of its train_net -- or the given state dict (parity_check: the oracle's)."""
+    ynet, trainer = pkg("models.ynet"), pkg("models.trainer")
+    torch.manual_seed(seed)
+    model = ynet.YNet(cfg.obs_len, cfg.pred_len, None, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
+                      n_waypoints=len(cfg.waypoints), train_net=cfg.train_net, position=list(cfg.position),
+                      network=cfg.network, n_fusion=cfg.n_fusion)
+    if state_dict is not None:
+        model.load_state_dict(state_dict, strict=True)
+    else:
+        g = torch.Generator().manual_seed(seed + 17)
+        with torch.no_grad():
+            for m in model.modules():
+                if getattr(m, "r", 0) and hasattr(m, "lora_B"):
+                    m.lora_B.copy_(torch.randn(m.lora_B.shape, generator=g) * lora_b_std)
+    trainer.apply_freeze_policy(model, cfg.train_net, cfg.position, cfg.network)
+    return model.to(dev)
+
+
+def templates(cfg, dev):
+    """(input template, ground-truth template) as YNetTrainer.templates() builds them on a HIP device (analytic: the windows
+    are computed in the kernel, bit-identical to slices of the S x S arrays of utils/image_utils.py:15-37)."""
+    iu = pkg("utils.image_utils")
+    return (iu.analytic_dist_template(cfg.template_size, dev),
+            iu.analytic_gaussian_template(cfg.template_size, cfg.kernlen, cfg.nsig, False, dev))
 
 
 def loader_for(traj):
@@ -91,14 +168,16 @@ class ConvTimer:
             byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]) * (2 if relu_of else (1.25 if pooled else 1)))
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
+            cc = plan >> 21                       # input channels per staged chunk (the kernel's CC template argument)
             if dma:
-                cc = 4
+                if cc > 8 and (mask or relu_of or pooled):
+                    cc = 8                        # (launch_dma_small: 16-channel chunks are for plain launches only)
                 x4 = (plan >> 18) & 1
                 fold = 1 << ((plan >> 19) & 3)
                 name = (f"conv_dma_{'emask_' if relu_of else ('pool_' if pooled else '')}kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "
                         f"{'true' if x4 else 'false'}, {fold}>")
             else:
-                name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, { {1: 16, 3: 8, 5: 4}[K] }, {'true' if mask else 'false'}, "
+                name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "
                         f"{'true' if m16 else 'false'}>")
             self.rec.append((name, e0, e1, flops, byts, (B, H, W, cin, cout, K, bool(mask))))
         self.ops.conv2d_raw = timed
@@ -211,7 +290,7 @@ def readout_roofline(ops, ynet_mod, cfg, B, H, W, dev):
 
 
 def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0, big_batch=None):
-    """CPU oracle (port of the reference's ATen-op path) on the host cores: bounded sample."""
+    """CPU oracle (port of the reference's ATen-op path) on the host cores: bounded sample.  `cfg`: the oracle's Cfg."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # torch's intra-op pool degrades badly when oversubscribed (256 threads on the GPU box's host ran
     # 30x slower than 32): pick the fastest of a few thread counts on a quick conv probe.
@@ -230,6 +309,7 @@ def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0, big_batch=None):
     torch.set_num_threads(cores)
     sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.05)
     scene = O.synthetic_scene(cfg, H, W, 0)
+    replay = {"state_dict": {k: v.clone() for k, v in sd.items()}, "scene": scene, "trajectories": []}      # what parity_check re-runs on the HIP path
     S = cfg.template_size
     in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
     names = O.trainable_names(cfg, sd)
@@ -244,6 +324,7 @@ def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0, big_batch=None):
         t0 = time.perf_counter()
         r = O.train_step(sd, cfg, scene, traj, in_t, gt_t, names)
         if len(first) < 3:       # kept for parity_check: the HIP path repeats exactly these steps (eager, capture, replay)
+            replay["trajectories"].append(traj)
             first.append({"batch": batch, "loss": float(r["loss"]), "ade": float(r["ade"].mean()), "fde": float(r["fde"].mean())})
         for n in names:
             sd[n], ms[n], vs[n] = O.adam_update(sd[n], r["grads"][n], ms[n], vs[n], step + 1, 1e-3)
@@ -270,7 +351,7 @@ def cpu_baseline(O, cfg, H, W, batch, seconds_budget=20.0, big_batch=None):
             tb.append(time.perf_counter() - t0)
         out["at_benchmarked_batch"] = {"batch": big_batch, "value": big_batch / tb[-1], "unit": "trajectories/s",
                                        "sample": f"2nd of 2 steps of batch {big_batch}, {tb[-1] * 1e3:.0f} ms, same {cores} threads"}
-    return out, first
+    return out, first, replay
 
 
 def parity_check(first, gpu_steps, launched):
@@ -294,6 +375,22 @@ def parity_check(first, gpu_steps, launched):
             "tolerance": {"loss_rel": 2e-5, "ade_fde_abs": 1e-4}, "ok": ok}
 
 
+def step_roofline(value_per_gpu, gf, mb, executed_gflop_per_traj):
+    """The whole step against both roofs (per GPU); the dominant kernel's figure is in "roofline"."""
+    return {
+        "algorithmic_gflop_per_trajectory": gf, "tflops_per_gpu": value_per_gpu * gf / 1e3,
+        "frac_of_fp32_peak": value_per_gpu * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+        # what the launches of one step really compute (counted at the op layer in one eager step; without tile padding):
+        # below the algorithmic figure where the product shares work (C4 scene branch, C5 shared skip terms); only THIS
+        # fraction is hardware utilisation
+        "executed_gflop_per_trajectory": executed_gflop_per_traj,
+        "executed_tflops_per_gpu": value_per_gpu * executed_gflop_per_traj / 1e3,
+        "executed_frac_of_fp32_peak": value_per_gpu * executed_gflop_per_traj / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+        "algorithmic_mb_per_trajectory": mb,
+        "hbm_gbs_per_gpu": None if mb is None else value_per_gpu * mb / 1e3,
+        "frac_of_hbm_peak": None if mb is None else value_per_gpu * mb / 1e3 / PEAK_HBM_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +404,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-repeats", action="store_true", help="time the contract's region only (no two repeat regions)")
     ap.add_argument("--no-c5", action="store_true", help="skip the short C5 leg of the default run")
+    ap.add_argument("--no-legs", action="store_true", help="skip the short C1 / C4 legs of the default run")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained region after the contract's timed region")
+    ap.add_argument("--sustained-seconds", type=float, default=5.5)
     ap.add_argument("--layers", action="store_true", help="print one line per conv launch of the instrumented step (stderr)")
     args = ap.parse_args()
 
@@ -339,7 +439,6 @@ def main():
             print(f"bench.py: a rank failed (torch.distributed.run exit code {rc})", file=sys.stderr)
         raise SystemExit(rc if rc else 0)
 
-    from oracle import ynet_oracle as O      # cpu_baseline / parity_check legs + synthetic-input generators only
     D = pkg("dist")
     rank, local, world = D.init_from_env()
     if world != args.gpus:
@@ -354,46 +453,55 @@ def main():
     if os.environ.get("YNET_BENCH_FAIL_RANK") == str(rank) and world > 1:      # (tests: the launcher must report a dying rank)
         raise SystemExit(f"rank {rank} fails on purpose (YNET_BENCH_FAIL_RANK)")
     ynet, trainer, te, ops = pkg("models.ynet"), pkg("models.trainer"), pkg("utils.train_epoch"), pkg("ops")
-    cfg, H, W, workload = make_cfg(O, args.config)
+    cfg, H, W, workload = make_cfg(args.config)
     if args.batch is None:
         args.batch = {"C4": 16, "C5": 128}.get(args.config, 32)
     B, N = args.batch, world
-    sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.05)
-    model = ynet.YNet(cfg.obs_len, cfg.pred_len, None, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
-                      n_waypoints=len(cfg.waypoints), train_net=cfg.train_net, position=list(cfg.position),
-                      network=cfg.network, n_fusion=cfg.n_fusion)
-    model.load_state_dict(sd, strict=True)
-    trainer.apply_freeze_policy(model, cfg.train_net, cfg.position, cfg.network)
-    model.to(dev)
+    # model, templates, scene: built by the PACKAGE (the oracle is imported further down, inside the cpu_baseline / parity_check legs only)
+    model = build_model(cfg, dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     dp = D.DataParallel(model.parameters()) if world > 1 else None
     crit = trainer.HipBCEWithLogitsLoss()
-    S = cfg.template_size
-    in_t, gt_t = O.dist_template(S).to(dev), O.gaussian_template(S, cfg.kernlen, cfg.nsig).to(dev)
-    images = {"scene0": O.synthetic_scene(cfg, H, W, 0)[0].to(dev)}
+    in_t, gt_t = templates(cfg, dev)
+    images = {"scene0": synthetic_scene(cfg, H, W, 0)[0].to(dev)}
 
     ev = pkg("utils.evaluate")
-    soft_rec = []
 
-    def run_eval(n_steps, seed):
-        traj = O.synthetic_trajectories(cfg, B * N * n_steps, H, W, seed)
-        a, f, _, _ = ev.evaluate(model, loader_for(traj), images, dev, "sdd", None, in_t, list(cfg.waypoints), "test",
-                                 20, 1, cfg.obs_len, B * N, cfg.resize_factor, cfg.temperature, dp=dp)
-        return a, f, 0.0
+    def prep(n_steps, seed):
+        """The inputs of `n_steps` steps (host coordinates, as the reference's loader hands them over) -- generated BEFORE a timed region."""
+        return loader_for(synthetic_trajectories(cfg, B * N * n_steps, H, W, seed))
 
-    def run(n_steps, seed, graph=None):
+    def go(loader, graph=None):
         if args.config == "C5":
-            return run_eval(n_steps, seed)
-        traj = O.synthetic_trajectories(cfg, B * N * n_steps, H, W, seed)
-        return te.train_epoch(model, loader_for(traj), images, opt, crit, cfg.loss_scale, dev, "sdd", None, gt_t, in_t,
+            a, f, _, _ = ev.evaluate(model, loader, images, dev, "sdd", None, in_t, list(cfg.waypoints), "test",
+                                     20, 1, cfg.obs_len, B * N, cfg.resize_factor, cfg.temperature, dp=dp)
+            return a, f, 0.0
+        return te.train_epoch(model, loader, images, opt, crit, cfg.loss_scale, dev, "sdd", None, gt_t, in_t,
                               list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B * N, 10000, cfg.resize_factor,
                               cfg.network, False, dp=dp, graph=graph)
+
+    def run(n_steps, seed, graph=None):
+        return go(prep(n_steps, seed), graph)
 
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def timed(n_steps, seed):
+        """One timed region: inputs generated first, then EXACTLY n_steps steps between two fences; MAX over ranks."""
+        loader = prep(n_steps, seed)
+        fence()
+        t0 = time.perf_counter()
+        res = go(loader)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, res
 
     # Per-kernel roofline of the dominant kernel: three instrumented EAGER steps on one stream, before the timed region
     # (eager launches are the only place where a HIP-event pair brackets one kernel: the timed region replays a captured
@@ -417,29 +525,21 @@ def main():
 
     if args.warmup > 0:
         run(args.warmup, 1)
-    fence()
-    t0 = time.perf_counter()
-    ade, fde, loss = run(args.steps, 2)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, (ade, fde, loss) = timed(args.steps, 2)
     value = B * N * args.steps / elapsed
     # The contract's timed region is the one above (EXACTLY --steps steps); two more identical regions give the spread
     regions = [elapsed / args.steps * 1e3]
     for rep in range(0 if args.no_repeats else 2):
-        fence()
-        t0 = time.perf_counter()
-        run(args.steps, 5 + rep)
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        regions.append(dt / args.steps * 1e3)
+        regions.append(timed(args.steps, 5 + rep)[0] / args.steps * 1e3)
+    # >= 5 s of the same replayed steps after the contract region: long enough for the driver's SMI sampler to see the GPU busy,
+    # and a check of the clocks under sustained load (the contract region is 0.2-0.5 s)
+    sustained = None
+    if not args.no_sustained and args.config != "C5":
+        n_sus = max(args.steps, int(np.ceil(args.sustained_seconds * 1e3 / regions[0])))
+        dt_s, _ = timed(n_sus, 9)
+        sustained = {"steps": n_sus, "seconds": dt_s, "ms_per_step": dt_s / n_sus * 1e3, "value": B * N * n_sus / dt_s,
+                     "unit": "trajectories/s", "note": "one more timed region of the same replayed steps, sized for >= "
+                     f"{args.sustained_seconds:g} s; `value` / `ms_per_step` of the line stay the contract region's"}
 
     out = {
         "metric": ("trajectories/sec eval sweep K=20 (Y-Net, SDD longterm)" if args.config == "C5"
@@ -453,13 +553,18 @@ def main():
         "timed_regions": {"ms_per_step": [round(r_, 4) for r_ in regions], "median_ms_per_step": float(np.median(regions)),
                           "min_ms_per_step": min(regions), "max_ms_per_step": max(regions),
                           "median_value": B * N / (float(np.median(regions)) * 1e-3),
-                          "note": "region 0 is the contract's timed region (value / ms_per_step); the others repeat it"},
+                          "note": "region 0 is the contract's timed region (value / ms_per_step); the others repeat it; the inputs of "
+                                  "every region are generated before its clock starts"},
         "step_launch": "hipGraph replay" if pkg("utils.step_graph").enabled(None, dev) and args.config != "C5" else "eager",
     }
+    if sustained is not None:
+        out["sustained"] = sustained
     if out["step_launch"] != "eager":      # what the step cache really holds: a failed capture means the timed steps ran eagerly
         sg = pkg("utils.step_graph")
         entries = [e for c in sg._caches.get(model, {}).values() for e in c.entries.values()]
-        out["step_graphs"] = {"captured": sum(1 for e in entries if e.ready), "failed": sum(1 for e in entries if e.failed)}
+        out["step_graphs"] = {"captured": sum(1 for e in entries if e.ready), "failed": sum(1 for e in entries if e.failed),
+                              "graphs_per_step": max([len(e.graphs) for e in entries if e.ready] or [0]),
+                              "collective_in_graph": any(getattr(e, "collective_in_graph", False) for e in entries if e.ready)}
         if not any(e.ready for e in entries):
             out["step_launch"] = "eager (no step was captured)"
     # proof of the process group the step ran on: size and backend as torch.distributed reports them, and every rank's device
@@ -478,18 +583,7 @@ def main():
     else:
         out["world"] = {"world_size": 1, "backend": None, "ranks": [mine], "allreduce_floats_per_step": 0}
     gf, mb = STEP_WORK[args.config]
-    out["step_roofline"] = {      # the whole step against both roofs (per GPU); the dominant kernel's figure is in "roofline"
-        "algorithmic_gflop_per_trajectory": gf, "tflops_per_gpu": value / N * gf / 1e3,
-        "frac_of_fp32_peak": value / N * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS,
-        # what the launches of one step really compute (counted at the op layer in one eager step; without tile padding):
-        # below the algorithmic figure where the product shares work (C4 scene branch, C5 shared skip terms); only THIS
-        # fraction is hardware utilisation
-        "executed_gflop_per_trajectory": executed_gflop_per_traj,
-        "executed_tflops_per_gpu": value / N * executed_gflop_per_traj / 1e3,
-        "executed_frac_of_fp32_peak": value / N * executed_gflop_per_traj / 1e3 / PEAK_FP32_MFMA_TFLOPS,
-        "algorithmic_mb_per_trajectory": mb,
-        "hbm_gbs_per_gpu": None if mb is None else value / N * mb / 1e3,
-        "frac_of_hbm_peak": None if mb is None else value / N * mb / 1e3 / PEAK_HBM_GBS}
+    out["step_roofline"] = step_roofline(value / N, gf, mb, executed_gflop_per_traj)
 
     if args.no_roofline:
         pass
@@ -585,24 +679,20 @@ def main():
         # ---- BASELINE.json's HBM-bound roofline point (configs[4]: K = 20 goal-decoder sweep, B = 128) in the default run:
         # two warm-up batches (the first ones grow the caching allocator's pools: 150 instead of 121 ms per batch) + four timed
         # batches of the evaluation sweep, and its read-out kernel timed in isolation
-        cfg5, H5, W5, workload5 = make_cfg(O, "C5")
-        m5 = ynet.YNet(cfg5.obs_len, cfg5.pred_len, None, encoder_channels=list(cfg5.enc), decoder_channels=list(cfg5.dec),
-                       n_waypoints=len(cfg5.waypoints), train_net=cfg5.train_net, position=list(cfg5.position),
-                       network=cfg5.network, n_fusion=cfg5.n_fusion)
-        m5.load_state_dict(O.make_state_dict(cfg5, seed=0), strict=True)
-        m5.to(dev)
+        cfg5, H5, W5, workload5 = make_cfg("C5")
+        m5 = build_model(cfg5, dev)
         B5 = 128
-        in5 = O.dist_template(cfg5.template_size).to(dev)
-        img5 = {"scene0": O.synthetic_scene(cfg5, H5, W5, 0)[0].to(dev)}
+        in5, _ = templates(cfg5, dev)
+        img5 = {"scene0": synthetic_scene(cfg5, H5, W5, 0)[0].to(dev)}
 
-        def sweep(n_batches, seed):
-            traj = O.synthetic_trajectories(cfg5, B5 * n_batches, H5, W5, seed)
-            return ev.evaluate(m5, loader_for(traj), img5, dev, "sdd", None, in5, list(cfg5.waypoints), "test", 20, 1,
+        def sweep(loader):
+            return ev.evaluate(m5, loader, img5, dev, "sdd", None, in5, list(cfg5.waypoints), "test", 20, 1,
                                cfg5.obs_len, B5, cfg5.resize_factor, cfg5.temperature)
-        sweep(2, 11)
+        sweep(loader_for(synthetic_trajectories(cfg5, B5 * 2, H5, W5, 11)))
+        l5 = loader_for(synthetic_trajectories(cfg5, B5 * 4, H5, W5, 12))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        a5, f5, _, _ = sweep(4, 12)
+        a5, f5, _, _ = sweep(l5)
         torch.cuda.synchronize()
         dt5 = time.perf_counter() - t0
         out["c5"] = {"workload": workload5, "batch": B5, "batches_timed": 4, "value": 4 * B5 / dt5, "unit": "trajectories/s",
@@ -610,23 +700,50 @@ def main():
                      "sweep_launch": pkg("utils.evaluate").last_sweep_launch(),
                      "roofline": readout_roofline(ops, ynet, cfg5, B5, H5, W5, dev)}
         del m5
+    if rank == 0 and N == 1 and args.config == "C2" and not args.no_legs:
+        # ---- the other single-GPU training configs of BASELINE.json, driver-timed: C1 (every weight trains: the filter-gradient
+        # kernels and ynet_adam_step over 1.64 M parameters) and C4 (Y-Net-Mod, 512x512, per-GPU batch 16): 3 steps of warm-up
+        # (eager, capture + replay, replay), then 5 replayed steps between two synchronisations
+        for leg, Bl in (("C1", 32), ("C4", 16)):
+            cl, Hl, Wl, wl = make_cfg(leg)
+            ml = build_model(cl, dev)
+            optl = torch.optim.Adam(ml.parameters(), lr=1e-3)
+            inl, gtl = templates(cl, dev)
+            imgl = {"scene0": synthetic_scene(cl, Hl, Wl, 0)[0].to(dev)}
+
+            def leg_run(loader, graph=None):
+                return te.train_epoch(ml, loader, imgl, optl, crit, cl.loss_scale, dev, "sdd", None, gtl, inl, list(cl.waypoints), 0,
+                                      cl.obs_len, cl.pred_len, Bl, 10000, cl.resize_factor, cl.network, False, graph=graph)
+            with FlopCounter(ops) as fcl:
+                leg_run(loader_for(synthetic_trajectories(cl, Bl, Hl, Wl, 20)), graph=False)
+            leg_run(loader_for(synthetic_trajectories(cl, Bl * 3, Hl, Wl, 21)))
+            ll = loader_for(synthetic_trajectories(cl, Bl * 5, Hl, Wl, 22))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            leg_run(ll)
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - t0
+            sgl = pkg("utils.step_graph")
+            captured = sum(1 for c in sgl._caches.get(ml, {}).values() for e in c.entries.values() if e.ready)
+            gfl, mbl = STEP_WORK[leg]
+            out[leg.lower()] = {"workload": wl, "batch": Bl, "steps_timed": 5, "value": 5 * Bl / dtl, "unit": "trajectories/s",
+                                "ms_per_step": dtl / 5 * 1e3, "step_launch": "hipGraph replay" if captured else "eager",
+                                "step_roofline": step_roofline(5 * Bl / dtl, gfl, mbl, fcl.flops / Bl / 1e9)}
+            del ml, optl
     if rank == 0 and N == 1 and not args.no_cpu_baseline and args.config != "C5":
-        out["cpu_baseline"], first = cpu_baseline(O, cfg, H, W, args.cpu_batch, big_batch=B)
-        # the same three steps on the HIP path: fresh model from the same state dict, same trajectories; one batch per
-        # train_epoch call, so the calls run [eager, capture + replay, replay] and each returns ITS step's loss / ADE / FDE
-        m2 = ynet.YNet(cfg.obs_len, cfg.pred_len, None, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
-                       n_waypoints=len(cfg.waypoints), train_net=cfg.train_net, position=list(cfg.position),
-                       network=cfg.network, n_fusion=cfg.n_fusion)
-        m2.load_state_dict(O.make_state_dict(cfg, seed=0, lora_b_std=0.05), strict=True)
-        trainer.apply_freeze_policy(m2, cfg.train_net, cfg.position, cfg.network)
-        m2.to(dev)
+        # ---- the ONLY place the oracle is imported: the CPU baseline and the parity check (oracle = checker)
+        from oracle import ynet_oracle as O
+        out["cpu_baseline"], first, replay = cpu_baseline(O, oracle_cfg(O, cfg), H, W, args.cpu_batch, big_batch=B)
+        # the same three steps on the HIP path: fresh model from the oracle's state dict, its scene, its trajectories; one batch
+        # per train_epoch call, so the calls run [eager, capture + replay, replay] and each returns ITS step's loss / ADE / FDE
+        m2 = build_model(cfg, dev, state_dict=replay["state_dict"])
         opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+        images2 = {"scene0": replay["scene"][0].to(dev)}
         sg = pkg("utils.step_graph")
         gpu_steps, launched = [], []
-        for i in range(len(first)):
-            traj = O.synthetic_trajectories(cfg, args.cpu_batch, H, W, 100 + i)
+        for i, traj in enumerate(replay["trajectories"]):
             before = sum(1 for c in sg._caches.get(m2, {}).values() for e in c.entries.values() if e.ready)
-            gpu_steps.append(te.train_epoch(m2, loader_for(traj), images, opt2, crit, cfg.loss_scale, dev, "sdd", None, gt_t, in_t,
+            gpu_steps.append(te.train_epoch(m2, loader_for(traj), images2, opt2, crit, cfg.loss_scale, dev, "sdd", None, gt_t, in_t,
                                             list(cfg.waypoints), i, cfg.obs_len, cfg.pred_len, args.cpu_batch, 10000,
                                             cfg.resize_factor, cfg.network, False))
             after = sum(1 for c in sg._caches.get(m2, {}).values() for e in c.entries.values() if e.ready)

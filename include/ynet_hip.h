@@ -87,9 +87,9 @@ int ynet_conv2d_add(const float* const* src, const int* src_c, const long long* 
                     void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
- * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19  ->  conv_mfma_kernel<K, tiles, rows,
- * CC, mask, m16>, or with dma the LDS-DMA generation conv_dma_kernel<tiles, rows, CC, mask, x4, fold>, in a
- * rocprof trace. */
+ * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,
+ * rows, CC, mask, m16>, or with dma the LDS-DMA generation conv_dma_kernel<tiles, rows, CC, mask, x4, fold>, in a
+ * rocprof trace (CC = input channels per staged chunk). */
 int ynet_conv2d_plan(int B, int H, int W, int cout, int K);
 
 /* convolution_backward -> grad_weight [Cout][Cin][K][K] and grad_bias [Cout] (db may be NULL).
@@ -283,6 +283,11 @@ int ynet_pad2d(const float* x, float* y, long long N, int H, int W, int Hp, int 
 /* pad + preprocess_image_for_segmentation(seg_mask = True) (utils/image_utils.py:74-81, 95-107): an int32 label map
  * [H][W] -> `classes` one-hot fp32 planes [classes][Hp][Wp]; the border is padded BEFORE the encoding, i.e. it is class 0. */
 int ynet_seg_onehot_pad(const int* labels, float* y, int H, int W, int Hp, int Wp, int classes, void* stream);
+/* resize(images, factor, seg_mask = True) (utils/image_utils.py:83-87: cv2.resize(image, (0, 0), fx = fy = factor, INTER_NEAREST)) of
+ * an int32 label map [H][W] -> [Ho][Wo], Ho = cvRound(H * fy), Wo = cvRound(W * fx) computed by the caller (half-to-even);
+ * out[y][x] = labels[min(floor(y * (1 / fy)), H - 1)][min(floor(x * (1 / fx)), W - 1)], products in double -- OpenCV's published
+ * nearest-neighbour rule.  PARITY UNPINNED: cv2 is not in the image; restated from the published algorithm, known-answer tests only. */
+int ynet_resize_nearest(const int* labels, int* out, int H, int W, int Ho, int Wo, double fx, double fy, void* stream);
 
 /* y[i] = sum over b of x[b * batch_stride + i], i < n, in batch order (bitwise reproducible): the backward of `semantic_img.expand(B, ...)`
  * (utils/train_epoch.py:87) and of the batch-broadcast scene features of Y-Net-Mod -- the gradient of a one-image tensor that every

@@ -10,17 +10,19 @@
 //   mailbox (fine-grained device memory, exported with hipIpcGetMemHandle):
 //       flag[2]            epoch number of the data in slot 0 / 1, written with a system-scope release
 //       slot[2][capacity]  double buffer: call number e uses slot e & 1
-//   call e (epochs count from 1, kept on the host, equal on every rank because the calls are collective):
+//   call e (epochs count from 1 in a DEVICE-resident counter, equal on every rank because the calls are collective; every
+//   workgroup reads it at entry, the last workgroup to publish advances it):
 //       1. every workgroup copies its part of buf into slot[e & 1]; the last one to finish publishes flag[e & 1] = e
 //       2. every workgroup waits until each peer's flag[e & 1] == e (system-scope acquire), then adds the peers' parts to
 //          its own in rank order and writes buf
 //   Slot reuse is safe with two slots: a rank enters call e only after call e - 1 returned on its stream, call e - 1
 //   needed every peer's flag e - 1, and a peer publishes flag e - 1 only after ITS call e - 2 finished reading.
 // A peer that never arrives (a crashed rank) would spin forever: the wait gives up after ~20 s of s_memrealtime (every
-// workgroup on its own), records the failure in the mailbox and POISONS its part of buf and the loss slot with NaN, so the
+// workgroup on its own), records the failure in the mailbox and POISONS its part of buf with NaN; the workgroup that
+// FINISHES LAST (a ticket) poisons the loss slot when any workgroup failed -- after every other write to it --, so the
 // step cannot silently continue on un-reduced gradients; ynet_comm_status reports it (dist.DataParallel.check raises).
-// The epoch is a kernel argument: the call cannot be captured into a hipGraph (utils/step_graph.py keeps the collective
-// between its two graphs).
+// The launch has no per-call argument (the epoch lives on the device), so it can be captured INTO a hipGraph:
+// utils/step_graph.py records it between the backward pass and the optimizer step -- one graph per step.
 #include "ynet_common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -34,7 +36,8 @@ struct YnetComm {
     unsigned long long epoch;
     unsigned char* local;               // this rank's mailbox (device)
     unsigned char* peer[YNET_COMM_MAX_RANKS];
-    unsigned* done_counter;             // device: workgroups that finished copying (reset by the kernel)
+    unsigned* done_counter;             // device: [0] workgroups that finished copying, [1] workgroups that finished the call,
+                                        //   [2] a workgroup of this call timed out (all three reset by the kernel), [3] calls so far
     int connected;
 };
 
@@ -44,12 +47,16 @@ struct AllreduceArgs {
     unsigned char* mbox[YNET_COMM_MAX_RANKS];
     long long capacity;
     unsigned* done_counter;
-    unsigned epoch;
     int rank, world;
 };
 
 __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const AllreduceArgs a) {
-    const int slot = (int)(a.epoch & 1u);
+    // the call number: read by every workgroup before it publishes; advanced by the last workgroup to publish (below), i.e.
+    // after all of them have read it (0 is the flags' initial value and is skipped)
+    unsigned epoch = __hip_atomic_load(a.done_counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (epoch == 0u) epoch = 1u;
+    epoch = __builtin_amdgcn_readfirstlane(epoch);
+    const int slot = (int)(epoch & 1u);
     unsigned* my_flags = reinterpret_cast<unsigned*>(a.mbox[a.rank]);
     float* my_slot = reinterpret_cast<float*>(a.mbox[a.rank] + YNET_COMM_HEADER_BYTES) + (long long)slot * a.capacity;
     const long long per = ((a.n + gridDim.x - 1) / gridDim.x + 3) & ~3ll;      // this workgroup's part (multiple of 4 floats)
@@ -62,7 +69,8 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const AllreduceA
         const unsigned arrived = atomicAdd(a.done_counter, 1u) + 1u;
         if (arrived == gridDim.x) {
             *a.done_counter = 0u;
-            __hip_atomic_store(my_flags + slot, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.done_counter + 3, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(my_flags + slot, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     // ---- 2. wait for every peer's epoch, then reduce in rank order
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const AllreduceA
         for (int r = 0; r < a.world && !failed; ++r) {
             if (r == a.rank) continue;
             const unsigned* f = reinterpret_cast<const unsigned*>(a.mbox[r]) + slot;
-            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.epoch) {
+            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
                 __builtin_amdgcn_s_sleep(8);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {      // ~20 s
                     failed = 1;
@@ -86,22 +94,34 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const AllreduceA
     __syncthreads();
     if (failed) {
         // A peer never arrived: this workgroup's part of buf cannot be reduced.  Leaving it un-reduced would let the ranks
-        // apply DIFFERENT gradients silently (the replicated Adam states diverge), so the part -- and the loss that rides in
-        // the last slot -- is poisoned with NaN: the step fails loudly on this rank (NaN loss, NaN weights), and
-        // ynet_comm_status / DataParallel.check() report the time-out at the next synchronisation point.
+        // apply DIFFERENT gradients silently (the replicated Adam states diverge), so the part is poisoned with NaN; the loss
+        // that rides in the last slot is poisoned by the call's last workgroup (below): the step fails loudly on this rank
+        // (NaN loss, NaN weights), and ynet_comm_status / DataParallel.check() report the time-out at the next
+        // synchronisation point.
         const float poison = __builtin_nanf("");
         for (long long i = lo + threadIdx.x; i < hi; i += 256) a.buf[i] = poison;
-        if (threadIdx.x == 0) a.buf[a.n - 1] = poison;
-        return;
-    }
-    __threadfence_system();
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        float s = 0.f;
-        for (int r = 0; r < a.world; ++r) {     // rank order on every rank: identical sums everywhere
-            const float* ps = reinterpret_cast<const float*>(a.mbox[r] + YNET_COMM_HEADER_BYTES) + (long long)slot * a.capacity;
-            s += r == a.rank ? a.buf[i] : __builtin_nontemporal_load(ps + i);
+    } else {
+        __threadfence_system();
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+            float s = 0.f;
+            for (int r = 0; r < a.world; ++r) {     // rank order on every rank: identical sums everywhere
+                const float* ps = reinterpret_cast<const float*>(a.mbox[r] + YNET_COMM_HEADER_BYTES) + (long long)slot * a.capacity;
+                s += r == a.rank ? a.buf[i] : __builtin_nontemporal_load(ps + i);
+            }
+            a.buf[i] = s;
         }
-        a.buf[i] = s;
+    }
+    // ---- 3. the loss slot is decided by ONE workgroup, the last to finish: a failed workgroup's NaN and the owning
+    // workgroup's sum can then not race
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (failed) atomicOr(a.done_counter + 2, 1u);
+        const unsigned finished = atomicAdd(a.done_counter + 1, 1u) + 1u;
+        if (finished == gridDim.x) {
+            if (atomicExch(a.done_counter + 2, 0u) != 0u) a.buf[a.n - 1] = __builtin_nanf("");
+            a.done_counter[1] = 0u;
+        }
     }
 }
 
@@ -186,8 +206,7 @@ int ynet_allreduce_sum(void* comm, float* buf, long long n, void* stream) {
     for (int r = 0; r < c->world; ++r) a.mbox[r] = c->peer[r];
     a.capacity = c->capacity;
     a.done_counter = c->done_counter;
-    a.epoch = (unsigned)(++c->epoch);
-    if (a.epoch == 0u) a.epoch = (unsigned)(++c->epoch);      // (0 is the initial flag value)
+    ++c->epoch;                                               // (host-side count of the calls issued; the kernel keeps its own)
     a.rank = c->rank;
     a.world = c->world;
     int blocks = (int)((n + 4095) / 4096);                    // 16 floats per thread; a few workgroups for the large buffers

@@ -1550,8 +1550,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 extern "C" {
 
 // The kernel instantiation the dispatcher picks for this problem, for naming it in profiles:
-// returns rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19
-//   ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16> or, with dma, conv_dma_kernel<tiles, rows, CC, mask, x4, fold>.
+// returns rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21
+//   ->  conv_mfma_kernel<K, tiles, rows, CC, mask, m16> or, with dma, conv_dma_kernel<tiles, rows, CC, mask, x4, fold>
+//   (CC of a 16-channel-chunk small tile drops to 8 for a masked / output-masked / pooled launch).
 int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     ConvArgs a{};
     a.B = B;
@@ -1570,7 +1571,13 @@ int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     if (fold > 1) rows = 1;
     const int dma = (can && (fold > 1 || rows >= 2 || dma_r1)) ? 1 : 0;
     const int flog = fold == 4 ? 2 : (fold == 2 ? 1 : 0);
-    return rows | (tiles << 8) | ((nt16 ? 1 : 0) << 16) | (dma << 17) | (dma << 18) | (flog << 19);
+    // input channels per staged chunk (the CC template argument): the small tiles of launch_dma_small take deeper chunks
+    int cc = K == 1 ? 16 : (K == 5 ? 4 : 8);
+    if (dma) {
+        const bool small = nt16 <= 2 && (fold > 1 || rows == 1 || (rows == 2 && nt16 == 1));
+        cc = small ? (small_cc() >= 16 ? 16 : (small_cc() >= 8 ? 8 : 4)) : 4;
+    }
+    return rows | (tiles << 8) | ((nt16 ? 1 : 0) << 16) | (dma << 17) | (dma << 18) | (flog << 19) | (cc << 21);
 }
 
 long long ynet_packed_weight_floats(int cout, int cin, int K, int mode) {

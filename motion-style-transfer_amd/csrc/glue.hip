@@ -1243,6 +1243,22 @@ __global__ __launch_bounds__(256) void seg_onehot_pad_kernel(const int* __restri
     }
 }
 
+// resize(images, factor, seg_mask = True) (utils/image_utils.py:83-87): cv2.resize(..., INTER_NEAREST) of a label map, restated from
+// OpenCV's published rule (imgproc resize.cpp, resizeNN): destination size cvRound(src * f) (the caller computes it, half-to-even),
+// source column of destination column x = min(cvFloor(x * (1 / fx)), W - 1) with the product in double, rows alike.  PARITY UNPINNED:
+// cv2 is absent from the image (like loralib), nothing reference-held can pin it; known-answer tests only.
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const int* __restrict__ src, int* __restrict__ dst, int H, int W, int Ho, int Wo,
+                                                            double ifx, double ify) {
+    const long long total = (long long)Ho * Wo;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % Wo), y = (int)(i / Wo);
+        int sx = (int)floor((double)x * ifx), sy = (int)floor((double)y * ify);
+        sx = sx < W - 1 ? sx : W - 1;
+        sy = sy < H - 1 ? sy : H - 1;
+        dst[i] = src[(long long)sy * W + sx];
+    }
+}
+
 extern "C" {
 
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
@@ -1536,6 +1552,13 @@ int ynet_seg_onehot_pad(const int* labels, float* y, int H, int W, int Hp, int W
     hipLaunchKernelGGL(seg_onehot_pad_kernel, dim3(grid_for((long long)classes * Hp * Wp, 256)), dim3(256), 0, (hipStream_t)stream,
                        labels, y, H, W, Hp, Wp, classes);
     return ynet_check_launch("seg_onehot_pad");
+}
+
+int ynet_resize_nearest(const int* labels, int* out, int H, int W, int Ho, int Wo, double fx, double fy, void* stream) {
+    YNET_REQUIRE(labels && out && H > 0 && W > 0 && Ho > 0 && Wo > 0 && fx > 0.0 && fy > 0.0, "resize_nearest: bad arguments");
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for((long long)Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream,
+                       labels, out, H, W, Ho, Wo, 1.0 / fx, 1.0 / fy);
+    return ynet_check_launch("resize_nearest");
 }
 
 static void pred_softargmax_plan(int H, int W, int* gpw, int* nchunk) {

@@ -177,12 +177,18 @@ class DataParallel:
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
+    def capturable_collective(self) -> bool:
+        """Can allreduce() be recorded into a hipGraph?  The one-shot kernel can (its call counter lives on the device);
+        torch.distributed collectives stay between the two graphs of a captured step (utils/step_graph.py)."""
+        return self._comm is not None
+
     def loss_value(self) -> torch.Tensor:
         return self.flat[-1].clone()
 
     def allreduce_grads(self, loss: torch.Tensor = None) -> torch.Tensor:
-        """stage + allreduce; returns the global loss.  (The captured step runs the three parts separately: the
-        collective stays outside the hipGraphs, utils/step_graph.py.)"""
+        """stage + allreduce; returns the global loss.  (The captured step runs the three parts separately: a
+        torch.distributed collective stays between its two hipGraphs, the one-shot kernel is recorded into its single graph,
+        utils/step_graph.py.)"""
         self.stage(loss)
         self.allreduce()
         return self.loss_value()

@@ -322,9 +322,13 @@ class YNetTrainer:
                 images[k] = ops.seg_onehot_pad(t.to(self.device), classes=self.params.get("n_semantic_classes", 6) if hasattr(self.params, "get") else 6,
                                                division_factor=self.division_factor)
             elif t.shape[-1] % self.division_factor or t.shape[-2] % self.division_factor:
-                if not (t.is_cuda or self.device.type == "cuda"):
-                    raise ValueError(f"scene {k}: {tuple(t.shape)} is not padded to a multiple of {self.division_factor}")
-                images[k] = ops.pad_planes(t.to(self.device).float(), self.division_factor)
+                # PRE-PROCESSED planes cannot be padded correctly here: the reference pads the raw image / label map first and
+                # encodes afterwards (models/trainer.py:581-582), so its border is class 0 (plane 0 == 1) for a label map and
+                # (0 - mean) / std for RGB -- a zero border in every plane would be neither.  Raw label maps [H, W]
+                # take the branch above (ynet_seg_onehot_pad pads before it encodes, like the reference).
+                raise ValueError(f"scene {k}: pre-processed planes {tuple(t.shape)} are not padded to a multiple of "
+                                 f"{self.division_factor}; pass the raw label map [H, W] (padded and encoded on the device) "
+                                 f"or pad before pre-processing (utils.image_utils.pad)")
             else:
                 images[k] = t
         image_path = images

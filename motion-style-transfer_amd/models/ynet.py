@@ -498,6 +498,7 @@ class _SharedSkipTerms:
                     continue
                 cx = up.out_channels
                 terms[lvl] = (ops.shared_conv_term(f, conv0.weight, cx, cx + cf, conv0._packed), f)
+                ops.rest_filter(conv0.weight, cx, cx + cf, conv0._packed)      # packed HERE, on the caller's stream (see ops.rest_filter)
         dec._shared_terms = terms or None
         return self
 

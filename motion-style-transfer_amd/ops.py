@@ -380,11 +380,7 @@ def conv2d_shared_term(x, x_times: int, rest, weight, bias, relu: bool, cache: d
         _need_gpu(t, "conv2d_shared_term")
     cout, cin, k, _ = weight.shape
     B, _, H, W = parts[0].shape
-    wkey = ("rest", c0, c1, weight.data_ptr(), weight._version)
-    if cache.get("rest_key") != wkey:
-        with torch.no_grad():
-            w_rest = torch.cat([weight[:, :c0], weight[:, c1:]], dim=1).contiguous()
-            cache["rest_key"], cache["rest_wp"] = wkey, pack_weight(w_rest, 0)
+    rest_filter(weight, c0, c1, cache)
     descs = []
     for p_ in parts:
         t, c, bs = _plane_desc(p_.detach(), "conv2d_shared_term input")
@@ -398,6 +394,18 @@ def conv2d_shared_term(x, x_times: int, rest, weight, bias, relu: bool, cache: d
                                 bias.detach().data_ptr() if bias is not None else None, y.data_ptr(), cout, cout * H * W,
                                 B, H, W, k, 1 if relu else 0, term.data_ptr(), cout * H * W, term.shape[0], _stream()), lib)
     return y
+
+
+def rest_filter(weight, c0: int, c1: int, cache: dict) -> torch.Tensor:
+    """The packed filter over the input channels OUTSIDE [c0, c1) (conv2d_shared_term's convolution), cached per layer.
+    utils/evaluate.py runs its K-sample passes on two streams: _SharedSkipTerms packs it on the main stream BEFORE the fork
+    (a lazy pack on one lane would be read by the other lane's cache hit with no dependency on the pack kernel)."""
+    wkey = ("rest", c0, c1, weight.data_ptr(), weight._version)
+    if cache.get("rest_key") != wkey:
+        with torch.no_grad():
+            w_rest = torch.cat([weight[:, :c0], weight[:, c1:]], dim=1).contiguous()
+            cache["rest_key"], cache["rest_wp"] = wkey, pack_weight(w_rest, 0)
+    return cache["rest_wp"]
 
 
 def shared_conv_term(x: torch.Tensor, weight, c0: int, c1: int, cache: dict) -> torch.Tensor:
@@ -1315,6 +1323,32 @@ def seg_onehot_pad(labels: torch.Tensor, classes: int = 6, division_factor: int 
     lib = _lib()
     L.check(lib.ynet_seg_onehot_pad(lab.data_ptr(), y.data_ptr(), H, W, Hp, Wp, int(classes), _stream()), lib)
     return y
+
+
+def cv_round(v: float) -> int:
+    """OpenCV's cvRound: nearest integer, halves to even (what cv2.resize applies to src * factor for the output size)."""
+    return int(np.rint(np.float64(v)))
+
+
+def resize_nearest(labels: torch.Tensor, factor: float) -> torch.Tensor:
+    """resize(images, factor, seg_mask=True) (utils/image_utils.py:83-87 = cv2.resize(im, (0, 0), fx=factor, fy=factor,
+    interpolation=cv2.INTER_NEAREST)) of ONE integer label map [H, W] on the device, restating OpenCV's published rule (see
+    ynet_resize_nearest).  PARITY UNPINNED: cv2 is absent from the image.  -> [round(H * f), round(W * f)], same dtype."""
+    if not torch.is_tensor(labels) or not labels.is_cuda:
+        raise RuntimeError("resize_nearest: the MI355X path runs on HIP devices only (no CPU fallback exists by design)")
+    if labels.dim() != 2 or labels.is_floating_point() and bool((labels != labels.round()).any()):
+        raise ValueError("resize_nearest: expected a 2-D map of integer class labels")
+    if not factor > 0:
+        raise ValueError("resize_nearest: the factor must be positive")
+    lab = labels.to(torch.int32).contiguous()
+    H, W = lab.shape
+    Ho, Wo = cv_round(H * float(factor)), cv_round(W * float(factor))
+    if Ho < 1 or Wo < 1:
+        raise ValueError(f"resize_nearest: {H}x{W} * {factor} leaves an empty map")
+    out = torch.empty((Ho, Wo), device=lab.device, dtype=torch.int32)
+    lib = _lib()
+    L.check(lib.ynet_resize_nearest(lab.data_ptr(), out.data_ptr(), H, W, Ho, Wo, float(factor), float(factor), _stream()), lib)
+    return out.to(labels.dtype)
 
 
 def kmeans2d(points: torch.Tensor, init_idx: torch.Tensor, tol: float = 1e-3, iter_limit: int = 1000):

@@ -46,6 +46,11 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
         trajs_dict = None
 
     with torch.no_grad():
+        # Every packed filter is (re)written HERE, on the caller's stream: the K-sample passes below run the trajectory decoder on two
+        # side streams, and a filter packed lazily by the first pass on one of them (after a training epoch bumped the parameter
+        # versions: in place, into the layer's persistent buffers) would be read by the other stream's cache hit with no
+        # dependency on the pack kernel.  The side streams wait for this stream before their first launch.
+        ops.refresh_filters(model)
         for trajectory, df_batch, scene_id in val_loader:
             scene_image = model.segmentation(val_images[scene_id].to(device).unsqueeze(0))
             scene_image = model.adapt_semantic(scene_image)

@@ -9,7 +9,9 @@
       device sampler with a documented counter-based generator (YNET_SAMPLER=torch: torch.multinomial instead).
   pad / preprocess_image_for_segmentation(seg_mask=True) : the part of the scene pipeline that needs neither OpenCV nor the
       segmentation backbone (utils/image_utils.py:66-81, 95-107), on the device (ynet_pad2d, ynet_seg_onehot_pad).
-Image decoding, cv2.resize and the smp normalisation of RGB images need cv2 + smp and stay out of scope.
+  resize(seg_mask=True) : cv2.resize(..., INTER_NEAREST) of label maps (utils/image_utils.py:83-87) restated from OpenCV's
+      published rule on the device (ynet_resize_nearest) -- parity unpinned, cv2 is absent from the image.
+Image decoding, cv2.resize(INTER_AREA) of RGB images and their smp normalisation need cv2 + smp and stay out of scope.
 """
 import os
 
@@ -145,4 +147,20 @@ def _needs_cv2(name):
     return fn
 
 
-resize = _needs_cv2("resize")      # cv2.resize (INTER_AREA / INTER_NEAREST): nothing in this image can pin it
+def resize(images, factor, seg_mask=False, device=None):
+    """utils/image_utils.py:83-92, in place on the dict like the reference -- for segmentation MASKS (seg_mask=True): label maps
+    [H, W] -> [round(H f), round(W f)] by nearest-neighbour (ynet_resize_nearest: OpenCV's published INTER_NEAREST rule, PARITY
+    UNPINNED -- cv2 is absent from this image).  Device tensors stay tensors; NumPy arrays (what cv2.imread returns) go through
+    the device and come back as NumPy arrays of the same dtype.  The RGB branch (INTER_AREA) needs OpenCV and stays out of scope."""
+    if not seg_mask:
+        raise ImportError("resize(seg_mask=False) is cv2.resize(..., INTER_AREA) of RGB images: OpenCV image I/O is outside the "
+                          "MI355X hot path; pre-process scene images with the reference and pass tensors")
+    for key, im in images.items():
+        if torch.is_tensor(im):
+            images[key] = ops.resize_nearest(im if device is None else im.to(device), factor)
+        else:
+            arr = np.ascontiguousarray(im)
+            if not torch.cuda.is_available():
+                raise RuntimeError("resize: label maps are resized by the HIP kernel: a HIP device is required")
+            t = torch.from_numpy(arr.astype(np.int32)).to(device if device is not None else "cuda")
+            images[key] = ops.resize_nearest(t, factor).cpu().numpy().astype(arr.dtype)

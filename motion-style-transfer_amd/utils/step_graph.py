@@ -9,9 +9,10 @@ replayed with a single launch:
                     optimizer step, soft-argmax read-out, ADE / FDE
     static outputs  loss, per-trajectory ADE and FDE
 
-Under data parallelism with more than one rank the collective stays outside the graphs: [zero_grad ... backward] is one
-graph, the all-reduce of the flat gradient buffer runs eagerly on the same stream, [optimizer step, read-out] is a second
-graph.  All graphs of a model share one memory pool (they never run concurrently).  A step is captured on the second
+Under data parallelism with more than one rank a torch.distributed collective stays outside the graphs: [zero_grad ...
+backward] is one graph, the all-reduce of the flat gradient buffer runs eagerly on the same stream, [optimizer step,
+read-out] is a second graph.  The one-shot all-reduce of csrc/comm.hip (YNET_ALLREDUCE=oneshot) has no per-call argument
+and is captured INTO the step: one graph per step.  All graphs of a model share one memory pool (they never run concurrently).  A step is captured on the second
 sighting of its key; the first sighting runs eagerly and is the warm-up that the capture needs (lazy initialisation of
 kernel attributes, optimizer state, packed-filter caches).  Anything that cannot be captured (an optimizer without a
 capturable step, an exception during capture) falls back to the eager step, once, with a warning.
@@ -186,7 +187,8 @@ class _AdamTables:
                            "chunk_tensor": torch.tensor(ct, dtype=torch.int32).to(dev), "chunk_first": torch.tensor(cf, dtype=torch.int64).to(dev),
                            "chunks": len(ct), "lr": float(g["lr"]), "betas": (float(g["betas"][0]), float(g["betas"][1])),
                            "eps": float(g["eps"]), "wd": float(g.get("weight_decay", 0.0)),
-                           "adamw": 1 if type(optimizer) is torch.optim.AdamW else 0})
+                           # (torch.optim.Adam(decoupled_weight_decay=True) IS AdamW's rule)
+                           "adamw": 1 if (type(optimizer) is torch.optim.AdamW or g.get("decoupled_weight_decay")) else 0})
         return groups or None
 
     @staticmethod
@@ -300,7 +302,10 @@ class CapturedStep:
             self.scene = scene_image.detach().clone()
             self.scene_src = None
             self.dp = dp
-            self.split = dp is not None and dp.world > 1
+            # the one-shot all-reduce (ynet_allreduce_sum) keeps its call counter on the device: it is recorded INTO the graph, one
+            # graph per step; a torch.distributed collective stays between two graphs
+            self.collective_in_graph = dp is not None and dp.world > 1 and dp.capturable_collective()
+            self.split = dp is not None and dp.world > 1 and not self.collective_in_graph
             self.params = [p for g in optimizer.param_groups for p in g["params"]]
             # Under a process group other threads (the NCCL / RCCL watchdog) may query events while this thread captures:
             # only the capturing thread is held to capture-safe calls then.
@@ -322,6 +327,7 @@ class CapturedStep:
                     dp.stage(loss)
                 if not self.split:
                     if dp is not None:
+                        dp.allreduce()               # (captured: the one-shot kernel; nothing at world 1)
                         loss = dp.loss_value()
                     opt_step()
                     ade, fde = finish(fb)

@@ -137,6 +137,9 @@ def _step_forward_backward(model, criterion, coords, scene_image, gt_template, i
         # gradients there were measured twice: every one of them in round 2 -- 5 % slower at C1 -- and those of the <= 32^2 / 64^2 / 128^2
         # maps only in round 3 -- 14.09 -> 14.34 / 14.29 / 14.43 ms: one more branch couples the two decoders' backward streams)
         loss.backward()
+        # the adapter-gradient branch joins HERE (not only at the context's exit): anything that reads lora_A.grad / lora_B.grad
+        # after backward() -- dp.stage, gradient clipping, the optimizer -- is then ordered behind it
+        ops.join_wgrad_branch()
         if early is not None:
             cur = torch.cuda.current_stream(device)
             cur.wait_stream(s_m)

@@ -71,3 +71,4 @@ def test_argument_validation_without_gpu():
     assert lib.ynet_conv2d_workspace_floats(32, 256, 256, 32) == 0
     plan = lib.ynet_conv2d_plan(32, 256, 256, 32, 3)
     assert plan & 255 == 4 and (plan >> 8) & 255 == 2 and (plan >> 16) & 1 == 1      # 4 rows, two 16-wide tiles
+    assert (plan >> 21) == 4 and (lib.ynet_conv2d_plan(32, 16, 16, 64, 3) >> 21) == 8   # chunk depth: large tiles 4, small tiles 8

@@ -78,6 +78,10 @@ def test_train_step_at_headline_batch_matches_oracle(dev, tag):
 TIMED_PATH = {
     "C2_B32": (lambda: O.sdd_short(train_net="mosa_1", position=["0", "1", "2", "3", "4"]), 256, 256, 32),
     "C4_B16": (lambda: O.ind_long(network="fusion", n_fusion=2, train_net="mosa_3", position=["scene"]), 512, 512, 16),
+    # the replayed graph of `bench.py --config C1` carries 46 filter gradients (a side branch per decoder) and
+    # ynet_adam_step over 1.64 M parameters; C3 is the rank-4 adapter chain (wgrad -> reduce -> rank-r GEMMs on the adapter branch)
+    "C1_B32_all_weights": (lambda: O.sdd_short(train_net="train"), 256, 256, 32),
+    "C3_B32_rank4": (lambda: O.sdd_short(train_net="mosa_4", position=["0", "1", "2", "3", "4"]), 256, 256, 32),
 }
 
 
@@ -103,12 +107,13 @@ def test_timed_path_eager_capture_replay_matches_oracle(dev, tag):
     sd = {k: v.clone() for k, v in sd0.items()}
     ms = {n: torch.zeros_like(sd[n]) for n in names}
     vs = {n: torch.zeros_like(sd[n]) for n in names}
-    want = []
+    want, want_w = [], [{n: sd[n].clone() for n in names}]
     for i, traj in enumerate(trajs):
         r = O.train_step(sd, cfg, scene, traj, in_t, gt_t, names)
         want.append(r)
         for n in names:
             sd[n], ms[n], vs[n] = O.adam_update(sd[n], r["grads"][n], ms[n], vs[n], i + 1, lr)
+        want_w.append({n: sd[n].clone() for n in names})
 
     # ---- product: one epoch per batch -> eager, capture + replay, replay
     model = build_model(cfg, sd0, dev)
@@ -118,12 +123,15 @@ def test_timed_path_eager_capture_replay_matches_oracle(dev, tag):
     gt_d, in_d = gt_t.to(dev), in_t.to(dev)
     images = {"scene0": scene[0].to(dev)}
     launched = []
+    named = dict(model.named_parameters())
+    got_w = [{n: named[n].detach().cpu().clone() for n in names}]
     for i, traj in enumerate(trajs):
         ade, fde, loss = te.train_epoch(
             model, loader_for(traj), images, opt, crit, cfg.loss_scale, dev, "sdd", None, gt_d, in_d, list(cfg.waypoints), i,
             cfg.obs_len, cfg.pred_len, B, 10000, cfg.resize_factor, cfg.network, False)
         entries = [e for c in sg._caches.get(model, {}).values() for e in c.entries.values()]
         launched.append("replay" if any(e.ready for e in entries) else "eager")
+        got_w.append({n: named[n].detach().cpu().clone() for n in names})
         w = want[i]
         assert abs(loss - float(w["loss"])) <= 2e-5 * abs(float(w["loss"])), (i, launched[-1], loss, float(w["loss"]))
         assert abs(ade - float(w["ade"].mean())) <= 1e-4, (i, launched[-1], ade, float(w["ade"].mean()))
@@ -131,29 +139,34 @@ def test_timed_path_eager_capture_replay_matches_oracle(dev, tag):
     if sg.enabled(None, dev):
         assert launched == ["eager", "replay", "replay"], launched      # the third step is a pure replay of the captured graph
         assert not any(e.failed for c in sg._caches.get(model, {}).values() for e in c.entries.values())
-    # ---- the last (replayed) step's gradients and the weights after three updates
-    named = dict(model.named_parameters())
+    # ---- the last (replayed) step's gradients, and EVERY step's weight update (the tiny-fixture form, tests/test_gpu_model.py:
+    # the update of a step within 2 % of lr).  Adam normalises every entry's gradient, so an entry whose gradient is at rounding
+    # level moves by +-lr whatever its sign: the entries compared are those whose gradient stood clear (>= 1 % of the tensor's
+    # maximum, twenty times the gradient tolerance) in this and every earlier step -- the moments carry the earlier ones.
     for n in names:
         g, w = named[n].grad.detach().cpu().double(), want[-1]["grads"][n].double()
         err, tol = float((g - w).abs().max()), 5e-4 * float(w.abs().max()) + 1e-7
         assert err <= tol, f"grad {n} of the replayed step: max err {err:.3e} > {tol:.3e}"
-        # Adam normalises every entry's gradient, so an entry whose gradient is at rounding level moves by +-lr whatever its
-        # sign: compare the entries whose gradient stood clear of the error bound in all three steps
         clear = torch.ones_like(sd0[n], dtype=torch.bool)
-        for r in want:
-            clear &= r["grads"][n].abs() >= 0.05 * r["grads"][n].abs().max()
-        if bool(clear.any()):
-            d = float((named[n].detach().cpu() - sd[n])[clear].abs().max())
-            assert d <= 0.05 * lr * 3, f"weight {n} after 3 Adam steps: {d:.3e} (lr {lr})"
+        for i, r in enumerate(want):
+            clear &= r["grads"][n].abs() >= 1e-2 * r["grads"][n].abs().max()
+            if not bool(clear.any()):
+                break
+            upd_got = got_w[i + 1][n] - got_w[i][n]
+            upd_want = want_w[i + 1][n] - want_w[i][n]
+            d = float((upd_got - upd_want)[clear].abs().max())
+            assert d <= 0.02 * lr, f"weight update of {n} in step {i} ({launched[i]}): off by {d:.3e} = {d / lr:.4f} lr"
 
 
-def test_eval_sweep_at_headline_batch_matches_oracle(dev):
+@pytest.mark.parametrize("K", [4, 20])
+def test_eval_sweep_at_headline_batch_matches_oracle(dev, K):
     """C5 shape at B = 128: the K decoder passes run folded into the batch, G = max_effective_batch // B = 2 goal samples
-    per pass (256 virtual batch items, encoder features read in place through the batch modulus), exactly the launches
-    of the K = 20 sweep; K = 4 here keeps the CPU oracle to a fifth of the time (its cost is linear in K)."""
+    per pass (256 virtual batch items, encoder features read in place through the batch modulus).  K = 20 is BASELINE.json's
+    configs[4] itself -- ten folded passes alternating between the two sweep streams, the full B = 128 batch against the host
+    oracle (its cost is linear in K: about a minute on the box's host) --, K = 4 the quick form of it."""
     cfg = O.sdd_long(train_net="train")
     H = W = 256
-    B, K = 128, 4
+    B = 128
     sd = O.make_state_dict(cfg, seed=0)
     scene, traj = O.synthetic_scene(cfg, H, W, 0), O.synthetic_trajectories(cfg, B, H, W, 22)
     in_t = O.dist_template(cfg.template_size)
@@ -167,7 +180,7 @@ def test_eval_sweep_at_headline_batch_matches_oracle(dev):
         model, loader_for(traj), {"scene0": scene[0]}, dev, "sdd", None, in_t.to(dev), list(cfg.waypoints), "test", K, 1,
         cfg.obs_len, B, cfg.resize_factor, cfg.temperature, forced_samples={0: want["waypoint_samples"]})
     h.remove()
-    assert len(caught) == 2 and caught[0].shape[0] == 256, [c.shape for c in caught]      # two folded passes of 2 x 128
+    assert len(caught) == K // 2 and caught[0].shape[0] == 256, [c.shape for c in caught]      # K / 2 folded passes of 2 x 128
     got = torch.cat(caught).view(K, B, cfg.pred_len, 2)
     np.testing.assert_allclose(got.numpy(), want["trajs"].numpy(), rtol=0, atol=1e-4)
     np.testing.assert_allclose(df["ade"].to_numpy(), want["ade"].numpy(), rtol=0, atol=1e-4)

@@ -994,6 +994,35 @@ def test_scene_padding_and_label_one_hot_known_answers(dev):
         ops.seg_onehot_pad(torch.rand(4, 4, device=dev), classes=6)
 
 
+@pytest.mark.parametrize("H,W,f", [(16, 24, 0.25), (10, 6, 0.25), (100, 133, 0.33), (7, 5, 2.0), (50, 50, 0.5), (33, 65, 0.33)])
+def test_label_map_nearest_resize_known_answers(dev, H, W, f):
+    """resize(images, factor, seg_mask=True) = cv2.resize(im, (0, 0), fx=f, fy=f, interpolation=INTER_NEAREST)
+    (utils/image_utils.py:83-87) restated from OpenCV's published rule -- output size cvRound(src * f) (halves to even: 10 * 0.25 ->
+    2, 6 * 0.25 -> 2), source index min(floor(dst * (1 / f)), src - 1) with the product in double.  PARITY UNPINNED (cv2 is absent from
+    the image, like loralib): known answers written from the rule, not reference outputs."""
+    ops, iu = pkg("ops"), pkg("utils.image_utils")
+    g = np.random.default_rng(H * 131 + W)
+    lab = g.integers(0, 6, size=(H, W)).astype(np.uint8)
+    Ho, Wo = int(np.rint(H * f)), int(np.rint(W * f))
+    inv = 1.0 / f
+    sy = np.minimum(np.floor(np.arange(Ho) * inv).astype(np.int64), H - 1)
+    sx = np.minimum(np.floor(np.arange(Wo) * inv).astype(np.int64), W - 1)
+    want = lab[sy][:, sx]
+    got = ops.resize_nearest(torch.from_numpy(lab).to(dev), f)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (Ho, Wo)
+    assert np.array_equal(got.cpu().numpy(), want)
+    if f == 0.25:
+        assert np.array_equal(want, lab[::4, ::4][:Ho, :Wo])              # every fourth pixel, starting at 0
+    if f == 2.0:
+        assert np.array_equal(want, np.repeat(np.repeat(lab, 2, axis=0), 2, axis=1))
+    images = {"s": lab.copy(), "t": torch.from_numpy(lab.astype(np.int64)).to(dev)}       # dict in, dict out, in place like the reference
+    iu.resize(images, f, seg_mask=True)
+    assert isinstance(images["s"], np.ndarray) and images["s"].dtype == np.uint8 and np.array_equal(images["s"], want)
+    assert images["t"].is_cuda and images["t"].dtype == torch.int64 and np.array_equal(images["t"].cpu().numpy(), want)
+    with pytest.raises(ValueError, match="integer class labels"):
+        ops.resize_nearest(torch.rand(4, 4, device=dev), 0.5)
+
+
 @pytest.mark.parametrize("B,P,H,W,rf", [(3, 12, 64, 64, 0.25), (2, 30, 32, 96, 0.33), (5, 1, 16, 16, 1.0)])
 def test_train_readout_in_two_launches(dev, B, P, H, W, rf):
     """ynet_train_readout (utils/train_epoch.py:118-126): both soft-argmax calls and the ADE / FDE arithmetic against the

@@ -112,7 +112,9 @@ def test_templates_and_sampling_match_oracle():
     y = iu.swap_pavement_terrain(x.clone())
     assert torch.equal(y[:, 1], x[:, 2]) and torch.equal(y[:, 2], x[:, 1]) and torch.equal(y[:, 0], x[:, 0])
     with pytest.raises(ImportError):
-        iu.resize({}, 0.25)                      # cv2.resize: out of scope (nothing here can pin it)
+        iu.resize({}, 0.25)                      # cv2.resize(INTER_AREA) of RGB images: out of scope (nothing here can pin it)
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        iu.resize({"s": torch.zeros(8, 8, dtype=torch.int64)}, 0.25, seg_mask=True)      # label maps: a device op, no CPU fallback
     with pytest.raises(ImportError):
         iu.preprocess_image_for_segmentation({}, seg_mask=False)      # the RGB branch needs segmentation_models_pytorch
 

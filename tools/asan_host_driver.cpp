@@ -113,6 +113,8 @@ int main() {
     EXPECT_REJECT(ynet_multinomial(cfp, 1, 4, 4, 99, 0, 0.f, 1ull, (long long*)dummy, &status, nullptr));
     EXPECT_REJECT(ynet_multinomial(cfp, 1, 4, 4, 1, 0, 2.f, 1ull, (long long*)dummy, &status, nullptr));
     EXPECT_REJECT(ynet_cws_prior(cfp, 4, 1, cfp, cfp, 1, 2, 2, 0.f, 1.f, 0, fp, fp, nullptr));
+    EXPECT_REJECT(ynet_resize_nearest(nullptr, (int*)dummy, 4, 4, 2, 2, 0.5, 0.5, nullptr));
+    EXPECT_REJECT(ynet_resize_nearest((const int*)dummy, (int*)dummy, 4, 4, 2, 2, 0.0, 0.5, nullptr));      // factor 0
     void* comm = nullptr;
     EXPECT_REJECT(ynet_comm_create(3, 2, 16, &comm));
     EXPECT_REJECT(ynet_comm_create(0, 99, 16, &comm));

@@ -17,16 +17,16 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
 rm -rf /tmp/tr_*
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_graph -o t -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-c5 --no-repeats > "$OUT/trace_graph.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_graph -o t -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-c5 --no-legs --no-sustained --no-repeats > "$OUT/trace_graph.log" 2>&1
 echo "trace graph rc=$?"; python3 "$R/tools/trace_summary.py" /tmp/tr_graph "$OUT/${TAG}_bench_C2" --tail-frac 0.6 > "$OUT/timeline_graph.txt"
 export YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_serial -o t -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-c5 --no-repeats > "$OUT/trace_serial.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_serial -o t -- $B --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-c5 --no-legs --no-sustained --no-repeats > "$OUT/trace_serial.log" 2>&1
 echo "trace serial rc=$?"; python3 "$R/tools/trace_summary.py" /tmp/tr_serial "$OUT/${TAG}_bench_C2_serial" --tail-frac 0.6 > "$OUT/timeline_serial.txt"
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_c1 -o t -- $B --config C1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-repeats > "$OUT/trace_c1_serial.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_c1 -o t -- $B --config C1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-sustained --no-repeats > "$OUT/trace_c1_serial.log" 2>&1
 echo "trace C1 serial rc=$?"; python3 "$R/tools/trace_summary.py" /tmp/tr_c1 "$OUT/${TAG}_bench_C1_serial" --tail-frac 0.6 > "$OUT/timeline_c1_serial.txt"
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-c5 --no-repeats > "$OUT/fetch.log" 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-c5 --no-legs --no-sustained --no-repeats > "$OUT/fetch.log" 2>&1
 echo "fetch rc=$?"
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-c5 --no-repeats > "$OUT/write.log" 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-c5 --no-legs --no-sustained --no-repeats > "$OUT/write.log" 2>&1
 echo "write rc=$?"
 python3 "$R/tools/pmc_aggregate.py" "$TAG" --to "$OUT"      # per-kernel HBM bytes -> $OUT/pmc_traffic.json; the counter databases stay on the box
 rm -rf "$OUT/fetch" "$OUT/write"

@@ -20,24 +20,16 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--batch", type=int, default=32)
     args = ap.parse_args()
-    from oracle import ynet_oracle as O      # synthetic-input generators only
     pkg = bench.pkg
-    ynet, trainer, te = pkg("models.ynet"), pkg("models.trainer"), pkg("utils.train_epoch")
+    trainer, te = pkg("models.trainer"), pkg("utils.train_epoch")
     dev = torch.device("cuda", 0)
-    cfg, H, W, workload = bench.make_cfg(O, args.config)
-    sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.05)
-    model = ynet.YNet(cfg.obs_len, cfg.pred_len, None, encoder_channels=list(cfg.enc), decoder_channels=list(cfg.dec),
-                      n_waypoints=len(cfg.waypoints), train_net=cfg.train_net, position=list(cfg.position),
-                      network=cfg.network, n_fusion=cfg.n_fusion)
-    model.load_state_dict(sd, strict=True)
-    trainer.apply_freeze_policy(model, cfg.train_net, cfg.position, cfg.network)
-    model.to(dev)
+    cfg, H, W, workload = bench.make_cfg(args.config)
+    model = bench.build_model(cfg, dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     crit = trainer.HipBCEWithLogitsLoss()
-    S = cfg.template_size
-    in_t, gt_t = O.dist_template(S).to(dev), O.gaussian_template(S, cfg.kernlen, cfg.nsig).to(dev)
-    images = {"scene0": O.synthetic_scene(cfg, H, W, 0)[0].to(dev)}
-    traj = O.synthetic_trajectories(cfg, args.batch * args.steps, H, W, 7)      # the same data every epoch: the loss must fall
+    in_t, gt_t = bench.templates(cfg, dev)
+    images = {"scene0": bench.synthetic_scene(cfg, H, W, 0)[0].to(dev)}
+    traj = bench.synthetic_trajectories(cfg, args.batch * args.steps, H, W, 7)      # the same data every epoch: the loss must fall
     peaks = []
     for ep in range(args.epochs):
         torch.cuda.reset_peak_memory_stats()
