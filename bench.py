@@ -154,10 +154,10 @@ class ConvTimer:
         self.ops, self.orig, self.rec = ops, ops.conv2d_raw, []
 
     def __enter__(self):
-        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None):
+        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled)
+            self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits)
             e1.record()
             cin = sum(s[1] for s in srcs)
             dl = list(dsts)
@@ -165,16 +165,21 @@ class ConvTimer:
                 dl.pop()
             cout = sum(d[1] for d in dl)
             flops = 2.0 * B * H * W * cin * cout * K * K
-            byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1) + sum(d[1] for d in dl if d[0]) * (2 if relu_of else (1.25 if pooled else 1)))
+            byts = 4.0 * B * H * W * (sum(s[1] for s in srcs if s[2] != 0) * (2 if mask else 1)
+                                      + sum(d[1] for d in dl if d[0]) * (2 if relu_of else (1.25 if pooled else (1 + 1 / 32 if (bits_out or relu_bits) else 1))))
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             cc = plan >> 21                       # input channels per staged chunk (the kernel's CC template argument)
             if dma:
-                if cc > 8 and (mask or relu_of or pooled):
-                    cc = 8                        # (launch_dma_small: 16-channel chunks are for plain launches only)
+                if cc > 8:                        # launch_dma_small: the deep chunks are for plain launches with enough input channels
+                    if relu_of or pooled or bits_out or relu_bits:
+                        cc = 8
+                    while cc > 8 and cin <= cc // 2:
+                        cc //= 2
                 x4 = (plan >> 18) & 1
                 fold = 1 << ((plan >> 19) & 3)
-                name = (f"conv_dma_{'emask_' if relu_of else ('pool_' if pooled else '')}kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "
+                kind = "emask_" if relu_of else ("pool_" if pooled else ("bits_" if bits_out else ("emaskb_" if relu_bits else "")))
+                name = (f"conv_dma_{kind}kernel<{tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "
                         f"{'true' if x4 else 'false'}, {fold}>")
             else:
                 name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "

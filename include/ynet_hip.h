@@ -86,6 +86,19 @@ int ynet_conv2d_add(const float* const* src, const int* src_c, const long long* 
                     int B, int H, int W, int K, int relu, const float* addend, long long addend_bs, int addend_bmod,
                     void* stream);
 
+/* The 1-bit form of a ReLU mask between two convolutions (conv -> ReLU -> conv, models/ynet.py:196,206,421-445): the forward
+ * convolution of the FIRST layer writes, next to its post-ReLU output y [B][cout][H][W], one bit per element (y > 0) in the register
+ * layout of its own tiles -- ynet_conv2d_relu_bits_words(B, H, W, cout, K) uint32 words, 0 when the shape is not served --, and
+ * the data gradient of the SECOND layer, whose result dx has that very shape and therefore the same tiling, applies it to what it
+ * writes (dx = bit ? conv(dy) : 0): ynet_conv2d_dgrad_relu with 1/32 of the mask bytes and no wait for activation quads in the
+ * epilogue.  Replaces the same ATen calls as ynet_conv2d / ynet_conv2d_dgrad_relu (conv2d + relu; convolution_backward +
+ * threshold_backward). */
+long long ynet_conv2d_relu_bits_words(int B, int H, int W, int cout, int K);
+int ynet_conv2d_relu_bits(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* wp, const float* bias,
+                          float* dst, int cout, long long dst_bs, unsigned* bits, int B, int H, int W, int K, void* stream);
+int ynet_conv2d_dgrad_relu_bits(const float* dy, int dy_c, long long dy_bs, const float* mask, long long mask_bs, const float* wp,
+                                float* dx, int dx_c, long long dx_bs, const unsigned* bits, int B, int H, int W, int K, void* stream);
+
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,
  * rows, CC, mask, m16>, or with dma the LDS-DMA generation conv_dma_kernel<tiles, rows, CC, mask, x4, fold>, in a

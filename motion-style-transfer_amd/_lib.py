@@ -32,6 +32,9 @@ SIGNATURES = {
     "ynet_conv2d_pool": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_dgrad_relu_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_dgrad_relu": (c_i, [c_fp, c_i, c_ll, c_fp, c_ll, c_fp, c_fp, c_i, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp, c_ll, c_fp]),
+    "ynet_conv2d_relu_bits_words": (c_ll, [c_i, c_i, c_i, c_i, c_i]),
+    "ynet_conv2d_relu_bits": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_conv2d_dgrad_relu_bits": (c_i, [c_fp, c_i, c_ll, c_fp, c_ll, c_fp, c_fp, c_i, c_ll, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_add_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_add": (c_i, [PP, PI, PLL, PI, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp]),
     "ynet_conv2d_plan": (c_i, [c_i, c_i, c_i, c_i, c_i]),

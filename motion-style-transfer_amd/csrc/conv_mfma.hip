@@ -51,6 +51,9 @@ struct ConvArgs {
     const float* emask;     // optional [B][cout][H][W] post-ReLU activation whose backward is applied to the OUTPUT (one destination):
     long long emask_bs;     //   dst = emask > 0 ? conv(...) : 0 -- a data gradient written for a consumer that then needs no mask
     int emask_done, pool_done;      //   (host side) the launched kernels applied it / wrote the pooled copy
+    unsigned* bits_out;     // optional: the epilogue of a ReLU convolution also writes the 1-bit form of its activation mask (y > 0), in the
+    const unsigned* bits_in;        //   register layout of its own tiles [tile][256 lanes][WPL words]; bits_in: a data gradient applies such a mask
+    int bits_done;                  //   (written by the forward convolution with the SAME output shape, hence the same tiling) instead of emask
     float* pool;            // optional second output [B][cout][H/2][W/2] = MaxPool2d(2, 2) of the (post-ReLU) first one, written by
     long long pool_bs;      //   the epilogue (conv_dma_pool_kernel): models/ynet.py:202,215 without the stand-alone pass over y
     int vec_store;          // 16-byte epilogue stores are legal (W % 4 == 0, aligned destinations)
@@ -525,6 +528,15 @@ struct DmaCfg {
     static constexpr int WS_FLOATS = CC * KK * CB;            // one buffer of the filter slice
     static constexpr int BUF_FLOATS = XS_FLOATS * ((MASK && !X4) ? 2 : 1) + WS_FLOATS;     // (X4: the mask quads stay in registers)
     static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+    // FLAT (the deep-chunk small tiles, CC >= 8): the CC * CHS / 4 quads of a chunk's tile image are ONE flat list of DMA items dealt
+    // round-robin to the 256 threads (item q = tid + 256 k lands at LDS quad q; its channel q / (CHS / 4) goes into the per-lane
+    // offset), so every wave issues the same CC * CHS / 1024 instructions per chunk.  Without it the lanes tid < PLANE / 4 issue
+    // one instruction per channel -- for a folded tile (60 / 72 quads per channel) ALL of them in wave 0, a serial issue stream of
+    // CC x ~130 cycles per chunk in front of that wave's MFMAs (round 4; the large tiles keep the per-channel form).
+    static constexpr bool FLAT = X4 && CC >= 8;
+    static constexpr int XNP = CHS / 4;                       // quads per channel in LDS (the tile's quads + pad)
+    static constexpr int NITEM = CC * XNP;
+    static constexpr int FI = FLAT ? (NITEM + 255) / 256 : 1;
     static_assert(FOLD == 1 || X4, "folded tiles use the quad layout");
     static_assert(!X4 || (CHS % 32 == (FOLD == 4 ? 8 : 16) && CHS % 4 == 0 && XI == 1), "X4 tile geometry");
 };
@@ -553,7 +565,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sgpr_rsrc(const void* p, unsig
 }
 
 // EPI: 0 plain epilogue, 1 + the batch-shared additive term (ConvArgs::addend), 2 ReLU backward on the output (ConvArgs::emask),
-//      3 + the 2 x 2 max-pooled copy of the output (ConvArgs::pool)
+//      3 + the 2 x 2 max-pooled copy of the output (ConvArgs::pool), 4 + the 1-bit activation mask of the (post-ReLU) output
+//      (ConvArgs::bits_out), 5 ReLU backward on the output from such a bit mask (ConvArgs::bits_in)
+// Bit masks (EPI 4 / 5): a lane's NCB * R * 8 accumulator elements in the order j = ((i * R + r) * 2 + g) * 4 + e are pushed MSB-first
+// into WPL = ceil(NCB * R * 8 / 32) words: 8 bytes per lane and tile instead of NCB * R * 2 16-byte quads of activations, fetched with the
+// tile's first DMA (like the bias) -- the float form (EPI 2) waits for up to 64 registers of activation quads in its epilogue.
+template <int NCB, int R>
+struct BitsCfg {
+    static constexpr int N = NCB * R * 8, WPL = (N + 31) / 32;
+    static constexpr int count(int w) { return N - 32 * w < 32 ? N - 32 * w : 32; }      // elements pushed into word w
+};
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, int EPI>
 __device__ __forceinline__ void conv_dma_body() {
     using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
@@ -635,10 +656,27 @@ __device__ __forceinline__ void conv_dma_body() {
     };
 
     f32x4 acc[NCB][R][2];
-    u32x4 mreg[(MASK && X4) ? CC : 1];      // ReLU-mask quads of the chunk in flight (this lane's part of the tile)
+    constexpr bool FLAT = C::FLAT;
+    constexpr int FI = C::FI;
+    u32x4 mreg[(MASK && X4) ? (FLAT ? FI : CC) : 1];      // ReLU-mask quads of the chunk in flight (this lane's part of the tile)
+    unsigned goff_f[FLAT ? FI : 1];         // FLAT: per-item offsets (pixel + channel * plane) of this lane's DMA items
     float bias_r[NCB];           // bias of the tile whose first chunk was queued last (0 without a bias / under ksplit)
+    using BC = BitsCfg<NCB, R>;
+    unsigned bits_nxt[EPI == 5 ? BC::WPL : 1], bits_cur[EPI == 5 ? BC::WPL : 1];      // mask words of the tile queued last / being computed
     unsigned goff[XI];
     auto set_goff = [&](const TileCoord& t) {
+        if constexpr (FLAT) {
+#pragma unroll
+            for (int k = 0; k < FI; ++k) {
+                const int qi = tid + k * 256;
+                const int c = qi / C::XNP, l = qi - c * C::XNP;
+                const int ty = l / (TCOLS / 4), q = l - ty * (TCOLS / 4);
+                const int gy = t.y0 + ty - PAD, gx = t.x0 - 4 + 4 * q;
+                const bool ok = l < C::XN && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                goff_f[k] = ok ? (unsigned)(gy * W + gx) * 4u + (unsigned)c * plane_bytes : 0x80000000u;
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < XI; ++k) {
             const int i = tid + k * 256;
@@ -680,7 +718,7 @@ __device__ __forceinline__ void conv_dma_body() {
         return min(CC, cs - j * CC);
     };
     // issue the DMA of chunk j of tile t into buffer `buf` (and, with the tile's first chunk, the load of its bias)
-    auto dma_chunk = [&](const TileCoord& t, int j, int buf, bool first) {
+    auto dma_chunk = [&](const TileCoord& t, int j, int buf, bool first, int tile_idx) {
         const conv_kargs_t kb = conv_kargs();
         int s = 0, cs = kb->src[0].c, start = 0;
         while (s + 1 < nsrc && j >= (cs + CC - 1) / CC) {
@@ -695,7 +733,12 @@ __device__ __forceinline__ void conv_dma_body() {
         const __amdgpu_buffer_rsrc_t rx = sgpr_rsrc(base, (unsigned)cnt * plane_bytes);
         const unsigned xdst = lds0 + (unsigned)(buf * C::BUF_FLOATS) * 4u;
         // channels past the source's end (cnt < CC) are zero-filled through the marker offset
-        if constexpr (X4) {
+        if constexpr (FLAT) {
+            // (channels past the source's end lie outside the descriptor: the range check zero-fills them)
+#pragma unroll
+            for (int k = 0; k < FI; ++k)
+                if (tid + k * 256 < C::NITEM) dma16s(rx, xdst + (unsigned)(k * 256 + wave * 64) * 16u, goff_f[k], 0u);
+        } else if constexpr (X4) {
             if (tid < C::XN) {
 #pragma unroll
                 for (int c = 0; c < CC; ++c) {
@@ -715,7 +758,11 @@ __device__ __forceinline__ void conv_dma_body() {
         if (MASK) {
             const __amdgpu_buffer_rsrc_t rm =
                 sgpr_rsrc(kb->mask + (long long)t.b * kb->mask_bs + (long long)cglob * HW, (unsigned)cnt * plane_bytes);
-            if constexpr (X4) {
+            if constexpr (FLAT) {
+#pragma unroll
+                for (int k = 0; k < FI; ++k)
+                    if (tid + k * 256 < C::NITEM) mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rm, goff_f[k], 0u, 0);
+            } else if constexpr (X4) {
                 // the mask quads go to registers (not through LDS): no second tile image -> 32 KB instead of
                 // 55 KB of LDS per workgroup, and no LDS traffic for them; consumed by mask_in_place after the
                 // wait that precedes the next barrier
@@ -749,6 +796,12 @@ __device__ __forceinline__ void conv_dma_body() {
 #pragma unroll
             for (int i = 0; i < NCB; ++i)
                 bias_r[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (unsigned)(i * 16 + r16) * 4u, (unsigned)(t.cg * CB) * 4u, 0));
+            if constexpr (EPI == 5) {
+                const __amdgpu_buffer_rsrc_t rq = sgpr_rsrc(kb->bits_in, 0x7fffffffu);
+#pragma unroll
+                for (int w = 0; w < BC::WPL; ++w)
+                    bits_nxt[w] = __builtin_amdgcn_raw_buffer_load_b32(rq, (unsigned)(tid * BC::WPL + w) * 4u, (unsigned)tile_idx * (unsigned)(256 * BC::WPL * 4), 0);
+            }
         }
     };
 
@@ -812,7 +865,19 @@ __device__ __forceinline__ void conv_dma_body() {
     // lane instead of 144 selects inside the MFMA stream.
     auto mask_in_place = [&](int buf, int cnt) {
         float* xs = xs_of(buf);
-        if constexpr (X4) {
+        if constexpr (FLAT) {
+#pragma unroll
+            for (int k = 0; k < FI; ++k) {
+                if (tid + k * 256 < C::NITEM) {      // (quads of channels past the source's end: x and mask both read 0)
+                    f32x4* xp = reinterpret_cast<f32x4*>(xs) + (tid + k * 256);
+                    const f32x4 m = __builtin_bit_cast(f32x4, mreg[k]);
+                    f32x4 v = *xp;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+                    *xp = v;
+                }
+            }
+        } else if constexpr (X4) {
             if (tid < C::XN) {
 #pragma unroll
                 for (int c = 0; c < CC; ++c) {
@@ -844,7 +909,7 @@ __device__ __forceinline__ void conv_dma_body() {
     // image b, the per-lane offset carries (channel - first channel of the destination) and the column (lanes of
     // another destination, of channels >= cout, or of columns >= W fall outside the descriptor and are dropped by
     // the range check), the row goes into the scalar offset: ~10 vector-ALU instructions per destination.
-    auto epilogue = [&](const TileCoord& t) {
+    auto epilogue = [&](const TileCoord& t, int tile_idx) {
         const conv_kargs_t ke = conv_kargs();
         unsigned lo[NCB][2];       // ((16 i + r16) * HW + row-in-unit * W + x) * 4 for the two pixel groups, marker when x >= W
 #pragma unroll
@@ -906,6 +971,45 @@ __device__ __forceinline__ void conv_dma_body() {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[i][r][g][e] = em[r][e] > 0.f ? acc[i][r][g][e] : 0.f;
                 }
+        }
+        if constexpr (EPI == 4) {
+            // the 1-bit form of this (post-ReLU) tile's activation mask: bit = value > 0 (NaN and -0: 0, as the float comparison of the
+            // consumers), two vector instructions per element (compare into vcc, add-with-carry = shift the bit in)
+            unsigned wv[BC::WPL];
+#pragma unroll
+            for (int w = 0; w < BC::WPL; ++w) wv[w] = 0u;
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = ((i * R + r) * 2 + g) * 4 + e;
+                            asm volatile("v_cmp_gt_f32 vcc, %1, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(wv[j >> 5]) : "v"(acc[i][r][g][e]) : "vcc");
+                        }
+            const __amdgpu_buffer_rsrc_t rq = sgpr_rsrc(ke->bits_out, 0x7fffffffu);
+#pragma unroll
+            for (int w = 0; w < BC::WPL; ++w)
+                __builtin_amdgcn_raw_buffer_store_b32(wv[w], rq, (unsigned)(tid * BC::WPL + w) * 4u, (unsigned)tile_idx * (unsigned)(256 * BC::WPL * 4), 0);
+        }
+        if constexpr (EPI == 5) {
+            // ReLU backward on the OUTPUT from the bit mask the forward convolution of the layer below wrote for this very tile
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = ((i * R + r) * 2 + g) * 4 + e;
+                            const int pos = BC::count(j >> 5) - 1 - (j & 31);
+                            const int m = __builtin_amdgcn_sbfe((int)bits_cur[j >> 5], pos, 1);       // 0 or -1
+                            const float v = acc[i][r][g][e];       // (a scalar copy first: __builtin_bit_cast of the vector ELEMENT reads element 0)
+                            acc[i][r][g][e] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
+                        }
         }
         if constexpr (EPI == 3) {
             // MaxPool2d(2, 2) of the tile: a lane holds 4 consecutive pixels of R rows per channel -- two pooled pixels per row pair,
@@ -992,10 +1096,10 @@ __device__ __forceinline__ void conv_dma_body() {
             }
         }
     };
-    dma_chunk(lt, lt.ks * cps, 0, true);
+    dma_chunk(lt, lt.ks * cps, 0, true, lt_idx);
     advance_load();
 
-    int ct_idx = tile_first, cch = 0, buf = 0;
+    int ct_idx = tile_first, cch = 0, buf = 0, pt_idx = tile_first;
     TileCoord ct = decode(ct_idx), pt = ct;
     int ccnt = item_chunks(ct);
     bool pending = false;
@@ -1007,7 +1111,7 @@ __device__ __forceinline__ void conv_dma_body() {
         if (MASK && have) mask_in_place(buf, chunk_cnt(ct.ks * cps + cch));
         __syncthreads();
         if (pending) {
-            epilogue(pt);
+            epilogue(pt, pt_idx);
             pending = false;
         }
         if (!have) break;
@@ -1016,6 +1120,13 @@ __device__ __forceinline__ void conv_dma_body() {
             // places its wait before the next DMAs are queued, where the counter is already 0)
 #pragma unroll
             for (int i = 0; i < NCB; ++i) asm volatile("" : "+v"(bias_r[i]));
+            if constexpr (EPI == 5) {
+#pragma unroll
+                for (int w = 0; w < BC::WPL; ++w) {
+                    asm volatile("" : "+v"(bits_nxt[w]));
+                    bits_cur[w] = bits_nxt[w];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NCB; ++i)
 #pragma unroll
@@ -1024,7 +1135,7 @@ __device__ __forceinline__ void conv_dma_body() {
                     for (int q = 0; q < 4; ++q) acc[i][r][0][q] = acc[i][r][1][q] = bias_r[i];
         }
         if (lt_idx < ntiles) {
-            dma_chunk(lt, lt.ks * cps + lch, buf ^ 1, lch == 0);
+            dma_chunk(lt, lt.ks * cps + lch, buf ^ 1, lch == 0, lt_idx);
             advance_load();
         }
         mfma_chunk(chunk_cnt(ct.ks * cps + cch), buf);
@@ -1033,6 +1144,7 @@ __device__ __forceinline__ void conv_dma_body() {
             cch = 0;
             pending = true;
             pt = ct;
+            pt_idx = ct_idx;
             ct_idx += gstride;
             if (ct_idx < ntiles) {
                 advance_tile(ct);
@@ -1063,6 +1175,18 @@ __global__ __launch_bounds__(256, 2) void conv_dma_pool_kernel(const ConvArgs) {
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
 __global__ __launch_bounds__(256, 2) void conv_dma_emask_kernel(const ConvArgs) {
     conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 2>();
+}
+
+// the same with the 1-bit activation mask of the post-ReLU output as a second product (ConvArgs::bits_out)
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
+__global__ __launch_bounds__(256, 2) void conv_dma_bits_kernel(const ConvArgs) {
+    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 4>();
+}
+
+// the same with the ReLU backward of the layer below applied to the output from its 1-bit mask (ConvArgs::bits_in)
+template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD>
+__global__ __launch_bounds__(256, 2) void conv_dma_emaskb_kernel(const ConvArgs) {
+    conv_dma_body<NCB, R, CC, MASK, X4, FOLD, 5>();
 }
 
 // Split of the input-channel loop over workgroups for launches with fewer work items than CUs.
@@ -1200,6 +1324,8 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         if constexpr (EPI == 1) return &conv_dma_add_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else if constexpr (EPI == 2) return &conv_dma_emask_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else if constexpr (EPI == 3) return &conv_dma_pool_kernel<NCB, R, CC, MASK, X4, FOLD>;
+        else if constexpr (EPI == 4) return &conv_dma_bits_kernel<NCB, R, CC, MASK, X4, FOLD>;
+        else if constexpr (EPI == 5) return &conv_dma_emaskb_kernel<NCB, R, CC, MASK, X4, FOLD>;
         else return &conv_dma_kernel<NCB, R, CC, MASK, X4, FOLD>;
     }();
     a.tiles_x = ceil_div(a.W, C::TW);
@@ -1210,7 +1336,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
         int nchunks = 0;
         for (int i = 0; i < a.nsrc; ++i) nchunks += ceil_div(a.src[i].c, CC);
         a.ksplit = 1;
-        if (a.partial != nullptr && !ADD && EPI != 3) a.ksplit = conv_ksplit(nt, nchunks);
+        if (a.partial != nullptr && !ADD && EPI < 3) a.ksplit = conv_ksplit(nt, nchunks);
         while (a.ksplit > 1 && (long long)a.ksplit * a.B * a.cout * a.H * a.W > a.partial_cap) --a.ksplit;
         a.cps = ceil_div(nchunks, a.ksplit);
         a.ksplit = ceil_div(nchunks, a.cps);
@@ -1255,6 +1381,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     }
     if (EPI == 2 || a.ksplit > 1) a.emask_done = 1;       // (in the epilogue, or in the reduction of a split channel loop)
     if (EPI == 3) a.pool_done = 1;
+    if (EPI == 4 || EPI == 5) a.bits_done = 1;
     return ynet_check_launch("conv2d");
 }
 
@@ -1266,6 +1393,9 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
 // hide (a 64 -> 64 layer on a 16^2 map ran 16 chunks x 1.3 us = 21 us for 0.6 GFLOP); YNET_CONV_SMALL_CC chunks of 8 or 16
 // channels make it 8 or 4 round trips (their LDS tiles are small).
 static int small_cc() {
+    // Round 4 measured 8 / 16 / 32 with the flat DMA items (captured C2 step, one box): 8.92 / 8.95 / 9.00 ms at B 32 and 3.53 / 3.56 /
+    // 3.56 ms at B 10; per-kernel averages of the folded tiles in the serial trace 17.6 / - / 17.4 us (16^2) and 21.3 / - / 23.8 us (8^2):
+    // the number of DMA round trips is NOT what bounds these launches, so the default stays 8.
     static const int cc = getenv("YNET_CONV_SMALL_CC") ? atoi(getenv("YNET_CONV_SMALL_CC")) : 8;
     return cc;
 }
@@ -1273,18 +1403,46 @@ static int small_cc() {
 template <int NCB, int R, int FOLD = 1, int CC = 4>
 static int launch_dma(ConvArgs& a, hipStream_t st) {
     if constexpr (R >= 2 && FOLD == 1) {      // the large-map tiles (ynet_conv2d_dgrad_relu_supported)
+        if (a.bits_in) return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD, 5>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD, 5>(a, st);
+        if (a.bits_out && !a.mask) return launch_dma_m<NCB, R, CC, false, true, FOLD, 4>(a, st);
         if (a.emask) return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD, 2>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD, 2>(a, st);
         if (a.pool && !a.mask) return launch_dma_m<NCB, R, CC, false, true, FOLD, 3>(a, st);
     }
     return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD>(a, st);
 }
 
+// The small tiles: the deepest chunk (8 / 16 / 32 input channels, YNET_CONV_SMALL_CC caps it) whose double buffer fits the LDS --
+// two resident workgroups per CU for the two-row tiles of the 32^2 / 64^2 maps (<= 72 KB), one for the folded 8^2 / 16^2 tiles
+// (their launches have at most one workgroup per CU anyway) -- so that a 64-channel layer is 2-4 DMA round trips instead of 8;
+// the variants with an epilogue extra (output mask, pooled copy, bit masks) keep 8.
 template <int NCB, int R, int FOLD = 1>
 static int launch_dma_small(ConvArgs& a, hipStream_t st) {
     const int cc = small_cc();
-    if (cc >= 16 && !a.mask && !a.emask && !a.pool) return launch_dma_m<NCB, R, 16, false, true, FOLD>(a, st);      // (a masked dgrad holds CC mask quads in registers: 8 at most)
+    // (one-row / folded tiles have no epilogue variants: an output mask is applied by the split reduction or a pass of its own, so
+    // the launch is the plain kernel whatever the caller asked for -- and a masked call must sum in the same order as a plain one)
+    const bool plain = !(R >= 2 && FOLD == 1) || (!a.emask && !a.pool && !a.bits_out && !a.bits_in);
+    constexpr int budget = (R >= 2 && FOLD == 1) ? 72 * 1024 : 152 * 1024;
+    if constexpr (DmaCfg<NCB, R, 32, false, true, FOLD>::LDS_BYTES <= budget) {
+        if (plain && cc >= 32 && a.cin > 16)
+            return a.mask ? launch_dma_m<NCB, R, 32, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, 32, false, true, FOLD>(a, st);
+    }
+    if constexpr (DmaCfg<NCB, R, 16, false, true, FOLD>::LDS_BYTES <= budget) {
+        if (plain && cc >= 16 && a.cin > 8)
+            return a.mask ? launch_dma_m<NCB, R, 16, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, 16, false, true, FOLD>(a, st);
+    }
     if (cc >= 8) return launch_dma<NCB, R, FOLD, 8>(a, st);
     return launch_dma<NCB, R, FOLD, 4>(a, st);
+}
+
+// Host mirror of launch_dma_small's choice for a PLAIN launch with `cin` input channels (ynet_conv2d_plan).
+static int small_chunk_depth(int ncb, int rows, int fold, int cin) {
+    const int tw = 32 / fold, th = 4 * rows * fold, plane = (th + 2) * (tw + 8);
+    const int chs = plane + (fold == 4 ? ((8 - plane % 32) + 32) % 32 : 0);
+    const int budget = (rows >= 2 && fold == 1) ? 72 * 1024 : 152 * 1024;
+    const int cap = small_cc();
+    for (int cc = 32; cc >= 16; cc >>= 1)
+        if (cap >= cc && cin > cc / 2 && 2 * cc * (chs + 9 * 16 * ncb) * 4 <= budget) return cc;
+    return cap >= 8 ? 8 : 4;
 }
 
 // Large maps: rows >= 2 per wave (R = 4 only up to 32 output channels per workgroup: registers).
@@ -1508,7 +1666,12 @@ __global__ __launch_bounds__(256) void conv_emask_kernel(float* __restrict__ dst
 static int conv_dispatch(ConvArgs& a, int K, hipStream_t st) {
     a.emask_done = 0;
     a.pool_done = 0;
+    a.bits_done = 0;
     int rc = conv_dispatch_kernels(a, K, st);
+    if (!rc && (a.bits_out != nullptr || a.bits_in != nullptr) && !a.bits_done) {
+        ynet_set_error("conv2d (bit mask): shape B=%d %dx%d cout=%d is not served by the bit-mask epilogues (ask ynet_conv2d_relu_bits_words)", a.B, a.H, a.W, a.cout);
+        return 1;
+    }
     if (!rc && a.pool != nullptr && !a.pool_done) {
         ynet_set_error("conv2d_pool: shape B=%d %dx%d cout=%d is not served by the pooling epilogue (ask ynet_conv2d_pool_supported)", a.B, a.H, a.W, a.cout);
         return 1;
@@ -1575,7 +1738,7 @@ int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     int cc = K == 1 ? 16 : (K == 5 ? 4 : 8);
     if (dma) {
         const bool small = nt16 <= 2 && (fold > 1 || rows == 1 || (rows == 2 && nt16 == 1));
-        cc = small ? (small_cc() >= 16 ? 16 : (small_cc() >= 8 ? 8 : 4)) : 4;
+        cc = small ? small_chunk_depth(nt16, rows, fold, 1 << 30) : 4;
     }
     return rows | (tiles << 8) | ((nt16 ? 1 : 0) << 16) | (dma << 17) | (dma << 18) | (flog << 19) | (cc << 21);
 }
@@ -1614,7 +1777,8 @@ static int conv2d_impl(const float* const* src, const int* src_c, const long lon
                        float* const* dst, const int* dst_c, const long long* dst_bs, int ndst,
                        int B, int H, int W, int K, int relu, float* workspace, long long workspace_floats,
                        const float* addend, long long addend_bs, int addend_bmod, void* stream,
-                       const float* emask = nullptr, long long emask_bs = 0, float* pool = nullptr, long long pool_bs = 0) {
+                       const float* emask = nullptr, long long emask_bs = 0, float* pool = nullptr, long long pool_bs = 0,
+                       unsigned* bits_out = nullptr, const unsigned* bits_in = nullptr) {
     YNET_REQUIRE(nsrc >= 1 && nsrc <= YNET_MAX_SRC && ndst >= 1 && ndst <= YNET_MAX_SRC,
                  "conv2d: 1..%d sources/destinations supported (got %d/%d)", YNET_MAX_SRC, nsrc, ndst);
     YNET_REQUIRE(B > 0 && H > 0 && W > 0, "conv2d: empty problem B=%d H=%d W=%d", B, H, W);
@@ -1656,6 +1820,13 @@ static int conv2d_impl(const float* const* src, const int* src_c, const long lon
     if (pool != nullptr) {
         YNET_REQUIRE(a.ndst == 1 && a.dst[0].p != nullptr && mask == nullptr && addend == nullptr && emask == nullptr, "conv2d_pool: one destination, no mask / additive term");
         YNET_REQUIRE((H & 1) == 0 && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(pool) & 7) == 0 && (pool_bs & 1) == 0, "conv2d_pool: even H, W and an 8-byte aligned pooled output");
+    }
+    a.bits_out = bits_out;
+    a.bits_in = bits_in;
+    if (bits_out != nullptr || bits_in != nullptr) {
+        YNET_REQUIRE(a.ndst == 1 && a.dst[0].p != nullptr && addend == nullptr && emask == nullptr && pool == nullptr && !(bits_out && bits_in),
+                     "conv2d (bit mask): one destination, no additive term / float mask / pooled copy");
+        YNET_REQUIRE((reinterpret_cast<uintptr_t>(bits_out ? bits_out : const_cast<unsigned*>(bits_in)) & 3) == 0, "conv2d (bit mask): unaligned mask words");
     }
     a.emask = emask;
     a.emask_bs = emask_bs;
@@ -1704,6 +1875,56 @@ int ynet_conv2d_dgrad_relu(const float* dy, int dy_c, long long dy_bs, const flo
     const long long db[1] = {dx_bs};
     return conv2d_impl(srcs, sc, sb, nullptr, 1, mask, mask_bs, wp, nullptr, dsts, dc, db, 1, B, H, W, K, 0, workspace, workspace_floats,
                        nullptr, 0, 0, stream, relu_of, relu_of_bs);
+}
+
+static int conv_rows_tiles_ok(int B, int H, int W, int cout, int K);
+
+// Words (uint32) of the 1-bit activation mask a ReLU convolution with this OUTPUT shape writes next to its output
+// (ynet_conv2d_relu_bits) and the data gradient of the following convolution applies to ITS output, which has that same
+// shape (ynet_conv2d_dgrad_relu_bits); 0: this shape is not served (then ynet_conv2d + ynet_conv2d_dgrad_relu with the float
+// activation).  Both launches tile the [B, cout, H, W] tensor identically (the tiling is a function of B, H, W, cout, K only),
+// and the mask lives in the register layout of those tiles: [tile][256 lanes][ceil(tiles * rows * 8 / 32)].
+long long ynet_conv2d_relu_bits_words(int B, int H, int W, int cout, int K) {
+    static const int on = getenv("YNET_RELU_BITS") ? atoi(getenv("YNET_RELU_BITS")) : 1;
+    if (!on || !conv_rows_tiles_ok(B, H, W, cout, K)) return 0;
+    ConvArgs a{};
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.cout = cout;
+    const int nt16 = narrow_tiles(a, m16_tiles(K, cout));
+    int rows = pick_rows(a, 16 * nt16);
+    if (nt16 >= 3 && rows == 4) rows = 2;
+    const long long tiles = (long long)ceil_div(W, 32) * ceil_div(H, 4 * rows) * ceil_div(cout, 16 * nt16) * B;
+    return tiles * 256 * ((nt16 * rows * 8 + 31) / 32);
+}
+
+// relu(conv(cat(src...), wp) + bias) -> dst, and the 1-bit mask (dst > 0) -> bits [ynet_conv2d_relu_bits_words(...)]
+int ynet_conv2d_relu_bits(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* wp, const float* bias,
+                          float* dst, int cout, long long dst_bs, unsigned* bits, int B, int H, int W, int K, void* stream) {
+    YNET_REQUIRE(dst != nullptr && bits != nullptr, "conv2d_relu_bits: null destination");
+    YNET_REQUIRE(ynet_conv2d_relu_bits_words(B, H, W, cout, K) > 0, "conv2d_relu_bits: shape B=%d %dx%d cout=%d K=%d is not served (ask ynet_conv2d_relu_bits_words)", B, H, W, cout, K);
+    float* dsts[1] = {dst};
+    const int dc[1] = {cout};
+    const long long db[1] = {dst_bs};
+    return conv2d_impl(src, src_c, src_bs, nullptr, nsrc, nullptr, 0, wp, bias, dsts, dc, db, 1, B, H, W, K, 1, nullptr, 0,
+                       nullptr, 0, 0, stream, nullptr, 0, nullptr, 0, bits, nullptr);
+}
+
+// ynet_conv2d_dgrad_relu with the activation of the layer below given as the bit mask its forward convolution wrote:
+// dx = bit ? conv(dy [masked where mask <= 0], wp) : 0
+int ynet_conv2d_dgrad_relu_bits(const float* dy, int dy_c, long long dy_bs, const float* mask, long long mask_bs, const float* wp,
+                                float* dx, int dx_c, long long dx_bs, const unsigned* bits, int B, int H, int W, int K, void* stream) {
+    YNET_REQUIRE(dy != nullptr && dx != nullptr && bits != nullptr, "conv2d_dgrad_relu_bits: null pointer");
+    YNET_REQUIRE(ynet_conv2d_relu_bits_words(B, H, W, dx_c, K) > 0, "conv2d_dgrad_relu_bits: shape B=%d %dx%d channels=%d K=%d is not served (ask ynet_conv2d_relu_bits_words)", B, H, W, dx_c, K);
+    const float* srcs[1] = {dy};
+    const int sc[1] = {dy_c};
+    const long long sb[1] = {dy_bs};
+    float* dsts[1] = {dx};
+    const int dc[1] = {dx_c};
+    const long long db[1] = {dx_bs};
+    return conv2d_impl(srcs, sc, sb, nullptr, 1, mask, mask_bs, wp, nullptr, dsts, dc, db, 1, B, H, W, K, 0, nullptr, 0,
+                       nullptr, 0, 0, stream, nullptr, 0, nullptr, 0, nullptr, bits);
 }
 
 // ynet_conv2d with one destination + its 2 x 2 max-pooled copy (MaxPool2d(2, 2) of the next encoder stage, models/ynet.py:202,215)

@@ -51,8 +51,8 @@ class HipConv2d(nn.Conv2d):
         super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
         self._packed = {}
 
-    def forward(self, x, relu=False, pool=False):
-        return ops.conv2d(x, self.weight, self.bias, relu, self._packed, pool=pool)
+    def forward(self, x, relu=False, pool=False, bits=False):
+        return ops.conv2d(x, self.weight, self.bias, relu, self._packed, pool=pool, bits=bits)
 
 
 class LoRAConv2d(HipConv2d):
@@ -80,10 +80,10 @@ class LoRAConv2d(HipConv2d):
             nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
             nn.init.zeros_(self.lora_B)
 
-    def forward(self, x, relu=False, pool=False):
+    def forward(self, x, relu=False, pool=False, bits=False):
         if self.r > 0:
-            return ops.conv2d(x, self.weight, self.bias, relu, self._packed, self.lora_A, self.lora_B, self.scaling, pool=pool)
-        return ops.conv2d(x, self.weight, self.bias, relu, self._packed, pool=pool)
+            return ops.conv2d(x, self.weight, self.bias, relu, self._packed, self.lora_A, self.lora_B, self.scaling, pool=pool, bits=bits)
+        return ops.conv2d(x, self.weight, self.bias, relu, self._packed, pool=pool, bits=bits)
 
 
 class HipMaxPool2d(nn.MaxPool2d):
@@ -186,7 +186,16 @@ class FusedSequential(nn.Sequential):
             if isinstance(m, HipConv2d):
                 fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 last = i + (2 if fuse else 1) >= len(mods)
-                x = m(x, relu=fuse, pool=True) if (pool_next and last and type(m) in (HipConv2d, LoRAConv2d)) else m(x, relu=fuse)
+                # conv -> ReLU -> conv: the next conv's data gradient is written through THIS ReLU's backward; ask this launch for the
+                # 1-bit form of its mask (ops.conv2d(bits=True))
+                chain = (fuse and i + 2 < len(mods) and type(m) in (HipConv2d, LoRAConv2d) and type(mods[i + 2]) in (HipConv2d, LoRAConv2d)
+                         and m.kernel_size[0] == 3 and mods[i + 2].kernel_size[0] == 3)
+                if pool_next and last and type(m) in (HipConv2d, LoRAConv2d):
+                    x = m(x, relu=fuse, pool=True)
+                elif chain:
+                    x = m(x, relu=fuse, bits=True)
+                else:
+                    x = m(x, relu=fuse)
                 i += 2 if fuse else 1
             else:
                 if isinstance(m, nn.ReLU):
@@ -376,7 +385,11 @@ class YNetEncoderFusion(nn.Module):
                 while j < len(mods):
                     fuse = j + 1 < len(mods) and isinstance(mods[j + 1], nn.ReLU)
                     last = j + (2 if fuse else 1) >= len(mods)
-                    x = mods[j](x, relu=fuse, pool=True) if (pool_next and last and type(mods[j]) in (HipConv2d, LoRAConv2d)) else mods[j](x, relu=fuse)
+                    chain = (fuse and j + 2 < len(mods) and type(mods[j]) in (HipConv2d, LoRAConv2d) and type(mods[j + 2]) in (HipConv2d, LoRAConv2d))
+                    if pool_next and last and type(mods[j]) in (HipConv2d, LoRAConv2d):
+                        x = mods[j](x, relu=fuse, pool=True)
+                    else:
+                        x = mods[j](x, relu=fuse, bits=True) if chain else mods[j](x, relu=fuse)
                     j += 2 if fuse else 1
                 if isinstance(x, ops.LazyCat):      # n_fusion == 0: only the final pool
                     x = x.materialize()

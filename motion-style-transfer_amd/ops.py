@@ -331,12 +331,26 @@ def join_wgrad_branch():
     _wgrad_pending.clear()
 
 
-def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None):
+def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None.  pooled: (ptr,
-    batch_stride) of a second output, the 2 x 2 max-pooled copy of the single destination (ynet_conv2d_pool), or None."""
+    batch_stride) of a second output, the 2 x 2 max-pooled copy of the single destination (ynet_conv2d_pool), or None.
+    bits_out: address of the 1-bit activation mask a forward ReLU convolution writes next to its output (ynet_conv2d_relu_bits);
+    relu_bits: address of such a mask, applied to the single destination of a data gradient (ynet_conv2d_dgrad_relu_bits)."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
+    if bits_out is not None:
+        if len(dsts) != 1 or mask is not None or relu_of is not None or pooled is not None or not relu or _bmods(srcs) is not None:
+            raise ValueError("conv2d_raw: bits_out is for a forward ReLU convolution with one destination")
+        L.check(lib.ynet_conv2d_relu_bits(sp, sc, sb, len(srcs), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                          dsts[0][0], dsts[0][1], dsts[0][2], bits_out, B, H, W, K, _stream()), lib)
+        return
+    if relu_bits is not None:
+        if len(srcs) != 1 or len(dsts) != 1 or bias is not None or relu or relu_of is not None:
+            raise ValueError("conv2d_raw: relu_bits is for a data gradient with one source and one destination")
+        L.check(lib.ynet_conv2d_dgrad_relu_bits(srcs[0][0], srcs[0][1], srcs[0][2], mask[0] if mask else None, mask[1] if mask else 0,
+                                                wp.data_ptr(), dsts[0][0], dsts[0][1], dsts[0][2], relu_bits, B, H, W, K, _stream()), lib)
+        return
     if pooled is not None:
         if len(dsts) != 1 or mask is not None or relu_of is not None or _bmods(srcs) is not None:
             raise ValueError("conv2d_raw: pooled is for a forward convolution with one destination")
@@ -560,6 +574,7 @@ _premasked = {}
 premask = False                                                     # switched on by fold_skip_gradients() only
 premask_stats = {"unmasked_backwards": 0}                           # conv backwards that ran without their own mask (tests)
 _premask_allowed = _os.environ.get("YNET_PREMASK", "1") != "0"          # YNET_PREMASK=0: every conv backward masks itself
+_relu_bits_allowed = _os.environ.get("YNET_RELU_BITS", "1") != "0"      # YNET_RELU_BITS=0: output-side masks read the float activation
 
 
 def _is_relu_output(t: torch.Tensor) -> bool:
@@ -649,8 +664,17 @@ class _Conv2dFn(torch.autograd.Function):
                 and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs) and _lib().ynet_conv2d_pool_supported(B, H, W, cout, k)):
             # the next module is MaxPool2d(2, 2): its output comes out of this launch's epilogue (see _MaxPool2Fn.forward)
             pooled = torch.empty((B, cout, H // 2, W // 2), device=weight.device, dtype=torch.float32)
+        bits = None
+        if (meta.get("bits") and relu and premask and _relu_bits_allowed and pooled is None and not meta.get("repeat")
+                and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs)):
+            # the next conv of a conv -> ReLU -> conv chain will write its data gradient THROUGH this ReLU's backward: leave it the
+            # 1-bit form of the mask (1/32 of the bytes of y, in the register layout of the tiles both launches share)
+            n_words = _lib().ynet_conv2d_relu_bits_words(B, H, W, cout, k)
+            if n_words > 0:
+                bits = torch.empty(n_words, device=weight.device, dtype=torch.int32)
         conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu,
-                   pooled=None if pooled is None else (pooled.data_ptr(), cout * (H // 2) * (W // 2)))
+                   pooled=None if pooled is None else (pooled.data_ptr(), cout * (H // 2) * (W // 2)),
+                   bits_out=None if bits is None else bits.data_ptr())
         if pooled is not None:
             for k_ in [k_ for k_, e_ in _pooled_outputs.items() if e_[0]() is None]:      # (a pool that never followed)
                 del _pooled_outputs[k_]
@@ -662,7 +686,7 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(weight, lora_a, lora_b, y if relu else None, *keep)
         ctx.w_key = _weight_key(weight, lora_a, lora_b)
         if relu and premask:
-            _relu_outputs[y.data_ptr()] = (weakref.ref(y), tuple(y.shape))
+            _relu_outputs[y.data_ptr()] = (weakref.ref(y), tuple(y.shape), bits, k)
         return y
 
     @staticmethod
@@ -712,7 +736,17 @@ class _Conv2dFn(torch.autograd.Function):
                     and s0.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and not (skip_fold and _skip_entry(s0) is not None)
                     and _lib().ynet_conv2d_dgrad_relu_supported(B, H, W, int(s0.shape[1]), int(k))):
                 emask = (s0.data_ptr(), s0.shape[1] * H * W)
-            conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_of=emask)
+            ebits = None
+            if emask is not None:
+                e0 = _relu_outputs.get(s0.data_ptr())
+                if (e0 is not None and e0[2] is not None and e0[3] == k and d_srcs[0].data_ptr() % 16 == 0
+                        and _lib().ynet_conv2d_relu_bits_words(B, H, W, int(s0.shape[1]), int(k)) == e0[2].numel()):
+                    ebits = e0[2]          # (written by s0's own forward launch, for exactly this tiling)
+                    premask_stats["bit_masks"] = premask_stats.get("bit_masks", 0) + 1
+            if ebits is not None:
+                conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_bits=ebits.data_ptr())
+            else:
+                conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_of=emask)
             if emask is not None:
                 _premasked[d_srcs[0].data_ptr()] = (s0.data_ptr(), d_srcs[0]._version, tuple(d_srcs[0].shape))
             if skip_fold:
@@ -816,11 +850,14 @@ def lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a, lora_b, scale):
     return d_a, d_b
 
 
-def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0, pool: bool = False):
+def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0, pool: bool = False,
+           bits: bool = False):
     """[ReLU](conv(cat(x), W_eff) + bias); x is a tensor or a LazyCat.  pool: the caller applies max_pool2 to the result next --
-    where the kernel can, the pooled copy is written by this launch and that max_pool2 call finds it (no kernel)."""
+    where the kernel can, the pooled copy is written by this launch and that max_pool2 call finds it (no kernel).  bits: the
+    caller feeds the (post-ReLU) result to another convolution next -- inside fold_skip_gradients() this launch then also writes
+    the 1-bit form of its ReLU mask, which that convolution's data gradient applies to what it writes (ynet_conv2d_relu_bits)."""
     parts = [p.expand() if isinstance(p, BatchExpand) else p for p in _parts(x)]      # (a fresh expand node per consumer)
-    meta = {"relu": bool(relu), "scale": float(scale), "cache": cache, "pool": bool(pool)}
+    meta = {"relu": bool(relu), "scale": float(scale), "cache": cache, "pool": bool(pool), "bits": bool(bits) and torch.is_grad_enabled()}
     if any(isinstance(p, BatchRepeat) for p in parts):
         if torch.is_grad_enabled() and any(t.requires_grad for t in (weight, bias, lora_a, lora_b) if t is not None):
             raise NotImplementedError("conv2d: batch-repeated inputs are for inference (torch.no_grad) only")

@@ -591,6 +591,58 @@ def test_conv2d_dgrad_relu_writes_through_the_relu_backward_of_the_layer_below(d
     assert bool(ops._lib().ynet_conv2d_dgrad_relu_supported(B, H, W, cin, 3)) == (case in DGRAD_RELU_CASES[:3])
 
 
+# B, H, W, channels of the first layer's output (= of dx), channels of dy, dy masked too, input channels of the first layer
+RELU_BITS_CASES = [
+    (8, 128, 128, 32, 16, False, 14),     # two 16-channel tiles x 4 rows: 64 mask bits per lane
+    (8, 128, 128, 32, 32, True, 32),      # ... with the consumer-side mask of dy on top
+    (8, 64, 128, 64, 16, False, 48),      # four tiles x 2 rows
+    (4, 128, 128, 48, 64, True, 20),      # three tiles x 2 rows: 48 bits, the second word half filled
+    (8, 128, 128, 16, 32, False, 8),      # one tile: 32 bits or fewer, one word per lane
+    (2, 200, 136, 32, 32, False, 16),     # ragged tile rows / columns (H % 16, W % 32 != 0)
+]
+
+
+@pytest.mark.parametrize("case", RELU_BITS_CASES, ids=[str(c) for c in RELU_BITS_CASES])
+def test_one_bit_relu_mask_between_two_convolutions(dev, case):
+    """conv -> ReLU -> conv.  The first layer's forward launch also writes one bit per output element (y > 0) in
+    the register layout of its tiles (ynet_conv2d_relu_bits); the second layer's data gradient -- same output shape, same tiling --
+    applies it to what it writes (ynet_conv2d_dgrad_relu_bits).  Bit-identical to the float-activation form (ynet_conv2d_dgrad_relu)
+    and the forward output bit-identical to the plain launch; -0.0 and NaN activations count as "not positive" in both."""
+    ops = pkg("ops")
+    lib = ops._lib()
+    B, H, W, c1, c2, masked, c0 = case
+    n_words = lib.ynet_conv2d_relu_bits_words(B, H, W, c1, 3)
+    assert n_words > 0 and lib.ynet_conv2d_dgrad_relu_supported(B, H, W, c1, 3)
+    x, w1, b1 = rnd(B, c0, H, W, seed=1).to(dev), rnd(c1, c0, 3, 3, seed=2, scale=0.2).to(dev), rnd(c1, seed=3, scale=0.1).to(dev)
+    x[0, 0, 3, 5] = float("nan")                         # a NaN activation patch: the bit must be 0 where y is NaN
+    wp1 = ops.pack_weight(w1, 0)
+    y_plain, y_bits = torch.empty(B, c1, H, W, device=dev), torch.full((B, c1, H, W), float("nan"), device=dev)
+    bits = torch.full((n_words,), -1, device=dev, dtype=torch.int32)
+    ops.conv2d_raw([(x.data_ptr(), c0, c0 * H * W)], None, wp1, b1, [(y_plain.data_ptr(), c1, c1 * H * W)], B, H, W, 3, True)
+    ops.conv2d_raw([(x.data_ptr(), c0, c0 * H * W)], None, wp1, b1, [(y_bits.data_ptr(), c1, c1 * H * W)], B, H, W, 3, True,
+                   bits_out=bits.data_ptr())
+    assert torch.equal(torch.nan_to_num(y_bits, nan=-7.0), torch.nan_to_num(y_plain, nan=-7.0))
+    assert bool(torch.isnan(y_plain).any())
+    # the second layer's data gradient through the first layer's ReLU backward
+    dy, w2 = rnd(B, c2, H, W, seed=4).to(dev), rnd(c2, c1, 3, 3, seed=5, scale=0.2).to(dev)
+    y2 = torch.relu(rnd(B, c2, H, W, seed=6)).to(dev)
+    wp2 = ops.pack_weight(w2, 1)
+    mask = (y2.data_ptr(), c2 * H * W) if masked else None
+    want, got = torch.empty(B, c1, H, W, device=dev), torch.full((B, c1, H, W), float("nan"), device=dev)
+    ops.conv2d_raw([(dy.data_ptr(), c2, c2 * H * W)], mask, wp2, None, [(want.data_ptr(), c1, c1 * H * W)], B, H, W, 3, False,
+                   relu_of=(y_plain.data_ptr(), c1 * H * W))
+    ops.conv2d_raw([(dy.data_ptr(), c2, c2 * H * W)], mask, wp2, None, [(got.data_ptr(), c1, c1 * H * W)], B, H, W, 3, False,
+                   relu_bits=bits.data_ptr())
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert float(got[torch.isnan(y_plain)].abs().sum()) == 0.0
+    # a shape the bit-mask epilogues do not serve is refused, loudly
+    assert lib.ynet_conv2d_relu_bits_words(2, 16, 16, 64, 3) == 0
+    small = torch.zeros(2, 64, 16, 16, device=dev)
+    with pytest.raises(RuntimeError, match="not served"):
+        ops.conv2d_raw([(small.data_ptr(), 64, 64 * 256)], None, ops.pack_weight(rnd(64, 64, 3, 3, seed=7).to(dev), 0), None,
+                       [(small.data_ptr(), 64, 64 * 256)], 2, 16, 16, 3, True, bits_out=bits.data_ptr())
+
+
 def test_relu_backward_applied_by_upsampling_and_by_the_next_data_gradient(dev):
     """conv0-ReLU -> conv1-ReLU -> bilinear x2 -> conv2 (no ReLU): conv1's output gradient comes from the up-sampling backward
     (ynet_upsample2x_bwd_relu), conv0's from conv1's data gradient (ynet_conv2d_dgrad_relu); both then run unmasked dgrad /
@@ -607,14 +659,18 @@ def test_relu_backward_applied_by_upsampling_and_by_the_next_data_gradient(dev):
         old = ops._premask_allowed
         ops._premask_allowed = on
         ops.premask_stats["unmasked_backwards"] = 0
+        ops.premask_stats["bit_masks"] = 0
         try:
             with ops.fold_skip_gradients():
                 xd, w0d, w1d = x.to(dev).requires_grad_(True), w0.to(dev).requires_grad_(True), w1.to(dev).requires_grad_(True)
-                gd = ops.conv2d(ops.conv2d(xd, w0d, None, True, {}), w1d, None, True, {})
+                # (bits=True: what FusedSequential asks of the first conv of a conv -> ReLU -> conv chain -- conv1's data gradient
+                # then takes conv0's ReLU mask in its 1-bit form)
+                gd = ops.conv2d(ops.conv2d(xd, w0d, None, True, {}, bits=True), w1d, None, True, {})
                 ops.conv2d(ops.upsample2x(gd), w2.to(dev), None, False, {}).square().sum().backward()
         finally:
             ops._premask_allowed = old
         assert ops.premask_stats["unmasked_backwards"] == (2 if on else 0)
+        assert ops.premask_stats["bit_masks"] == (1 if (on and ops._relu_bits_allowed) else 0)
         assert not ops._premasked
         close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx (premask={on})")
         close(w0d.grad, w0c.grad, rtol=1e-4, scale_rel=1e-5, msg=f"dW0 (premask={on})")

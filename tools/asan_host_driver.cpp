@@ -70,6 +70,13 @@ int main() {
     for (int b : {1, 32, 256})
         for (int hw : {8, 32, 64, 256})
             for (int c : {12, 32, 48, 64}) acc += ynet_conv2d_dgrad_relu_supported(b, hw, hw, c, 3) + ynet_conv2d_dgrad_relu_supported(b, hw, hw + 2, c, 3);
+    for (int b : {1, 10, 32, 256})
+        for (int hw : {8, 32, 64, 128, 256})
+            for (int c : {12, 16, 32, 48, 64, 130}) acc += ynet_conv2d_relu_bits_words(b, hw, hw, c, 3) + ynet_conv2d_relu_bits_words(b, hw, hw + 2, c, 3) + ynet_conv2d_relu_bits_words(b, hw, hw, c, 5);
+    EXPECT_REJECT(ynet_conv2d_relu_bits(srcs, &one, &bs, 1, cfp, nullptr, fp, 32, 64, nullptr, 8, 128, 128, 3, nullptr));                 // no mask words
+    EXPECT_REJECT(ynet_conv2d_relu_bits(srcs, &one, &bs, 1, cfp, nullptr, fp, 64, 64, (unsigned*)dummy, 2, 16, 16, 3, nullptr));            // shape not served
+    EXPECT_REJECT(ynet_conv2d_dgrad_relu_bits(cfp, 4, 64, nullptr, 0, cfp, fp, 32, 64, nullptr, 8, 128, 128, 3, nullptr));                 // no mask words
+    EXPECT_REJECT(ynet_conv2d_dgrad_relu_bits(cfp, 4, 64, nullptr, 0, cfp, fp, 64, 64, (const unsigned*)dummy, 2, 16, 16, 3, nullptr));     // shape not served
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 0, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 7, cfp, 4, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_lora_compose(nullptr, cfp, cfp, 1.f, fp, 4, 4, 3, 1, nullptr));
