@@ -286,9 +286,20 @@ def readout_roofline(ops, ynet_mod, cfg, B, H, W, dev):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
     gbs = x.numel() * 4 / us / 1e3
+    traffic, src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic_c5.json")
+    if fused and os.path.exists(pmc):
+        with open(pmc) as f:
+            tab = json.load(f)
+        ent = next((v for k, v in tab.items() if k.startswith(f"pred_softargmax_kernel<{cin},")), None)
+        if ent and n_img == 256:       # (the committed counters are per launch of the 256-image pass of C5)
+            # 16-byte-per-lane streaming reads are tallied at half their bytes on gfx950 (MI355X_MICROARCH.md, HBM section)
+            traffic = ent["hbm_bytes_per_launch_fetch_x2"]
+            src = ("profiles/pmc_traffic_c5.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --config C5` with the sample "
+                   "groups on one stream, tools/profile_c5.sh; NOT measured in this run)")
     return {"bound": "hbm", "kernel": f"pred_softargmax_kernel<{cin}> (+ combine)" if fused else "softargmax_kernel",
             "achieved": gbs, "peak": PEAK_HBM_GBS,
-            "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": us,
+            "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src, "avg_launch_us": us,
             "algorithmic_mb_per_launch": x.numel() * 4 / 1e6, "images_per_launch": n_img,
             "note": "20 back-to-back launches between one HIP-event pair; algorithmic bytes = the input tensor "
                     "read once (outputs are B x pred x 2 floats)"}
@@ -560,11 +571,12 @@ def main():
                           "median_value": B * N / (float(np.median(regions)) * 1e-3),
                           "note": "region 0 is the contract's timed region (value / ms_per_step); the others repeat it; the inputs of "
                                   "every region are generated before its clock starts"},
-        "step_launch": "hipGraph replay" if pkg("utils.step_graph").enabled(None, dev) and args.config != "C5" else "eager",
+        "step_launch": (pkg("utils.evaluate").last_sweep_launch() if args.config == "C5" else
+                        ("hipGraph replay" if pkg("utils.step_graph").enabled(None, dev) else "eager")),
     }
     if sustained is not None:
         out["sustained"] = sustained
-    if out["step_launch"] != "eager":      # what the step cache really holds: a failed capture means the timed steps ran eagerly
+    if out["step_launch"] != "eager" and args.config != "C5":      # what the step cache really holds: a failed capture means the timed steps ran eagerly
         sg = pkg("utils.step_graph")
         entries = [e for c in sg._caches.get(model, {}).values() for e in c.entries.values()]
         out["step_graphs"] = {"captured": sum(1 for e in entries if e.ready), "failed": sum(1 for e in entries if e.failed),
@@ -630,9 +642,9 @@ def main():
                 traffic = entry["hbm_bytes_per_launch_fetch_x2" if name.startswith("conv_dma") else "hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                           "profile": "profiles/r03_bench_C2_serial_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command "
+                           "profile": "profiles/r04_bench_C2_serial_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command "
                                       "with YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1: the same isolated launches); "
-                                      "profiles/r03_bench_C2_kernel_stats.csv is the default command (captured step, concurrent branches)",
+                                      "profiles/r04_bench_C2_kernel_stats.csv is the default command (captured step, concurrent branches)",
                            "traffic_source": None if traffic is None else
                            "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
                            "earlier run of the same build; NOT measured in this run)",
@@ -642,12 +654,12 @@ def main():
                            "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
                            "note": "per-kernel HIP-event timing of 3 instrumented EAGER steps on one stream, run before the "
                                    "warm-up of the timed region (YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1 reproduces the condition under "
-                                   "rocprofv3: profiles/r03_bench_C2_serial_kernel_stats.csv; a HIP-event pair also reads the marker / dispatch "
+                                   "rocprofv3: profiles/r04_bench_C2_serial_kernel_stats.csv; a HIP-event pair also reads the marker / dispatch "
                                    "latency around the kernel -- `event_pair_floor_us` is what it reads around a 1-element fill -- so "
                                    "`avg_launch_us` sits that much above rocprofv3's kernel-only average and `frac` below "
                                    "the fraction computed from the profile).  The timed region itself "
                                    "replays the captured step, whose decoder branches run CONCURRENTLY: per-kernel durations "
-                                   "inside it are inflated by sharing the GPU (profiles/r03_bench_C2_kernel_stats.csv) and "
+                                   "inside it are inflated by sharing the GPU (profiles/r04_bench_C2_kernel_stats.csv) and "
                                    "are not a kernel-quality measure; `value` and `step_roofline` are."}
         out["conv_kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}

@@ -279,6 +279,11 @@ int ynet_kmeans2d(const float* points, const int* init_idx, float* centers, int*
  * *status (device int, zero it first) becomes 1 if a row has too few (replacement: no) positive entries. */
 int ynet_multinomial(const float* prob, long long rows, long long row_stride, int n, int K, int replacement,
                      float rel_threshold, unsigned long long seed, long long* out, int* status, void* stream);
+/* The same with the seed read from device memory by the kernel (seed_dev: 8 bytes, 8-byte aligned): no per-call argument, so the
+ * launch can be recorded into a hipGraph -- the captured evaluation sweep (utils/evaluate.py:248-266 as one graph per batch shape)
+ * copies the seeds it draws on the host into a static device buffer before every replay. */
+int ynet_multinomial_devseed(const float* prob, long long rows, long long row_stride, int n, int K, int replacement,
+                             float rel_threshold, const unsigned long long* seed_dev, long long* out, int* status, void* stream);
 /* Conditioned waypoint sampling prior (utils/evaluate.py:9-34 torch_multivariate_gaussian_heatmap, 198-211): for row r
  * (person r % n_persons) the anisotropic Gaussian centred at mean_xy[r] with its long axis along dist_xy[r], std
  * (|dist| + 5) / sigma_factor along it and that / ratio across (rot: axes swapped), on linspace(0, H, H) x

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ynet_comm_status": (c_i, [c_fp]),
     "ynet_comm_destroy": (c_i, [c_fp]),
     "ynet_multinomial": (c_i, [c_fp, c_ll, c_ll, c_i, c_i, c_i, c_f, ctypes.c_ulonglong, c_fp, c_fp, c_fp]),
+    "ynet_multinomial_devseed": (c_i, [c_fp, c_ll, c_ll, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "ynet_cws_prior": (c_i, [c_fp, c_ll, c_i, c_fp, c_fp, c_i, c_i, c_i, c_f, c_f, c_i, c_fp, c_fp, c_fp]),
 }
 

@@ -77,7 +77,13 @@ __device__ float block_row_max(const float* __restrict__ p, int n, float* red) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void multinomial_topk_kernel(const float* __restrict__ prob, long long row_stride, int n,
                                                                int K, float rel_threshold, unsigned k0, unsigned k1,
-                                                               long long* __restrict__ out, int* __restrict__ status) {
+                                                               long long* __restrict__ out, int* __restrict__ status,
+                                                               const unsigned long long* __restrict__ seed_ptr) {
+    if (seed_ptr != nullptr) {      // the seed as a device input (a captured evaluation sweep: ynet_multinomial_devseed)
+        const unsigned long long sd = *seed_ptr;
+        k0 = (unsigned)(sd & 0xffffffffull);
+        k1 = (unsigned)(sd >> 32);
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double* lkey = reinterpret_cast<double*>(lds_raw);                 // [K][256]
     int* lidx = reinterpret_cast<int*>(lkey + (size_t)K * 256);        // [K][256]
@@ -159,7 +165,13 @@ __global__ __launch_bounds__(256) void multinomial_topk_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void multinomial_cdf_kernel(const float* __restrict__ prob, long long row_stride, int n, int K,
                                                               float rel_threshold, unsigned k0, unsigned k1,
-                                                              long long* __restrict__ out, int* __restrict__ status) {
+                                                              long long* __restrict__ out, int* __restrict__ status,
+                                                              const unsigned long long* __restrict__ seed_ptr) {
+    if (seed_ptr != nullptr) {
+        const unsigned long long sd = *seed_ptr;
+        k0 = (unsigned)(sd & 0xffffffffull);
+        k1 = (unsigned)(sd >> 32);
+    }
     __shared__ float red[4];
     __shared__ double seg_off[257];      // exclusive sums of the segment totals, [256] = total
     const int tid = threadIdx.x, row = blockIdx.x;
@@ -291,17 +303,16 @@ __global__ __launch_bounds__(256) void cws_prior_kernel(const float* __restrict_
     }
 }
 
-extern "C" {
-
-int ynet_multinomial(const float* prob, long long rows, long long row_stride, int n, int K, int replacement,
-                     float rel_threshold, unsigned long long seed, long long* out, int* status, void* stream) {
+static int multinomial_impl(const float* prob, long long rows, long long row_stride, int n, int K, int replacement,
+                            float rel_threshold, unsigned long long seed, const unsigned long long* seed_ptr, long long* out, int* status,
+                            void* stream) {
     YNET_REQUIRE(prob && out && status, "multinomial: null pointer");
     YNET_REQUIRE(rows > 0 && rows < (1ll << 31) && n > 0 && K > 0, "multinomial: bad shape rows=%lld n=%d K=%d", rows, n, K);
     YNET_REQUIRE(rel_threshold >= 0.f && rel_threshold <= 1.f, "multinomial: rel_threshold must lie in [0, 1]");
     const unsigned k0 = (unsigned)(seed & 0xffffffffull), k1 = (unsigned)(seed >> 32);
     if (replacement) {
         hipLaunchKernelGGL(multinomial_cdf_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, prob, row_stride, n, K,
-                           rel_threshold, k0, k1, out, status);
+                           rel_threshold, k0, k1, out, status, seed_ptr);
         return ynet_check_launch("multinomial(replacement)");
     }
     YNET_REQUIRE(K <= 48 && K <= n, "multinomial: without replacement K <= min(48, n) is supported (got K=%d, n=%d)", K, n);
@@ -314,8 +325,23 @@ int ynet_multinomial(const float* prob, long long rows, long long row_stride, in
         attr_set = true;
     }
     hipLaunchKernelGGL(multinomial_topk_kernel, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, prob, row_stride, n, K,
-                       rel_threshold, k0, k1, out, status);
+                       rel_threshold, k0, k1, out, status, seed_ptr);
     return ynet_check_launch("multinomial");
+}
+
+extern "C" {
+
+int ynet_multinomial(const float* prob, long long rows, long long row_stride, int n, int K, int replacement,
+                     float rel_threshold, unsigned long long seed, long long* out, int* status, void* stream) {
+    return multinomial_impl(prob, rows, row_stride, n, K, replacement, rel_threshold, seed, nullptr, out, status, stream);
+}
+
+// ynet_multinomial with the seed read from device memory by the kernel (8 bytes, 8-byte aligned): the launch has no per-call
+// argument and can be recorded into a hipGraph (utils/evaluate.py: the captured sweep copies the seeds it draws into a static buffer)
+int ynet_multinomial_devseed(const float* prob, long long rows, long long row_stride, int n, int K, int replacement,
+                             float rel_threshold, const unsigned long long* seed_dev, long long* out, int* status, void* stream) {
+    YNET_REQUIRE(seed_dev != nullptr && (reinterpret_cast<uintptr_t>(seed_dev) & 7) == 0, "multinomial_devseed: null / unaligned seed pointer");
+    return multinomial_impl(prob, rows, row_stride, n, K, replacement, rel_threshold, 0ull, seed_dev, out, status, stream);
 }
 
 int ynet_cws_prior(const float* sig, long long sig_batch_stride, int n_persons, const float* mean_xy, const float* dist_xy,

@@ -1415,7 +1415,7 @@ def _status_flag(store, dev):
     return st
 
 
-def multinomial(prob: torch.Tensor, num_samples: int, replacement: bool = False, rel_threshold=None, seed: int = 0) -> torch.Tensor:
+def multinomial(prob: torch.Tensor, num_samples: int, replacement: bool = False, rel_threshold=None, seed=0) -> torch.Tensor:
     """torch.multinomial(prob [rows, n], num_samples, replacement) on the device with the documented Philox4x32-10
     generator of ynet_multinomial (include/ynet_hip.h): the draws are a pure function of (prob, seed), reproduced on
     the CPU by oracle/ynet_oracle.py:device_multinomial.  -> int64 [rows, num_samples]."""
@@ -1428,6 +1428,14 @@ def multinomial(prob: torch.Tensor, num_samples: int, replacement: bool = False,
     out = torch.empty((rows, num_samples), device=prob.device, dtype=torch.int64)
     st = _status_flag(_sample_status, prob.device)
     lib = _lib()
+    if torch.is_tensor(seed):
+        # the seed as a device input (one int64 element, read by the kernel): what a captured evaluation sweep passes
+        if not (seed.is_cuda and seed.dtype == torch.int64 and seed.numel() == 1):
+            raise ValueError("multinomial: a tensor seed must be one int64 element on the device")
+        L.check(lib.ynet_multinomial_devseed(prob.data_ptr(), rows, prob.stride(0) if rows > 1 else n, n, int(num_samples),
+                                             1 if replacement else 0, float(rel_threshold or 0.0), seed.data_ptr(),
+                                             out.data_ptr(), st.data_ptr(), _stream()), lib)
+        return out
     L.check(lib.ynet_multinomial(prob.data_ptr(), rows, prob.stride(0) if rows > 1 else n, n, int(num_samples),
                                  1 if replacement else 0, float(rel_threshold or 0.0), int(seed) & (2 ** 64 - 1),
                                  out.data_ptr(), st.data_ptr(), _stream()), lib)

@@ -7,13 +7,15 @@ decoder, soft-argmax}; best-of-K ADE/FDE.  Same signature and return value as th
 """
 import contextlib
 import os
+import weakref
 
 import numpy as np
 import pandas as pd
 import torch
 
 from .. import ops
-from .image_utils import gather_patches, image2world, sampling, swap_pavement_terrain
+from . import step_graph
+from .image_utils import SAMPLER, draw_seed, gather_patches, image2world, sampling, swap_pavement_terrain
 
 
 # YNET_SWEEP_STREAMS=0: the K-sample decoder passes of a batch run back to back on one stream
@@ -24,6 +26,147 @@ _last_sweep_launch = "eager"
 def last_sweep_launch() -> str:
     """How the most recent evaluate() call launched its K-sample decoder passes: "eager" or "hipGraph replay" (bench.py)."""
     return _last_sweep_launch
+
+
+def _decoder_passes(model, features, waypoint_samples, input_template, n_local, n_wp, H, W, max_effective_batch, device):
+    """The K = n_goal * n_traj trajectory-decoder passes of utils/evaluate.py:248-266, folded into the batch: G samples at a time run
+    as ONE pass over G * n_local virtual batch items whose encoder features repeat along the batch (read in place by the conv
+    kernels, never replicated).  -> [K, n_local, pred_len, 2]"""
+    K = waypoint_samples.shape[0]
+    G = max(1, min(K, max_effective_batch // max(n_local, 1)))
+    trajs_samples = []
+    # The sample groups are independent of each other: they alternate between two HIP streams, so that the
+    # HBM-bound launches of one pass (bilinear x2, patch gather, pyramid, read-out: ~15 % of a pass) and its
+    # latency-bound 8^2 .. 32^2 layers run beside the other pass's MFMA-bound convolutions.
+    two = SWEEP_STREAMS and K > G and torch.device(device).type == "cuda"
+    global _last_sweep_launch
+    _last_sweep_launch = "eager, sample groups alternate between two streams" if two else "eager"
+    main = torch.cuda.current_stream(device) if two else None
+    lanes = ops.side_streams(device) if two else None
+    # (the skip-feature part of each decoder level's first conv is the same for all K samples: once per batch)
+    with model.traj_decoder.share_skip_features(features):
+        if two:
+            for st in lanes:
+                st.wait_stream(main)          # features, shared terms and way-point samples are ready
+        for idx, k0 in enumerate(range(0, K, G)):
+            g = min(G, K - k0)
+            with (torch.cuda.stream(lanes[idx & 1]) if two else contextlib.nullcontext()):
+                coords = waypoint_samples[k0:k0 + g].reshape(-1, 2)            # [g * n_local * n_wp, 2]
+                waypoint_map = gather_patches(input_template, coords, H, W).view(g * n_local, n_wp, H, W)
+                pyramid = ops.avgpool_pyramid(waypoint_map, len(features))
+                traj_input = [ops.lazy_cat([ops.batch_repeat(f, g), p]) for f, p in zip(features, pyramid)]
+                pred_traj = model.pred_traj_coords(traj_input)                  # [g * n_local, pred, 2] = softargmax(pred_traj(.))
+                trajs_samples.append(pred_traj.view(g, n_local, -1, 2))
+        if two:
+            for st in lanes:
+                main.wait_stream(st)
+            for t in trajs_samples:
+                t.record_stream(main)
+    return torch.cat(trajs_samples)
+
+
+def _plain_sweep(model, coords, scene_image, input_template, waypoints, n_goal, n_traj, obs_len, temperature, resize_factor, network,
+                 max_effective_batch, device, seeds=None):
+    """One batch of the sweep as every shipped configuration runs it (no TTST, no CWS, nothing forced, utils/evaluate.py:109-291):
+    encoder + goal decoder, sigmoid(x / T), goal and way-point draws, the K decoder passes, best-of-K ADE / FDE.  `coords`
+    [n_local, obs + pred, 2]: host tensor (eager: window checks on the host) or device tensor (captured sweep).  `seeds`: None --
+    each draw takes its seed from torch's CPU generator, in this order -- or a device int64 tensor with one seed per draw.
+    -> (ade [n_local], fde [n_local])"""
+    _, _, H, W = scene_image.shape
+    n_local, n_wp = coords.shape[0], len(waypoints)
+    observed_map = gather_patches(input_template, coords[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
+    gt_future = coords[:, obs_len:].to(device)
+    if network == "embed":      # utils/evaluate.py:119-121
+        observed_map = model.motion_embedding(observed_map)
+    features = model.pred_features(scene_image.expand(n_local, -1, -1, -1), observed_map)
+    pred_goal_map = model.pred_goal(features)
+    wp_sigmoid = ops.sigmoid_temp(pred_goal_map, waypoints, temperature)
+    goal_samples = sampling(wp_sigmoid[:, -1:], num_samples=n_goal, seed=None if seeds is None else seeds[0:1]).permute(2, 0, 1, 3)
+    if n_wp > 1:
+        waypoint_samples = sampling(wp_sigmoid[:, :-1], num_samples=n_goal * n_traj,
+                                    seed=None if seeds is None else seeds[1:2]).permute(2, 0, 1, 3)
+        waypoint_samples = torch.cat([waypoint_samples, goal_samples.repeat(n_traj, 1, 1, 1)], dim=2)
+    else:
+        waypoint_samples = goal_samples
+    trajs_samples = _decoder_passes(model, features, waypoint_samples, input_template, n_local, n_wp, H, W, max_effective_batch, device)
+    gt_goal = gt_future[:, -1:]
+    ade_batch = ((((gt_future - trajs_samples) / resize_factor) ** 2).sum(dim=3) ** 0.5).mean(dim=2)
+    fde_batch = ((((gt_goal - waypoint_samples[:, :, -1:]) / resize_factor) ** 2).sum(dim=3) ** 0.5)
+    return ade_batch.min(dim=0)[0], fde_batch.min(dim=0)[0][:, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# The sweep as a hipGraph (VERDICT r3 item 8): at the reference scripts' batch of 10 a batch of the K = 20 sweep is ~200 short
+# launches behind ~1 ms of Python / ctypes per pass.  Like the training step (utils/step_graph.py) a batch of the PLAIN sweep is
+# captured on the second sighting of its shape and replayed afterwards: per batch the host copies the coordinates and the seeds
+# its draws would have taken (drawn from torch's CPU generator in the same order, so a replayed sweep takes exactly the draws of
+# the eager one) into static buffers and issues one graph launch.  YNET_EVAL_GRAPH=0 keeps the sweep eager.
+# ------------------------------------------------------------------------------------------------
+EVAL_GRAPH = os.environ.get("YNET_EVAL_GRAPH", "1") != "0"
+_sweep_graphs = weakref.WeakKeyDictionary()      # model -> {"token": weights token, "pool": graph memory pool, "entries": {key: _CapturedSweep}}
+
+
+def _weights_token(model):
+    """Any in-place change of a parameter (an optimizer step, load_state_dict) changes it: a captured sweep reads packed filters
+    written before the capture, so it belongs to one state of the weights."""
+    return sum(p._version for p in model.parameters()), sum(1 for _ in model.parameters())
+
+
+class _CapturedSweep:
+    MAX_ENTRIES = 8
+
+    def __init__(self):
+        self.seen = self.ready = self.failed = False
+
+    def capture(self, cache, batch, scene_image, n_seeds, body):
+        import gc
+        dev = scene_image.device
+        gc.collect()
+        was = gc.isenabled()
+        gc.disable()          # (no hipGraphExecDestroy / hipFree of unrelated objects inside an open capture: utils/step_graph.py)
+        try:
+            stream = torch.cuda.current_stream(dev)
+            if stream == torch.cuda.default_stream(dev):
+                raise RuntimeError("capture needs a non-default stream")
+            if cache.get("pool") is None:
+                cache["pool"] = torch.cuda.graph_pool_handle()
+            self.coords = torch.empty(tuple(batch.shape), device=dev, dtype=torch.float32)
+            self.coords.copy_(batch)
+            self.seeds = torch.zeros(max(n_seeds, 1), device=dev, dtype=torch.int64)
+            self.scene = scene_image.detach().clone()
+            self.scene_src = None
+            pg = torch.distributed.is_available() and torch.distributed.is_initialized()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=cache["pool"], stream=stream, capture_error_mode="thread_local" if pg else "global"):
+                self.ade, self.fde = body(self.coords, self.scene, self.seeds)
+            self.graph = g
+            self.ready = True
+        except Exception as e:      # noqa: BLE001 -- any capture failure means: this shape stays eager
+            import warnings
+            self.failed, self.ready = True, False
+            cache["pool"] = None
+            warnings.warn(f"hipGraph capture of the evaluation sweep failed ({type(e).__name__}: {e}); running it eagerly")
+        finally:
+            if was:
+                gc.enable()
+
+    def replay(self, batch, scene_image, seeds_host):
+        self.coords.copy_(batch)
+        if seeds_host is not None:
+            self.seeds.copy_(seeds_host)
+        if self.scene_src is not scene_image:
+            self.scene.copy_(scene_image)
+            self.scene_src = scene_image
+        self.graph.replay()
+        return self.ade.clone(), self.fde.clone()
+
+
+def _sweep_cache(model):
+    c = _sweep_graphs.get(model)
+    token = _weights_token(model)
+    if c is None or c["token"] != token:
+        c = _sweep_graphs[model] = {"token": token, "pool": None if c is None else c.get("pool"), "entries": {}}
+    return c
 
 
 def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, input_template, waypoints, mode,
@@ -51,124 +194,134 @@ def evaluate(model, val_loader, val_images, device, dataset_name, homo_mat, inpu
         # versions: in place, into the layer's persistent buffers) would be read by the other stream's cache hit with no
         # dependency on the pack kernel.  The side streams wait for this stream before their first launch.
         ops.refresh_filters(model)
-        for trajectory, df_batch, scene_id in val_loader:
-            scene_image = model.segmentation(val_images[scene_id].to(device).unsqueeze(0))
-            scene_image = model.adapt_semantic(scene_image)
-            meta_ids = df_batch[0].metaId.unique()
-            n_data = trajectory.shape[0]
-            if swap_semantic:
-                scene_image = swap_pavement_terrain(scene_image)
-            if network == "embed":          # utils/evaluate.py:98-100
-                scene_image = model.scene_embedding(scene_image)
-            if dataset_name == "eth":
-                print(counter)
-                counter += batch_size
-                if counter > 30 and mode == "val":
-                    break
-            _, _, H, W = scene_image.shape
+        plain = (forced_samples is None and forced_goals is None and not use_TTST and not use_CWS and not return_preds
+                 and not return_samples and dataset_name != "eth")
+        sa = getattr(model, "softargmax_", None)
+        hooked = sa is not None and (sa._forward_hooks or sa._forward_pre_hooks)
+        graphs = None
+        if plain and EVAL_GRAPH and not hooked and step_graph.enabled(None, device) and SAMPLER == "device":
+            graphs = _sweep_cache(model)
+        global _last_sweep_launch
+        # (captures need a non-default stream: with the graphs on, the whole sweep -- eager first batch, capture, replays -- runs on
+        # the persistent side stream of utils/step_graph.py; the caller's stream waits for it at the end)
+        sweep_stream = step_graph.enter_stream(device) if graphs is not None else None
+        try:
+            for trajectory, df_batch, scene_id in val_loader:
+                scene_image = model.segmentation(val_images[scene_id].to(device).unsqueeze(0))
+                scene_image = model.adapt_semantic(scene_image)
+                meta_ids = df_batch[0].metaId.unique()
+                n_data = trajectory.shape[0]
+                if swap_semantic:
+                    scene_image = swap_pavement_terrain(scene_image)
+                if network == "embed":          # utils/evaluate.py:98-100
+                    scene_image = model.scene_embedding(scene_image)
+                if dataset_name == "eth":
+                    print(counter)
+                    counter += batch_size
+                    if counter > 30 and mode == "val":
+                        break
+                _, _, H, W = scene_image.shape
 
-            for b in range(0, len(trajectory), batch_size):
-                batch = trajectory[b:b + batch_size]
-                n_global = len(batch)
-                lo = 0
-                if dp is not None:
-                    lo, hi = dp.shard(n_global)
-                    batch = batch[lo:hi]
-                n_local = len(batch)
-                if n_local > 0:
-                    observed_map = gather_patches(input_template, batch[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
-                    gt_future = batch[:, obs_len:].to(device)
-                    if network == "embed":      # utils/evaluate.py:119-121
-                        observed_map = model.motion_embedding(observed_map)
-                    features = model.pred_features(scene_image.expand(n_local, -1, -1, -1), observed_map)
-                    pred_goal_map = model.pred_goal(features)
-                    # sigmoid(pred_goal_map[:, waypoints] / T): channel gather + scale + sigmoid in one pass
-                    wp_sigmoid = ops.sigmoid_temp(pred_goal_map, waypoints, temperature)
+                for b in range(0, len(trajectory), batch_size):
+                    batch = trajectory[b:b + batch_size]
+                    n_global = len(batch)
+                    lo = 0
+                    if dp is not None:
+                        lo, hi = dp.shard(n_global)
+                        batch = batch[lo:hi]
+                    n_local = len(batch)
+                    if n_local > 0 and plain:
+                        # ---- every shipped configuration: nothing forced, no TTST / CWS, only ADE / FDE wanted
+                        def body(coords, scene, seeds):
+                            return _plain_sweep(model, coords, scene, input_template, waypoints, n_goal, n_traj, obs_len, temperature,
+                                                resize_factor, network, max_effective_batch, device, seeds)
+                        entry = None
+                        if graphs is not None:
+                            key = (tuple(scene_image.shape), n_local, obs_len, tuple(waypoints), n_goal, n_traj, float(temperature),
+                                   float(resize_factor), network, input_template.data_ptr(), max_effective_batch, SWEEP_STREAMS)
+                            entry = graphs["entries"].get(key)
+                            if entry is None:
+                                while len(graphs["entries"]) >= _CapturedSweep.MAX_ENTRIES:
+                                    graphs["entries"].pop(next(iter(graphs["entries"])))
+                                entry = graphs["entries"][key] = _CapturedSweep()
+                        n_seeds = 1 + (1 if n_wp > 1 else 0)
+                        if entry is not None and not entry.ready and entry.seen and not entry.failed:
+                            ops.check_patch_windows(input_template.shape, batch[:, :obs_len], H, W)
+                            entry.capture(graphs, batch, scene_image, n_seeds, body)      # (the capture itself launches nothing and draws nothing)
+                        if entry is not None and entry.ready:
+                            ops.check_patch_windows(input_template.shape, batch[:, :obs_len], H, W)
+                            # the seeds the eager draws would take, in their order (torch.manual_seed makes the sweep reproducible either way)
+                            seeds_host = torch.tensor([draw_seed() for _ in range(n_seeds)], dtype=torch.int64)
+                            ade, fde = entry.replay(batch, scene_image, seeds_host)
+                            _last_sweep_launch = "hipGraph replay"
+                        else:
+                            if entry is not None:
+                                entry.seen = True
+                            ade, fde = body(batch, scene_image, None)
+                    elif n_local > 0:
+                        observed_map = gather_patches(input_template, batch[:, :obs_len].reshape(-1, 2), H, W).view(-1, obs_len, H, W)
+                        gt_future = batch[:, obs_len:].to(device)
+                        if network == "embed":      # utils/evaluate.py:119-121
+                            observed_map = model.motion_embedding(observed_map)
+                        features = model.pred_features(scene_image.expand(n_local, -1, -1, -1), observed_map)
+                        pred_goal_map = model.pred_goal(features)
+                        # sigmoid(pred_goal_map[:, waypoints] / T): channel gather + scale + sigmoid in one pass
+                        wp_sigmoid = ops.sigmoid_temp(pred_goal_map, waypoints, temperature)
 
-                    if forced_samples is not None:
-                        waypoint_samples = forced_samples[b][:, lo:lo + n_local].to(device)
+                        if forced_samples is not None:
+                            waypoint_samples = forced_samples[b][:, lo:lo + n_local].to(device)
+                        else:
+                            if forced_goals is not None:
+                                goal_samples = forced_goals[b][:, lo:lo + n_local].to(device)
+                            elif use_TTST:
+                                draw = None if forced_ttst_samples is None else forced_ttst_samples[b][:, lo:lo + n_local].to(device)
+                                goal_samples = ttst_goals(model, wp_sigmoid[:, -1:], pred_goal_map[:, waypoints[-1:]], n_goal,
+                                                          rel_thresh, draw)
+                            else:
+                                goal_samples = sampling(wp_sigmoid[:, -1:], num_samples=n_goal).permute(2, 0, 1, 3)
+                            if use_CWS and n_wp > 1:
+                                last_observed = batch[:, obs_len - 1].to(device)
+                                waypoint_samples = cws_waypoints(model, wp_sigmoid, goal_samples, last_observed, n_goal, n_traj,
+                                                                 CWS_params["sigma_factor"], CWS_params["ratio"], CWS_params["rot"])
+                            elif n_wp > 1:
+                                waypoint_samples = sampling(wp_sigmoid[:, :-1], num_samples=n_goal * n_traj).permute(2, 0, 1, 3)
+                                waypoint_samples = torch.cat([waypoint_samples, goal_samples.repeat(n_traj, 1, 1, 1)], dim=2)
+                            else:
+                                waypoint_samples = goal_samples
+
+                        if return_samples:
+                            trajs_dict["goal_map"].append(pred_goal_map.cpu().numpy())
+                            trajs_dict["goal_sigmoid_map"].append(model.sigmoid(pred_goal_map / temperature).cpu().numpy())
+                            trajs_dict["waypoint_sample"].append(waypoint_samples.permute(1, 2, 0, 3).cpu().numpy())
+
+                        trajs_samples = _decoder_passes(model, features, waypoint_samples, input_template, n_local, n_wp, H, W,
+                                                        max_effective_batch, device)
+                        gt_goal = gt_future[:, -1:]
+                        if dataset_name == "eth":
+                            waypoint_samples = image2world(waypoint_samples, scene_id, homo_mat, resize_factor)
+                            gt_future = image2world(gt_future, scene_id, homo_mat, resize_factor)
+                        ade_batch = ((((gt_future - trajs_samples) / resize_factor) ** 2).sum(dim=3) ** 0.5).mean(dim=2)
+                        fde_batch = ((((gt_goal - waypoint_samples[:, :, -1:]) / resize_factor) ** 2).sum(dim=3) ** 0.5)
+                        if return_preds:
+                            if b == 0:
+                                trajs_dict["groundtruth"].append(trajectory.cpu().numpy() / resize_factor)
+                            best = ade_batch.argmin(dim=0)
+                            trajs_dict["prediction"].append(
+                                (trajs_samples[best, torch.arange(trajs_samples.shape[1], device=device)] / resize_factor).cpu().numpy())
+                        ade = ade_batch.min(dim=0)[0]
+                        fde = fde_batch.min(dim=0)[0][:, 0]
                     else:
-                        if forced_goals is not None:
-                            goal_samples = forced_goals[b][:, lo:lo + n_local].to(device)
-                        elif use_TTST:
-                            draw = None if forced_ttst_samples is None else forced_ttst_samples[b][:, lo:lo + n_local].to(device)
-                            goal_samples = ttst_goals(model, wp_sigmoid[:, -1:], pred_goal_map[:, waypoints[-1:]], n_goal,
-                                                      rel_thresh, draw)
-                        else:
-                            goal_samples = sampling(wp_sigmoid[:, -1:], num_samples=n_goal).permute(2, 0, 1, 3)
-                        if use_CWS and n_wp > 1:
-                            last_observed = batch[:, obs_len - 1].to(device)
-                            waypoint_samples = cws_waypoints(model, wp_sigmoid, goal_samples, last_observed, n_goal, n_traj,
-                                                             CWS_params["sigma_factor"], CWS_params["ratio"], CWS_params["rot"])
-                        elif n_wp > 1:
-                            waypoint_samples = sampling(wp_sigmoid[:, :-1], num_samples=n_goal * n_traj).permute(2, 0, 1, 3)
-                            waypoint_samples = torch.cat([waypoint_samples, goal_samples.repeat(n_traj, 1, 1, 1)], dim=2)
-                        else:
-                            waypoint_samples = goal_samples
-
-                    if return_samples:
-                        trajs_dict["goal_map"].append(pred_goal_map.cpu().numpy())
-                        trajs_dict["goal_sigmoid_map"].append(model.sigmoid(pred_goal_map / temperature).cpu().numpy())
-                        trajs_dict["waypoint_sample"].append(waypoint_samples.permute(1, 2, 0, 3).cpu().numpy())
-
-                    # The K = n_goal * n_traj decoder passes of the reference loop are folded into the batch:
-                    # G samples at a time run as ONE pass over G * n_local virtual batch items whose encoder
-                    # features repeat along the batch (read in place by the conv kernels, never replicated).
-                    K = waypoint_samples.shape[0]
-                    G = max(1, min(K, max_effective_batch // max(n_local, 1)))
-                    trajs_samples = []
-                    # The sample groups are independent of each other: they alternate between two HIP streams, so that the
-                    # HBM-bound launches of one pass (bilinear x2, patch gather, pyramid, read-out: ~15 % of a pass) and its
-                    # latency-bound 8^2 .. 32^2 layers run beside the other pass's MFMA-bound convolutions.
-                    two = SWEEP_STREAMS and K > G and torch.device(device).type == "cuda"
-                    global _last_sweep_launch
-                    _last_sweep_launch = "eager, sample groups alternate between two streams" if two else "eager"
-                    main = torch.cuda.current_stream(device) if two else None
-                    lanes = ops.side_streams(device) if two else None
-                    # (the skip-feature part of each decoder level's first conv is the same for all K samples: once per batch)
-                    with model.traj_decoder.share_skip_features(features):
-                        if two:
-                            for st in lanes:
-                                st.wait_stream(main)          # features, shared terms and way-point samples are ready
-                        for idx, k0 in enumerate(range(0, K, G)):
-                            g = min(G, K - k0)
-                            with (torch.cuda.stream(lanes[idx & 1]) if two else contextlib.nullcontext()):
-                                coords = waypoint_samples[k0:k0 + g].reshape(-1, 2)            # [g * n_local * n_wp, 2]
-                                waypoint_map = gather_patches(input_template, coords, H, W).view(g * n_local, n_wp, H, W)
-                                pyramid = ops.avgpool_pyramid(waypoint_map, len(features))
-                                traj_input = [ops.lazy_cat([ops.batch_repeat(f, g), p]) for f, p in zip(features, pyramid)]
-                                pred_traj = model.pred_traj_coords(traj_input)                  # [g * n_local, pred, 2] = softargmax(pred_traj(.))
-                                trajs_samples.append(pred_traj.view(g, n_local, -1, 2))
-                        if two:
-                            for st in lanes:
-                                main.wait_stream(st)
-                            for t in trajs_samples:
-                                t.record_stream(main)
-                    trajs_samples = torch.cat(trajs_samples)
-                    gt_goal = gt_future[:, -1:]
-                    if dataset_name == "eth":
-                        waypoint_samples = image2world(waypoint_samples, scene_id, homo_mat, resize_factor)
-                        gt_future = image2world(gt_future, scene_id, homo_mat, resize_factor)
-                    ade_batch = ((((gt_future - trajs_samples) / resize_factor) ** 2).sum(dim=3) ** 0.5).mean(dim=2)
-                    fde_batch = ((((gt_goal - waypoint_samples[:, :, -1:]) / resize_factor) ** 2).sum(dim=3) ** 0.5)
-                    if return_preds:
-                        if b == 0:
-                            trajs_dict["groundtruth"].append(trajectory.cpu().numpy() / resize_factor)
-                        best = ade_batch.argmin(dim=0)
-                        trajs_dict["prediction"].append(
-                            (trajs_samples[best, torch.arange(trajs_samples.shape[1], device=device)] / resize_factor).cpu().numpy())
-                    ade = ade_batch.min(dim=0)[0]
-                    fde = fde_batch.min(dim=0)[0][:, 0]
-                else:
-                    ade = fde = torch.zeros(0, device=device)
-                if dp is not None:
-                    sizes = dp.shard_sizes(n_global)
-                    ade, fde = dp.gather_rows(ade, sizes), dp.gather_rows(fde, sizes)
-                ade_list.append(ade.cpu().numpy())
-                fde_list.append(fde.cpu().numpy())
-                ops.check_patch_status()      # (the batch is synchronised by the copies above: a window that left the template raises here)
-            meta_id_list.append(meta_ids)
-            scene_id_list.append([scene_id] * n_data)
+                        ade = fde = torch.zeros(0, device=device)
+                    if dp is not None:
+                        sizes = dp.shard_sizes(n_global)
+                        ade, fde = dp.gather_rows(ade, sizes), dp.gather_rows(fde, sizes)
+                    ade_list.append(ade.cpu().numpy())
+                    fde_list.append(fde.cpu().numpy())
+                    ops.check_patch_status()      # (the batch is synchronised by the copies above: a window that left the template raises here)
+                meta_id_list.append(meta_ids)
+                scene_id_list.append([scene_id] * n_data)
+        finally:
+            step_graph.leave_stream(sweep_stream)
 
     ops.check_patch_status()
     val_ade_arr, val_fde_arr = np.concatenate(ade_list), np.concatenate(fde_list)

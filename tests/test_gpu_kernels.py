@@ -598,7 +598,7 @@ RELU_BITS_CASES = [
     (8, 64, 128, 64, 16, False, 48),      # four tiles x 2 rows
     (4, 128, 128, 48, 64, True, 20),      # three tiles x 2 rows: 48 bits, the second word half filled
     (8, 128, 128, 16, 32, False, 8),      # one tile: 32 bits or fewer, one word per lane
-    (2, 200, 136, 32, 32, False, 16),     # ragged tile rows / columns (H % 16, W % 32 != 0)
+    (8, 204, 136, 32, 32, False, 16),     # ragged tile rows / columns (H % 8, W % 32 != 0)
 ]
 
 
