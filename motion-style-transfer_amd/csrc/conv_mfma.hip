@@ -1602,7 +1602,7 @@ static int conv_dispatch_kernels(ConvArgs& a, int K, hipStream_t st) {
     const int nt16 = (a.addend == nullptr) ? narrow_tiles(a, nt16_full) : nt16_full;
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
-    static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 0;
+    static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 1;      // (round 4: with the flat DMA items the one-row LDS-DMA tile beats the register-staged kernel: B 10 3.525 -> 3.49 ms, B 32 8.965 -> 8.94)
     if (a.addend != nullptr) {
         // the additive term is implemented by the large-map LDS-DMA kernels only (what evaluate()'s shared skip features
         // need); callers ask ynet_conv2d_add_supported first
@@ -1728,7 +1728,7 @@ int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     if (nt16 >= 3 && rows == 4) rows = 2;
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;      // 16-byte input DMA (aligned planes assumed)
-    static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 0;
+    static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 1;      // (round 4: with the flat DMA items the one-row LDS-DMA tile beats the register-staged kernel: B 10 3.525 -> 3.49 ms, B 32 8.965 -> 8.94)
     const bool can = nt16 && use_dma && use_x4 && (W % 4) == 0;
     const int fold = can ? conv_fold(H, W) : 1;
     if (fold > 1) rows = 1;

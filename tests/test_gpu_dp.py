@@ -95,3 +95,38 @@ def test_bench_launcher_reports_a_failing_rank(dev):
                        "--no-cpu-baseline", "--no-roofline", "--no-repeats"], env=env, timeout=600)
     assert rc != 0
     assert "rank 1 fails on purpose" in tail and "a rank failed" in tail, tail[-1500:]
+
+
+@pytest.mark.parametrize("collective", ["rccl", "oneshot"])
+def test_bench_multi_rank_line_reports_the_collective_and_the_step_graphs(dev, collective):
+    """`python bench.py --gpus 2` on the development path (one device, gloo control plane) prints the fields the
+    driver's SCALE run will carry -- the process group, the transport, `allreduce_us_per_step` -- and how the replayed step is
+    launched: with a torch.distributed collective two graphs around the eager all-reduce (`replayed_step_split_ms` = graph A /
+    collective / graph B), with the one-shot HIP-IPC all-reduce ONE graph per step with the collective recorded inside it
+    (device-resident call counter, csrc/comm.hip)."""
+    import json
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "YNET_ALLREDUCE": collective}
+    n_gpu = torch.cuda.device_count()
+    if n_gpu < 2:
+        env.update(YNET_DIST_BACKEND="gloo", YNET_BENCH_SINGLE_DEVICE="1")
+    rc, tail = launch([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--batch", "4",
+                       "--no-cpu-baseline", "--no-roofline", "--no-repeats", "--no-sustained"], env=env, timeout=900)
+    assert rc == 0, tail[-3000:]
+    lines = [ln[ln.index('{"metric"'):] for ln in tail.splitlines() if '{"metric"' in ln]
+    assert lines, tail[-2000:]
+    d = json.loads(lines[-1])
+    w = d["world"]
+    assert d["n_gpus"] == 2 and w["world_size"] == 2 and len({r["pid"] for r in w["ranks"]}) == 2
+    assert w["backend"] == ("nccl" if n_gpu >= 2 else "gloo") and w["distinct_devices"] == (2 if n_gpu >= 2 else 1)
+    assert w["allreduce_floats_per_step"] == d["config"]["trainable_floats"] + 1 and w["allreduce_us_per_step"] > 0
+    assert d["config"]["global_batch"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    sgr = d["step_graphs"]
+    assert d["step_launch"] == "hipGraph replay" and sgr["captured"] >= 1 and sgr["failed"] == 0
+    if collective == "oneshot":
+        assert w["transport_note"] is None and w["allreduce_transport"].startswith("oneshot")
+        assert sgr["graphs_per_step"] == 1 and sgr["collective_in_graph"] is True and w["replayed_step_split_ms"] is None
+    else:
+        assert w["allreduce_transport"].startswith("torch.distributed")
+        assert sgr["graphs_per_step"] == 2 and sgr["collective_in_graph"] is False
+        split = w["replayed_step_split_ms"]
+        assert set(split) >= {"graph_a", "allreduce", "graph_b"} and split["graph_a"] > split["graph_b"] > 0
