@@ -1395,7 +1395,7 @@ static int launch_dma_m(ConvArgs& a, hipStream_t st) {
 static int small_cc() {
     // Round 4 measured 8 / 16 / 32 with the flat DMA items (captured C2 step, one box): 8.92 / 8.95 / 9.00 ms at B 32 and 3.53 / 3.56 /
     // 3.56 ms at B 10; per-kernel averages of the folded tiles in the serial trace 17.6 / - / 17.4 us (16^2) and 21.3 / - / 23.8 us (8^2):
-    // the number of DMA round trips is NOT what bounds these launches (DESIGN.md section 4.16), so the default stays 8.
+    // the number of DMA round trips is NOT what bounds these launches (DESIGN.md section 4.17), so the default stays 8.
     static const int cc = getenv("YNET_CONV_SMALL_CC") ? atoi(getenv("YNET_CONV_SMALL_CC")) : 8;
     return cc;
 }
