@@ -1316,6 +1316,19 @@ static int pick_rows(const ConvArgs& a, int cb) {
     return 1;
 }
 
+// Rows per wave of an LDS-DMA launch with nt16 16-channel tiles per workgroup.  Where pick_rows says 4, the two-tile kernel (Cout 17 .. 32 per
+// workgroup: the level-3 / level-4 layers of both decoders) takes THREE (round 4): 48 accumulator registers instead of 64 -> <= 96 VGPRs
+// -> five resident workgroups per CU instead of four, the occupancy at which the 48-channel kernel <3,2,4> reaches 0.92 MFMA-busy against
+// 0.85 for <2,4,4>; the map's height need not divide by 12 (the last row unit is cut by the range checks).  A launch with the pooled copy
+// keeps 4 (its epilogue pairs rows inside a wave's rows).
+static int dma_rows(const ConvArgs& a, int nt16) {
+    static const int r3 = getenv("YNET_CONV_R3") ? atoi(getenv("YNET_CONV_R3")) : 0;
+    int rows = pick_rows(a, 16 * nt16);
+    if (nt16 >= 3 && rows == 4) rows = 2;
+    if (r3 && nt16 == 2 && rows == 4 && a.pool == nullptr) rows = 3;
+    return rows;
+}
+
 template <int NCB, int R, int CC, bool MASK, bool X4, int FOLD, int EPI = 0>
 static int launch_dma_m(ConvArgs& a, hipStream_t st) {
     using C = DmaCfg<NCB, R, CC, MASK, X4, FOLD>;
@@ -1406,7 +1419,9 @@ static int launch_dma(ConvArgs& a, hipStream_t st) {
         if (a.bits_in) return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD, 5>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD, 5>(a, st);
         if (a.bits_out && !a.mask) return launch_dma_m<NCB, R, CC, false, true, FOLD, 4>(a, st);
         if (a.emask) return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD, 2>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD, 2>(a, st);
-        if (a.pool && !a.mask) return launch_dma_m<NCB, R, CC, false, true, FOLD, 3>(a, st);
+        if constexpr (R % 2 == 0) {
+            if (a.pool && !a.mask) return launch_dma_m<NCB, R, CC, false, true, FOLD, 3>(a, st);
+        }
     }
     return a.mask ? launch_dma_m<NCB, R, CC, true, true, FOLD>(a, st) : launch_dma_m<NCB, R, CC, false, true, FOLD>(a, st);
 }
@@ -1450,6 +1465,9 @@ template <int NCB>
 static int launch_dma_r(ConvArgs& a, hipStream_t st, int rows) {
     if (rows == 4) {
         if constexpr (NCB < 3) return launch_dma<NCB, 4>(a, st);
+    }
+    if (rows == 3) {
+        if constexpr (NCB == 2) return launch_dma<NCB, 3>(a, st);
     }
     if (rows >= 2) {
         if constexpr (NCB <= 2) return NCB == 1 ? launch_dma_small<NCB, 2>(a, st) : launch_dma<NCB, 2>(a, st);
@@ -1606,14 +1624,15 @@ static int conv_dispatch_kernels(ConvArgs& a, int K, hipStream_t st) {
     if (a.addend != nullptr) {
         // the additive term is implemented by the large-map LDS-DMA kernels only (what evaluate()'s shared skip features
         // need); callers ask ynet_conv2d_add_supported first
-        const int rows_a = (nt16 == 2 || nt16 == 4) ? pick_rows(a, 16 * nt16) : 0;
+        const int rows_a = (nt16 == 2 || nt16 == 4) ? dma_rows(a, nt16) : 0;
         const bool ok = use_dma && use_x4 && a.vec_store && a.vec_load && a.mask == nullptr && a.ndst == 1 && conv_fold(a.H, a.W) == 1 &&
                         rows_a >= 2 && (reinterpret_cast<uintptr_t>(a.addend) & 15) == 0 && (a.addend_bs & 3) == 0;
         if (!ok) {
             ynet_set_error("conv2d_add: shape B=%d %dx%d cout=%d is not served by the additive-term kernels", a.B, a.H, a.W, a.cout);
             return 1;
         }
-        if (nt16 == 2) return rows_a == 4 ? launch_dma_m<2, 4, 4, false, true, 1, 1>(a, st) : launch_dma_m<2, 2, 4, false, true, 1, 1>(a, st);
+        if (nt16 == 2) return rows_a == 4 ? launch_dma_m<2, 4, 4, false, true, 1, 1>(a, st) :
+                              (rows_a == 3 ? launch_dma_m<2, 3, 4, false, true, 1, 1>(a, st) : launch_dma_m<2, 2, 4, false, true, 1, 1>(a, st));
         return launch_dma_m<4, 2, 4, false, true, 1, 1>(a, st);
     }
     if (nt16 && use_dma && use_x4 && a.vec_store && a.vec_load) {
@@ -1626,8 +1645,7 @@ static int conv_dispatch_kernels(ConvArgs& a, int K, hipStream_t st) {
                 default: return launch_dma_fold<4>(a, st, fold);
             }
         }
-        int rows = pick_rows(a, 16 * nt16);
-        if (nt16 >= 3 && rows == 4) rows = 2;
+        const int rows = dma_rows(a, nt16);
         if (rows >= 2 || dma_r1) {
             switch (nt16) {
                 case 1: return launch_dma_r<1>(a, st, rows);
@@ -1724,10 +1742,11 @@ int ynet_conv2d_plan(int B, int H, int W, int cout, int K) {
     a.cout = cout;
     const int nt16 = narrow_tiles(a, m16_tiles(K, cout));
     const int tiles = nt16 ? nt16 : (cout > 32 ? 2 : 1);
-    int rows = K == 5 ? 4 : pick_rows(a, nt16 ? 16 * nt16 : 32 * tiles);
-    if (nt16 >= 3 && rows == 4) rows = 2;
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;      // 16-byte input DMA (aligned planes assumed)
+    int rows = K == 5 ? 4 : pick_rows(a, nt16 ? 16 * nt16 : 32 * tiles);
+    if (nt16 >= 3 && rows == 4) rows = 2;
+    if (nt16 && use_dma && use_x4 && (W % 4) == 0 && conv_fold(H, W) == 1) rows = dma_rows(a, nt16);      // (a pooled launch of the two-tile kernel keeps 4 rows)
     static const int dma_r1 = getenv("YNET_CONV_DMA_R1") ? atoi(getenv("YNET_CONV_DMA_R1")) : 1;      // (round 4: with the flat DMA items the one-row LDS-DMA tile beats the register-staged kernel: B 10 3.525 -> 3.49 ms, B 32 8.965 -> 8.94)
     const bool can = nt16 && use_dma && use_x4 && (W % 4) == 0;
     const int fold = can ? conv_fold(H, W) : 1;
@@ -1893,8 +1912,7 @@ long long ynet_conv2d_relu_bits_words(int B, int H, int W, int cout, int K) {
     a.W = W;
     a.cout = cout;
     const int nt16 = narrow_tiles(a, m16_tiles(K, cout));
-    int rows = pick_rows(a, 16 * nt16);
-    if (nt16 >= 3 && rows == 4) rows = 2;
+    const int rows = dma_rows(a, nt16);
     const long long tiles = (long long)ceil_div(W, 32) * ceil_div(H, 4 * rows) * ceil_div(cout, 16 * nt16) * B;
     return tiles * 256 * ((nt16 * rows * 8 + 31) / 32);
 }
@@ -1940,8 +1958,7 @@ static int conv_rows_tiles_ok(int B, int H, int W, int cout, int K) {
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
     if (!(use_dma && use_x4) || K != 3 || (W & 3) || nt16 == 0 || conv_fold(H, W) != 1) return 0;
-    int rows = pick_rows(a, 16 * nt16);
-    if (nt16 >= 3 && rows == 4) rows = 2;
+    const int rows = dma_rows(a, nt16);
     return rows >= 2 ? 1 : 0;
 }
 
@@ -1972,8 +1989,7 @@ int ynet_conv2d_dgrad_relu_supported(int B, int H, int W, int dx_c, int K) {
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
     if (!(use_dma && use_x4) || K != 3 || (W & 3) || nt16 == 0 || conv_fold(H, W) != 1) return 0;
-    int rows = pick_rows(a, 16 * nt16);
-    if (nt16 >= 3 && rows == 4) rows = 2;
+    const int rows = dma_rows(a, nt16);
     return rows >= 2 ? 1 : 0;
 }
 
@@ -1988,7 +2004,7 @@ int ynet_conv2d_add_supported(int B, int H, int W, int cout, int K) {
     static const int use_dma = getenv("YNET_CONV_DMA") ? atoi(getenv("YNET_CONV_DMA")) : 1;
     static const int use_x4 = getenv("YNET_CONV_X4") ? atoi(getenv("YNET_CONV_X4")) : 1;
     if (!(use_dma && use_x4) || K != 3 || (W & 3) || (nt16 != 2 && nt16 != 4) || conv_fold(H, W) != 1) return 0;
-    return pick_rows(a, 16 * nt16) >= 2 ? 1 : 0;
+    return dma_rows(a, nt16) >= 2 ? 1 : 0;
 }
 
 // y = [relu](conv(cat(src...), wp) + bias + addend[b % addend_bmod]): ynet_conv2d with one destination, no mask, plus a

@@ -956,6 +956,12 @@ def test_device_multinomial_matches_its_cpu_restatement(dev, rows, n, K, replace
     wide = torch.stack([prob, prob.flip(0)], dim=1).reshape(2 * rows, n).to(dev)
     got2 = ops.multinomial(wide[::2], K, replacement, thr, seed).cpu()
     assert torch.equal(got2, want)
+    # the seed as a DEVICE input (ynet_multinomial_devseed: what a captured evaluation sweep passes): the same draws
+    seeds = torch.tensor([7, seed, 9], dtype=torch.int64, device=dev)
+    got3 = ops.multinomial(prob.to(dev), K, replacement, thr, seeds[1:2]).cpu()
+    assert torch.equal(got3, want)
+    with pytest.raises(ValueError, match="one int64 element"):
+        ops.multinomial(prob.to(dev), K, replacement, thr, seeds)
 
 
 def test_device_multinomial_frequencies(dev):
