@@ -730,7 +730,7 @@ def test_upsample2x_bwd_relu(dev, shape):
     assert torch.equal(got, torch.where(act > 0, plain, torch.zeros_like(plain)))
 
 
-@pytest.mark.parametrize("cls,wd", [("Adam", 0.0), ("Adam", 0.01), ("AdamW", 0.05)])
+@pytest.mark.parametrize("cls,wd", [("Adam", 0.0), ("Adam", 0.01), ("AdamW", 0.05), ("Adam+decoupled", 0.05)])
 def test_adam_step_kernel_matches_torch(dev, cls, wd):
     """ynet_adam_step (what a captured step launches instead of torch's fused multi-tensor Adam) against torch.optim.Adam / AdamW on the
     device: five steps over tensors of 1 .. 70,000 elements, one of them without a gradient; the step counters advance as torch's do."""
@@ -740,7 +740,13 @@ def test_adam_step_kernel_matches_torch(dev, cls, wd):
     shapes = [(1,), (7, 3), (1025,), (64, 64, 3, 3), (70000,), (5,)]
     ps = [torch.nn.Parameter(rnd(*sh, seed=i).to(dev)) for i, sh in enumerate(shapes)]
     qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
-    make = getattr(torch.optim, cls)
+    if cls == "Adam+decoupled":      # torch.optim.Adam(decoupled_weight_decay=True) IS AdamW's rule (the kernel must follow it)
+        import inspect
+        if "decoupled_weight_decay" not in inspect.signature(torch.optim.Adam.__init__).parameters:
+            pytest.skip("this torch has no Adam(decoupled_weight_decay=)")
+        make = lambda params, **kw: torch.optim.Adam(params, decoupled_weight_decay=True, **kw)      # noqa: E731
+    else:
+        make = getattr(torch.optim, cls)
     ref, mine = make(ps, lr=1e-3, weight_decay=wd), make(qs, lr=1e-3, weight_decay=wd, capturable=True, fused=True)
     for step in range(5):
         for i, (p, q) in enumerate(zip(ps, qs)):

@@ -163,6 +163,10 @@ def test_trainer_checkpoint_format_cpu(tmp_path):
         t.prepare_data(pd.DataFrame(), "some/dir", "sdd", "train", 8, 12, 0.25, False)
     with pytest.raises(ValueError):
         t.prepare_data(pd.DataFrame(), {}, "kitti", "train", 8, 12, 0.25, False)
+    # pre-processed planes must arrive padded: their border value depends on the pre-processing (class 0 for one-hot planes, (0 - mean) / std
+    # for RGB), so a zero border would be silently wrong; raw label maps [H, W] are padded and encoded on the device instead
+    with pytest.raises(ValueError, match="pre-processed planes"):
+        t.prepare_data(pd.DataFrame(), {"s": torch.zeros(6, 40, 64)}, "sdd", "train", 8, 12, 0.25, False)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
