@@ -44,7 +44,7 @@ struct Args {
     const u32x4* wpk;      // [chunk of 8 channels][tap pair 5][plane][cb][64 lanes] filter fragments
     const float* bias;
     u32x4* yp;             // output planes P[b][Cout/8][3][H][W]
-    int B, Cin, Cout, H, W, relu, ntiles, diag, skew;      // diag (timing ablations, wrong results): 1 no DMA after the first chunk, 2 no epilogue, 4 no filter loads after the first, 8 no MFMAs
+    int B, Cin, Cout, H, W, relu, ntiles, diag, skew;      // diag (timing ablations, wrong results): 1 no DMA after the first chunk, 2 no epilogue, 4 no filter loads after the first (the "no MFMAs" ablation, bit 8, was a run-time branch around every MFMA and is gone: it made hipcc shuttle the accumulators between AGPRs and VGPRs)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3s_kernel(const Args a) {
                         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                             for (int nb = 0; nb < 4; ++nb)
-                                if (!(a.diag & 8) || p == 0) acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[p & 1][i][cb], xf[nb][j], acc[nb][cb], 0, 0, 0);
+                                acc[nb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[p & 1][i][cb], xf[nb][j], acc[nb][cb], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (p + 1 < 5) read_x(p + 1, j);
@@ -287,6 +287,202 @@ __global__ __launch_bounds__(256, 2) void conv_b3s_kernel(const Args a) {
     }
     if constexpr (SPREAD)
         for (int c = 0; c < nspread; ++c) store_part(c);      // the last tile's epilogue
+}
+
+
+// ================================================================================================
+// Second form (round 4, after the first one's phases turned out additive): ONE workgroup per CU, filter fragments RESIDENT in
+// LDS for the whole kernel (Cin / 8 x 15 KB: the first form re-read them from L2 per tile, 12 TB/s of L2 -> L1 traffic chip-wide),
+// (4 + 2) x (64 + 2)-pixel tiles in a RING of three 21 KB chunk buffers filled two chunks ahead (the DMA latency is longer than
+// one chunk's MFMA phase), progressive `s_waitcnt vmcnt(n)` instead of vmcnt(0).  RES=1 selects it.
+// ================================================================================================
+#define TC2 64
+#define LCOLS2 (TC2 + 2)
+#define PLANE_U2 (LROWS * LCOLS2)          // 396 units per plane image
+#define PLANE_P2 448                       // ... padded to 7 wave instructions
+#define BUF2_BYTES (3 * PLANE_P2 * 16)     // 21,504 per 8-channel chunk
+#define NRING 3
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 1) void conv_b3r_kernel(const Args a) {
+    extern __shared__ u32x4 tile[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, HW = H * W;
+    const int tiles_x = W / TC2, tiles_y = H / TR;
+    const int nchunk = a.Cin / 8;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile);
+    const unsigned wbytes = (unsigned)(nchunk * 15 * 64 * 16);       // resident filter fragments [chunk][pair 5][plane 3][64 lanes]
+    const unsigned ring0 = lds0 + wbytes;
+
+    // ---- filter fragments -> LDS, once
+    {
+        const __amdgpu_buffer_rsrc_t rwd = rsrc(a.wpk, wbytes);
+        for (int j = wave; j < nchunk * 15; j += 4) dma16(rwd, lds0 + (unsigned)j * 1024u, (unsigned)(j * 1024 + lane * 16), 0u);
+    }
+    // ---- static DMA geometry: a chunk is 3 planes x 7 wave instructions; this wave issues j = wave + 4 k (k < 6, j < 21)
+    int rel[6];
+    unsigned leftbits = 0, rightbits = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int j = wave + 4 * k, sub = j % 7, u = sub * 64 + lane;
+        const int r = u / LCOLS2, col = u - r * LCOLS2;
+        const bool ok = j < 21 && u < PLANE_U2;
+        rel[k] = ok ? (r * W + col) * 16 : -1;
+        if (ok && col == 0) leftbits |= 1u << k;
+        if (ok && col == LCOLS2 - 1) rightbits |= 1u << k;
+    }
+    unsigned tapoff[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        int t = 2 * p + (lane >> 5);
+        t = t > 8 ? 8 : t;
+        tapoff[p] = (unsigned)(((t / 3) * LCOLS2 + (t % 3) + wave * LCOLS2 + (lane & 31)) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t rb = rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+    const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    const int gstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tile_first = xcd_walk ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tile_end = xcd_walk ? min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : a.ntiles;
+
+    auto dma_chunk = [&](int t, int c, int buf) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int row0 = ty * TR, col0 = tx * TC2;
+        const unsigned edge = (col0 == 0 ? leftbits : 0u) | (col0 + TC2 == W ? rightbits : 0u);
+        const int org = ((row0 - 1) * W + (col0 - 1)) * 16;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int j = wave + 4 * k;
+            if (j < 21) {
+                const int pl = j / 7, sub = j - pl * 7;
+                const u32x4* pbase = a.xp + ((long long)(b * nchunk + c) * 3 + pl) * HW;
+                const __amdgpu_buffer_rsrc_t rp = rsrc(pbase, (unsigned)HW * 16u);
+                const unsigned vo = (rel[k] < 0 || ((edge >> k) & 1u)) ? 0x80000000u : (unsigned)(rel[k] + org);
+                dma16(rp, ring0 + (unsigned)(buf * BUF2_BYTES + (pl * PLANE_P2 + sub * 64) * 16), vo, 0u);
+            }
+        }
+    };
+    // load cursor: two chunks ahead of the compute cursor
+    int lt = tile_first, lc = 0, lbuf = 0, inflight = 0;
+    auto advance_load = [&]() {
+        if (lt < tile_end) {
+            dma_chunk(lt, lc, lbuf);
+            ++inflight;
+            lbuf = lbuf + 1 == NRING ? 0 : lbuf + 1;
+            if (++lc == nchunk) { lc = 0; lt += gstride; }
+        }
+    };
+    float bias_r[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((q * 8 + (lane >> 5) * 4) * 4), 0u, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned ub = bq[e];
+            bias_r[4 * q + e] = __builtin_bit_cast(float, ub);
+        }
+    }
+    if (tile_first < tile_end) {
+        advance_load();
+        advance_load();
+    }
+    const unsigned char* lbase = reinterpret_cast<const unsigned char*>(tile);
+    int buf = 0;
+    f32x16 acc[2], pend[2];
+    int p_row0 = 0, p_col0 = 0, p_b = -1;
+    // the producer's side of the format for the PREVIOUS tile: ReLU, three-way split, 8-byte stores.  It is issued right after the
+    // barrier of the next tile's first chunk, so that the stores drain under that chunk's MFMAs: the `vmcnt` waits below count
+    // loads AND stores, and a store issued just before a wait would be waited for.
+    auto flush = [&]() {
+        if (p_b < 0 || (a.diag & 2)) return;
+        const int ncblk_out = a.Cout / 8;
+        const unsigned vo = (unsigned)((((p_row0 + wave) * W + p_col0 + (lane & 31)) * 16) + (lane >> 5) * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x4* obase = a.yp + ((long long)(p_b * ncblk_out + q) * 3) * HW;
+            const __amdgpu_buffer_rsrc_t ry = rsrc(obase, (unsigned)(3 * HW) * 16u);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                u32x2 h2, m2, l2;
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    float v0 = pend[nb][4 * q + 2 * e2], v1 = pend[nb][4 * q + 2 * e2 + 1];
+                    if (a.relu) {
+                        v0 = v0 > 0.f ? v0 : 0.f;
+                        v1 = v1 > 0.f ? v1 : 0.f;
+                    }
+                    const unsigned h = pk_bf16(v0, v1);
+                    const float r0 = v0 - __builtin_bit_cast(float, h << 16), r1 = v1 - __builtin_bit_cast(float, h & 0xffff0000u);
+                    const unsigned m = pk_bf16(r0, r1);
+                    const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+                    h2[e2] = h;
+                    m2[e2] = m;
+                    l2[e2] = pk_bf16(s0, s1);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(h2, ry, vo + (unsigned)(nb * 32 * 16), 0u, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(m2, ry, vo + (unsigned)(nb * 32 * 16), (unsigned)HW * 16u, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(l2, ry, vo + (unsigned)(nb * 32 * 16), (unsigned)HW * 32u, 0);
+            }
+        }
+        p_b = -1;
+    };
+    for (int tile_id = tile_first; tile_id < tile_end; tile_id += gstride) {
+        const int tx = tile_id % tiles_x, ty = (tile_id / tiles_x) % tiles_y, b = tile_id / (tiles_x * tiles_y);
+        const int row0 = ty * TR, col0 = tx * TC2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = bias_r[i];
+        for (int c = 0; c < nchunk; ++c) {
+            // the chunk about to be consumed has landed when at most the NEXT chunk's DMAs of this wave are outstanding: loads return
+            // in order among themselves (wave 0 issues 6 per chunk, the others 5); stores are counted too and may retire in any order
+            // relative to the loads, which can only make this wait longer, never shorter than needed
+            if (inflight < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            __syncthreads();
+            --inflight;
+            advance_load();          // two chunks ahead, into the buffer whose readers all passed the barrier above
+            if (c == 0) flush();     // the previous tile's epilogue: its stores drain under this chunk's MFMAs
+            const unsigned char* xb = lbase + wbytes + buf * BUF2_BYTES;
+            const unsigned char* wb = lbase + (unsigned)(c * 15) * 1024u + lane * 16;
+            bf16x8 xf[2][3], wf[2][3];
+            auto read_x = [&](int p, int pl) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    xf[nb][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + tapoff[p] + (unsigned)((pl * PLANE_P2 + nb * 32) * 16)));
+            };
+            auto read_w = [&](int p, int wbuf) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[wbuf][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wb + (unsigned)((p * 3 + pl) * 1024)));
+            };
+            read_w(0, 0);
+            read_x(0, 2); read_x(0, 1); read_x(0, 0);
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                if (p + 1 < 5) read_w(p + 1, (p + 1) & 1);
+#pragma unroll
+                for (int j = 2; j >= 0; --j) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 2; i >= 0; --i) {
+                        if (NPROD == 6 && i + j > 2) continue;
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[p & 1][i], xf[nb][j], acc[nb], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + 1 < 5) read_x(p + 1, j);
+                }
+            }
+            buf = buf + 1 == NRING ? 0 : buf + 1;
+        }
+        pend[0] = acc[0];
+        pend[1] = acc[1];
+        p_row0 = row0;
+        p_col0 = col0;
+        p_b = b;
+    }
+    flush();
 }
 
 // fp32 NCHW -> split planes (what the glue producers -- bilinear x2, patch gather, the previous conv -- would write)
@@ -399,6 +595,31 @@ static void run(const Args& a, int grid, const char* what, const std::vector<flo
     printf("%s  grid %d: %.1f us  %.1f TFLOP/s fp32-equivalent  (%.2f TB/s of split planes in + out)\n", what, grid, ms * 1e3, fl / ms / 1e9, bytes / ms / 1e9);
 }
 
+template <int NPROD>
+static void run_res(const Args& a, const char* what) {
+    auto kern = conv_b3r_kernel<NPROD>;
+    const int lds = (a.Cin / 8) * 15 * 1024 + NRING * BUF2_BYTES;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Args b = a;
+    b.ntiles = a.B * (a.H / TR) * (a.W / TC2);
+    int grid = 256;
+    if (getenv("GRID")) grid = atoi(getenv("GRID"));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, b);
+    CK(hipGetLastError());
+    CK(hipEventRecord(e0));
+    const int reps = 20;
+    for (int rep = 0; rep < reps; ++rep) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, b);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cin * a.Cout * 9;
+    printf("%s  resident filters, ring of %d, grid %d, LDS %d: %.1f us  %.1f TFLOP/s fp32-equivalent\n", what, NRING, grid, lds, ms * 1e3, fl / ms / 1e9);
+}
+
 int main(int argc, char** argv) {
     int B = 32, Cin = 32, Cout = 32, H = 256, W = 256;
     if (argc >= 6) { B = atoi(argv[1]); Cin = atoi(argv[2]); Cout = atoi(argv[3]); H = atoi(argv[4]); W = atoi(argv[5]); }
@@ -436,6 +657,22 @@ int main(int argc, char** argv) {
     Args a{dxp, dw, db, dyp, B, Cin, Cout, H, W, 1, B * (H / TR) * (W / TC), getenv("DIAG") ? atoi(getenv("DIAG")) : 0, getenv("SKEW") ? atoi(getenv("SKEW")) : 0};
     int grid = a.ntiles < 512 ? a.ntiles : 512;
     if (getenv("GRID")) grid = atoi(getenv("GRID"));
+    if (getenv("RES") && atoi(getenv("RES")) && NCB == 1 && (W % TC2) == 0) {
+        // (correctness of this form: the output planes are compared with the first form's below)
+        run_res<9>(a, "9 products");
+        std::vector<unsigned short> y_res(nyu * 8), y_ref(nyu * 8);
+        CK(hipMemcpy(y_res.data(), dyp, nyu * 16, hipMemcpyDeviceToHost));
+        auto k9 = conv_b3s_kernel<1, 9, false>;
+        CK(hipFuncSetAttribute((const void*)k9, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        hipLaunchKernelGGL(k9, dim3(grid), dim3(256), LDS_BYTES, 0, a);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(y_ref.data(), dyp, nyu * 16, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < y_res.size(); ++i) bad += y_res[i] != y_ref[i];
+        printf("resident-filter form vs first form (9 products): %zu of %zu bf16 words differ\n", bad, y_res.size());
+        run_res<6>(a, "6 products");
+        return bad ? 1 : 0;
+    }
     const bool spread = getenv("SPREAD") && atoi(getenv("SPREAD"));
     if (NCB == 1) {
         if (spread) {
