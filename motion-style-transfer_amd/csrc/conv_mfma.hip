@@ -929,6 +929,28 @@ __device__ __forceinline__ void conv_dma_body() {
             const float* ap = ke->addend + (long long)(abm > 0 ? t.b % abm : t.b) * ke->addend_bs;
             const __amdgpu_buffer_rsrc_t ra = sgpr_rsrc(ap, (unsigned)ke->cout * plane_bytes);
             const unsigned ub = (unsigned)(c_lo * HW + ybase * W) * 4u;
+#ifdef YNET_ADD_PREFETCH
+            // (experiment, round 4: ALL addend quads in flight at once -- one round trip instead of NCB * 2 batches of R, but NCB * R * 8 more
+            // registers: 176 VGPRs for <2,4,4> = two resident workgroups per CU instead of four; measured on C5: see DESIGN.md section 8, 4b)
+            f32x4 ad[NCB][R][2];
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const unsigned vo = lo[i][g] + ub;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        ad[i][r][g] = (ybase + r * FOLD < H) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, vo, (unsigned)(r * FOLD * W) * 4u, 0))
+                                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NCB; ++i)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[i][r][g] += ad[i][r][g];
+#else
 #pragma unroll
             for (int i = 0; i < NCB; ++i)
 #pragma unroll
@@ -939,6 +961,7 @@ __device__ __forceinline__ void conv_dma_body() {
                         if (ybase + r * FOLD < H)
                             acc[i][r][g] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, vo, (unsigned)(r * FOLD * W) * 4u, 0));
                 }
+#endif
         }
         if (ke->relu && ksplit == 1) {
 #pragma unroll
