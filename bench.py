@@ -191,6 +191,17 @@ class ConvTimer:
     def __exit__(self, *a):
         self.ops.conv2d_raw = self.orig
 
+    def layers(self, steps):
+        """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, TFLOP/s]."""
+        torch.cuda.synchronize()
+        per = len(self.rec) // steps
+        out = []
+        for i in range(per):
+            us = sorted(self.rec[i + s * per][1].elapsed_time(self.rec[i + s * per][2]) * 1e3 for s in range(steps))[steps // 2]
+            name, _, _, fl, _, shape = self.rec[i]
+            out.append([name, list(shape), round(us, 2), round(fl / us / 1e6, 2)])
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
@@ -421,6 +432,8 @@ def main():
     ap.add_argument("--no-repeats", action="store_true", help="time the contract's region only (no two repeat regions)")
     ap.add_argument("--no-c5", action="store_true", help="skip the short C5 leg of the default run")
     ap.add_argument("--no-legs", action="store_true", help="skip the short C1 / C4 legs of the default run")
+    ap.add_argument("--conv-layers", default=None, metavar="FILE",
+                    help="also write the instrumented step's convolution launches one by one (kernel, shape, microseconds) to FILE")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained region after the contract's timed region")
     ap.add_argument("--sustained-seconds", type=float, default=5.5)
     ap.add_argument("--layers", action="store_true", help="print one line per conv launch of the instrumented step (stderr)")
@@ -609,6 +622,9 @@ def main():
             out["roofline"] = readout_roofline(ops, pkg("models.ynet"), cfg, B, H, W, dev)
     elif rank == 0:
         agg = ct.summary()
+        if args.conv_layers:
+            with open(args.conv_layers, "w") as f:
+                json.dump(ct.layers(n_inst), f)
         for v in agg.values():               # per step
             for k in ("launches", "ms", "flops", "bytes"):
                 v[k] = v[k] / n_inst

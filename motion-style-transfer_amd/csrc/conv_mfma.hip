@@ -1332,7 +1332,10 @@ static int pick_rows(const ConvArgs& a, int cb) {
     static const int forced = getenv("YNET_CONV_R") ? atoi(getenv("YNET_CONV_R")) : 0;
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     static const int r4_min = getenv("YNET_CONV_R4_MIN") ? atoi(getenv("YNET_CONV_R4_MIN")) : 1024;
-    static const int r2_min = getenv("YNET_CONV_R2_MIN") ? atoi(getenv("YNET_CONV_R2_MIN")) : 512;
+    // (round 4: 512 -> 64.  At the reference scripts' batch of 10 the 32^2 / 64^2 layers fell below 512 two-row units and took the
+    //  register-staged one-row kernel at 17-25 TFLOP/s; the two-row LDS-DMA tile runs them at 22-37: captured step 3.49 -> 3.44 ms at
+    //  B 10, 8.93 -> 8.90 at B 32; 32 and 128 measure the same as 64)
+    static const int r2_min = getenv("YNET_CONV_R2_MIN") ? atoi(getenv("YNET_CONV_R2_MIN")) : 64;
     const long long per_img_x = ceil_div(a.W, 32), cg = ceil_div(a.cout, cb);
     for (int r = 4; r > 1; r >>= 1) {
         const long long nblk = per_img_x * ceil_div(a.H, 4 * r) * cg * a.B;

@@ -561,7 +561,7 @@ DGRAD_RELU_CASES = [
     (8, 128, 128, 32, 16, False),       # two-row tiles, one 16-channel tile per workgroup: mask inside the conv kernel
     (8, 128, 128, 32, 32, True),        # ... with the consumer-side mask of dy on top (masked instantiation)
     (8, 64, 128, 16, 64, False),        # four 16-channel tiles
-    (4, 64, 64, 64, 48, True),          # three tiles
+    (4, 64, 64, 64, 48, True),          # three tiles (64 two-row units: the smallest launch that takes them)
     (2, 16, 32, 8, 8, False),           # small map: the fall-back pass
     (4, 16, 16, 64, 64, False),         # folded tiles, split channel loop: the mask is applied by the reduction
     (3, 24, 40, 5, 7, True),            # ragged edges, register-staged kernel + fall-back pass
@@ -587,8 +587,8 @@ def test_conv2d_dgrad_relu_writes_through_the_relu_backward_of_the_layer_below(d
     assert torch.equal(got, want), float((got - want).abs().max())
     ref = F.conv_transpose2d((dy * (y > 0)) if masked else dy, w, padding=1) * (act > 0)
     close(got, ref, rtol=1e-4, scale_rel=2e-6, msg="dgrad_relu vs torch")
-    # (the first three cases are the ones the conv kernel itself masks; the others take the reduction / the fall-back pass)
-    assert bool(ops._lib().ynet_conv2d_dgrad_relu_supported(B, H, W, cin, 3)) == (case in DGRAD_RELU_CASES[:3])
+    # (the first four cases are the ones the conv kernel itself masks; the others take the reduction / the fall-back pass)
+    assert bool(ops._lib().ynet_conv2d_dgrad_relu_supported(B, H, W, cin, 3)) == (case in DGRAD_RELU_CASES[:4])
 
 
 # B, H, W, channels of the first layer's output (= of dx), channels of dy, dy masked too, input channels of the first layer
