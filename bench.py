@@ -154,10 +154,11 @@ class ConvTimer:
         self.ops, self.orig, self.rec = ops, ops.conv2d_raw, []
 
     def __enter__(self):
-        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None):
+        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits)
+            took = self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits,
+                             wino=wino)
             e1.record()
             cin = sum(s[1] for s in srcs)
             dl = list(dsts)
@@ -170,7 +171,9 @@ class ConvTimer:
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             cc = plan >> 21                       # input channels per staged chunk (the kernel's CC template argument)
-            if dma:
+            if took == "winograd":            # (csrc/conv_wino.hip: NCB 16-channel output blocks, chunks of 8 input channels)
+                name = f"conv_wino_kernel<{cout // 16}, {cin // 8}>"
+            elif dma:
                 if cc > 8:                        # launch_dma_small: the deep chunks are for plain launches with enough input channels
                     if relu_of or pooled or bits_out or relu_bits:
                         cc = 8

@@ -99,6 +99,24 @@ int ynet_conv2d_relu_bits(const float* const* src, const int* src_c, const long 
 int ynet_conv2d_dgrad_relu_bits(const float* dy, int dy_c, long long dy_bs, const float* mask, long long mask_bs, const float* wp,
                                 float* dx, int dx_c, long long dx_bs, const unsigned* bits, int B, int H, int W, int K, void* stream);
 
+/* The Winograd F(2x2, 3x3) generation of the 3x3 convolution (csrc/conv_wino.hip; round 4): 2.25x fewer fp32 MFMAs than the implicit
+ * GEMM behind ynet_conv2d, fp32 throughout -- results differ from ynet_conv2d's by rounding only (the error against fp64 is smaller:
+ * fewer additions reach an accumulator).  One source, one destination, no mask / epilogue variant; serves
+ *   K = 3, cin in {16, 32}, cout in {16, 32}, H % 16 == 0, W % 32 == 0, B * H * W >= 128 * 128 * 16   (ynet_conv2d_winograd_supported)
+ * i.e. the plain large-map convolutions and data gradients of both decoders (models/ynet.py:196,206: Conv2d(3x3) + ReLU; their
+ * convolution_backward -> grad_input).  Replaces the same ATen calls as ynet_conv2d.
+ *   ynet_winograd_filter        u = G g G^T of every (cout, cin) pair in MFMA fragment order, from a packed filter of ynet_pack_weight
+ *                               (mode 0 for the forward convolution, mode 1 for the data gradient: cin / cout are the CONVOLUTION's
+ *                               input / output channels either way); ynet_winograd_filter_floats(cin, cout) floats, 16-byte aligned;
+ *                               once per weight version.
+ *   ynet_conv2d_winograd        dst[b][co] = [relu](conv3x3(src[b], filter) + bias[co]); src / dst: cin / cout planes of H x W per image,
+ *                               batch strides in floats (>= the image), 16- / 8-byte aligned; bias may be NULL. */
+int ynet_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K);
+long long ynet_winograd_filter_floats(int cin, int cout);
+int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, void* stream);
+int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
+                         int B, int H, int W, int relu, void* stream);
+
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,
  * rows, CC, mask, m16>, or with dma the LDS-DMA generation conv_dma_kernel<tiles, rows, CC, mask, x4, fold>, in a

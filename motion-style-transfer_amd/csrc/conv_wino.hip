@@ -1,0 +1,343 @@
+// 3x3 convolution in the Winograd F(2x2, 3x3) form on the fp32 matrix cores (round 4; DESIGN.md section 4.20 / section 8 item 7;
+// the measured prototype with its ablations is tools/conv_wino_proto.hip).
+//
+//   Y = A^T [ sum over cin (G g G^T) (.) (B^T d B) ] A       per 2x2 output block: 16 multiplies per input channel instead of 36,
+//   i.e. 2.25x fewer v_mfma_f32_16x16x4_f32 than the implicit GEMM of conv_mfma.hip -- in fp32 throughout (the error against fp64 is
+//   BELOW the direct form's: fewer additions reach an accumulator).  The same kernel serves the forward convolution and the data
+//   gradient (flipped / transposed filter = the mode-1 packing of ynet_pack_weight).
+//
+//   MFMA        D[m = cout][n = block] += U[xi,nu][cout][cin 4] * V[xi,nu][cin 4][block]; a wave owns one PAIR of output rows x 32
+//               columns = 16 blocks and NCB * 16 output channels: 16 (xi,nu) * NCB accumulators of 4 registers.  The lane that
+//               needs V = B^T d B computes it from its own 4x4 patch (four 8-byte-aligned LDS reads, 16 packed additions).
+//   filters     transformed once per weight version by wino_filter_kernel into MFMA fragment order; ALL of them stay in LDS for
+//               the launch (64 * Cin * Cout bytes <= 64 KB: the shapes ynet_conv2d_winograd_supported admits).
+//   staging     every wave stages ITS OWN four input rows of 8 channels per chunk (5 LDS-DMA instructions of 64 lanes x 16 bytes =
+//               8 channels x 4 rows x 10 units exactly) into a private two-slot ring: no barrier in the loop.  The rows are shifted by
+//               4 bytes in LDS (a 16-byte LDS-DMA takes a 4-byte aligned destination: tools/lds_dma_align_probe.hip), which puts
+//               every patch's first column on an 8-byte boundary while the global units stay whole inside / outside the image; plane
+//               pitch 640 bytes = 128 (mod 256): conflict-free.  Addresses are a static per-lane offset + a scalar offset.
+//   scheduling  the two waves of a SIMD are served oldest-first, so a workgroup hands its row pairs out from a counter in LDS, one
+//               ahead of the pair being computed (a static split left the younger four waves 25 % behind).
+//   epilogue    Y = A^T M A packed over channel pairs, bias through M[1][1], ReLU, 8-byte stores.
+#include "ynet_common.h"
+#include <math.h>
+#include <stdlib.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define WN_TH 16
+#define WN_TW 32
+#define WN_LQ 10                          // 16-byte units per staged row: columns x0 - 4 .. x0 + 35
+#define WN_ROWF 40
+#define WN_PLANE_F 160                    // 4 rows
+#define WN_SLOT_BYTES (320 * 16 + 16)     // 8 channels x 4 rows x 10 units, + the 4-byte shift
+#define WN_RING_BYTES (2 * WN_SLOT_BYTES)
+#define WN_THREADS 512
+
+struct WinoArgs {
+    const float* x;        // [B] x (x_bs floats) : cin planes of H x W
+    const f32x4* u;        // transformed filters in fragment order (ynet_winograd_filter)
+    const float* bias;     // cout floats or NULL
+    float* y;              // [B] x (y_bs floats) : cout planes
+    long long x_bs, y_bs;
+    int B, H, W, relu, ntiles;
+};
+
+__device__ __forceinline__ f32x2 wn_v01(f32x2 tl, f32x2 th) {      // (t0 - t2, t1 + t2)
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(tl), "v"(th));
+    return r;
+}
+__device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, t1 - t3)
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(tl), "v"(th));
+    return r;
+}
+
+// NCB: 16-channel output blocks (cout = 16 NCB), NCH: chunks of 8 input channels (cin = 8 NCH; even: chunk c lives in slot c & 1 of the
+// wave's ring, and the chunk two ahead -- of this pair or the next -- takes the slot just read)
+template <int NCB, int NCH>
+__global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs a) {
+    extern __shared__ f32x4 smem[];
+    constexpr int WQ = 8 * NCB * 64;      // units of one chunk's filters: [2 k-steps][4 quads of (xi,nu)][NCB][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, HW = H * W;
+    const int tiles_x = W / WN_TW, tiles_y = H / WN_TH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const unsigned ring0 = lds0 + (unsigned)(NCH * WQ * 16) + (unsigned)(wave * WN_RING_BYTES);
+
+    // static DMA geometry of this lane: unit j * 64 + lane -> (channel of the chunk, row, unit of the row)
+    unsigned rel[5], edge[5];             // edge bits: 1 top row, 2 bottom row, 4 left unit, 8 right unit
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int u = j * 64 + lane, plane = u / 40, rem = u - plane * 40, r = rem / WN_LQ, xq = rem - r * WN_LQ;
+        rel[j] = (unsigned)((plane * HW + r * W + 4 * xq) * 4);
+        edge[j] = (r == 0 ? 1u : 0u) | (r == 3 ? 2u : 0u) | (xq == 0 ? 4u : 0u) | (xq == WN_LQ - 1 ? 8u : 0u);
+    }
+    // the input descriptor starts one row and one unit BEFORE the tensor: the scalar offset of a chunk (its first output row and
+    // column) is then never negative, and the lanes that would read in front of / behind a plane are exactly the edge lanes
+    // (sent to an offset beyond the descriptor: zero fill)
+    const unsigned lead = (unsigned)((W + 4) * 4);
+    const unsigned x_bytes = (unsigned)(((long long)(a.B - 1) * a.x_bs + (long long)NCH * 8 * HW) * 4);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x) - lead),
+                                                                        0, x_bytes + lead, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u), 0, (unsigned)(NCH * WQ * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(((long long)(a.B - 1) * a.y_bs + (long long)NCB * 16 * HW) * 4),
+                                                                        0x00020000);
+
+    // XCD-aware walk (workgroups are dealt round-robin over the 8 XCDs): each XCD sweeps its own contiguous eighth of the tiles
+    const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    const int gstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tile_first = xcd_walk ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tile_end = xcd_walk ? min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : a.ntiles;
+    if (tile_first >= tile_end) return;
+    const int my_tiles = (tile_end - tile_first + gstride - 1) / gstride;
+    const int total_units = my_tiles * 8;
+
+    const int n = lane & 15, kq = lane >> 4;
+    const float floor_v = a.relu ? 0.f : -INFINITY;
+    f32x2 bias2[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            bias2[cb][h] = a.bias ? f32x2{a.bias[cb * 16 + 4 * kq + 2 * h], a.bias[cb * 16 + 4 * kq + 2 * h + 1]} : f32x2{0.f, 0.f};
+    // (the bias loads are complete before the first DMA: hipcc would otherwise drain the DMA queue where the epilogue first reads them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bias2[cb][h]));
+    // static store offsets of this lane: output channel 4 kq (+ the rest by the scalar offset), column 2 n, rows 0 / 1 of the pair
+    const unsigned st0 = (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
+
+    // all transformed filters -> LDS, once; the workgroup's unit counter
+#pragma unroll
+    for (int j = 0; j < NCH * WQ / WN_THREADS; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(uintptr_t)(lds0 + (unsigned)(j * 8192 + wave * 1024)), 16,
+                                                 (unsigned)((j * WN_THREADS + tid) * 16), 0, 0, 0);
+    unsigned* unit_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(smem) + NCH * WQ * 16 + 8 * WN_RING_BYTES);
+    if (tid == 0) *unit_ctr = 8u;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    auto next_unit = [&]() {
+        unsigned u = 0;
+        if (lane == 0) u = atomicAdd(unit_ctr, 1u);
+        return (int)__builtin_amdgcn_readfirstlane(u);
+    };
+
+    auto dma_chunk = [&](int unit, int c) {       // the four input rows of row pair `unit` (tile unit / 8, pair unit % 8), chunk c -> slot c & 1
+        const int t = tile_first + (unit >> 3) * gstride, slot = c & 1;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int y0 = ty * WN_TH + 2 * (unit & 7), x0 = tx * WN_TW;
+        const unsigned em = (y0 == 0 ? 1u : 0u) | (y0 + 2 == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + WN_TW == W ? 8u : 0u);
+        const unsigned so = (unsigned)(((long long)b * a.x_bs + (long long)c * 8 * HW + y0 * W + x0) * 4);
+        const unsigned sb = ring0 + (unsigned)(slot * WN_SLOT_BYTES) + 4u;
+        if (em == 0) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + (unsigned)(j * 1024)), 16, rel[j], so, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + (unsigned)(j * 1024)), 16,
+                                                         (edge[j] & em) ? 0x80000000u : rel[j], so, 0, 0);
+        }
+    };
+
+    int cur = wave, nxt = next_unit();
+    dma_chunk(cur, 0);
+    dma_chunk(cur, 1);
+
+    f32x4 acc[16][NCB];
+    while (cur < total_units) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // chunk c has landed (the loads issued after it are those of the next chunk, if there is one)
+            if (c + 1 < NCH || nxt < total_units) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const f32x4* wl = smem + c * WQ;
+            const float* il = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(smem) + NCH * WQ * 16 + wave * WN_RING_BYTES +
+                                                             (c & 1) * WN_SLOT_BYTES + 4);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // the lane's 4x4 patch of channel s * 4 + kq: staged rows 0 .. 3, floats 3 + 2n .. 6 + 2n of the row
+                const float* ip = il + (s * 4 + kq) * WN_PLANE_F + 3 + 2 * n;
+                f32x2 dl[4], dh[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dl[r] = *reinterpret_cast<const f32x2*>(ip + r * WN_ROWF);
+                    dh[r] = *reinterpret_cast<const f32x2*>(ip + r * WN_ROWF + 2);
+                }
+                if (s == 1) {
+                    // the slot is read out (this wave's own reads): it takes the chunk two ahead
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (c + 2 < NCH) dma_chunk(cur, c + 2);
+                    else if (nxt < total_units) dma_chunk(nxt, c + 2 - NCH);
+                }
+                // V = B^T d B: rows, then the columns with source selection
+                const f32x2 tl[4] = {dl[0] - dl[2], dl[1] + dl[2], dl[2] - dl[1], dl[1] - dl[3]};
+                const f32x2 th[4] = {dh[0] - dh[2], dh[1] + dh[2], dh[2] - dh[1], dh[1] - dh[3]};
+                f32x2 v01[4], v23[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v01[i] = wn_v01(tl[i], th[i]);
+                    v23[i] = wn_v23(tl[i], th[i]);
+                }
+                // (inline asm is opaque to hipcc's hazard recognizer: the wait states between a vector write and the MFMA that reads
+                //  it are spent here)
+                asm volatile("s_nop 3" : "+v"(v01[0]), "+v"(v01[1]), "+v"(v01[2]), "+v"(v01[3]), "+v"(v23[0]), "+v"(v23[1]), "+v"(v23[2]), "+v"(v23[3]));
+                // 16 NCB MFMAs: (xi,nu) = 4 q + e, cout block cb; the pair's first k-step accumulates onto 0
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 w[NCB];
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) w[cb] = wl[((s * 4 + q) * NCB + cb) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bv = e < 2 ? v01[q][e] : v23[q][e - 2];
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb) {
+                            const float av = w[cb][e];
+                            if (c == 0 && s == 0) acc[q * 4 + e][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            else acc[q * 4 + e][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[q * 4 + e][cb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- epilogue: Y = A^T M A packed over channel pairs, bias through M[1][1], ReLU, 8-byte stores at static + scalar offsets
+        {
+            const int t = tile_first + (cur >> 3) * gstride;
+            const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+            const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 m[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        m[e] = h == 0 ? __builtin_shufflevector(acc[e][cb], acc[e][cb], 0, 1) : __builtin_shufflevector(acc[e][cb], acc[e][cb], 2, 3);
+                    m[5] = m[5] + bias2[cb][h];
+                    f32x2 r0[4], r1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        r0[j] = m[j] + m[4 + j] + m[8 + j];
+                        r1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+                    }
+                    const f32x2 o00 = r0[0] + r0[1] + r0[2], o01 = r0[1] - r0[2] - r0[3];
+                    const f32x2 o10 = r1[0] + r1[1] + r1[2], o11 = r1[1] - r1[2] - r1[3];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {      // channel cb * 16 + 4 kq + 2 h + k
+                        const f32x2 row0 = {fmaxf(o00[k], floor_v), fmaxf(o01[k], floor_v)};
+                        const f32x2 row1 = {fmaxf(o10[k], floor_v), fmaxf(o11[k], floor_v)};
+                        const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), ry, st0, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), ry, st1, so, 0);
+                    }
+                }
+        }
+        cur = nxt;
+        if (cur < total_units) nxt = next_unit();
+    }
+}
+
+// U = G g G^T of every (cout, cin) pair, in the fragment order the kernel reads: unit ((c * 2 + s) * 4 + q) * NCB + cb) * 64 + lane holds
+// (xi = q, nu = 0..3) of output channel cb * 16 + (lane & 15), input channel c * 8 + s * 4 + (lane >> 4).
+// wp: a packed filter of ynet_pack_weight, [k][tap][m] with m padded to cols_pad (k = the conv's input channels, m = its outputs).
+__global__ void wino_filter_kernel(const float* __restrict__ wp, f32x4* __restrict__ u, int cols_pad, int ncb, int nunits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nunits) return;
+    const int l = i & 63, cb = (i >> 6) % ncb, q = ((i >> 6) / ncb) & 3, s = (((i >> 6) / ncb) >> 2) & 1, c = ((i >> 6) / ncb) >> 3;
+    const int co = cb * 16 + (l & 15), ci = c * 8 + s * 4 + (l >> 4);
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = wp[((long long)ci * 9 + t) * cols_pad + co];
+    // row q of G g (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]), then times G^T
+    float gr[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        gr[j] = q == 0 ? g[0][j] : (q == 3 ? g[2][j] : 0.5f * ((g[0][j] + g[2][j]) + (q == 1 ? g[1][j] : -g[1][j])));
+    f32x4 o;
+    o[0] = gr[0];
+    o[1] = 0.5f * ((gr[0] + gr[2]) + gr[1]);
+    o[2] = 0.5f * ((gr[0] + gr[2]) - gr[1]);
+    o[3] = gr[2];
+    u[i] = o;
+}
+
+// The packed filter's column padding (conv_mfma.hip: YNET_COUT_PAD)
+static int wino_cols_pad(int cols) { return ceil_div(cols, 64) * 64; }
+
+static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
+    static const int on = getenv("YNET_WINOGRAD") ? atoi(getenv("YNET_WINOGRAD")) : 1;
+    if (!on || K != 3 || B <= 0) return false;
+    if (H % WN_TH || W % WN_TW || H < WN_TH || W < WN_TW) return false;
+    if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return false;
+    static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 16;
+    return (long long)B * H * W >= min_pixels;      // (one workgroup of eight waves per CU: small launches stay with the direct tiles)
+}
+
+template <int NCB, int NCH>
+static int launch_wino(WinoArgs& a, hipStream_t st) {
+    constexpr int lds = NCH * 8 * NCB * 64 * 16 + 8 * WN_RING_BYTES + 16;
+    static bool attr_dev[YNET_MAX_DEV] = {false};
+    static int cus_dev[YNET_MAX_DEV] = {0};
+    const int slot = ynet_device_slot();
+    if (!attr_dev[slot]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus_dev[slot] = cus < 8 ? 8 : cus;
+        attr_dev[slot] = true;
+    }
+    int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
+    if (grid >= 8) grid &= ~7;          // (the XCD-aware walk wants a multiple of 8)
+    hipLaunchKernelGGL((conv_wino_kernel<NCB, NCH>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    return ynet_check_launch("conv2d_winograd");
+}
+
+extern "C" {
+
+int ynet_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K) { return wino_shape_ok(B, H, W, cin, cout, K) ? 1 : 0; }
+
+long long ynet_winograd_filter_floats(int cin, int cout) {
+    if (cin <= 0 || cout <= 0) return 0;
+    return 16ll * (ceil_div(cin, 8) * 8) * (ceil_div(cout, 16) * 16);
+}
+
+int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, void* stream) {
+    YNET_REQUIRE(wp && u, "winograd_filter: null pointer");
+    YNET_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 16 == 0, "winograd_filter: cin %d must be a multiple of 8, cout %d of 16", cin, cout);
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(u) & 15) == 0, "winograd_filter: the output must be 16-byte aligned");
+    const int ncb = cout / 16, nunits = (cin / 8) * 8 * ncb * 64;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(ceil_div(nunits, 256)), dim3(256), 0, (hipStream_t)stream, wp, reinterpret_cast<f32x4*>(u),
+                       wino_cols_pad(cout), ncb, nunits);
+    return ynet_check_launch("winograd_filter");
+}
+
+int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
+                         int B, int H, int W, int relu, void* stream) {
+    YNET_REQUIRE(src && u && dst, "conv2d_winograd: null pointer");
+    YNET_REQUIRE(wino_shape_ok(B, H, W, cin, cout, 3), "conv2d_winograd: shape B=%d %dx%d %d -> %d is not served (ask ynet_conv2d_winograd_supported)", B, H, W,
+                 cin, cout);
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 &&
+                     (src_bs & 3) == 0 && (dst_bs & 1) == 0,
+                 "conv2d_winograd: planes must be 16-byte (input, filters) / 8-byte (output) aligned");
+    const long long HW = (long long)H * W;
+    YNET_REQUIRE(src_bs >= cin * HW && dst_bs >= cout * HW, "conv2d_winograd: batch strides smaller than the images");
+    YNET_REQUIRE(((long long)(B - 1) * src_bs + cin * HW) * 4 + (W + 4) * 4 < (1ll << 32) && ((long long)(B - 1) * dst_bs + cout * HW) * 4 < (1ll << 32),
+                 "conv2d_winograd: tensors beyond 4 GB are not addressed by one buffer descriptor");
+    WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW)};
+    hipStream_t st = (hipStream_t)stream;
+    if (cout == 32) return cin == 32 ? launch_wino<2, 4>(a, st) : launch_wino<2, 2>(a, st);
+    return cin == 32 ? launch_wino<1, 4>(a, st) : launch_wino<1, 2>(a, st);
+}
+
+}  // extern "C"

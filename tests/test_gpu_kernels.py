@@ -591,6 +591,75 @@ def test_conv2d_dgrad_relu_writes_through_the_relu_backward_of_the_layer_below(d
     assert bool(ops._lib().ynet_conv2d_dgrad_relu_supported(B, H, W, cin, 3)) == (case in DGRAD_RELU_CASES[:4])
 
 
+# B, H, W, cin, cout, ReLU, bias, packing mode (0 forward, 1 data gradient), destination = a channel slice of a wider tensor
+WINOGRAD_CASES = [
+    (16, 128, 128, 32, 32, True, True, 0, False),      # the decoders' 32 -> 32 layers
+    (4, 256, 256, 32, 16, True, True, 0, True),        # the layer in front of the predictor, written into a wider tensor
+    (4, 256, 256, 16, 32, False, False, 1, False),     # its data gradient (mode-1 packing: flipped taps, transposed roles)
+    (48, 64, 96, 16, 16, False, True, 0, False),       # ragged tile counts: 4 x 3 tiles per image, 576 tiles over 256 workgroups
+    (3, 304, 320, 32, 32, True, False, 0, False),      # edges everywhere: 19 x 10 tiles, a batch that is no multiple of anything
+]
+
+
+@pytest.mark.parametrize("case", WINOGRAD_CASES, ids=[str(c) for c in WINOGRAD_CASES])
+def test_winograd_convolution_matches_the_direct_form(dev, case):
+    """ynet_conv2d_winograd (F(2x2, 3x3) on the fp32 matrix cores): the same values as torch's convolution and as ynet_conv2d within fp32
+    rounding -- tolerance 2e-6 of the largest output (the bound the implicit-GEMM kernels are held to), since the two forms round
+    differently; its error against an fp64 reference is not larger than the direct kernel's."""
+    ops = pkg("ops")
+    B, H, W, cin, cout, relu, has_bias, mode, wide = case
+    assert ops._lib().ynet_conv2d_winograd_supported(B, H, W, cin, cout, 3)
+    x = torch.relu(rnd(B, cin, H, W, seed=1)).to(dev)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=0.2).to(dev) if mode == 0 else rnd(cin, cout, 3, 3, seed=2, scale=0.2).to(dev)
+    bias = rnd(cout, seed=3).to(dev) if has_bias else None
+    wp = ops.pack_weight(w, mode)
+    u = ops.winograd_filter(wp, cin, cout)
+    ctot = cout + 8 if wide else cout
+    got = torch.full((B, ctot, H, W), float("nan"), device=dev)
+    c0 = 8 if wide else 0
+    ops.conv2d_winograd_raw((x.data_ptr(), cin * H * W), u, bias, (got[:, c0:].data_ptr(), ctot * H * W), cin, cout, B, H, W, relu)
+    direct = torch.empty(B, cout, H, W, device=dev)
+    assert ops.conv2d_raw([(x.data_ptr(), cin, cin * H * W)], None, wp, bias, [(direct.data_ptr(), cout, cout * H * W)], B, H, W, 3, relu) is None
+    if mode == 0:
+        ref64 = F.conv2d(x.double(), w.double(), bias.double() if has_bias else None, padding=1)
+    else:
+        ref64 = F.conv_transpose2d(x.double(), w.double(), padding=1)
+    ref64 = torch.relu(ref64) if relu else ref64
+    y = got[:, c0:]
+    if wide:
+        assert bool(torch.isnan(got[:, :c0]).all()), "the channels in front of the slice were written"
+    close(y, ref64, rtol=1e-5, scale_rel=2e-6, msg="winograd vs fp64")
+    close(y, direct, rtol=1e-5, scale_rel=2e-6, msg="winograd vs ynet_conv2d")
+    e_w, e_d = float((y.double() - ref64).abs().max()), float((direct.double() - ref64).abs().max())
+    assert e_w <= 1.5 * e_d + 1e-7, (e_w, e_d)
+
+
+def test_winograd_path_of_the_model_layer_and_its_switch(dev):
+    """ops.conv2d takes the Winograd kernel for a plain 32 -> 32 layer -- forward AND data gradient -- and the implicit GEMM with
+    YNET_WINOGRAD off; outputs and input gradients of the two agree within fp32 rounding.  (A layer without ReLU: behind a ReLU
+    the two forms' masks differ wherever a pre-activation rounds to the other side of zero -- 576 of 8.4 M elements here.)"""
+    ops = pkg("ops")
+    B, H, W = 16, 128, 128
+    w = rnd(32, 32, 3, 3, seed=5, scale=0.2).to(dev)
+    bias = rnd(32, seed=6).to(dev)
+    outs = []
+    for allowed in (True, False):
+        x = rnd(B, 32, H, W, seed=7).to(dev).requires_grad_(True)
+        old, n0 = ops._wino_allowed, ops.wino_stats["launches"]
+        ops._wino_allowed = allowed
+        try:
+            y = ops.conv2d(x, w, bias, False, {})
+            (y * rnd(B, 32, H, W, seed=8).to(dev)).sum().backward()
+        finally:
+            ops._wino_allowed = old
+        assert ops.wino_stats["launches"] - n0 == (2 if allowed else 0)
+        outs.append((y.detach(), x.grad))
+    close(outs[0][0], outs[1][0], rtol=1e-5, scale_rel=2e-6, msg="forward")
+    close(outs[0][1], outs[1][1], rtol=1e-5, scale_rel=2e-6, msg="input gradient")
+    ref = F.conv2d(rnd(B, 32, H, W, seed=7).to(dev), w, bias, padding=1)
+    close(outs[0][0], ref, rtol=1e-4, scale_rel=2e-6, msg="forward vs torch")
+
+
 # B, H, W, channels of the first layer's output (= of dx), channels of dy, dy masked too, input channels of the first layer
 RELU_BITS_CASES = [
     (8, 128, 128, 32, 16, False, 14),     # two 16-channel tiles x 4 rows: 64 mask bits per lane

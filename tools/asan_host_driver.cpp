@@ -77,6 +77,15 @@ int main() {
     EXPECT_REJECT(ynet_conv2d_relu_bits(srcs, &one, &bs, 1, cfp, nullptr, fp, 64, 64, (unsigned*)dummy, 2, 16, 16, 3, nullptr));            // shape not served
     EXPECT_REJECT(ynet_conv2d_dgrad_relu_bits(cfp, 4, 64, nullptr, 0, cfp, fp, 32, 64, nullptr, 8, 128, 128, 3, nullptr));                 // no mask words
     EXPECT_REJECT(ynet_conv2d_dgrad_relu_bits(cfp, 4, 64, nullptr, 0, cfp, fp, 64, 64, (const unsigned*)dummy, 2, 16, 16, 3, nullptr));     // shape not served
+    for (int b : {1, 10, 32, 256})
+        for (int hw : {8, 32, 64, 128, 256, 512})
+            for (int c : {8, 16, 24, 32, 48, 64}) acc += ynet_conv2d_winograd_supported(b, hw, hw, c, 32, 3) + ynet_conv2d_winograd_supported(b, hw, hw + 2, 32, c, 3) + ynet_conv2d_winograd_supported(b, hw, hw, c, c, 5) + ynet_winograd_filter_floats(c, c);
+    EXPECT_REJECT(ynet_winograd_filter(nullptr, fp, 32, 32, nullptr));
+    EXPECT_REJECT(ynet_winograd_filter(cfp, fp, 12, 32, nullptr));                                                                    // cin not a multiple of 8
+    EXPECT_REJECT(ynet_conv2d_winograd(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 48, 32, 256, 256, 1, nullptr));               // cout not served
+    EXPECT_REJECT(ynet_conv2d_winograd(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 250, 256, 1, nullptr));               // H not a multiple of 16
+    EXPECT_REJECT(ynet_conv2d_winograd(cfp, 16 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));               // batch stride smaller than the image
+    EXPECT_REJECT(ynet_conv2d_winograd(nullptr, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 0, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 7, cfp, 4, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_lora_compose(nullptr, cfp, cfp, 1.f, fp, 4, 4, 3, 1, nullptr));

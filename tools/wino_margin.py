@@ -1,0 +1,56 @@
+"""How far a training step at the headline batch sizes moves against the CPU oracle with and without the Winograd convolutions
+(development aid; the checks themselves are tests/test_gpu_headline.py): prints the largest deviation of the loss, the batch ADE / FDE,
+every trajectory's read-out and the gradients for the chosen configuration with ops._wino_allowed on and off.
+    gpurun --timeout 900 -- 'python tools/wino_margin.py C2_B32 C4_B16'
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_headline as T       # noqa: E402
+from conftest import build_model, pkg      # noqa: E402
+from oracle import ynet_oracle as O        # noqa: E402
+
+
+def main(tags):
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    dev = torch.device("cuda:0")
+    ops = pkg("ops")
+    for tag in tags:
+        mk, H, W, B = T.HEADLINE[tag]
+        cfg = mk()
+        sd = O.make_state_dict(cfg, seed=0, lora_b_std=0.05)
+        scene, traj = O.synthetic_scene(cfg, H, W, 0), O.synthetic_trajectories(cfg, B, H, W, 21)
+        S = cfg.template_size
+        in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+        names = O.trainable_names(cfg, sd)
+        want = O.train_step(sd, cfg, scene, traj, in_t, gt_t, names)
+        for allowed in (True, False):
+            ops._wino_allowed = allowed
+            n0 = ops.wino_stats["launches"]
+            model = build_model(cfg, sd, dev)
+            te, trn = pkg("utils.train_epoch"), pkg("models.trainer")
+            caught = []
+            h = model.softargmax_.register_forward_hook(lambda m, i, o: caught.append(o.detach().cpu()))
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            ade, fde, loss = te.train_epoch(
+                model, T.loader_for(traj), {"scene0": scene[0]}, opt, trn.HipBCEWithLogitsLoss(), cfg.loss_scale, dev, "sdd", None,
+                gt_t.to(dev), in_t.to(dev), list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B, 10000, cfg.resize_factor,
+                cfg.network, False)
+            h.remove()
+            named = dict(model.named_parameters())
+            gerr = max(float((named[n].grad.detach().cpu().double() - want["grads"][n].double()).abs().max()) /
+                       (float(want["grads"][n].abs().max()) + 1e-30) for n in names)
+            print(f"{tag} winograd={'on ' if allowed else 'off'} ({ops.wino_stats['launches'] - n0} launches): loss rel {abs(loss - float(want['loss'])) / abs(float(want['loss'])):.2e}  "
+                  f"ADE {abs(ade - float(want['ade'].mean())):.2e}  FDE {abs(fde - float(want['fde'].mean())):.2e}  "
+                  f"read-out traj {float((caught[0] - want['pred_traj']).abs().max()):.2e} goal {float((caught[1] - want['pred_goal']).abs().max()):.2e} px  "
+                  f"grads {gerr:.2e} of max", flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or ["C2_B32"])
