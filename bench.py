@@ -172,7 +172,8 @@ class ConvTimer:
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             cc = plan >> 21                       # input channels per staged chunk (the kernel's CC template argument)
             if took == "winograd":            # (csrc/conv_wino.hip: NCB 16-channel output blocks, chunks of 8 input channels)
-                name = f"conv_wino_kernel<{cout // 16}, {cin // 8}>"
+                blocks = [2] * (cout // 32) + [1] * ((cout % 32) // 16)      # (48 / 64 output channels: two launches over slices)
+                name = f"conv_wino_kernel<{'+'.join(str(b_) for b_ in blocks)}, {cin // 8}>"
             elif dma:
                 if cc > 8:                        # launch_dma_small: the deep chunks are for plain launches with enough input channels
                     if relu_of or pooled or bits_out or relu_bits:

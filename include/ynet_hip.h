@@ -107,13 +107,14 @@ int ynet_conv2d_dgrad_relu_bits(const float* dy, int dy_c, long long dy_bs, cons
  * convolution_backward -> grad_input).  Replaces the same ATen calls as ynet_conv2d.
  *   ynet_winograd_filter        u = G g G^T of every (cout, cin) pair in MFMA fragment order, from a packed filter of ynet_pack_weight
  *                               (mode 0 for the forward convolution, mode 1 for the data gradient: cin / cout are the CONVOLUTION's
- *                               input / output channels either way); ynet_winograd_filter_floats(cin, cout) floats, 16-byte aligned;
- *                               once per weight version.
+ *                               input / output channels either way), for the output channels [col0, col0 + cout) of a filter with
+ *                               cols_total of them -- a convolution with 48 or 64 outputs runs as two launches over channel slices;
+ *                               ynet_winograd_filter_floats(cin, cout) floats, 16-byte aligned; once per weight version.
  *   ynet_conv2d_winograd        dst[b][co] = [relu](conv3x3(src[b], filter) + bias[co]); src / dst: cin / cout planes of H x W per image,
  *                               batch strides in floats (>= the image), 16- / 8-byte aligned; bias may be NULL. */
 int ynet_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K);
 long long ynet_winograd_filter_floats(int cin, int cout);
-int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, void* stream);
+int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, int col0, int cols_total, void* stream);
 int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
                          int B, int H, int W, int relu, void* stream);
 

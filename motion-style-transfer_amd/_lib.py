@@ -37,7 +37,7 @@ SIGNATURES = {
     "ynet_conv2d_dgrad_relu_bits": (c_i, [c_fp, c_i, c_ll, c_fp, c_ll, c_fp, c_fp, c_i, c_ll, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "ynet_winograd_filter_floats": (c_ll, [c_i, c_i]),
-    "ynet_winograd_filter": (c_i, [c_fp, c_fp, c_i, c_i, c_fp]),
+    "ynet_winograd_filter": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_add_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_add": (c_i, [PP, PI, PLL, PI, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp]),

@@ -250,11 +250,11 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs
 // U = G g G^T of every (cout, cin) pair, in the fragment order the kernel reads: unit ((c * 2 + s) * 4 + q) * NCB + cb) * 64 + lane holds
 // (xi = q, nu = 0..3) of output channel cb * 16 + (lane & 15), input channel c * 8 + s * 4 + (lane >> 4).
 // wp: a packed filter of ynet_pack_weight, [k][tap][m] with m padded to cols_pad (k = the conv's input channels, m = its outputs).
-__global__ void wino_filter_kernel(const float* __restrict__ wp, f32x4* __restrict__ u, int cols_pad, int ncb, int nunits) {
+__global__ void wino_filter_kernel(const float* __restrict__ wp, f32x4* __restrict__ u, int cols_pad, int col0, int ncb, int nunits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nunits) return;
     const int l = i & 63, cb = (i >> 6) % ncb, q = ((i >> 6) / ncb) & 3, s = (((i >> 6) / ncb) >> 2) & 1, c = ((i >> 6) / ncb) >> 3;
-    const int co = cb * 16 + (l & 15), ci = c * 8 + s * 4 + (l >> 4);
+    const int co = col0 + cb * 16 + (l & 15), ci = c * 8 + s * 4 + (l >> 4);
     float g[3][3];
 #pragma unroll
     for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = wp[((long long)ci * 9 + t) * cols_pad + co];
@@ -312,13 +312,14 @@ long long ynet_winograd_filter_floats(int cin, int cout) {
     return 16ll * (ceil_div(cin, 8) * 8) * (ceil_div(cout, 16) * 16);
 }
 
-int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, void* stream) {
+int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, int col0, int cols_total, void* stream) {
     YNET_REQUIRE(wp && u, "winograd_filter: null pointer");
     YNET_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 16 == 0, "winograd_filter: cin %d must be a multiple of 8, cout %d of 16", cin, cout);
+    YNET_REQUIRE(col0 >= 0 && cols_total >= col0 + cout, "winograd_filter: output channels %d .. %d are not inside the filter's %d", col0, col0 + cout, cols_total);
     YNET_REQUIRE((reinterpret_cast<uintptr_t>(u) & 15) == 0, "winograd_filter: the output must be 16-byte aligned");
     const int ncb = cout / 16, nunits = (cin / 8) * 8 * ncb * 64;
     hipLaunchKernelGGL(wino_filter_kernel, dim3(ceil_div(nunits, 256)), dim3(256), 0, (hipStream_t)stream, wp, reinterpret_cast<f32x4*>(u),
-                       wino_cols_pad(cout), ncb, nunits);
+                       wino_cols_pad(cols_total), col0, ncb, nunits);
     return ynet_check_launch("winograd_filter");
 }
 

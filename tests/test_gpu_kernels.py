@@ -634,6 +634,34 @@ def test_winograd_convolution_matches_the_direct_form(dev, case):
     assert e_w <= 1.5 * e_d + 1e-7, (e_w, e_d)
 
 
+@pytest.mark.parametrize("case", [(8, 256, 256, 32, [32, 16]), (16, 128, 128, 32, [64]), (8, 256, 256, 16, [32, None])], ids=str)
+def test_winograd_launches_over_output_channel_slices(dev, case):
+    """A data gradient with 48 or 64 output channels (the decoders' first convolutions: up-sampled part + skip part) runs as two
+    Winograd launches over slices of the filter, each into its own destination / its own channels of the one destination; a
+    destination nobody wants is not computed.  Same values as the one implicit-GEMM launch within fp32 rounding."""
+    ops = pkg("ops")
+    B, H, W, cin, couts = case
+    sizes = [c if c is not None else 16 for c in couts]
+    ctot = sum(sizes)
+    dy = rnd(B, cin, H, W, seed=1).to(dev)
+    w = rnd(cin, ctot, 3, 3, seed=2, scale=0.2).to(dev)          # the forward layer's filter [Cout_fwd = cin here][Cin_fwd = ctot]
+    wp = ops.pack_weight(w, 1)
+    want = [torch.empty(B, c, H, W, device=dev) for c in sizes]
+    got = [torch.full((B, c, H, W), float("nan"), device=dev) for c in sizes]
+    ops.conv2d_raw([(dy.data_ptr(), cin, cin * H * W)], None, wp, None, [(t.data_ptr(), t.shape[1], t.shape[1] * H * W) for t in want], B, H, W, 3, False)
+    dsts = [(t.data_ptr() if c is not None else None, t.shape[1], t.shape[1] * H * W if c is not None else 0) for t, c in zip(got, couts)]
+    n0 = ops.wino_stats["launches"]
+    assert ops.conv2d_raw([(dy.data_ptr(), cin, cin * H * W)], None, wp, None, dsts, B, H, W, 3, False, wino=({}, "dgrad")) == "winograd"
+    assert ops.wino_stats["launches"] - n0 == (2 if None not in couts else 1)
+    for g, t, c in zip(got, want, couts):
+        if c is None:
+            assert bool(torch.isnan(g).all())
+        else:
+            close(g, t, rtol=1e-5, scale_rel=2e-6, msg=f"slice of {c} channels")
+    ref = F.conv_transpose2d(dy, w, padding=1)
+    close(torch.cat([g for g, c in zip(got, couts) if c is not None], 1), ref[:, :sum(c for c in couts if c is not None)], rtol=1e-4, scale_rel=2e-6, msg="vs torch")
+
+
 def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     """ops.conv2d takes the Winograd kernel for a plain 32 -> 32 layer -- forward AND data gradient -- and the implicit GEMM with
     YNET_WINOGRAD off; outputs and input gradients of the two agree within fp32 rounding.  (A layer without ReLU: behind a ReLU

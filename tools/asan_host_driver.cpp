@@ -80,8 +80,9 @@ int main() {
     for (int b : {1, 10, 32, 256})
         for (int hw : {8, 32, 64, 128, 256, 512})
             for (int c : {8, 16, 24, 32, 48, 64}) acc += ynet_conv2d_winograd_supported(b, hw, hw, c, 32, 3) + ynet_conv2d_winograd_supported(b, hw, hw + 2, 32, c, 3) + ynet_conv2d_winograd_supported(b, hw, hw, c, c, 5) + ynet_winograd_filter_floats(c, c);
-    EXPECT_REJECT(ynet_winograd_filter(nullptr, fp, 32, 32, nullptr));
-    EXPECT_REJECT(ynet_winograd_filter(cfp, fp, 12, 32, nullptr));                                                                    // cin not a multiple of 8
+    EXPECT_REJECT(ynet_winograd_filter(nullptr, fp, 32, 32, 0, 32, nullptr));
+    EXPECT_REJECT(ynet_winograd_filter(cfp, fp, 12, 32, 0, 32, nullptr));                                                             // cin not a multiple of 8
+    EXPECT_REJECT(ynet_winograd_filter(cfp, fp, 32, 32, 32, 48, nullptr));                                                            // slice beyond the filter
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 48, 32, 256, 256, 1, nullptr));               // cout not served
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 250, 256, 1, nullptr));               // H not a multiple of 16
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 16 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));               // batch stride smaller than the image

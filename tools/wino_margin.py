@@ -52,5 +52,43 @@ def main(tags):
                   f"grads {gerr:.2e} of max", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and (len(sys.argv) < 2 or sys.argv[1] != "sweep"):
     main(sys.argv[1:] or ["C2_B32"])
+
+
+def sweep(K=20):
+    """The C5 sweep (tests/test_gpu_headline.py::test_eval_sweep_at_headline_batch_matches_oracle) with the Winograd kernels forced on
+    under no_grad, and off: python tools/wino_margin.py sweep"""
+    import pandas as pd      # noqa: F401
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    dev = torch.device("cuda:0")
+    ops = pkg("ops")
+    cfg = O.sdd_long(train_net="train")
+    H = W = 256
+    B = 128
+    sd = O.make_state_dict(cfg, seed=0)
+    scene, traj = O.synthetic_scene(cfg, H, W, 0), O.synthetic_trajectories(cfg, B, H, W, 22)
+    in_t = O.dist_template(cfg.template_size)
+    gen = torch.Generator().manual_seed(5)
+    want = O.eval_batch(sd, cfg, scene, traj, in_t, n_goal=K, n_traj=1, generator=gen)
+    ev = pkg("utils.evaluate")
+    for on in (True, False):
+        ops._wino_eval = on
+        n0 = ops.wino_stats["launches"]
+        model = build_model(cfg, sd, dev)
+        caught = []
+        h = model.softargmax_.register_forward_hook(lambda m, i, o: caught.append(o.detach().cpu()))
+        ade, fde, df, _ = ev.evaluate(
+            model, T.loader_for(traj), {"scene0": scene[0]}, dev, "sdd", None, in_t.to(dev), list(cfg.waypoints), "test", K, 1,
+            cfg.obs_len, B, cfg.resize_factor, cfg.temperature, forced_samples={0: want["waypoint_samples"]})
+        h.remove()
+        got = torch.cat(caught).view(K, B, cfg.pred_len, 2)
+        dc = (got - want["trajs"]).abs()
+        print(f"sweep K={K} winograd={'on ' if on else 'off'} ({ops.wino_stats['launches'] - n0} launches): coordinates max {float(dc.max()):.2e} px, "
+              f"{int((dc > 1e-4).sum())} of {dc.numel()} beyond 1e-4; per-trajectory ADE max {np.abs(df['ade'].to_numpy() - want['ade'].numpy()).max():.2e} "
+              f"FDE max {np.abs(df['fde'].to_numpy() - want['fde'].numpy()).max():.2e}; mean ADE {abs(ade - float(want['ade'].mean())):.2e} "
+              f"FDE {abs(fde - float(want['fde'].mean())):.2e}", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
+    sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 20)
