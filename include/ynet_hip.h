@@ -117,6 +117,11 @@ long long ynet_winograd_filter_floats(int cin, int cout);
 int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, int col0, int cols_total, void* stream);
 int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
                          int B, int H, int W, int relu, void* stream);
+/*   ynet_conv2d_winograd_dgrad_relu   the data gradient written THROUGH the ReLU backward of the layer below, as ynet_conv2d_dgrad_relu:
+ *                               dx = relu_of > 0 ? conv3x3(dy, mode-1 filter) : 0, relu_of = that layer's post-ReLU output [B][dx_c][H][W]
+ *                               (8-byte aligned), read by the epilogue at the addresses it stores to. */
+int ynet_conv2d_winograd_dgrad_relu(const float* dy, long long dy_bs, const float* u, float* dx, long long dx_bs, const float* relu_of, long long relu_of_bs,
+                                    int dy_c, int dx_c, int B, int H, int W, void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,

@@ -43,6 +43,8 @@ struct WinoArgs {
     float* y;              // [B] x (y_bs floats) : cout planes
     long long x_bs, y_bs;
     int B, H, W, relu, ntiles;
+    const float* emask;    // EM: [B] x (emask_bs floats), cout planes -- the post-ReLU activation whose backward is applied to y (y = emask > 0 ? y : 0)
+    long long emask_bs;
 };
 
 __device__ __forceinline__ f32x2 wn_v01(f32x2 tl, f32x2 th) {      // (t0 - t2, t1 + t2)
@@ -58,7 +60,7 @@ __device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, 
 
 // NCB: 16-channel output blocks (cout = 16 NCB), NCH: chunks of 8 input channels (cin = 8 NCH; even: chunk c lives in slot c & 1 of the
 // wave's ring, and the chunk two ahead -- of this pair or the next -- takes the slot just read)
-template <int NCB, int NCH>
+template <int NCB, int NCH, bool EM>
 __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs a) {
     extern __shared__ f32x4 smem[];
     constexpr int WQ = 8 * NCB * 64;      // units of one chunk's filters: [2 k-steps][4 quads of (xi,nu)][NCB][64 lanes]
@@ -87,6 +89,9 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u), 0, (unsigned)(NCH * WQ * 16), 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(((long long)(a.B - 1) * a.y_bs + (long long)NCB * 16 * HW) * 4),
                                                                         0x00020000);
+
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EM ? a.emask : a.y), 0,
+                                                                        (unsigned)(((long long)(a.B - 1) * (EM ? a.emask_bs : a.y_bs) + (long long)NCB * 16 * HW) * 4), 0x00020000);
 
     // XCD-aware walk (workgroups are dealt round-robin over the 8 XCDs): each XCD sweeps its own contiguous eighth of the tiles
     const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
@@ -215,8 +220,21 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs
             const int t = tile_first + (cur >> 3) * gstride;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
             const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            const unsigned sm_t = (unsigned)(((long long)b * a.emask_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
+            for (int cb = 0; cb < NCB; ++cb) {
+                // EM: the activation of this block's 2 x 2 x 4 outputs per lane, fetched before the transform they gate
+                u32x2 mk[2][2][2];
+                if constexpr (EM) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const unsigned sm = sm_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
+                            mk[h][k][0] = __builtin_amdgcn_raw_buffer_load_b64(rm, st0, sm, 0);
+                            mk[h][k][1] = __builtin_amdgcn_raw_buffer_load_b64(rm, st1, sm, 0);
+                        }
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     f32x2 m[16];
@@ -234,13 +252,19 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs
                     const f32x2 o10 = r1[0] + r1[1] + r1[2], o11 = r1[1] - r1[2] - r1[3];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {      // channel cb * 16 + 4 kq + 2 h + k
-                        const f32x2 row0 = {fmaxf(o00[k], floor_v), fmaxf(o01[k], floor_v)};
-                        const f32x2 row1 = {fmaxf(o10[k], floor_v), fmaxf(o11[k], floor_v)};
+                        f32x2 row0 = {fmaxf(o00[k], floor_v), fmaxf(o01[k], floor_v)};
+                        f32x2 row1 = {fmaxf(o10[k], floor_v), fmaxf(o11[k], floor_v)};
+                        if constexpr (EM) {
+                            const f32x2 m0 = __builtin_bit_cast(f32x2, mk[h][k][0]), m1 = __builtin_bit_cast(f32x2, mk[h][k][1]);
+                            row0 = f32x2{m0[0] > 0.f ? row0[0] : 0.f, m0[1] > 0.f ? row0[1] : 0.f};
+                            row1 = f32x2{m1[0] > 0.f ? row1[0] : 0.f, m1[1] > 0.f ? row1[1] : 0.f};
+                        }
                         const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), ry, st0, so, 0);
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), ry, st1, so, 0);
                     }
                 }
+            }
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -283,14 +307,14 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
     return (long long)B * H * W >= min_pixels;      // (one workgroup of eight waves per CU: small launches stay with the direct tiles)
 }
 
-template <int NCB, int NCH>
+template <int NCB, int NCH, bool EM>
 static int launch_wino(WinoArgs& a, hipStream_t st) {
     constexpr int lds = NCH * 8 * NCB * 64 * 16 + 8 * WN_RING_BYTES + 16;
     static bool attr_dev[YNET_MAX_DEV] = {false};
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
     if (!attr_dev[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH, EM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -299,7 +323,7 @@ static int launch_wino(WinoArgs& a, hipStream_t st) {
     }
     int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
     if (grid >= 8) grid &= ~7;          // (the XCD-aware walk wants a multiple of 8)
-    hipLaunchKernelGGL((conv_wino_kernel<NCB, NCH>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    hipLaunchKernelGGL((conv_wino_kernel<NCB, NCH, EM>), dim3(grid), dim3(WN_THREADS), lds, st, a);
     return ynet_check_launch("conv2d_winograd");
 }
 
@@ -323,22 +347,41 @@ int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, int col0,
     return ynet_check_launch("winograd_filter");
 }
 
-int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
-                         int B, int H, int W, int relu, void* stream) {
-    YNET_REQUIRE(src && u && dst, "conv2d_winograd: null pointer");
-    YNET_REQUIRE(wino_shape_ok(B, H, W, cin, cout, 3), "conv2d_winograd: shape B=%d %dx%d %d -> %d is not served (ask ynet_conv2d_winograd_supported)", B, H, W,
-                 cin, cout);
+static int wino_launch_any(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, const float* emask,
+                           long long emask_bs, int cin, int cout, int B, int H, int W, int relu, void* stream, const char* what) {
+    YNET_REQUIRE(src && u && dst, "%s: null pointer", what);
+    YNET_REQUIRE(wino_shape_ok(B, H, W, cin, cout, 3), "%s: shape B=%d %dx%d %d -> %d is not served (ask ynet_conv2d_winograd_supported)", what, B, H, W, cin,
+                 cout);
     YNET_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 &&
                      (src_bs & 3) == 0 && (dst_bs & 1) == 0,
-                 "conv2d_winograd: planes must be 16-byte (input, filters) / 8-byte (output) aligned");
+                 "%s: planes must be 16-byte (input, filters) / 8-byte (output) aligned", what);
     const long long HW = (long long)H * W;
-    YNET_REQUIRE(src_bs >= cin * HW && dst_bs >= cout * HW, "conv2d_winograd: batch strides smaller than the images");
+    YNET_REQUIRE(src_bs >= cin * HW && dst_bs >= cout * HW, "%s: batch strides smaller than the images", what);
     YNET_REQUIRE(((long long)(B - 1) * src_bs + cin * HW) * 4 + (W + 4) * 4 < (1ll << 32) && ((long long)(B - 1) * dst_bs + cout * HW) * 4 < (1ll << 32),
-                 "conv2d_winograd: tensors beyond 4 GB are not addressed by one buffer descriptor");
-    WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW)};
+                 "%s: tensors beyond 4 GB are not addressed by one buffer descriptor", what);
+    if (emask != nullptr)
+        YNET_REQUIRE((reinterpret_cast<uintptr_t>(emask) & 7) == 0 && (emask_bs & 1) == 0 && emask_bs >= cout * HW &&
+                         ((long long)(B - 1) * emask_bs + cout * HW) * 4 < (1ll << 32),
+                     "%s: the activation must be 8-byte aligned, its batch stride not smaller than the image, below 4 GB", what);
+    WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW), emask, emask_bs};
     hipStream_t st = (hipStream_t)stream;
-    if (cout == 32) return cin == 32 ? launch_wino<2, 4>(a, st) : launch_wino<2, 2>(a, st);
-    return cin == 32 ? launch_wino<1, 4>(a, st) : launch_wino<1, 2>(a, st);
+    if (emask != nullptr) {
+        if (cout == 32) return cin == 32 ? launch_wino<2, 4, true>(a, st) : launch_wino<2, 2, true>(a, st);
+        return cin == 32 ? launch_wino<1, 4, true>(a, st) : launch_wino<1, 2, true>(a, st);
+    }
+    if (cout == 32) return cin == 32 ? launch_wino<2, 4, false>(a, st) : launch_wino<2, 2, false>(a, st);
+    return cin == 32 ? launch_wino<1, 4, false>(a, st) : launch_wino<1, 2, false>(a, st);
+}
+
+int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
+                         int B, int H, int W, int relu, void* stream) {
+    return wino_launch_any(src, src_bs, u, bias, dst, dst_bs, nullptr, 0, cin, cout, B, H, W, relu, stream, "conv2d_winograd");
+}
+
+int ynet_conv2d_winograd_dgrad_relu(const float* dy, long long dy_bs, const float* u, float* dx, long long dx_bs, const float* relu_of, long long relu_of_bs,
+                                    int dy_c, int dx_c, int B, int H, int W, void* stream) {
+    YNET_REQUIRE(relu_of != nullptr, "conv2d_winograd_dgrad_relu: the activation whose ReLU backward is applied is null");
+    return wino_launch_any(dy, dy_bs, u, nullptr, dx, dx_bs, relu_of, relu_of_bs, dy_c, dx_c, B, H, W, 0, stream, "conv2d_winograd_dgrad_relu");
 }
 
 }  // extern "C"

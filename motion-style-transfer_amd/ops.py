@@ -345,9 +345,15 @@ def winograd_filter(wp: torch.Tensor, cin: int, cout: int, col0: int = 0, cols_t
     return u
 
 
-def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu):
-    """src / dst: (ptr, batch_stride in floats); u: winograd_filter(...) of the layer's packed filter."""
+def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None):
+    """src / dst: (ptr, batch_stride in floats); u: winograd_filter(...) of the layer's packed filter; relu_of: (ptr, batch_stride) of the
+    post-ReLU activation whose backward is applied to dst (ynet_conv2d_winograd_dgrad_relu: a data gradient, no bias / ReLU)."""
     lib = _lib()
+    if relu_of is not None:
+        if bias is not None or relu:
+            raise ValueError("conv2d_winograd_raw: relu_of is for a data gradient")
+        L.check(lib.ynet_conv2d_winograd_dgrad_relu(src[0], src[1], u.data_ptr(), dst[0], dst[1], relu_of[0], relu_of[1], cin, cout, B, H, W, _stream()), lib)
+        return
     L.check(lib.ynet_conv2d_winograd(src[0], src[1], u.data_ptr(), bias.data_ptr() if bias is not None else None, dst[0], dst[1],
                                      cin, cout, B, H, W, 1 if relu else 0, _stream()), lib)
 
@@ -381,8 +387,8 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
         L.check(lib.ynet_conv2d_pool(sp, sc, sb, len(srcs), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                      dsts[0][0], dsts[0][1], dsts[0][2], pooled[0], pooled[1], B, H, W, K, 1 if relu else 0, _stream()), lib)
         return
-    if (wino is not None and _wino_allowed and K == 3 and mask is None and relu_of is None and len(srcs) == 1 and len(srcs[0]) == 3
-            and srcs[0][0] % 16 == 0 and srcs[0][2] % 4 == 0):
+    if (wino is not None and _wino_allowed and K == 3 and mask is None and len(srcs) == 1 and len(srcs[0]) == 3
+            and srcs[0][0] % 16 == 0 and srcs[0][2] % 4 == 0 and (relu_of is None or (relu_of[0] % 8 == 0 and relu_of[1] % 2 == 0))):
         # destination channels in pieces of 32 / 16 (a 48- or 64-channel data gradient is two launches over slices of the filter; the
         # input is read once per piece -- from L2 --, pieces nobody wants are not computed)
         cin, ctot, HW = srcs[0][1], sum(d[1] for d in dsts), H * W
@@ -400,7 +406,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 pieces = None
                 break
             c0 += c
-        if (pieces and len(pieces) <= 2 and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
+        if (pieces and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
                 and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces)):
             cache, what = wino
             for ptr, n, bs, col0 in pieces:
@@ -408,7 +414,8 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 ent = cache.get(key)
                 if ent is None or ent[0] is not wp:
                     ent = cache[key] = (wp, winograd_filter(wp, cin, n, col0, ctot))
-                conv2d_winograd_raw((srcs[0][0], srcs[0][2]), ent[1], None if bias is None else bias[col0:col0 + n], (ptr, bs), cin, n, B, H, W, relu)
+                conv2d_winograd_raw((srcs[0][0], srcs[0][2]), ent[1], None if bias is None else bias[col0:col0 + n], (ptr, bs), cin, n, B, H, W, relu,
+                                    relu_of=relu_of)
                 wino_stats["launches"] += 1
             return "winograd"
     dp, dc, db = _arrays(dsts)
@@ -796,8 +803,12 @@ class _Conv2dFn(torch.autograd.Function):
                 if (e0 is not None and e0[2] is not None and e0[3] == k and d_srcs[0].data_ptr() % 16 == 0
                         and _lib().ynet_conv2d_relu_bits_words(B, H, W, int(s0.shape[1]), int(k)) == e0[2].numel()):
                     ebits = e0[2]          # (written by s0's own forward launch, for exactly this tiling)
-                    premask_stats["bit_masks"] = premask_stats.get("bit_masks", 0) + 1
-            if ebits is not None:
+            # (where the Winograd generation serves the launch it applies the float mask itself -- faster than the implicit GEMM with
+            #  the 1-bit mask, whose layout belongs to that kernel's tiles)
+            wino_em = (emask is not None and mask is None and meta.get("wino") and _wino_allowed and k == 3 and dy.data_ptr() % 16 == 0
+                       and d_srcs[0].data_ptr() % 8 == 0 and _lib().ynet_conv2d_winograd_supported(B, H, W, cout, int(s0.shape[1]), int(k)))
+            if ebits is not None and not wino_em:
+                premask_stats["bit_masks"] = premask_stats.get("bit_masks", 0) + 1
                 conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_bits=ebits.data_ptr())
             else:
                 conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_of=emask,

@@ -662,6 +662,27 @@ def test_winograd_launches_over_output_channel_slices(dev, case):
     close(torch.cat([g for g, c in zip(got, couts) if c is not None], 1), ref[:, :sum(c for c in couts if c is not None)], rtol=1e-4, scale_rel=2e-6, msg="vs torch")
 
 
+@pytest.mark.parametrize("case", [(8, 256, 256, 32, 32), (16, 128, 128, 32, 16), (16, 128, 128, 16, 32)], ids=str)
+def test_winograd_data_gradient_through_the_relu_backward_of_the_layer_below(dev, case):
+    """ynet_conv2d_winograd_dgrad_relu: dx = relu_of > 0 ? conv(dy, flipped filter) : 0 -- zero exactly where the activation is not
+    positive, the plain Winograd data gradient elsewhere (bit-identical to it: the mask is an exact zeroing), and the implicit GEMM's
+    ynet_conv2d_dgrad_relu within fp32 rounding."""
+    ops = pkg("ops")
+    B, H, W, dy_c, dx_c = case
+    dy, w = rnd(B, dy_c, H, W, seed=1).to(dev), rnd(dy_c, dx_c, 3, 3, seed=2, scale=0.2).to(dev)
+    act = torch.relu(rnd(B, dx_c, H, W, seed=3)).to(dev)
+    wp = ops.pack_weight(w, 1)
+    plain, got, direct = (torch.full((B, dx_c, H, W), float("nan"), device=dev) for _ in range(3))
+    src, cache = [(dy.data_ptr(), dy_c, dy_c * H * W)], {}
+    assert ops.conv2d_raw(src, None, wp, None, [(plain.data_ptr(), dx_c, dx_c * H * W)], B, H, W, 3, False, wino=(cache, "dgrad")) == "winograd"
+    assert ops.conv2d_raw(src, None, wp, None, [(got.data_ptr(), dx_c, dx_c * H * W)], B, H, W, 3, False, relu_of=(act.data_ptr(), dx_c * H * W),
+                          wino=(cache, "dgrad")) == "winograd"
+    assert ops.conv2d_raw(src, None, wp, None, [(direct.data_ptr(), dx_c, dx_c * H * W)], B, H, W, 3, False, relu_of=(act.data_ptr(), dx_c * H * W)) is None
+    assert torch.equal(got, torch.where(act > 0, plain, torch.zeros_like(plain)))
+    close(got, direct, rtol=1e-5, scale_rel=2e-6, msg="winograd vs implicit GEMM, both through the ReLU backward")
+    close(got, F.conv_transpose2d(dy, w, padding=1) * (act > 0), rtol=1e-4, scale_rel=2e-6, msg="vs torch")
+
+
 def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     """ops.conv2d takes the Winograd kernel for a plain 32 -> 32 layer -- forward AND data gradient -- and the implicit GEMM with
     YNET_WINOGRAD off; outputs and input gradients of the two agree within fp32 rounding.  (A layer without ReLU: behind a ReLU

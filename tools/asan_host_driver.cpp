@@ -87,6 +87,8 @@ int main() {
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 250, 256, 1, nullptr));               // H not a multiple of 16
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 16 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));               // batch stride smaller than the image
     EXPECT_REJECT(ynet_conv2d_winograd(nullptr, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));
+    EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, nullptr, 32 * 65536, 32, 32, 32, 256, 256, nullptr));   // no activation
+    EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, cfp, 16 * 65536, 32, 32, 32, 256, 256, nullptr));       // activation stride too small
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 0, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 7, cfp, 4, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
     EXPECT_REJECT(ynet_lora_compose(nullptr, cfp, cfp, 1.f, fp, 4, 4, 3, 1, nullptr));
