@@ -236,8 +236,13 @@ class FlopCounter:
             dl = list(dsts)
             while len(dl) > 1 and dl[-1][0] is None:
                 dl.pop()
-            me.flops += 2.0 * B * H * W * sum(s_[1] for s_ in srcs) * sum(d[1] for d in dl) * K * K
-            return me.saved["conv2d_raw"](srcs, mask, wp, bias, dsts, B, H, W, K, relu, **kw)
+            per = 2.0 * B * H * W * sum(s_[1] for s_ in srcs) * K * K
+            took = me.saved["conv2d_raw"](srcs, mask, wp, bias, dsts, B, H, W, K, relu, **kw)
+            if took == "winograd":      # 16 multiplies per 2 x 2 block and channel pair instead of 36; unwanted destinations are not computed
+                me.flops += per * sum(d[1] for d in dl if d[0] is not None) * (16.0 / 36.0)
+            else:
+                me.flops += per * sum(d[1] for d in dl)
+            return took
 
         def conv2d_wgrad_raw(srcs, dy, mask, weight, want_b, *a, **kw):
             cout, cin, k, _ = weight.shape
@@ -683,6 +688,10 @@ def main():
                                    "are not a kernel-quality measure; `value` and `step_roofline` are."}
         out["conv_kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}
+        for k, v in out["conv_kernels"].items():
+            if k.startswith("conv_wino"):      # `tflops` counts the convolution's (direct-form) FLOPs; the kernel executes 16 / 36 of them
+                v["tflops_executed"] = round(v["tflops"] / 2.25, 2)
+                v["form"] = "Winograd F(2x2, 3x3), csrc/conv_wino.hip: tflops = the direct form's 2 * 9 * Cin * Cout per pixel over the time"
         total_conv_ms = sum(v["ms"] for v in agg.values())
         out["conv_share_of_step"] = total_conv_ms / out["ms_per_step"]
     if world > 1:

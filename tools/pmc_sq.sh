@@ -25,7 +25,7 @@ for db in glob.glob(os.path.join(out, "p*", "*.db")):
         # (round 4: + the small-map kernels -- one / two rows per wave of one 16-channel tile, folded 8^2 / 16^2 maps, the register-staged
         # one-row kernel -- which had no counters: VERDICT r3 item 1)
         if any(k in name for k in ("kernel<2, 4, 4", "kernel<4, 2, 4", "kernel<3, 2, 4", "kernel<2, 2, 4", "wgrad_dma", "wgrad_roll", "lora_wgrad_kernel",
-                                   "kernel<1, 1, ", "kernel<1, 2, ", "kernel<1, 4, ", "kernel<2, 1, ", "conv_mfma_kernel<3, 1, 1, 8", "conv_chain", "pred_bce", "conv_split_reduce")):
+                                   "conv_wino", "kernel<1, 1, ", "kernel<1, 2, ", "kernel<1, 4, ", "kernel<2, 1, ", "conv_mfma_kernel<3, 1, 1, 8", "conv_chain", "pred_bce", "conv_split_reduce")):
             d = res.setdefault(name[:60], {}).setdefault(counter, [0.0, 0])
             d[0] += float(value); d[1] += 1
     con.close()
