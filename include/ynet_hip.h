@@ -111,7 +111,8 @@ int ynet_conv2d_dgrad_relu_bits(const float* dy, int dy_c, long long dy_bs, cons
  *                               cols_total of them -- a convolution with 48 or 64 outputs runs as two launches over channel slices;
  *                               ynet_winograd_filter_floats(cin, cout) floats, 16-byte aligned; once per weight version.
  *   ynet_conv2d_winograd        dst[b][co] = [relu](conv3x3(src[b], filter) + bias[co]); src / dst: cin / cout planes of H x W per image,
- *                               batch strides in floats (>= the image), 16- / 8-byte aligned; bias may be NULL. */
+ *                               batch strides in floats (>= the image; an input stride of 0 = one image for the whole batch), 16- / 8-byte
+ *                               aligned; bias may be NULL. */
 int ynet_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K);
 long long ynet_winograd_filter_floats(int cin, int cout);
 int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, int col0, int cols_total, void* stream);
@@ -122,6 +123,16 @@ int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, con
  *                               (8-byte aligned), read by the epilogue at the addresses it stores to. */
 int ynet_conv2d_winograd_dgrad_relu(const float* dy, long long dy_bs, const float* u, float* dx, long long dx_bs, const float* relu_of, long long relu_of_bs,
                                     int dy_c, int dx_c, int B, int H, int W, void* stream);
+/*   ynet_conv2d_winograd_cat    the same convolution over the (virtual) concatenation of up to three sources -- the decoders' first convolutions,
+ *                               conv(cat(up-sampled features, skip features[, way-point map])) (models/ynet.py:421-445) -- with 32 output channels and at
+ *                               most 56 input channels after every source is padded to a multiple of 4 (ynet_conv2d_winograd_cat_supported);
+ *                               ynet_winograd_filter_cat transforms the packed filter for that channel layout
+ *                               (ynet_winograd_filter_cat_floats(src_c, nsrc, cout) floats). */
+int ynet_conv2d_winograd_cat_supported(int B, int H, int W, const int* src_c, int nsrc, int cout, int K);
+long long ynet_winograd_filter_cat_floats(const int* src_c, int nsrc, int cout);
+int ynet_winograd_filter_cat(const float* wp, float* u, const int* src_c, int nsrc, int cout, int col0, int cols_total, void* stream);
+int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                             long long dst_bs, int cout, int B, int H, int W, int relu, void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,

@@ -22,6 +22,7 @@
 #include "ynet_common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -56,6 +57,87 @@ __device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, 
     f32x2 r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(tl), "v"(th));
     return r;
+}
+
+// Y = A^T M A packed over channel pairs, the bias through M[1][1], ReLU, 8-byte stores at static-lane + scalar offsets; EM: the
+// activation of the block's 2 x 2 x 4 outputs per lane is fetched before the transform it gates (y = act > 0 ? y : 0)
+template <int NCB, bool EM>
+__device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2 (&bias2)[NCB][2], float floor_v, __amdgpu_buffer_rsrc_t ry,
+                                              __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        u32x2 mk[2][2][2];
+        if constexpr (EM) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned sm = sm_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
+                    mk[h][k][0] = __builtin_amdgcn_raw_buffer_load_b64(rm, st0, sm, 0);
+                    mk[h][k][1] = __builtin_amdgcn_raw_buffer_load_b64(rm, st1, sm, 0);
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2 m[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                m[e] = h == 0 ? __builtin_shufflevector(acc[e][cb], acc[e][cb], 0, 1) : __builtin_shufflevector(acc[e][cb], acc[e][cb], 2, 3);
+            m[5] = m[5] + bias2[cb][h];
+            f32x2 r0[4], r1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r0[j] = m[j] + m[4 + j] + m[8 + j];
+                r1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+            }
+            const f32x2 o00 = r0[0] + r0[1] + r0[2], o01 = r0[1] - r0[2] - r0[3];
+            const f32x2 o10 = r1[0] + r1[1] + r1[2], o11 = r1[1] - r1[2] - r1[3];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {      // channel cb * 16 + 4 kq + 2 h + k
+                f32x2 row0 = {fmaxf(o00[k], floor_v), fmaxf(o01[k], floor_v)};
+                f32x2 row1 = {fmaxf(o10[k], floor_v), fmaxf(o11[k], floor_v)};
+                if constexpr (EM) {
+                    const f32x2 m0 = __builtin_bit_cast(f32x2, mk[h][k][0]), m1 = __builtin_bit_cast(f32x2, mk[h][k][1]);
+                    row0 = f32x2{m0[0] > 0.f ? row0[0] : 0.f, m0[1] > 0.f ? row0[1] : 0.f};
+                    row1 = f32x2{m1[0] > 0.f ? row1[0] : 0.f, m1[1] > 0.f ? row1[1] : 0.f};
+                }
+                const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), ry, st0, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), ry, st1, so, 0);
+            }
+        }
+    }
+}
+
+// one k-step of 4 input channels: V = B^T d B of the lane's patch (rows dl / dh), then 16 NCB MFMAs against the filter fragments at wl
+template <int NCB, bool FIRST>
+__device__ __forceinline__ void wino_kstep(f32x4 (&acc)[16][NCB], const f32x2 (&dl)[4], const f32x2 (&dh)[4], const f32x4* wl, int lane) {
+    const f32x2 tl[4] = {dl[0] - dl[2], dl[1] + dl[2], dl[2] - dl[1], dl[1] - dl[3]};
+    const f32x2 th[4] = {dh[0] - dh[2], dh[1] + dh[2], dh[2] - dh[1], dh[1] - dh[3]};
+    f32x2 v01[4], v23[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v01[i] = wn_v01(tl[i], th[i]);
+        v23[i] = wn_v23(tl[i], th[i]);
+    }
+    // (inline asm is opaque to hipcc's hazard recognizer: the wait states between a vector write and the MFMA that reads it)
+    asm volatile("s_nop 3" : "+v"(v01[0]), "+v"(v01[1]), "+v"(v01[2]), "+v"(v01[3]), "+v"(v23[0]), "+v"(v23[1]), "+v"(v23[2]), "+v"(v23[3]));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 w[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) w[cb] = wl[(q * NCB + cb) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float bv = e < 2 ? v01[q][e] : v23[q][e - 2];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float av = w[cb][e];
+                if constexpr (FIRST) acc[q * 4 + e][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else acc[q * 4 + e][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[q * 4 + e][cb], 0, 0, 0);
+            }
+        }
+    }
 }
 
 // NCB: 16-channel output blocks (cout = 16 NCB), NCH: chunks of 8 input channels (cin = 8 NCH; even: chunk c lives in slot c & 1 of the
@@ -215,73 +297,203 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs
                 }
             }
         }
-        // ---- epilogue: Y = A^T M A packed over channel pairs, bias through M[1][1], ReLU, 8-byte stores at static + scalar offsets
+        // ---- epilogue
         {
             const int t = tile_first + (cur >> 3) * gstride;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
             const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
             const unsigned sm_t = (unsigned)(((long long)b * a.emask_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                // EM: the activation of this block's 2 x 2 x 4 outputs per lane, fetched before the transform they gate
-                u32x2 mk[2][2][2];
-                if constexpr (EM) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const unsigned sm = sm_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
-                            mk[h][k][0] = __builtin_amdgcn_raw_buffer_load_b64(rm, st0, sm, 0);
-                            mk[h][k][1] = __builtin_amdgcn_raw_buffer_load_b64(rm, st1, sm, 0);
-                        }
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f32x2 m[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        m[e] = h == 0 ? __builtin_shufflevector(acc[e][cb], acc[e][cb], 0, 1) : __builtin_shufflevector(acc[e][cb], acc[e][cb], 2, 3);
-                    m[5] = m[5] + bias2[cb][h];
-                    f32x2 r0[4], r1[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        r0[j] = m[j] + m[4 + j] + m[8 + j];
-                        r1[j] = m[4 + j] - m[8 + j] - m[12 + j];
-                    }
-                    const f32x2 o00 = r0[0] + r0[1] + r0[2], o01 = r0[1] - r0[2] - r0[3];
-                    const f32x2 o10 = r1[0] + r1[1] + r1[2], o11 = r1[1] - r1[2] - r1[3];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {      // channel cb * 16 + 4 kq + 2 h + k
-                        f32x2 row0 = {fmaxf(o00[k], floor_v), fmaxf(o01[k], floor_v)};
-                        f32x2 row1 = {fmaxf(o10[k], floor_v), fmaxf(o11[k], floor_v)};
-                        if constexpr (EM) {
-                            const f32x2 m0 = __builtin_bit_cast(f32x2, mk[h][k][0]), m1 = __builtin_bit_cast(f32x2, mk[h][k][1]);
-                            row0 = f32x2{m0[0] > 0.f ? row0[0] : 0.f, m0[1] > 0.f ? row0[1] : 0.f};
-                            row1 = f32x2{m1[0] > 0.f ? row1[0] : 0.f, m1[1] > 0.f ? row1[1] : 0.f};
-                        }
-                        const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), ry, st0, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), ry, st1, so, 0);
-                    }
-                }
-            }
+            wino_epilogue<NCB, EM>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, sm_t, HW);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
     }
 }
 
-// U = G g G^T of every (cout, cin) pair, in the fragment order the kernel reads: unit ((c * 2 + s) * 4 + q) * NCB + cb) * 64 + lane holds
-// (xi = q, nu = 0..3) of output channel cb * 16 + (lane & 15), input channel c * 8 + s * 4 + (lane >> 4).
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The multi-source form: the input is the (virtual) concatenation of up to three tensors with up to 56 channels in all -- the decoders'
+// first convolutions, cat(up-sampled features 32, skip features 16 [, way-point map 1]) -> 32.  96-112 KB of transformed filters leave
+// 6-8 KB of LDS per wave, so a chunk is 4 input channels (one MFMA k-step): 4 channels x 4 rows x 10 units = 160 units = 2.5 DMA
+// instructions (the third with 32 lanes), two slots of 2.5 KB, the chunk two ahead issued right after a slot's patch is read.  Every
+// source is padded to a multiple of 4 channels (zero planes by out-of-range offsets, zero filters); a chunk never straddles sources.
+#define WC_SLOT_BYTES (160 * 16 + 16)
+#define WC_RING_BYTES (2 * WC_SLOT_BYTES)
+#define WC_MAX_SRC 3
+
+struct WinoCatArgs {
+    const float* x[WC_MAX_SRC];
+    long long x_bs[WC_MAX_SRC];
+    int x_c[WC_MAX_SRC];       // real channels of each source (its chunks: ceil(c / 4))
+    int nsrc, nchunks;         // chunks of 4 channels over all sources
+    const f32x4* u;
+    const float* bias;
+    float* y;
+    long long y_bs;
+    int B, H, W, relu, ntiles;
+};
+
+template <int NCB>
+__global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const WinoCatArgs a) {
+    extern __shared__ f32x4 smem[];
+    constexpr int WQ = 4 * NCB * 64;      // units of one chunk's filters: [4 quads of (xi,nu)][NCB][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, HW = H * W, nchunks = a.nchunks;
+    const int tiles_x = W / WN_TW, tiles_y = H / WN_TH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const unsigned wbytes = (unsigned)(nchunks * WQ * 16);
+    const unsigned ring0 = lds0 + wbytes + (unsigned)(wave * WC_RING_BYTES);
+
+    // static DMA geometry: unit j * 64 + lane -> (channel of the chunk, row, unit of the row); the third instruction has 32 lanes
+    unsigned rel[3], edge[3], planeof[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = j * 64 + lane, plane = u / 40, rem = u - plane * 40, r = rem / WN_LQ, xq = rem - r * WN_LQ;
+        rel[j] = (unsigned)((plane * HW + r * W + 4 * xq) * 4);
+        edge[j] = (r == 0 ? 1u : 0u) | (r == 3 ? 2u : 0u) | (xq == 0 ? 4u : 0u) | (xq == WN_LQ - 1 ? 8u : 0u);
+        planeof[j] = (unsigned)plane;
+    }
+    const unsigned lead = (unsigned)((W + 4) * 4);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u), 0, wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(((long long)(a.B - 1) * a.y_bs + (long long)NCB * 16 * HW) * 4), 0x00020000);
+
+    const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    const int gstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tile_first = xcd_walk ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tile_end = xcd_walk ? min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : a.ntiles;
+    if (tile_first >= tile_end) return;
+    const int my_tiles = (tile_end - tile_first + gstride - 1) / gstride;
+    const int total_units = my_tiles * 8;
+
+    const int n = lane & 15, kq = lane >> 4;
+    const float floor_v = a.relu ? 0.f : -INFINITY;
+    f32x2 bias2[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            bias2[cb][h] = a.bias ? f32x2{a.bias[cb * 16 + 4 * kq + 2 * h], a.bias[cb * 16 + 4 * kq + 2 * h + 1]} : f32x2{0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bias2[cb][h]));
+    const unsigned st0 = (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
+
+    // all transformed filters -> LDS, once (nchunks * WQ units, 512 per instruction); the workgroup's unit counter
+    for (int j = 0; j < nchunks * WQ / WN_THREADS; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(uintptr_t)(lds0 + (unsigned)(j * 8192 + wave * 1024)), 16,
+                                                 (unsigned)((j * WN_THREADS + tid) * 16), 0, 0, 0);
+    unsigned* unit_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(smem) + wbytes + 8 * WC_RING_BYTES);
+    if (tid == 0) *unit_ctr = 8u;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    auto next_unit = [&]() {
+        unsigned u = 0;
+        if (lane == 0) u = atomicAdd(unit_ctr, 1u);
+        return (int)__builtin_amdgcn_readfirstlane(u);
+    };
+
+    // chunk c of row pair `unit` -> slot `slot` (the wave's running chunk count & 1): three DMA instructions, always
+    auto dma_chunk = [&](int unit, int c, int slot) {
+        const int t = tile_first + (unit >> 3) * gstride;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int y0 = ty * WN_TH + 2 * (unit & 7), x0 = tx * WN_TW;
+        const unsigned em = (y0 == 0 ? 1u : 0u) | (y0 + 2 == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + WN_TW == W ? 8u : 0u);
+        // the chunk's source and its first channel there
+        int s = 0, ch = c * 4;
+        while (s + 1 < a.nsrc && ch >= ((a.x_c[s] + 3) & ~3)) {
+            ch -= (a.x_c[s] + 3) & ~3;
+            ++s;
+        }
+        const unsigned nvalid = (unsigned)min(4, a.x_c[s] - ch);
+        const unsigned bytes = (unsigned)(((long long)(a.B - 1) * a.x_bs[s] + (long long)a.x_c[s] * HW) * 4);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x[s]) - lead), 0, bytes + lead, 0x00020000);
+        const unsigned so = (unsigned)(((long long)b * a.x_bs[s] + (long long)ch * HW + y0 * W + x0) * 4);
+        const unsigned sb = ring0 + (unsigned)(slot * WC_SLOT_BYTES) + 4u;
+        if (em == 0 && nvalid == 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)sb, 16, rel[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + 1024u), 16, rel[1], so, 0, 0);
+            if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + 2048u), 16, rel[2], so, 0, 0);
+        } else {
+            const unsigned v0 = ((edge[0] & em) || planeof[0] >= nvalid) ? 0x80000000u : rel[0];
+            const unsigned v1 = ((edge[1] & em) || planeof[1] >= nvalid) ? 0x80000000u : rel[1];
+            const unsigned v2 = ((edge[2] & em) || planeof[2] >= nvalid) ? 0x80000000u : rel[2];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)sb, 16, v0, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + 1024u), 16, v1, so, 0, 0);
+            if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + 2048u), 16, v2, so, 0, 0);
+        }
+    };
+
+    int cur = wave, nxt = next_unit();
+    int g = 0;                              // the wave's running chunk count: chunk g lives in slot g & 1
+    dma_chunk(cur, 0, 0);
+    dma_chunk(cur, 1, 1);
+
+    f32x4 acc[16][NCB];
+    const unsigned char* ringp = reinterpret_cast<const unsigned char*>(smem) + wbytes + wave * WC_RING_BYTES;
+    while (cur < total_units) {
+        auto step = [&](int c, auto first) {
+            // chunk c has landed (the loads issued after it are those of the next chunk, if there is one)
+            if (c + 1 < nchunks || nxt < total_units) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int slot = g & 1;
+            const float* ip = reinterpret_cast<const float*>(ringp + slot * WC_SLOT_BYTES + 4) + kq * WN_PLANE_F + 3 + 2 * n;
+            f32x2 dl[4], dh[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dl[r] = *reinterpret_cast<const f32x2*>(ip + r * WN_ROWF);
+                dh[r] = *reinterpret_cast<const f32x2*>(ip + r * WN_ROWF + 2);
+            }
+            // the slot is read out (this wave's own reads): it takes the chunk two ahead
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (c + 2 < nchunks) dma_chunk(cur, c + 2, slot);
+            else if (nxt < total_units) dma_chunk(nxt, c + 2 - nchunks, slot);
+            wino_kstep<NCB, decltype(first)::value>(acc, dl, dh, smem + c * WQ, lane);
+            ++g;
+        };
+        step(0, std::true_type{});          // (the pair's first k-step accumulates onto 0: peeled, no run-time branch around the MFMAs)
+        for (int c = 1; c < nchunks; ++c) step(c, std::false_type{});
+        {
+            const int t = tile_first + (cur >> 3) * gstride;
+            const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+            const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            wino_epilogue<NCB, false>(acc, bias2, floor_v, ry, ry, st0, st1, so_t, 0u, HW);
+        }
+        cur = nxt;
+        if (cur < total_units) nxt = next_unit();
+    }
+}
+
+// U = G g G^T of every (cout, cin) pair, in the fragment order the kernels read: unit ((c4 * 4 + q) * NCB + cb) * 64 + lane holds
+// (xi = q, nu = 0..3) of output channel col0 + cb * 16 + (lane & 15), PADDED input channel c4 * 4 + (lane >> 4) -- the input channels
+// are the concatenation of up to three sources, each padded to a multiple of 4 (padded channels: zero filters); with one source of a
+// multiple-of-4 channel count the padded channel is the channel.
 // wp: a packed filter of ynet_pack_weight, [k][tap][m] with m padded to cols_pad (k = the conv's input channels, m = its outputs).
-__global__ void wino_filter_kernel(const float* __restrict__ wp, f32x4* __restrict__ u, int cols_pad, int col0, int ncb, int nunits) {
+__global__ void wino_filter_kernel(const float* __restrict__ wp, f32x4* __restrict__ u, int cols_pad, int col0, int ncb, int nunits, int c0, int c1, int c2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nunits) return;
-    const int l = i & 63, cb = (i >> 6) % ncb, q = ((i >> 6) / ncb) & 3, s = (((i >> 6) / ncb) >> 2) & 1, c = ((i >> 6) / ncb) >> 3;
-    const int co = col0 + cb * 16 + (l & 15), ci = c * 8 + s * 4 + (l >> 4);
+    const int l = i & 63, cb = (i >> 6) % ncb, q = ((i >> 6) / ncb) & 3, c4 = ((i >> 6) / ncb) >> 2;
+    const int co = col0 + cb * 16 + (l & 15);
+    // padded channel -> row of the packed filter, or none
+    int cp = c4 * 4 + (l >> 4), row = -1, base = 0;
+    const int cs[3] = {c0, c1, c2};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int pad = (cs[s] + 3) & ~3;
+        if (row < 0 && cp >= 0 && cp < pad) {
+            row = cp < cs[s] ? base + cp : -2;
+            cp = -1;
+        } else if (cp >= 0) {
+            cp -= pad;
+        }
+        base += cs[s];
+    }
     float g[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = wp[((long long)ci * 9 + t) * cols_pad + co];
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = row >= 0 ? wp[((long long)row * 9 + t) * cols_pad + co] : 0.f;
     // row q of G g (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]), then times G^T
     float gr[3];
 #pragma unroll
@@ -341,10 +553,95 @@ int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, int col0,
     YNET_REQUIRE(cin > 0 && cin % 8 == 0 && cout > 0 && cout % 16 == 0, "winograd_filter: cin %d must be a multiple of 8, cout %d of 16", cin, cout);
     YNET_REQUIRE(col0 >= 0 && cols_total >= col0 + cout, "winograd_filter: output channels %d .. %d are not inside the filter's %d", col0, col0 + cout, cols_total);
     YNET_REQUIRE((reinterpret_cast<uintptr_t>(u) & 15) == 0, "winograd_filter: the output must be 16-byte aligned");
-    const int ncb = cout / 16, nunits = (cin / 8) * 8 * ncb * 64;
+    const int ncb = cout / 16, nunits = (cin / 4) * 4 * ncb * 64;
     hipLaunchKernelGGL(wino_filter_kernel, dim3(ceil_div(nunits, 256)), dim3(256), 0, (hipStream_t)stream, wp, reinterpret_cast<f32x4*>(u),
-                       wino_cols_pad(cols_total), col0, ncb, nunits);
+                       wino_cols_pad(cols_total), col0, ncb, nunits, cin, 0, 0);
     return ynet_check_launch("winograd_filter");
+}
+
+// padded input channels of a concatenation: every source rounded up to a multiple of 4
+static int wino_cat_padded(const int* src_c, int nsrc) {
+    int n = 0;
+    for (int i = 0; i < nsrc; ++i) n += (src_c[i] + 3) & ~3;
+    return n;
+}
+
+static bool wino_cat_ok(int B, int H, int W, const int* src_c, int nsrc, int cout, int K) {
+    static const int on = getenv("YNET_WINOGRAD") ? atoi(getenv("YNET_WINOGRAD")) : 1;
+    static const int cat_on = getenv("YNET_WINOGRAD_CAT") ? atoi(getenv("YNET_WINOGRAD_CAT")) : 1;
+    if (!on || !cat_on || K != 3 || B <= 0 || nsrc < 1 || nsrc > WC_MAX_SRC || cout != 32) return false;
+    if (H % WN_TH || W % WN_TW || H < WN_TH || W < WN_TW) return false;
+    for (int i = 0; i < nsrc; ++i)
+        if (src_c[i] <= 0) return false;
+    const int nch = wino_cat_padded(src_c, nsrc) / 4;
+    if (nch < 2 || nch > 14) return false;          // 14 chunks of 8 KB of filters + eight 5 KB rings: 156 KB of LDS
+    static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 16;
+    return (long long)B * H * W >= min_pixels;
+}
+
+int ynet_conv2d_winograd_cat_supported(int B, int H, int W, const int* src_c, int nsrc, int cout, int K) {
+    return (src_c != nullptr && wino_cat_ok(B, H, W, src_c, nsrc, cout, K)) ? 1 : 0;
+}
+
+long long ynet_winograd_filter_cat_floats(const int* src_c, int nsrc, int cout) {
+    if (src_c == nullptr || nsrc < 1 || nsrc > WC_MAX_SRC || cout <= 0) return 0;
+    return 16ll * wino_cat_padded(src_c, nsrc) * (ceil_div(cout, 16) * 16);
+}
+
+int ynet_winograd_filter_cat(const float* wp, float* u, const int* src_c, int nsrc, int cout, int col0, int cols_total, void* stream) {
+    YNET_REQUIRE(wp && u && src_c, "winograd_filter_cat: null pointer");
+    YNET_REQUIRE(nsrc >= 1 && nsrc <= WC_MAX_SRC && cout > 0 && cout % 16 == 0, "winograd_filter_cat: 1..%d sources, cout %d a multiple of 16", WC_MAX_SRC, cout);
+    YNET_REQUIRE(col0 >= 0 && cols_total >= col0 + cout, "winograd_filter_cat: output channels %d .. %d are not inside the filter's %d", col0, col0 + cout, cols_total);
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(u) & 15) == 0, "winograd_filter_cat: the output must be 16-byte aligned");
+    for (int i = 0; i < nsrc; ++i) YNET_REQUIRE(src_c[i] > 0, "winograd_filter_cat: source %d has no channels", i);
+    const int ncb = cout / 16, nunits = wino_cat_padded(src_c, nsrc) * ncb * 64;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(ceil_div(nunits, 256)), dim3(256), 0, (hipStream_t)stream, wp, reinterpret_cast<f32x4*>(u),
+                       wino_cols_pad(cols_total), col0, ncb, nunits, src_c[0], nsrc > 1 ? src_c[1] : 0, nsrc > 2 ? src_c[2] : 0);
+    return ynet_check_launch("winograd_filter_cat");
+}
+
+int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                             long long dst_bs, int cout, int B, int H, int W, int relu, void* stream) {
+    YNET_REQUIRE(src && src_c && src_bs && u && dst, "conv2d_winograd_cat: null pointer");
+    YNET_REQUIRE(wino_cat_ok(B, H, W, src_c, nsrc, cout, 3), "conv2d_winograd_cat: shape B=%d %dx%d -> %d with %d sources is not served (ask ynet_conv2d_winograd_cat_supported)",
+                 B, H, W, cout, nsrc);
+    const long long HW = (long long)H * W;
+    WinoCatArgs a{};
+    for (int i = 0; i < nsrc; ++i) {
+        YNET_REQUIRE(src[i] != nullptr && (reinterpret_cast<uintptr_t>(src[i]) & 15) == 0 && (src_bs[i] & 3) == 0 && (src_bs[i] == 0 || src_bs[i] >= src_c[i] * HW),
+                     "conv2d_winograd_cat: source %d must be 16-byte aligned with a batch stride of 0 (one image for the batch) or not smaller than its image", i);
+        YNET_REQUIRE(((long long)(B - 1) * src_bs[i] + src_c[i] * HW) * 4 + (W + 4) * 4 < (1ll << 32), "conv2d_winograd_cat: source %d is beyond 4 GB", i);
+        a.x[i] = src[i];
+        a.x_bs[i] = src_bs[i];
+        a.x_c[i] = src_c[i];
+    }
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 && (dst_bs & 1) == 0 && dst_bs >= cout * HW &&
+                     ((long long)(B - 1) * dst_bs + cout * HW) * 4 < (1ll << 32),
+                 "conv2d_winograd_cat: the output must be 8-byte aligned, its batch stride not smaller than the image, below 4 GB");
+    a.nsrc = nsrc;
+    a.nchunks = wino_cat_padded(src_c, nsrc) / 4;
+    a.u = reinterpret_cast<const f32x4*>(u);
+    a.bias = bias;
+    a.y = dst;
+    a.y_bs = dst_bs;
+    a.B = B; a.H = H; a.W = W; a.relu = relu ? 1 : 0;
+    a.ntiles = B * (H / WN_TH) * (W / WN_TW);
+    const int lds = a.nchunks * 8192 + 8 * WC_RING_BYTES + 16;
+    static bool attr_dev[YNET_MAX_DEV] = {false};
+    static int cus_dev[YNET_MAX_DEV] = {0};
+    const int slot = ynet_device_slot();
+    if (!attr_dev[slot]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus_dev[slot] = cus < 8 ? 8 : cus;
+        attr_dev[slot] = true;
+    }
+    int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
+    if (grid >= 8) grid &= ~7;
+    hipLaunchKernelGGL((conv_wino_cat_kernel<2>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    return ynet_check_launch("conv2d_winograd_cat");
 }
 
 static int wino_launch_any(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, const float* emask,
@@ -356,7 +653,7 @@ static int wino_launch_any(const float* src, long long src_bs, const float* u, c
                      (src_bs & 3) == 0 && (dst_bs & 1) == 0,
                  "%s: planes must be 16-byte (input, filters) / 8-byte (output) aligned", what);
     const long long HW = (long long)H * W;
-    YNET_REQUIRE(src_bs >= cin * HW && dst_bs >= cout * HW, "%s: batch strides smaller than the images", what);
+    YNET_REQUIRE((src_bs == 0 || src_bs >= cin * HW) && dst_bs >= cout * HW, "%s: batch strides smaller than the images (input: 0 = one image for the batch)", what);
     YNET_REQUIRE(((long long)(B - 1) * src_bs + cin * HW) * 4 + (W + 4) * 4 < (1ll << 32) && ((long long)(B - 1) * dst_bs + cout * HW) * 4 < (1ll << 32),
                  "%s: tensors beyond 4 GB are not addressed by one buffer descriptor", what);
     if (emask != nullptr)

@@ -193,7 +193,7 @@ class FusedSequential(nn.Sequential):
                 if pool_next and last and type(m) in (HipConv2d, LoRAConv2d):
                     x = m(x, relu=fuse, pool=True)
                 elif chain:
-                    x = m(x, relu=fuse, bits=True)
+                    x = m(x, relu=fuse, bits=int(mods[i + 2].out_channels) if mods[i + 2].out_channels > 1 else True)
                 else:
                     x = m(x, relu=fuse)
                 i += 2 if fuse else 1
@@ -389,7 +389,7 @@ class YNetEncoderFusion(nn.Module):
                     if pool_next and last and type(mods[j]) in (HipConv2d, LoRAConv2d):
                         x = mods[j](x, relu=fuse, pool=True)
                     else:
-                        x = mods[j](x, relu=fuse, bits=True) if chain else mods[j](x, relu=fuse)
+                        x = mods[j](x, relu=fuse, bits=int(mods[j + 2].out_channels) if mods[j + 2].out_channels > 1 else True) if chain else mods[j](x, relu=fuse)
                     j += 2 if fuse else 1
                 if isinstance(x, ops.LazyCat):      # n_fusion == 0: only the final pool
                     x = x.materialize()

@@ -418,6 +418,24 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                                     relu_of=relu_of)
                 wino_stats["launches"] += 1
             return "winograd"
+    if (wino is not None and _wino_allowed and K == 3 and mask is None and relu_of is None and all(len(s_) == 3 for s_ in srcs)
+            and (len(srcs) > 1 or srcs[0][1] not in (16, 32)) and all(s_[0] % 16 == 0 and s_[2] % 4 == 0 for s_ in srcs)):
+        # the decoders' first convolutions: cat(up-sampled features, skip features[, way-point map]) -> 32 (ynet_conv2d_winograd_cat)
+        want = [d for d in dsts if d[0] is not None]
+        if len(want) == 1 and len(dsts) == 1 and want[0][1] == 32 and want[0][0] % 8 == 0 and want[0][2] % 2 == 0:
+            cs = (ctypes.c_int * len(srcs))(*[s_[1] for s_ in srcs])
+            if lib.ynet_conv2d_winograd_cat_supported(B, H, W, cs, len(srcs), 32, K):
+                cache, what = wino
+                key = "wino_cat_" + what
+                ent = cache.get(key)
+                if ent is None or ent[0] is not wp or ent[2] != tuple(cs):
+                    u = torch.empty(lib.ynet_winograd_filter_cat_floats(cs, len(srcs), 32), device=wp.device, dtype=torch.float32)
+                    L.check(lib.ynet_winograd_filter_cat(wp.data_ptr(), u.data_ptr(), cs, len(srcs), 32, 0, 32, _stream()), lib)
+                    ent = cache[key] = (wp, u, tuple(cs))
+                L.check(lib.ynet_conv2d_winograd_cat(sp, sc, sb, len(srcs), ent[1].data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                     want[0][0], want[0][2], 32, B, H, W, 1 if relu else 0, _stream()), lib)
+                wino_stats["launches"] += 1
+                return "winograd"
     dp, dc, db = _arrays(dsts)
     nws, ws = 0, None
     if B * H * W <= 65536:                                       # small maps only (see ynet_conv2d_workspace_floats)
@@ -726,7 +744,9 @@ class _Conv2dFn(torch.autograd.Function):
             # the next module is MaxPool2d(2, 2): its output comes out of this launch's epilogue (see _MaxPool2Fn.forward)
             pooled = torch.empty((B, cout, H // 2, W // 2), device=weight.device, dtype=torch.float32)
         bits = None
-        if (meta.get("bits") and relu and premask and _relu_bits_allowed and pooled is None and not meta.get("repeat")
+        consumer_wino = (isinstance(meta.get("bits"), int) and not isinstance(meta.get("bits"), bool) and meta.get("wino") and _wino_allowed and k == 3
+                         and cout in (16, 32) and bool(_lib().ynet_conv2d_winograd_supported(B, H, W, int(meta["bits"]), cout, k)))
+        if (meta.get("bits") and not consumer_wino and relu and premask and _relu_bits_allowed and pooled is None and not meta.get("repeat")
                 and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs)):
             # the next conv of a conv -> ReLU -> conv chain will write its data gradient THROUGH this ReLU's backward: leave it the
             # 1-bit form of the mask (1/32 of the bytes of y, in the register layout of the tiles both launches share)
@@ -917,11 +937,13 @@ def lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a, lora_b, scale):
 
 
 def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0, pool: bool = False,
-           bits: bool = False):
+           bits=False):
     """[ReLU](conv(cat(x), W_eff) + bias); x is a tensor or a LazyCat.  pool: the caller applies max_pool2 to the result next --
     where the kernel can, the pooled copy is written by this launch and that max_pool2 call finds it (no kernel).  bits: the
     caller feeds the (post-ReLU) result to another convolution next -- inside fold_skip_gradients() this launch then also writes
-    the 1-bit form of its ReLU mask, which that convolution's data gradient applies to what it writes (ynet_conv2d_relu_bits)."""
+    the 1-bit form of its ReLU mask, which that convolution's data gradient applies to what it writes (ynet_conv2d_relu_bits); an int:
+    that next convolution's output channels -- where its data gradient will be a Winograd launch (which reads the float activation) no
+    bits are written."""
     parts = [p.expand() if isinstance(p, BatchExpand) else p for p in _parts(x)]      # (a fresh expand node per consumer)
     # wino: the plain 16 / 32-channel large-map launches take the Winograd generation (conv2d_raw).  Its results differ from the
     # implicit GEMM's by fp32 rounding that is uncorrelated with the reference's own (the implicit GEMM sums in nearly the reference's
@@ -929,7 +951,7 @@ def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, s
     # and gradients deviate exactly as much with it as without; in evaluate()'s K-sample sweep every trajectory's ADE / FDE does too
     # (max 6e-5 / 3e-5 either way), while single coordinates of single goal samples -- 0.3 % of them, where the decoded heat-map is
     # diffuse -- move by up to 5e-3 px instead of 4e-5.  YNET_WINOGRAD_EVAL=0 keeps evaluate() on the implicit GEMM.
-    meta = {"relu": bool(relu), "scale": float(scale), "cache": cache, "pool": bool(pool), "bits": bool(bits) and torch.is_grad_enabled(),
+    meta = {"relu": bool(relu), "scale": float(scale), "cache": cache, "pool": bool(pool), "bits": bits if torch.is_grad_enabled() else False,
             "wino": torch.is_grad_enabled() or _wino_eval}
     if any(isinstance(p, BatchRepeat) for p in parts):
         if torch.is_grad_enabled() and any(t.requires_grad for t in (weight, bias, lora_a, lora_b) if t is not None):

@@ -683,6 +683,35 @@ def test_winograd_data_gradient_through_the_relu_backward_of_the_layer_below(dev
     close(got, F.conv_transpose2d(dy, w, padding=1) * (act > 0), rtol=1e-4, scale_rel=2e-6, msg="vs torch")
 
 
+@pytest.mark.parametrize("case", [(4, 256, 256, [32, 16, 1], True), (16, 128, 128, [32, 16], True), (8, 256, 256, [20, 7, 3], False), (16, 128, 128, [48], False)],
+                         ids=str)
+def test_winograd_convolution_over_concatenated_sources(dev, case):
+    """ynet_conv2d_winograd_cat: conv(cat(sources)) -> 32 channels with every source padded to a multiple of 4 channels inside the kernel
+    (zero planes, zero filters) -- the decoders' first convolutions, cat(up-sampled features, skip features[, way-point map]).  Same values
+    as torch's convolution of the concatenation and as the multi-source implicit GEMM within fp32 rounding."""
+    ops = pkg("ops")
+    B, H, W, cs, relu = case
+    cin = sum(cs)
+    xs = [torch.relu(rnd(B, c, H, W, seed=10 + i)).to(dev) for i, c in enumerate(cs)]
+    w, bias = rnd(32, cin, 3, 3, seed=2, scale=0.2).to(dev), rnd(32, seed=3).to(dev)
+    wp = ops.pack_weight(w, 0)
+    srcs = [(x.data_ptr(), c, c * H * W) for x, c in zip(xs, cs)]
+    if len(cs) == 2:       # the second source as ONE image shared by the batch (batch stride 0: Y-Net-Mod's scene features)
+        xs[1] = xs[1][:1].expand(B, -1, -1, -1).contiguous()
+        srcs[1] = (xs[1].data_ptr(), cs[1], 0)
+    got, direct = torch.full((B, 32, H, W), float("nan"), device=dev), torch.empty(B, 32, H, W, device=dev)
+    n0 = ops.wino_stats["launches"]
+    assert ops.conv2d_raw(srcs, None, wp, bias, [(got.data_ptr(), 32, 32 * H * W)], B, H, W, 3, relu, wino=({}, "fwd")) == "winograd"
+    assert ops.wino_stats["launches"] - n0 == 1
+    assert ops.conv2d_raw(srcs, None, wp, bias, [(direct.data_ptr(), 32, 32 * H * W)], B, H, W, 3, relu) is None
+    ref64 = F.conv2d(torch.cat(xs, 1).double(), w.double(), bias.double(), padding=1)
+    ref64 = torch.relu(ref64) if relu else ref64
+    close(got, ref64, rtol=1e-5, scale_rel=2e-6, msg="winograd (cat) vs fp64")
+    close(got, direct, rtol=1e-5, scale_rel=2e-6, msg="winograd (cat) vs ynet_conv2d")
+    e_w, e_d = float((got.double() - ref64).abs().max()), float((direct.double() - ref64).abs().max())
+    assert e_w <= 1.5 * e_d + 1e-7, (e_w, e_d)
+
+
 def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     """ops.conv2d takes the Winograd kernel for a plain 32 -> 32 layer -- forward AND data gradient -- and the implicit GEMM with
     YNET_WINOGRAD off; outputs and input gradients of the two agree within fp32 rounding.  (A layer without ReLU: behind a ReLU

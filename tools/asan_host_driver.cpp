@@ -87,6 +87,21 @@ int main() {
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 250, 256, 1, nullptr));               // H not a multiple of 16
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 16 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));               // batch stride smaller than the image
     EXPECT_REJECT(ynet_conv2d_winograd(nullptr, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));
+    {
+        const int cat3[3] = {32, 16, 1}, cat2[2] = {32, 32}, bad[2] = {32, 0};
+        const long long bs3[3] = {32 * 65536, 16 * 65536, 65536};
+        const float* s3[3] = {cfp, cfp, cfp};
+        for (int b : {1, 10, 32})
+            for (int hw : {32, 128, 256})
+                acc += ynet_conv2d_winograd_cat_supported(b, hw, hw, cat3, 3, 32, 3) + ynet_conv2d_winograd_cat_supported(b, hw, hw, cat2, 2, 32, 3) +
+                       ynet_conv2d_winograd_cat_supported(b, hw, hw, cat3, 3, 16, 3) + ynet_conv2d_winograd_cat_supported(b, hw, hw, bad, 2, 32, 3) +
+                       ynet_winograd_filter_cat_floats(cat3, 3, 32);
+        EXPECT_REJECT(ynet_winograd_filter_cat(cfp, fp, cat3, 4, 32, 0, 32, nullptr));                                                   // too many sources
+        EXPECT_REJECT(ynet_winograd_filter_cat(cfp, fp, bad, 2, 32, 0, 32, nullptr));                                                    // an empty source
+        EXPECT_REJECT(ynet_conv2d_winograd_cat(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 16, 32, 256, 256, 1, nullptr));              // 16 outputs: not served
+        EXPECT_REJECT(ynet_conv2d_winograd_cat(s3, cat2, bs3, 2, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr));              // 64 inputs: too many filters for LDS
+        EXPECT_REJECT(ynet_conv2d_winograd_cat(s3, cat3, bs3, 3, nullptr, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr));          // no filters
+    }
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, nullptr, 32 * 65536, 32, 32, 32, 256, 256, nullptr));   // no activation
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, cfp, 16 * 65536, 32, 32, 32, 256, 256, nullptr));       // activation stride too small
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 0, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));
