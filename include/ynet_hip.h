@@ -133,6 +133,12 @@ long long ynet_winograd_filter_cat_floats(const int* src_c, int nsrc, int cout);
 int ynet_winograd_filter_cat(const float* wp, float* u, const int* src_c, int nsrc, int cout, int col0, int cols_total, void* stream);
 int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                              long long dst_bs, int cout, int B, int H, int W, int relu, void* stream);
+/*   ynet_conv2d_winograd_cat_add   ... + a precomputed term in front of the ReLU, as ynet_conv2d_add: y = [relu](conv(cat(src)) + bias + addend[b % addend_bmod])
+ *                               (addend_bmod 0: image b) -- the K goal samples of utils/evaluate.py:248-283 share the skip-feature part of each decoder level's
+ *                               first convolution; addend 8-byte aligned, image stride addend_bs floats. */
+int ynet_conv2d_winograd_cat_add(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                                 long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod,
+                                 void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,

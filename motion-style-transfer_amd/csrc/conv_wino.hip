@@ -59,15 +59,16 @@ __device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, 
     return r;
 }
 
-// Y = A^T M A packed over channel pairs, the bias through M[1][1], ReLU, 8-byte stores at static-lane + scalar offsets; EM: the
-// activation of the block's 2 x 2 x 4 outputs per lane is fetched before the transform it gates (y = act > 0 ? y : 0)
-template <int NCB, bool EM>
+// Y = A^T M A packed over channel pairs, the bias through M[1][1], ReLU, 8-byte stores at static-lane + scalar offsets.  EPI 1: the
+// activation of the block's 2 x 2 x 4 outputs per lane is fetched before the transform it gates (y = act > 0 ? y : 0); EPI 2: a
+// precomputed term is fetched the same way and added in front of the ReLU (y = relu(conv + bias + addend))
+template <int NCB, int EPI>
 __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2 (&bias2)[NCB][2], float floor_v, __amdgpu_buffer_rsrc_t ry,
                                               __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         u32x2 mk[2][2][2];
-        if constexpr (EM) {
+        if constexpr (EPI != 0) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -94,9 +95,14 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
             const f32x2 o10 = r1[0] + r1[1] + r1[2], o11 = r1[1] - r1[2] - r1[3];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {      // channel cb * 16 + 4 kq + 2 h + k
-                f32x2 row0 = {fmaxf(o00[k], floor_v), fmaxf(o01[k], floor_v)};
-                f32x2 row1 = {fmaxf(o10[k], floor_v), fmaxf(o11[k], floor_v)};
-                if constexpr (EM) {
+                f32x2 row0 = {o00[k], o01[k]}, row1 = {o10[k], o11[k]};
+                if constexpr (EPI == 2) {
+                    row0 += __builtin_bit_cast(f32x2, mk[h][k][0]);
+                    row1 += __builtin_bit_cast(f32x2, mk[h][k][1]);
+                }
+                row0 = f32x2{fmaxf(row0[0], floor_v), fmaxf(row0[1], floor_v)};
+                row1 = f32x2{fmaxf(row1[0], floor_v), fmaxf(row1[1], floor_v)};
+                if constexpr (EPI == 1) {
                     const f32x2 m0 = __builtin_bit_cast(f32x2, mk[h][k][0]), m1 = __builtin_bit_cast(f32x2, mk[h][k][1]);
                     row0 = f32x2{m0[0] > 0.f ? row0[0] : 0.f, m0[1] > 0.f ? row0[1] : 0.f};
                     row1 = f32x2{m1[0] > 0.f ? row1[0] : 0.f, m1[1] > 0.f ? row1[1] : 0.f};
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
             const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
             const unsigned sm_t = (unsigned)(((long long)b * a.emask_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
-            wino_epilogue<NCB, EM>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, sm_t, HW);
+            wino_epilogue<NCB, EM ? 1 : 0>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, sm_t, HW);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -330,9 +336,12 @@ struct WinoCatArgs {
     float* y;
     long long y_bs;
     int B, H, W, relu, ntiles;
+    const float* addend;       // ADD: [images] x (addend_bs floats), cout planes, image b % addend_bmod (b when the modulus is 0): y = relu(conv + bias + addend)
+    long long addend_bs;
+    int addend_bmod;
 };
 
-template <int NCB>
+template <int NCB, bool ADD>
 __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const WinoCatArgs a) {
     extern __shared__ f32x4 smem[];
     constexpr int WQ = 4 * NCB * 64;      // units of one chunk's filters: [4 quads of (xi,nu)][NCB][64 lanes]
@@ -356,6 +365,9 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
     const unsigned lead = (unsigned)((W + 4) * 4);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u), 0, wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(((long long)(a.B - 1) * a.y_bs + (long long)NCB * 16 * HW) * 4), 0x00020000);
+    const int add_images = a.addend_bmod > 0 ? a.addend_bmod : a.B;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? a.addend : a.y), 0,
+                                                                        (unsigned)(((long long)(add_images - 1) * (ADD ? a.addend_bs : a.y_bs) + (long long)NCB * 16 * HW) * 4), 0x00020000);
 
     const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
     const int per_xcd = (a.ntiles + 7) >> 3;
@@ -460,7 +472,9 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
             const int t = tile_first + (cur >> 3) * gstride;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
             const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
-            wino_epilogue<NCB, false>(acc, bias2, floor_v, ry, ry, st0, st1, so_t, 0u, HW);
+            const int ab = a.addend_bmod > 0 ? b % a.addend_bmod : b;
+            const unsigned sa_t = (unsigned)(((long long)ab * a.addend_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            wino_epilogue<NCB, ADD ? 2 : 0>(acc, bias2, floor_v, ry, ra, st0, st1, so_t, sa_t, HW);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -600,24 +614,31 @@ int ynet_winograd_filter_cat(const float* wp, float* u, const int* src_c, int ns
     return ynet_check_launch("winograd_filter_cat");
 }
 
-int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
-                             long long dst_bs, int cout, int B, int H, int W, int relu, void* stream) {
-    YNET_REQUIRE(src && src_c && src_bs && u && dst, "conv2d_winograd_cat: null pointer");
-    YNET_REQUIRE(wino_cat_ok(B, H, W, src_c, nsrc, cout, 3), "conv2d_winograd_cat: shape B=%d %dx%d -> %d with %d sources is not served (ask ynet_conv2d_winograd_cat_supported)",
+static int wino_cat_launch(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                           long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod, void* stream,
+                           const char* what) {
+    YNET_REQUIRE(src && src_c && src_bs && u && dst, "%s: null pointer", what);
+    YNET_REQUIRE(wino_cat_ok(B, H, W, src_c, nsrc, cout, 3), "%s: shape B=%d %dx%d -> %d with %d sources is not served (ask ynet_conv2d_winograd_cat_supported)", what,
                  B, H, W, cout, nsrc);
     const long long HW = (long long)H * W;
     WinoCatArgs a{};
     for (int i = 0; i < nsrc; ++i) {
         YNET_REQUIRE(src[i] != nullptr && (reinterpret_cast<uintptr_t>(src[i]) & 15) == 0 && (src_bs[i] & 3) == 0 && (src_bs[i] == 0 || src_bs[i] >= src_c[i] * HW),
-                     "conv2d_winograd_cat: source %d must be 16-byte aligned with a batch stride of 0 (one image for the batch) or not smaller than its image", i);
-        YNET_REQUIRE(((long long)(B - 1) * src_bs[i] + src_c[i] * HW) * 4 + (W + 4) * 4 < (1ll << 32), "conv2d_winograd_cat: source %d is beyond 4 GB", i);
+                     "%s: source %d must be 16-byte aligned with a batch stride of 0 (one image for the batch) or not smaller than its image", what, i);
+        YNET_REQUIRE(((long long)(B - 1) * src_bs[i] + src_c[i] * HW) * 4 + (W + 4) * 4 < (1ll << 32), "%s: source %d is beyond 4 GB", what, i);
         a.x[i] = src[i];
         a.x_bs[i] = src_bs[i];
         a.x_c[i] = src_c[i];
     }
     YNET_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 && (dst_bs & 1) == 0 && dst_bs >= cout * HW &&
                      ((long long)(B - 1) * dst_bs + cout * HW) * 4 < (1ll << 32),
-                 "conv2d_winograd_cat: the output must be 8-byte aligned, its batch stride not smaller than the image, below 4 GB");
+                 "%s: the output must be 8-byte aligned, its batch stride not smaller than the image, below 4 GB", what);
+    if (addend != nullptr) {
+        const int images = addend_bmod > 0 ? addend_bmod : B;
+        YNET_REQUIRE(addend_bmod >= 0 && (reinterpret_cast<uintptr_t>(addend) & 7) == 0 && (addend_bs & 1) == 0 && addend_bs >= cout * HW &&
+                         ((long long)(images - 1) * addend_bs + cout * HW) * 4 < (1ll << 32),
+                     "%s: the additive term must be 8-byte aligned, its image stride not smaller than the image, below 4 GB, its modulus not negative", what);
+    }
     a.nsrc = nsrc;
     a.nchunks = wino_cat_padded(src_c, nsrc) / 4;
     a.u = reinterpret_cast<const f32x4*>(u);
@@ -626,12 +647,16 @@ int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const lo
     a.y_bs = dst_bs;
     a.B = B; a.H = H; a.W = W; a.relu = relu ? 1 : 0;
     a.ntiles = B * (H / WN_TH) * (W / WN_TW);
+    a.addend = addend;
+    a.addend_bs = addend_bs;
+    a.addend_bmod = addend_bmod;
     const int lds = a.nchunks * 8192 + 8 * WC_RING_BYTES + 16;
     static bool attr_dev[YNET_MAX_DEV] = {false};
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
     if (!attr_dev[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -640,8 +665,21 @@ int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const lo
     }
     int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
     if (grid >= 8) grid &= ~7;
-    hipLaunchKernelGGL((conv_wino_cat_kernel<2>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
-    return ynet_check_launch("conv2d_winograd_cat");
+    if (addend != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, true>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_wino_cat_kernel<2, false>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    return ynet_check_launch(what);
+}
+
+int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                             long long dst_bs, int cout, int B, int H, int W, int relu, void* stream) {
+    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, cout, B, H, W, relu, nullptr, 0, 0, stream, "conv2d_winograd_cat");
+}
+
+int ynet_conv2d_winograd_cat_add(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                                 long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod,
+                                 void* stream) {
+    YNET_REQUIRE(addend != nullptr, "conv2d_winograd_cat_add: the additive term is null");
+    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, cout, B, H, W, relu, addend, addend_bs, addend_bmod, stream, "conv2d_winograd_cat_add");
 }
 
 static int wino_launch_any(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, const float* emask,

@@ -512,6 +512,8 @@ class _SharedSkipTerms:
                 cx = up.out_channels
                 terms[lvl] = (ops.shared_conv_term(f, conv0.weight, cx, cx + cf, conv0._packed), f)
                 ops.rest_filter(conv0.weight, cx, cx + cf, conv0._packed)      # packed HERE, on the caller's stream (see ops.rest_filter)
+                # ... and its Winograd form, for per-sample launches over [the up-sampled features, what follows the skip features]
+                ops.rest_filter_winograd(conv0.weight, cx, cx + cf, conv0._packed, (cx, conv0.in_channels - cx - cf), B, H, W)
         dec._shared_terms = terms or None
         return self
 

@@ -483,6 +483,16 @@ def conv2d_shared_term(x, x_times: int, rest, weight, bias, relu: bool, cache: d
     y = torch.empty((B, cout, H, W), device=weight.device, dtype=torch.float32)
     lib = _lib()
     sp, sc, sb = _arrays(descs)
+    ent = cache.get("wino_rest")
+    if (ent is not None and ent[0] is cache["rest_wp"] and ent[2] == tuple(d[1] for d in descs) and _wino_allowed and _wino_eval and k == 3
+            and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs) and term.data_ptr() % 8 == 0
+            and lib.ynet_conv2d_winograd_cat_supported(B, H, W, (ctypes.c_int * len(descs))(*ent[2]), len(descs), cout, k)):
+        # the Winograd form of the same launch (its filter was transformed by rest_filter_winograd, before the sweep's streams fork)
+        L.check(lib.ynet_conv2d_winograd_cat_add(sp, sc, sb, len(descs), ent[1].data_ptr(), bias.detach().data_ptr() if bias is not None else None,
+                                                 y.data_ptr(), cout * H * W, cout, B, H, W, 1 if relu else 0, term.data_ptr(), cout * H * W,
+                                                 term.shape[0], _stream()), lib)
+        wino_stats["launches"] += 1
+        return y
     L.check(lib.ynet_conv2d_add(sp, sc, sb, None, len(descs), cache["rest_wp"].data_ptr(),
                                 bias.detach().data_ptr() if bias is not None else None, y.data_ptr(), cout, cout * H * W,
                                 B, H, W, k, 1 if relu else 0, term.data_ptr(), cout * H * W, term.shape[0], _stream()), lib)
@@ -499,6 +509,26 @@ def rest_filter(weight, c0: int, c1: int, cache: dict) -> torch.Tensor:
             w_rest = torch.cat([weight[:, :c0], weight[:, c1:]], dim=1).contiguous()
             cache["rest_key"], cache["rest_wp"] = wkey, pack_weight(w_rest, 0)
     return cache["rest_wp"]
+
+
+def rest_filter_winograd(weight, c0: int, c1: int, cache: dict, src_c, B: int, H: int, W: int):
+    """The Winograd-domain form of rest_filter(...) for sources of src_c channels each (conv2d_shared_term's launches), where
+    ynet_conv2d_winograd_cat serves them; like rest_filter it is made on the caller's stream before the sweep's streams fork."""
+    wp = rest_filter(weight, c0, c1, cache)
+    cout, k = weight.shape[0], weight.shape[2]
+    src_c = tuple(int(c) for c in src_c if c > 0)
+    lib = _lib()
+    cs = (ctypes.c_int * len(src_c))(*src_c)
+    if not (_wino_allowed and _wino_eval and k == 3 and src_c and lib.ynet_conv2d_winograd_cat_supported(B, H, W, cs, len(src_c), cout, k)):
+        cache.pop("wino_rest", None)
+        return None
+    ent = cache.get("wino_rest")
+    if ent is None or ent[0] is not wp or ent[2] != src_c:
+        with torch.no_grad():
+            u = torch.empty(lib.ynet_winograd_filter_cat_floats(cs, len(src_c), cout), device=wp.device, dtype=torch.float32)
+            L.check(lib.ynet_winograd_filter_cat(wp.data_ptr(), u.data_ptr(), cs, len(src_c), cout, 0, cout, _stream()), lib)
+        ent = cache["wino_rest"] = (wp, u, src_c)
+    return ent[1]
 
 
 def shared_conv_term(x: torch.Tensor, weight, c0: int, c1: int, cache: dict) -> torch.Tensor:

@@ -712,6 +712,35 @@ def test_winograd_convolution_over_concatenated_sources(dev, case):
     assert e_w <= 1.5 * e_d + 1e-7, (e_w, e_d)
 
 
+def test_winograd_shared_skip_term_launch(dev):
+    """evaluate()'s per-sample launch of a decoder level's first convolution, relu(conv(cat(up, way-point map), W_rest) + b + term[b % Bs])
+    with the batch-shared skip-feature term precomputed (ops.conv2d_shared_term): the Winograd form (ynet_conv2d_winograd_cat_add) against
+    the implicit GEMM (ynet_conv2d_add) and against torch's convolution of the full concatenation."""
+    ops = pkg("ops")
+    Bs, times, H, W = 4, 2, 256, 256
+    B = Bs * times
+    up, wmap = torch.relu(rnd(B, 32, H, W, seed=1)).to(dev), torch.relu(rnd(B, 1, H, W, seed=2)).to(dev)
+    skip = torch.relu(rnd(Bs, 16, H, W, seed=3)).to(dev)
+    w, bias = rnd(32, 49, 3, 3, seed=4, scale=0.2).to(dev), rnd(32, seed=5).to(dev)
+    outs = []
+    for allowed in (True, False):
+        old, n0, cache = ops._wino_allowed, ops.wino_stats["launches"], {}
+        ops._wino_allowed = allowed
+        try:
+            with torch.no_grad():
+                term = ops.shared_conv_term(skip, w, 32, 48, cache)
+                ops.rest_filter(w, 32, 48, cache)
+                ops.rest_filter_winograd(w, 32, 48, cache, (32, 1), Bs, H, W)
+                n1 = ops.wino_stats["launches"]
+                outs.append(ops.conv2d_shared_term(None, times, [up, wmap], w, bias, True, cache, term, 32, 48))
+        finally:
+            ops._wino_allowed = old
+        assert ops.wino_stats["launches"] - n1 == (1 if allowed else 0), (n0, n1)
+    ref = torch.relu(F.conv2d(torch.cat([up, skip.repeat(times, 1, 1, 1), wmap], 1), w, bias, padding=1))
+    close(outs[0], outs[1], rtol=1e-5, scale_rel=2e-6, msg="winograd vs implicit GEMM")
+    close(outs[0], ref, rtol=1e-4, scale_rel=2e-6, msg="vs torch")
+
+
 def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     """ops.conv2d takes the Winograd kernel for a plain 32 -> 32 layer -- forward AND data gradient -- and the implicit GEMM with
     YNET_WINOGRAD off; outputs and input gradients of the two agree within fp32 rounding.  (A layer without ReLU: behind a ReLU

@@ -101,6 +101,8 @@ int main() {
         EXPECT_REJECT(ynet_conv2d_winograd_cat(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 16, 32, 256, 256, 1, nullptr));              // 16 outputs: not served
         EXPECT_REJECT(ynet_conv2d_winograd_cat(s3, cat2, bs3, 2, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr));              // 64 inputs: too many filters for LDS
         EXPECT_REJECT(ynet_conv2d_winograd_cat(s3, cat3, bs3, 3, nullptr, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr));          // no filters
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_add(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr, 32 * 65536, 4, nullptr));   // no additive term
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_add(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, cfp, 32 * 65536, -1, nullptr));      // negative modulus
     }
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, nullptr, 32 * 65536, 32, 32, 32, 256, 256, nullptr));   // no activation
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, cfp, 16 * 65536, 32, 32, 32, 256, 256, nullptr));       // activation stride too small
