@@ -171,9 +171,11 @@ class ConvTimer:
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             cc = plan >> 21                       # input channels per staged chunk (the kernel's CC template argument)
-            if took == "winograd":            # (csrc/conv_wino.hip: NCB 16-channel output blocks, chunks of 8 input channels)
-                blocks = [2] * (cout // 32) + [1] * ((cout % 32) // 16)      # (48 / 64 output channels: two launches over slices)
-                name = f"conv_wino_kernel<{'+'.join(str(b_) for b_ in blocks)}, {cin // 8}>"
+            if took is not None and str(took).startswith("winograd"):
+                # (csrc/conv_wino.hip; the tag carries the template arguments of each launch -- 48 / 64 output channels are two launches)
+                kern, targs = str(took).split(":")
+                fam = "conv_wino_cat_kernel" if kern == "winograd_cat" else "conv_wino_kernel"
+                name = " + ".join(f"{fam}<{', '.join(t.split(','))}>" for t in targs.split("+"))
             elif dma:
                 if cc > 8:                        # launch_dma_small: the deep chunks are for plain launches with enough input channels
                     if relu_of or pooled or bits_out or relu_bits:
@@ -238,7 +240,7 @@ class FlopCounter:
                 dl.pop()
             per = 2.0 * B * H * W * sum(s_[1] for s_ in srcs) * K * K
             took = me.saved["conv2d_raw"](srcs, mask, wp, bias, dsts, B, H, W, K, relu, **kw)
-            if took == "winograd":      # 16 multiplies per 2 x 2 block and channel pair instead of 36; unwanted destinations are not computed
+            if took is not None and str(took).startswith("winograd"):      # 16 multiplies per 2 x 2 block and channel pair instead of 36; unwanted destinations are not computed
                 me.flops += per * sum(d[1] for d in dl if d[0] is not None) * (16.0 / 36.0)
             else:
                 me.flops += per * sum(d[1] for d in dl)
@@ -260,8 +262,10 @@ class FlopCounter:
         def conv2d_shared_term(x, x_times, rest, weight, bias, relu, cache, term, c0, c1):
             cout, cin, k, _ = weight.shape
             B, _, H, W = rest[0].shape
-            me.flops += 2.0 * B * H * W * (cin - (c1 - c0)) * cout * k * k
-            return me.saved["conv2d_shared_term"](x, x_times, rest, weight, bias, relu, cache, term, c0, c1)
+            n0 = ops.wino_stats["launches"]
+            y = me.saved["conv2d_shared_term"](x, x_times, rest, weight, bias, relu, cache, term, c0, c1)
+            me.flops += 2.0 * B * H * W * (cin - (c1 - c0)) * cout * k * k * (16.0 / 36.0 if ops.wino_stats["launches"] > n0 else 1.0)
+            return y
 
         def pred_bce(x, weight, bias, target, expected_grad, cache):
             B, cin, H, W = x.shape
@@ -664,7 +668,7 @@ def main():
             if entry:       # measured with rocprofv3 --pmc in separate passes, committed under profiles/
                 # LDS-DMA (buffer_load ... lds) reads are tallied at half their bytes on gfx950 (MI355X_MICROARCH.md,
                 # HBM section): the doubled-FETCH figure applies to conv_dma_kernel, the raw one to register staging
-                traffic = entry["hbm_bytes_per_launch_fetch_x2" if name.startswith("conv_dma") else "hbm_bytes_per_launch"]
+                traffic = entry["hbm_bytes_per_launch_fetch_x2" if name.startswith(("conv_dma", "conv_wino")) else "hbm_bytes_per_launch"]
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                            "profile": "profiles/r04_bench_C2_serial_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command "
@@ -686,6 +690,13 @@ def main():
                                    "replays the captured step, whose decoder branches run CONCURRENTLY: per-kernel durations "
                                    "inside it are inflated by sharing the GPU (profiles/r04_bench_C2_kernel_stats.csv) and "
                                    "are not a kernel-quality measure; `value` and `step_roofline` are."}
+        if name.startswith("conv_wino"):
+            # a Winograd launch executes 16 / 36 of the convolution's FLOPs: `achieved` / `frac` count what the reference computes
+            # (SURVEY 8d's per-unit figure), the `executed_*` pair what the matrix pipes do
+            out["roofline"]["executed_achieved"] = tf / 2.25
+            out["roofline"]["executed_frac"] = tf / 2.25 / PEAK_FP32_MFMA_TFLOPS
+            out["roofline"]["form"] = ("Winograd F(2x2, 3x3) on the fp32 matrix cores (csrc/conv_wino.hip): 16 multiplies per 2x2 output block and "
+                                       "channel pair instead of 36 -- `frac` above 1 is the algorithmic saving, not a measurement error")
         out["conv_kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}
         for k, v in out["conv_kernels"].items():

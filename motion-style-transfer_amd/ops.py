@@ -366,7 +366,8 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
     relu_bits: address of such a mask, applied to the single destination of a data gradient (ynet_conv2d_dgrad_relu_bits).
     wino: (the layer's filter cache, "fwd" | "dgrad") -- a plain launch (one source, one destination, no mask, no epilogue variant)
     of a shape ynet_conv2d_winograd_supported admits takes the Winograd F(2x2, 3x3) kernel, its transformed filter kept in that
-    cache next to the packed one; returns "winograd" then, None otherwise."""
+    cache next to the packed one; returns "winograd:<NCB>,<NCH>,<EM>[+...]" (one group per launch: the template arguments of
+    conv_wino_kernel) or "winograd_cat:2,false" then, None otherwise."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
     if bits_out is not None:
@@ -409,6 +410,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
         if (pieces and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
                 and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces)):
             cache, what = wino
+            tag = "winograd:" + "+".join("%d,%d,%s" % (p_[1] // 16, cin // 8, "true" if relu_of is not None else "false") for p_ in pieces)
             for ptr, n, bs, col0 in pieces:
                 key = "wino_%s_%d_%d" % (what, col0, n)
                 ent = cache.get(key)
@@ -417,7 +419,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 conv2d_winograd_raw((srcs[0][0], srcs[0][2]), ent[1], None if bias is None else bias[col0:col0 + n], (ptr, bs), cin, n, B, H, W, relu,
                                     relu_of=relu_of)
                 wino_stats["launches"] += 1
-            return "winograd"
+            return tag
     if (wino is not None and _wino_allowed and K == 3 and mask is None and relu_of is None and all(len(s_) == 3 for s_ in srcs)
             and (len(srcs) > 1 or srcs[0][1] not in (16, 32)) and all(s_[0] % 16 == 0 and s_[2] % 4 == 0 for s_ in srcs)):
         # the decoders' first convolutions: cat(up-sampled features, skip features[, way-point map]) -> 32 (ynet_conv2d_winograd_cat)
@@ -435,7 +437,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 L.check(lib.ynet_conv2d_winograd_cat(sp, sc, sb, len(srcs), ent[1].data_ptr(), bias.data_ptr() if bias is not None else None,
                                                      want[0][0], want[0][2], 32, B, H, W, 1 if relu else 0, _stream()), lib)
                 wino_stats["launches"] += 1
-                return "winograd"
+                return "winograd_cat:2,false"
     dp, dc, db = _arrays(dsts)
     nws, ws = 0, None
     if B * H * W <= 65536:                                       # small maps only (see ynet_conv2d_workspace_floats)

@@ -651,7 +651,7 @@ def test_winograd_launches_over_output_channel_slices(dev, case):
     ops.conv2d_raw([(dy.data_ptr(), cin, cin * H * W)], None, wp, None, [(t.data_ptr(), t.shape[1], t.shape[1] * H * W) for t in want], B, H, W, 3, False)
     dsts = [(t.data_ptr() if c is not None else None, t.shape[1], t.shape[1] * H * W if c is not None else 0) for t, c in zip(got, couts)]
     n0 = ops.wino_stats["launches"]
-    assert ops.conv2d_raw([(dy.data_ptr(), cin, cin * H * W)], None, wp, None, dsts, B, H, W, 3, False, wino=({}, "dgrad")) == "winograd"
+    assert ops.conv2d_raw([(dy.data_ptr(), cin, cin * H * W)], None, wp, None, dsts, B, H, W, 3, False, wino=({}, "dgrad")).startswith("winograd")
     assert ops.wino_stats["launches"] - n0 == (2 if None not in couts else 1)
     for g, t, c in zip(got, want, couts):
         if c is None:
@@ -674,9 +674,9 @@ def test_winograd_data_gradient_through_the_relu_backward_of_the_layer_below(dev
     wp = ops.pack_weight(w, 1)
     plain, got, direct = (torch.full((B, dx_c, H, W), float("nan"), device=dev) for _ in range(3))
     src, cache = [(dy.data_ptr(), dy_c, dy_c * H * W)], {}
-    assert ops.conv2d_raw(src, None, wp, None, [(plain.data_ptr(), dx_c, dx_c * H * W)], B, H, W, 3, False, wino=(cache, "dgrad")) == "winograd"
+    assert ops.conv2d_raw(src, None, wp, None, [(plain.data_ptr(), dx_c, dx_c * H * W)], B, H, W, 3, False, wino=(cache, "dgrad")).startswith("winograd")
     assert ops.conv2d_raw(src, None, wp, None, [(got.data_ptr(), dx_c, dx_c * H * W)], B, H, W, 3, False, relu_of=(act.data_ptr(), dx_c * H * W),
-                          wino=(cache, "dgrad")) == "winograd"
+                          wino=(cache, "dgrad")).startswith("winograd")
     assert ops.conv2d_raw(src, None, wp, None, [(direct.data_ptr(), dx_c, dx_c * H * W)], B, H, W, 3, False, relu_of=(act.data_ptr(), dx_c * H * W)) is None
     assert torch.equal(got, torch.where(act > 0, plain, torch.zeros_like(plain)))
     close(got, direct, rtol=1e-5, scale_rel=2e-6, msg="winograd vs implicit GEMM, both through the ReLU backward")
@@ -701,7 +701,7 @@ def test_winograd_convolution_over_concatenated_sources(dev, case):
         srcs[1] = (xs[1].data_ptr(), cs[1], 0)
     got, direct = torch.full((B, 32, H, W), float("nan"), device=dev), torch.empty(B, 32, H, W, device=dev)
     n0 = ops.wino_stats["launches"]
-    assert ops.conv2d_raw(srcs, None, wp, bias, [(got.data_ptr(), 32, 32 * H * W)], B, H, W, 3, relu, wino=({}, "fwd")) == "winograd"
+    assert ops.conv2d_raw(srcs, None, wp, bias, [(got.data_ptr(), 32, 32 * H * W)], B, H, W, 3, relu, wino=({}, "fwd")).startswith("winograd")
     assert ops.wino_stats["launches"] - n0 == 1
     assert ops.conv2d_raw(srcs, None, wp, bias, [(direct.data_ptr(), 32, 32 * H * W)], B, H, W, 3, relu) is None
     ref64 = F.conv2d(torch.cat(xs, 1).double(), w.double(), bias.double(), padding=1)
