@@ -148,10 +148,11 @@ __device__ __forceinline__ void wino_kstep(f32x4 (&acc)[16][NCB], const f32x2 (&
 
 // NCB: 16-channel output blocks (cout = 16 NCB), NCH: chunks of 8 input channels (cin = 8 NCH; even: chunk c lives in slot c & 1 of the
 // wave's ring, and the chunk two ahead -- of this pair or the next -- takes the slot just read)
-template <int NCB, int NCH, bool EM>
-__global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs a) {
+template <int NCB, int NCH, bool EM, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a) {
     extern __shared__ f32x4 smem[];
     constexpr int WQ = 8 * NCB * 64;      // units of one chunk's filters: [2 k-steps][4 quads of (xi,nu)][NCB][64 lanes]
+    constexpr int NT = NW * 64;           // NW waves: 8, or 12 for the 16-channel form (64 accumulator registers: three waves per SIMD)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W, HW = H * W;
@@ -210,11 +211,12 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs
 
     // all transformed filters -> LDS, once; the workgroup's unit counter
 #pragma unroll
-    for (int j = 0; j < NCH * WQ / WN_THREADS; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(uintptr_t)(lds0 + (unsigned)(j * 8192 + wave * 1024)), 16,
-                                                 (unsigned)((j * WN_THREADS + tid) * 16), 0, 0, 0);
-    unsigned* unit_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(smem) + NCH * WQ * 16 + 8 * WN_RING_BYTES);
-    if (tid == 0) *unit_ctr = 8u;
+    for (int j = 0; j < (NCH * WQ + NT - 1) / NT; ++j)
+        if (j * NT + wave * 64 < NCH * WQ)      // (whole wave instructions: NCH * WQ is a multiple of 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(uintptr_t)(lds0 + (unsigned)((j * NT + wave * 64) * 16)), 16,
+                                                     (unsigned)((j * NT + tid) * 16), 0, 0, 0);
+    unsigned* unit_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(smem) + NCH * WQ * 16 + NW * WN_RING_BYTES);
+    if (tid == 0) *unit_ctr = (unsigned)NW;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     auto next_unit = [&]() {
@@ -243,8 +245,10 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_kernel(const WinoArgs
     };
 
     int cur = wave, nxt = next_unit();
-    dma_chunk(cur, 0);
-    dma_chunk(cur, 1);
+    if (cur < total_units) {
+        dma_chunk(cur, 0);
+        dma_chunk(cur, 1);
+    }
 
     f32x4 acc[16][NCB];
     while (cur < total_units) {
@@ -533,14 +537,14 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
     return (long long)B * H * W >= min_pixels;      // (one workgroup of eight waves per CU: small launches stay with the direct tiles)
 }
 
-template <int NCB, int NCH, bool EM>
-static int launch_wino(WinoArgs& a, hipStream_t st) {
-    constexpr int lds = NCH * 8 * NCB * 64 * 16 + 8 * WN_RING_BYTES + 16;
+template <int NCB, int NCH, bool EM, int NW>
+static int launch_wino_nw(WinoArgs& a, hipStream_t st) {
+    constexpr int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16;
     static bool attr_dev[YNET_MAX_DEV] = {false};
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
     if (!attr_dev[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH, EM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH, EM, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -549,8 +553,21 @@ static int launch_wino(WinoArgs& a, hipStream_t st) {
     }
     int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
     if (grid >= 8) grid &= ~7;          // (the XCD-aware walk wants a multiple of 8)
-    hipLaunchKernelGGL((conv_wino_kernel<NCB, NCH, EM>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    hipLaunchKernelGGL((conv_wino_kernel<NCB, NCH, EM, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
     return ynet_check_launch("conv2d_winograd");
+}
+
+// 16 output channels per workgroup leave 64 accumulator registers per wave: twelve waves (three per SIMD) fit -- measured SLOWER than eight
+// (32 -> 16 @ 256^2, B 32: 123.5 against 130.5 TFLOP/s direct-equivalent, the captured C2 step 7.73 against 7.65 ms): the 16-channel form does
+// the same patch reads, input transform and staging per k-step for half the MFMAs, and a third wave adds to that contention, not to the
+// pipes' work.  Left as a switch (YNET_WINOGRAD_W12=1).
+template <int NCB, int NCH, bool EM>
+static int launch_wino(WinoArgs& a, hipStream_t st) {
+    static const int w12 = getenv("YNET_WINOGRAD_W12") ? atoi(getenv("YNET_WINOGRAD_W12")) : 0;
+    if constexpr (NCB == 1) {
+        if (w12) return launch_wino_nw<NCB, NCH, EM, 12>(a, st);
+    }
+    return launch_wino_nw<NCB, NCH, EM, 8>(a, st);
 }
 
 extern "C" {
