@@ -152,8 +152,20 @@ class ConvTimer:
 
     def __init__(self, ops):
         self.ops, self.orig, self.rec = ops, ops.conv2d_raw, []
+        self.orig_wino = ops.conv2d_winograd_raw
 
     def __enter__(self):
+        def timed_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None):
+            # one Winograd launch (a convolution with 48 / 64 outputs is two of them): its own event pair, rocprof's kernel name
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=relu_of)
+            e1.record()
+            name = f"conv_wino_kernel<{cout // 16}, {cin // 8}, {'true' if relu_of is not None else 'false'}, 8>"
+            self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin + cout * (2 if relu_of is not None else 1)),
+                             (B, H, W, cin, cout, 3, False)))
+        self.ops.conv2d_winograd_raw = timed_wino
+
         def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -171,11 +183,10 @@ class ConvTimer:
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             cc = plan >> 21                       # input channels per staged chunk (the kernel's CC template argument)
-            if took is not None and str(took).startswith("winograd"):
-                # (csrc/conv_wino.hip; the tag carries the template arguments of each launch -- 48 / 64 output channels are two launches)
-                kern, targs = str(took).split(":")
-                fam = "conv_wino_cat_kernel" if kern == "winograd_cat" else "conv_wino_kernel"
-                name = " + ".join(f"{fam}<{', '.join(t.split(','))}>" for t in targs.split("+"))
+            if took is not None and str(took).startswith("winograd:"):
+                return                            # (timed launch by launch in timed_wino)
+            if took is not None and str(took).startswith("winograd_cat"):
+                name = "conv_wino_cat_kernel<2, false>"      # (csrc/conv_wino.hip: concatenated sources, 4-channel chunks)
             elif dma:
                 if cc > 8:                        # launch_dma_small: the deep chunks are for plain launches with enough input channels
                     if relu_of or pooled or bits_out or relu_bits:
@@ -196,6 +207,7 @@ class ConvTimer:
 
     def __exit__(self, *a):
         self.ops.conv2d_raw = self.orig
+        self.ops.conv2d_winograd_raw = self.orig_wino
 
     def layers(self, steps):
         """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, TFLOP/s]."""
