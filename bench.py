@@ -153,6 +153,7 @@ class ConvTimer:
     def __init__(self, ops):
         self.ops, self.orig, self.rec = ops, ops.conv2d_raw, []
         self.orig_wino = ops.conv2d_winograd_raw
+        self.orig_cat = ops.conv2d_winograd_cat_raw
 
     def __enter__(self):
         def timed_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None):
@@ -165,6 +166,17 @@ class ConvTimer:
             self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin + cout * (2 if relu_of is not None else 1)),
                              (B, H, W, cin, cout, 3, False)))
         self.ops.conv2d_winograd_raw = timed_wino
+
+        def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig_cat(srcs, u, bias, dst, B, H, W, relu, addend=addend)
+            e1.record()
+            cin = sum(s_[1] for s_ in srcs)
+            name = f"conv_wino_cat_kernel<2, {'true' if addend is not None else 'false'}>"
+            self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * 32 * 9, 4.0 * B * H * W * (cin + 32 * (2 if addend is not None else 1)),
+                             (B, H, W, cin, 32, 3, False)))
+        self.ops.conv2d_winograd_cat_raw = timed_cat
 
         def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -183,11 +195,9 @@ class ConvTimer:
             plan = self.ops._lib().ynet_conv2d_plan(B, H, W, cout, K)
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             cc = plan >> 21                       # input channels per staged chunk (the kernel's CC template argument)
-            if took is not None and str(took).startswith("winograd:"):
-                return                            # (timed launch by launch in timed_wino)
-            if took is not None and str(took).startswith("winograd_cat"):
-                name = "conv_wino_cat_kernel<2, false>"      # (csrc/conv_wino.hip: concatenated sources, 4-channel chunks)
-            elif dma:
+            if took is not None and str(took).startswith("winograd"):
+                return                            # (timed launch by launch in timed_wino / timed_cat, under rocprof's kernel names)
+            if dma:
                 if cc > 8:                        # launch_dma_small: the deep chunks are for plain launches with enough input channels
                     if relu_of or pooled or bits_out or relu_bits:
                         cc = 8
@@ -208,6 +218,7 @@ class ConvTimer:
     def __exit__(self, *a):
         self.ops.conv2d_raw = self.orig
         self.ops.conv2d_winograd_raw = self.orig_wino
+        self.ops.conv2d_winograd_cat_raw = self.orig_cat
 
     def layers(self, steps):
         """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, TFLOP/s]."""

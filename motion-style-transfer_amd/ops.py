@@ -358,6 +358,19 @@ def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=Non
                                      cin, cout, B, H, W, 1 if relu else 0, _stream()), lib)
 
 
+def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None):
+    """srcs: [(ptr, channels, batch_stride)] (at most three, 56 padded channels); dst: (ptr, batch_stride), 32 channels; u: the filter in
+    ynet_winograd_filter_cat's layout for these sources; addend: (ptr, image_stride, modulus) of a term added in front of the ReLU."""
+    lib = _lib()
+    sp, sc, sb = _arrays(srcs)
+    b = bias.data_ptr() if bias is not None else None
+    if addend is None:
+        L.check(lib.ynet_conv2d_winograd_cat(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], 32, B, H, W, 1 if relu else 0, _stream()), lib)
+    else:
+        L.check(lib.ynet_conv2d_winograd_cat_add(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], 32, B, H, W, 1 if relu else 0,
+                                                 addend[0], addend[1], addend[2], _stream()), lib)
+
+
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None.  pooled: (ptr,
@@ -426,6 +439,30 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
         want = [d for d in dsts if d[0] is not None]
         if len(want) == 1 and len(dsts) == 1 and want[0][1] == 32 and want[0][0] % 8 == 0 and want[0][2] % 2 == 0:
             cs = (ctypes.c_int * len(srcs))(*[s_[1] for s_ in srcs])
+            first = srcs[0]
+            rest_c = [first[1] - 32] + [s_[1] for s_ in srcs[1:]] if first[1] >= 32 else None
+            rest_c = [c for c in rest_c if c > 0] if rest_c is not None else None
+            if (not lib.ynet_conv2d_winograd_cat_supported(B, H, W, cs, len(srcs), 32, K) and rest_c and len(rest_c) <= 3
+                    and lib.ynet_conv2d_winograd_supported(B, H, W, 32, 32, K)
+                    and lib.ynet_conv2d_winograd_cat_supported(B, H, W, (ctypes.c_int * len(rest_c))(*rest_c), len(rest_c), 32, K)):
+                # 57 .. 88 input channels (the 64 / 65 -> 32 layers at 128^2): two launches -- the first 32 channels into the destination,
+                # then the rest with the destination as the additive term in front of bias and ReLU (read and written by the same lane)
+                cache, what = wino
+                key = "wino_split_" + what
+                ent = cache.get(key)
+                rc = (ctypes.c_int * len(rest_c))(*rest_c)
+                if ent is None or ent[0] is not wp or ent[3] != tuple(rest_c):
+                    cols_pad = -(-32 // 64) * 64
+                    u0 = winograd_filter(wp, 32, 32, 0, 32)
+                    u1 = torch.empty(lib.ynet_winograd_filter_cat_floats(rc, len(rest_c), 32), device=wp.device, dtype=torch.float32)
+                    L.check(lib.ynet_winograd_filter_cat(wp.data_ptr() + 4 * 32 * 9 * cols_pad, u1.data_ptr(), rc, len(rest_c), 32, 0, 32, _stream()), lib)
+                    ent = cache[key] = (wp, u0, u1, tuple(rest_c))
+                HW = H * W
+                conv2d_winograd_raw((first[0], first[2]), ent[1], None, (want[0][0], want[0][2]), 32, 32, B, H, W, False)
+                rsrcs = ([(first[0] + 4 * 32 * HW, first[1] - 32, first[2])] if first[1] > 32 else []) + list(srcs[1:])
+                conv2d_winograd_cat_raw(rsrcs, ent[2], bias, (want[0][0], want[0][2]), B, H, W, relu, addend=(want[0][0], want[0][2], 0))
+                wino_stats["launches"] += 2
+                return "winograd_cat:2,true"
             if lib.ynet_conv2d_winograd_cat_supported(B, H, W, cs, len(srcs), 32, K):
                 cache, what = wino
                 key = "wino_cat_" + what
@@ -434,8 +471,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                     u = torch.empty(lib.ynet_winograd_filter_cat_floats(cs, len(srcs), 32), device=wp.device, dtype=torch.float32)
                     L.check(lib.ynet_winograd_filter_cat(wp.data_ptr(), u.data_ptr(), cs, len(srcs), 32, 0, 32, _stream()), lib)
                     ent = cache[key] = (wp, u, tuple(cs))
-                L.check(lib.ynet_conv2d_winograd_cat(sp, sc, sb, len(srcs), ent[1].data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                     want[0][0], want[0][2], 32, B, H, W, 1 if relu else 0, _stream()), lib)
+                conv2d_winograd_cat_raw(srcs, ent[1], bias, (want[0][0], want[0][2]), B, H, W, relu)
                 wino_stats["launches"] += 1
                 return "winograd_cat:2,false"
     dp, dc, db = _arrays(dsts)
@@ -490,9 +526,8 @@ def conv2d_shared_term(x, x_times: int, rest, weight, bias, relu: bool, cache: d
             and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs) and term.data_ptr() % 8 == 0
             and lib.ynet_conv2d_winograd_cat_supported(B, H, W, (ctypes.c_int * len(descs))(*ent[2]), len(descs), cout, k)):
         # the Winograd form of the same launch (its filter was transformed by rest_filter_winograd, before the sweep's streams fork)
-        L.check(lib.ynet_conv2d_winograd_cat_add(sp, sc, sb, len(descs), ent[1].data_ptr(), bias.detach().data_ptr() if bias is not None else None,
-                                                 y.data_ptr(), cout * H * W, cout, B, H, W, 1 if relu else 0, term.data_ptr(), cout * H * W,
-                                                 term.shape[0], _stream()), lib)
+        conv2d_winograd_cat_raw(descs, ent[1], bias.detach() if bias is not None else None, (y.data_ptr(), cout * H * W), B, H, W, relu,
+                                addend=(term.data_ptr(), cout * H * W, term.shape[0]))
         wino_stats["launches"] += 1
         return y
     L.check(lib.ynet_conv2d_add(sp, sc, sb, None, len(descs), cache["rest_wp"].data_ptr(),
