@@ -167,14 +167,14 @@ class ConvTimer:
                              (B, H, W, cin, cout, 3, False)))
         self.ops.conv2d_winograd_raw = timed_wino
 
-        def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None):
+        def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig_cat(srcs, u, bias, dst, B, H, W, relu, addend=addend)
+            self.orig_cat(srcs, u, bias, dst, B, H, W, relu, addend=addend, pool=pool)
             e1.record()
             cin = sum(s_[1] for s_ in srcs)
-            name = f"conv_wino_cat_kernel<2, {'true' if addend is not None else 'false'}>"
-            self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * 32 * 9, 4.0 * B * H * W * (cin + 32 * (2 if addend is not None else 1)),
+            name = f"conv_wino_cat_kernel<2, {2 if addend is not None else (3 if pool is not None else 0)}>"      # (epilogue: 0 plain, 2 additive term, 3 pooled copy)
+            self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * 32 * 9, 4.0 * B * H * W * (cin + 32 * (2 if addend is not None else (1.25 if pool is not None else 1))),
                              (B, H, W, cin, 32, 3, False)))
         self.ops.conv2d_winograd_cat_raw = timed_cat
 

@@ -139,6 +139,10 @@ int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const lo
 int ynet_conv2d_winograd_cat_add(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                                  long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod,
                                  void* stream);
+/*   ynet_conv2d_winograd_cat_pool  ... + the 2 x 2 max-pooled copy of the output [B][cout][H/2][W/2] from the same launch, as ynet_conv2d_pool (the encoder's
+ *                               conv + ReLU in front of MaxPool2d(2, 2), models/ynet.py:196-213): a lane of the Winograd tiling holds exactly the block it pools. */
+int ynet_conv2d_winograd_cat_pool(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                                  long long dst_bs, float* pooled, long long pooled_bs, int cout, int B, int H, int W, int relu, void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,

@@ -61,14 +61,16 @@ __device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, 
 
 // Y = A^T M A packed over channel pairs, the bias through M[1][1], ReLU, 8-byte stores at static-lane + scalar offsets.  EPI 1: the
 // activation of the block's 2 x 2 x 4 outputs per lane is fetched before the transform it gates (y = act > 0 ? y : 0); EPI 2: a
-// precomputed term is fetched the same way and added in front of the ReLU (y = relu(conv + bias + addend))
+// precomputed term is fetched the same way and added in front of the ReLU (y = relu(conv + bias + addend)); EPI 3: the 2 x 2 max-pooled
+// copy of the output is written too -- a lane holds exactly the 2 x 2 block it pools (rm / sm_t: the pooled tensor, stp: the lane's
+// static offset there, HW / 4 pixels per plane)
 template <int NCB, int EPI>
 __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2 (&bias2)[NCB][2], float floor_v, __amdgpu_buffer_rsrc_t ry,
-                                              __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW) {
+                                              __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW, unsigned stp = 0) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         u32x2 mk[2][2][2];
-        if constexpr (EPI != 0) {
+        if constexpr (EPI == 1 || EPI == 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -110,6 +112,11 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                 const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), ry, st0, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), ry, st1, so, 0);
+                if constexpr (EPI == 3) {      // max over the block, NaN if any element is (torch's max_pool2d)
+                    float pm = fmaxf(fmaxf(row0[0], row0[1]), fmaxf(row1[0], row1[1]));
+                    if (__builtin_isunordered(row0[0], row0[1]) || __builtin_isunordered(row1[0], row1[1])) pm = __builtin_nanf("");
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pm), rm, stp, sm_t + (unsigned)((cb * 16 + 2 * h + k) * (HW >> 2) * 4), 0);
+                }
             }
         }
     }
@@ -340,13 +347,16 @@ struct WinoCatArgs {
     float* y;
     long long y_bs;
     int B, H, W, relu, ntiles;
-    const float* addend;       // ADD: [images] x (addend_bs floats), cout planes, image b % addend_bmod (b when the modulus is 0): y = relu(conv + bias + addend)
+    const float* addend;       // EPI 2: [images] x (addend_bs floats), cout planes, image b % addend_bmod (b when the modulus is 0): y = relu(conv + bias + addend)
     long long addend_bs;
     int addend_bmod;
+    float* pool;               // EPI 3: [B] x (pool_bs floats), cout planes of (H / 2) x (W / 2): the 2 x 2 max-pooled copy of y
+    long long pool_bs;
 };
 
-template <int NCB, bool ADD>
+template <int NCB, int EPI>
 __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const WinoCatArgs a) {
+    constexpr bool ADD = EPI == 2;
     extern __shared__ f32x4 smem[];
     constexpr int WQ = 4 * NCB * 64;      // units of one chunk's filters: [4 quads of (xi,nu)][NCB][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -370,8 +380,10 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u), 0, wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(((long long)(a.B - 1) * a.y_bs + (long long)NCB * 16 * HW) * 4), 0x00020000);
     const int add_images = a.addend_bmod > 0 ? a.addend_bmod : a.B;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? a.addend : a.y), 0,
-                                                                        (unsigned)(((long long)(add_images - 1) * (ADD ? a.addend_bs : a.y_bs) + (long long)NCB * 16 * HW) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra =
+        EPI == 3 ? __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, (unsigned)(((long long)(a.B - 1) * a.pool_bs + (long long)NCB * 16 * (HW >> 2)) * 4), 0x00020000)
+                 : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? a.addend : a.y), 0,
+                                                     (unsigned)(((long long)(add_images - 1) * (ADD ? a.addend_bs : a.y_bs) + (long long)NCB * 16 * HW) * 4), 0x00020000);
 
     const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
     const int per_xcd = (a.ntiles + 7) >> 3;
@@ -396,6 +408,7 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
 #pragma unroll
         for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bias2[cb][h]));
     const unsigned st0 = (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
+    const unsigned stp = (unsigned)((4 * kq * (HW >> 2) + n) * 4);      // (pooled copy: one float per lane and channel)
 
     // all transformed filters -> LDS, once (nchunks * WQ units, 512 per instruction); the workgroup's unit counter
     for (int j = 0; j < nchunks * WQ / WN_THREADS; ++j)
@@ -477,8 +490,9 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
             const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
             const int ab = a.addend_bmod > 0 ? b % a.addend_bmod : b;
-            const unsigned sa_t = (unsigned)(((long long)ab * a.addend_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
-            wino_epilogue<NCB, ADD ? 2 : 0>(acc, bias2, floor_v, ry, ra, st0, st1, so_t, sa_t, HW);
+            const unsigned sa_t = EPI == 3 ? (unsigned)(((long long)b * a.pool_bs + (ty * (WN_TH / 2) + (cur & 7)) * (W >> 1) + tx * (WN_TW / 2)) * 4)
+                                           : (unsigned)(((long long)ab * a.addend_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            wino_epilogue<NCB, EPI>(acc, bias2, floor_v, ry, ra, st0, st1, so_t, sa_t, HW, stp);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -632,8 +646,8 @@ int ynet_winograd_filter_cat(const float* wp, float* u, const int* src_c, int ns
 }
 
 static int wino_cat_launch(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
-                           long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod, void* stream,
-                           const char* what) {
+                           long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod, float* pool,
+                           long long pool_bs, void* stream, const char* what) {
     YNET_REQUIRE(src && src_c && src_bs && u && dst, "%s: null pointer", what);
     YNET_REQUIRE(wino_cat_ok(B, H, W, src_c, nsrc, cout, 3), "%s: shape B=%d %dx%d -> %d with %d sources is not served (ask ynet_conv2d_winograd_cat_supported)", what,
                  B, H, W, cout, nsrc);
@@ -656,6 +670,11 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
                          ((long long)(images - 1) * addend_bs + cout * HW) * 4 < (1ll << 32),
                      "%s: the additive term must be 8-byte aligned, its image stride not smaller than the image, below 4 GB, its modulus not negative", what);
     }
+    if (pool != nullptr)
+        YNET_REQUIRE(addend == nullptr && (reinterpret_cast<uintptr_t>(pool) & 3) == 0 && pool_bs >= cout * (HW / 4) && ((long long)(B - 1) * pool_bs + cout * (HW / 4)) * 4 < (1ll << 32),
+                     "%s: the pooled copy must have a batch stride not smaller than its image, below 4 GB, and excludes an additive term", what);
+    a.pool = pool;
+    a.pool_bs = pool_bs;
     a.nsrc = nsrc;
     a.nchunks = wino_cat_padded(src_c, nsrc) / 4;
     a.u = reinterpret_cast<const f32x4*>(u);
@@ -672,8 +691,9 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
     if (!attr_dev[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -682,21 +702,28 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
     }
     int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
     if (grid >= 8) grid &= ~7;
-    if (addend != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, true>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv_wino_cat_kernel<2, false>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    if (addend != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 2>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    else if (pool != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 3>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_wino_cat_kernel<2, 0>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     return ynet_check_launch(what);
 }
 
 int ynet_conv2d_winograd_cat(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                              long long dst_bs, int cout, int B, int H, int W, int relu, void* stream) {
-    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, cout, B, H, W, relu, nullptr, 0, 0, stream, "conv2d_winograd_cat");
+    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, cout, B, H, W, relu, nullptr, 0, 0, nullptr, 0, stream, "conv2d_winograd_cat");
 }
 
 int ynet_conv2d_winograd_cat_add(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                                  long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod,
                                  void* stream) {
     YNET_REQUIRE(addend != nullptr, "conv2d_winograd_cat_add: the additive term is null");
-    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, cout, B, H, W, relu, addend, addend_bs, addend_bmod, stream, "conv2d_winograd_cat_add");
+    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, cout, B, H, W, relu, addend, addend_bs, addend_bmod, nullptr, 0, stream, "conv2d_winograd_cat_add");
+}
+
+int ynet_conv2d_winograd_cat_pool(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                                  long long dst_bs, float* pooled, long long pooled_bs, int cout, int B, int H, int W, int relu, void* stream) {
+    YNET_REQUIRE(pooled != nullptr, "conv2d_winograd_cat_pool: the pooled output is null");
+    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, cout, B, H, W, relu, nullptr, 0, 0, pooled, pooled_bs, stream, "conv2d_winograd_cat_pool");
 }
 
 static int wino_launch_any(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, const float* emask,

@@ -358,13 +358,17 @@ def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=Non
                                      cin, cout, B, H, W, 1 if relu else 0, _stream()), lib)
 
 
-def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None):
+def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None):
     """srcs: [(ptr, channels, batch_stride)] (at most three, 56 padded channels); dst: (ptr, batch_stride), 32 channels; u: the filter in
-    ynet_winograd_filter_cat's layout for these sources; addend: (ptr, image_stride, modulus) of a term added in front of the ReLU."""
+    ynet_winograd_filter_cat's layout for these sources; addend: (ptr, image_stride, modulus) of a term added in front of the ReLU;
+    pool: (ptr, batch_stride) of the 2 x 2 max-pooled copy of the output, written by the same launch."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
     b = bias.data_ptr() if bias is not None else None
-    if addend is None:
+    if pool is not None:
+        L.check(lib.ynet_conv2d_winograd_cat_pool(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], pool[0], pool[1], 32, B, H, W,
+                                                  1 if relu else 0, _stream()), lib)
+    elif addend is None:
         L.check(lib.ynet_conv2d_winograd_cat(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], 32, B, H, W, 1 if relu else 0, _stream()), lib)
     else:
         L.check(lib.ynet_conv2d_winograd_cat_add(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], 32, B, H, W, 1 if relu else 0,
@@ -380,7 +384,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
     wino: (the layer's filter cache, "fwd" | "dgrad") -- a plain launch (one source, one destination, no mask, no epilogue variant)
     of a shape ynet_conv2d_winograd_supported admits takes the Winograd F(2x2, 3x3) kernel, its transformed filter kept in that
     cache next to the packed one; returns "winograd:<NCB>,<NCH>,<EM>[+...]" (one group per launch: the template arguments of
-    conv_wino_kernel) or "winograd_cat:2,false" then, None otherwise."""
+    conv_wino_kernel) or "winograd_cat:2,<epilogue>" then, None otherwise."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
     if bits_out is not None:
@@ -398,6 +402,21 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
     if pooled is not None:
         if len(dsts) != 1 or mask is not None or relu_of is not None or _bmods(srcs) is not None:
             raise ValueError("conv2d_raw: pooled is for a forward convolution with one destination")
+        if (wino is not None and _wino_allowed and K == 3 and dsts[0][1] == 32 and dsts[0][0] % 8 == 0 and dsts[0][2] % 2 == 0
+                and all(len(s_) == 3 and s_[0] % 16 == 0 and s_[2] % 4 == 0 for s_ in srcs)):
+            cs = (ctypes.c_int * len(srcs))(*[s_[1] for s_ in srcs])
+            if lib.ynet_conv2d_winograd_cat_supported(B, H, W, cs, len(srcs), 32, K):
+                # the encoder's conv + ReLU in front of a max-pool: the Winograd launch writes the pooled copy itself (a lane holds the block)
+                cache, what = wino
+                key = "wino_cat_" + what
+                ent = cache.get(key)
+                if ent is None or ent[0] is not wp or ent[2] != tuple(cs):
+                    u = torch.empty(lib.ynet_winograd_filter_cat_floats(cs, len(srcs), 32), device=wp.device, dtype=torch.float32)
+                    L.check(lib.ynet_winograd_filter_cat(wp.data_ptr(), u.data_ptr(), cs, len(srcs), 32, 0, 32, _stream()), lib)
+                    ent = cache[key] = (wp, u, tuple(cs))
+                conv2d_winograd_cat_raw(srcs, ent[1], bias, (dsts[0][0], dsts[0][2]), B, H, W, relu, pool=pooled)
+                wino_stats["launches"] += 1
+                return "winograd_cat:2,3"
         L.check(lib.ynet_conv2d_pool(sp, sc, sb, len(srcs), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                      dsts[0][0], dsts[0][1], dsts[0][2], pooled[0], pooled[1], B, H, W, K, 1 if relu else 0, _stream()), lib)
         return
@@ -462,7 +481,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 rsrcs = ([(first[0] + 4 * 32 * HW, first[1] - 32, first[2])] if first[1] > 32 else []) + list(srcs[1:])
                 conv2d_winograd_cat_raw(rsrcs, ent[2], bias, (want[0][0], want[0][2]), B, H, W, relu, addend=(want[0][0], want[0][2], 0))
                 wino_stats["launches"] += 2
-                return "winograd_cat:2,true"
+                return "winograd_cat:2,2"
             if lib.ynet_conv2d_winograd_cat_supported(B, H, W, cs, len(srcs), 32, K):
                 cache, what = wino
                 key = "wino_cat_" + what
@@ -473,7 +492,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                     ent = cache[key] = (wp, u, tuple(cs))
                 conv2d_winograd_cat_raw(srcs, ent[1], bias, (want[0][0], want[0][2]), B, H, W, relu)
                 wino_stats["launches"] += 1
-                return "winograd_cat:2,false"
+                return "winograd_cat:2,0"
     dp, dc, db = _arrays(dsts)
     nws, ws = 0, None
     if B * H * W <= 65536:                                       # small maps only (see ynet_conv2d_workspace_floats)

@@ -713,6 +713,26 @@ def test_winograd_convolution_over_concatenated_sources(dev, case):
     assert e_w <= 1.5 * e_d + 1e-7, (e_w, e_d)
 
 
+@pytest.mark.parametrize("case", [(8, 256, 256, [6, 8]), (16, 128, 128, [32])], ids=str)
+def test_winograd_convolution_with_the_pooled_copy(dev, case):
+    """ynet_conv2d_winograd_cat_pool: conv + ReLU and its 2 x 2 max-pooled copy from one launch (the encoder's layers in front of a
+    MaxPool2d: cat(scene one-hot 6 -- one image for the batch --, observed maps 8) -> 32 at 256^2, 32 -> 32 at 128^2); the pooled copy is
+    bit-identical to max_pool2d of the full-resolution output of the same launch."""
+    ops = pkg("ops")
+    B, H, W, cs = case
+    cin = sum(cs)
+    xs = [torch.relu(rnd(B if i else 1, c, H, W, seed=10 + i)).to(dev) if len(cs) > 1 else torch.relu(rnd(B, c, H, W, seed=10)).to(dev) for i, c in enumerate(cs)]
+    srcs = [(x.data_ptr(), c, 0 if x.shape[0] == 1 and B > 1 else c * H * W) for x, c in zip(xs, cs)]
+    w, bias = rnd(32, cin, 3, 3, seed=2, scale=0.2).to(dev), rnd(32, seed=3).to(dev)
+    wp = ops.pack_weight(w, 0)
+    y, yp = torch.full((B, 32, H, W), float("nan"), device=dev), torch.full((B, 32, H // 2, W // 2), float("nan"), device=dev)
+    assert ops.conv2d_raw(srcs, None, wp, bias, [(y.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True, pooled=(yp.data_ptr(), 32 * (H // 2) * (W // 2)),
+                          wino=({}, "fwd")).startswith("winograd_cat")
+    ref = torch.relu(F.conv2d(torch.cat([x.expand(B, -1, -1, -1) for x in xs], 1), w, bias, padding=1))
+    close(y, ref, rtol=1e-4, scale_rel=2e-6, msg="output vs torch")
+    assert torch.equal(yp, F.max_pool2d(y, 2, 2))
+
+
 def test_winograd_shared_skip_term_launch(dev):
     """evaluate()'s per-sample launch of a decoder level's first convolution, relu(conv(cat(up, way-point map), W_rest) + b + term[b % Bs])
     with the batch-shared skip-feature term precomputed (ops.conv2d_shared_term): the Winograd form (ynet_conv2d_winograd_cat_add) against

@@ -103,6 +103,8 @@ int main() {
         EXPECT_REJECT(ynet_conv2d_winograd_cat(s3, cat3, bs3, 3, nullptr, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr));          // no filters
         EXPECT_REJECT(ynet_conv2d_winograd_cat_add(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr, 32 * 65536, 4, nullptr));   // no additive term
         EXPECT_REJECT(ynet_conv2d_winograd_cat_add(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, cfp, 32 * 65536, -1, nullptr));      // negative modulus
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_pool(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, nullptr, 32 * 16384, 32, 32, 256, 256, 1, nullptr));   // no pooled output
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_pool(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, fp, 16 * 16384, 32, 32, 256, 256, 1, nullptr));        // pooled stride too small
     }
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, nullptr, 32 * 65536, 32, 32, 32, 256, 256, nullptr));   // no activation
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, cfp, 16 * 65536, 32, 32, 32, 256, 256, nullptr));       // activation stride too small
