@@ -102,7 +102,7 @@ int ynet_conv2d_dgrad_relu_bits(const float* dy, int dy_c, long long dy_bs, cons
 /* The Winograd F(2x2, 3x3) generation of the 3x3 convolution (csrc/conv_wino.hip; round 4): 2.25x fewer fp32 MFMAs than the implicit
  * GEMM behind ynet_conv2d, fp32 throughout -- results differ from ynet_conv2d's by rounding only (the error against fp64 is smaller:
  * fewer additions reach an accumulator).  One source, one destination, no mask / epilogue variant; serves
- *   K = 3, cin in {16, 32}, cout in {16, 32}, H % 16 == 0, W % 32 == 0, B * H * W >= 128 * 128 * 16   (ynet_conv2d_winograd_supported)
+ *   K = 3, cin in {16, 32}, cout in {16, 32}, H % 16 == 0, W % 32 == 0, B * H * W >= 128 * 128 * 8   (ynet_conv2d_winograd_supported)
  * i.e. the plain large-map convolutions and data gradients of both decoders (models/ynet.py:196,206: Conv2d(3x3) + ReLU; their
  * convolution_backward -> grad_input).  Replaces the same ATen calls as ynet_conv2d.
  *   ynet_winograd_filter        u = G g G^T of every (cout, cin) pair in MFMA fragment order, from a packed filter of ynet_pack_weight

@@ -547,7 +547,7 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
     if (!on || K != 3 || B <= 0) return false;
     if (H % WN_TH || W % WN_TW || H < WN_TH || W < WN_TW) return false;
     if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return false;
-    static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 16;
+    static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 8;      // (round 4: 16 -> 8 -- batch 10 at 128^2 is 320 tiles: 3.15 -> 3.00 ms per step there, nothing lost at batch 32)
     return (long long)B * H * W >= min_pixels;      // (one workgroup of eight waves per CU: small launches stay with the direct tiles)
 }
 
@@ -620,7 +620,7 @@ static bool wino_cat_ok(int B, int H, int W, const int* src_c, int nsrc, int cou
         if (src_c[i] <= 0) return false;
     const int nch = wino_cat_padded(src_c, nsrc) / 4;
     if (nch < 2 || nch > 14) return false;          // 14 chunks of 8 KB of filters + eight 5 KB rings: 156 KB of LDS
-    static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 16;
+    static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 8;      // (round 4: 16 -> 8 -- batch 10 at 128^2 is 320 tiles: 3.15 -> 3.00 ms per step there, nothing lost at batch 32)
     return (long long)B * H * W >= min_pixels;
 }
 

@@ -852,11 +852,14 @@ def test_relu_backward_applied_by_upsampling_and_by_the_next_data_gradient(dev):
     g = F.relu(F.conv2d(F.relu(F.conv2d(xc, w0c, padding=1)), w1c, padding=1))
     F.conv2d(F.interpolate(g, scale_factor=2, mode="bilinear", align_corners=False), w2, padding=1).square().sum().backward()
     got = {}
-    for on in (True, False):
-        old = ops._premask_allowed
-        ops._premask_allowed = on
+    # wino: with the Winograd generation (this shape is served by it) conv1's data gradient is ynet_conv2d_winograd_dgrad_relu, which reads conv0's
+    # float activation -- no 1-bit mask --; without it the implicit GEMM takes the 1-bit form.  The producer-side masks work either way.
+    for on, wino in ((True, False), (False, False), (True, True)):
+        old, old_w = ops._premask_allowed, ops._wino_allowed
+        ops._premask_allowed, ops._wino_allowed = on, wino
         ops.premask_stats["unmasked_backwards"] = 0
         ops.premask_stats["bit_masks"] = 0
+        n_w = ops.wino_stats["launches"]
         try:
             with ops.fold_skip_gradients():
                 xd, w0d, w1d = x.to(dev).requires_grad_(True), w0.to(dev).requires_grad_(True), w1.to(dev).requires_grad_(True)
@@ -865,8 +868,14 @@ def test_relu_backward_applied_by_upsampling_and_by_the_next_data_gradient(dev):
                 gd = ops.conv2d(ops.conv2d(xd, w0d, None, True, {}, bits=True), w1d, None, True, {})
                 ops.conv2d(ops.upsample2x(gd), w2.to(dev), None, False, {}).square().sum().backward()
         finally:
-            ops._premask_allowed = old
+            ops._premask_allowed, ops._wino_allowed = old, old_w
         assert ops.premask_stats["unmasked_backwards"] == (2 if on else 0)
+        if wino:
+            assert ops.premask_stats["bit_masks"] == 0 and ops.wino_stats["launches"] - n_w >= 2      # (conv1's forward and its masked data gradient at least)
+            close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg="dx (Winograd launches)")
+            close(w0d.grad, w0c.grad, rtol=1e-4, scale_rel=1e-5, msg="dW0 (Winograd launches)")
+            close(w1d.grad, w1c.grad, rtol=1e-4, scale_rel=1e-5, msg="dW1 (Winograd launches)")
+            continue
         assert ops.premask_stats["bit_masks"] == (1 if (on and ops._relu_bits_allowed) else 0)
         assert not ops._premasked
         close(xd.grad, xc.grad, rtol=1e-4, scale_rel=2e-6, msg=f"dx (premask={on})")
