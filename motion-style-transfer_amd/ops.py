@@ -1033,7 +1033,7 @@ def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, s
     parts = [p.expand() if isinstance(p, BatchExpand) else p for p in _parts(x)]      # (a fresh expand node per consumer)
     # wino: the plain 16 / 32-channel large-map launches take the Winograd generation (conv2d_raw).  Its results differ from the
     # implicit GEMM's by fp32 rounding that is uncorrelated with the reference's own (the implicit GEMM sums in nearly the reference's
-    # order).  Measured against the CPU oracle (tools/wino_margin.py): a training step's loss / ADE / FDE / per-trajectory read-outs
+    # order).  Measured against the CPU oracle (tests/wino_margin.py): a training step's loss / ADE / FDE / per-trajectory read-outs
     # and gradients deviate exactly as much with it as without; in evaluate()'s K-sample sweep every trajectory's ADE / FDE does too
     # (max 6e-5 / 3e-5 either way), while single coordinates of single goal samples -- 0.3 % of them, where the decoded heat-map is
     # diffuse -- move by up to 5e-3 px instead of 4e-5.  YNET_WINOGRAD_EVAL=0 keeps evaluate() on the implicit GEMM.

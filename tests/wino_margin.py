@@ -1,7 +1,7 @@
 """How far a training step at the headline batch sizes moves against the CPU oracle with and without the Winograd convolutions
 (development aid; the checks themselves are tests/test_gpu_headline.py): prints the largest deviation of the loss, the batch ADE / FDE,
 every trajectory's read-out and the gradients for the chosen configuration with ops._wino_allowed on and off.
-    gpurun --timeout 900 -- 'python tools/wino_margin.py C2_B32 C4_B16'
+    gpurun --timeout 900 -- 'python tests/wino_margin.py C2_B32 C4_B16'
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # (lives in tests/: it runs the CPU oracle, which only tests / smoke / bench's baseline leg may)
 import test_gpu_headline as T       # noqa: E402
 from conftest import build_model, pkg      # noqa: E402
 from oracle import ynet_oracle as O        # noqa: E402
@@ -58,7 +58,7 @@ if __name__ == "__main__" and (len(sys.argv) < 2 or sys.argv[1] != "sweep"):
 
 def sweep(K=20):
     """The C5 sweep (tests/test_gpu_headline.py::test_eval_sweep_at_headline_batch_matches_oracle) with the Winograd kernels forced on
-    under no_grad, and off: python tools/wino_margin.py sweep"""
+    under no_grad, and off: python tests/wino_margin.py sweep"""
     import pandas as pd      # noqa: F401
     torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
     dev = torch.device("cuda:0")
