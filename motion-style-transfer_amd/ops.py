@@ -336,6 +336,27 @@ _wino_eval = _os.environ.get("YNET_WINOGRAD_EVAL", "1") != "0"  # YNET_WINOGRAD_
 wino_stats = {"launches": 0}
 
 
+def _wino_made(entry):
+    """A Winograd filter entry just made on the current stream: remembers that stream and an event behind the transform launch."""
+    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return entry + (None, None)
+    ev = torch.cuda.Event()
+    ev.record()
+    return entry + (torch.cuda.current_stream().cuda_stream, ev)
+
+
+def _wino_ready(entry):
+    """Filters are transformed lazily at a layer's first Winograd launch -- possibly on one of evaluate()'s two sweep streams, with the
+    other stream's cache hit a few microseconds behind and no dependency on the transform: a hit from another stream waits for the
+    maker's event until that has completed (the first call of a process only; never inside a capture, which follows an eager pass)."""
+    stream, ev = entry[-2], entry[-1]
+    if ev is not None and not torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != stream and not ev.query():
+            cur.wait_event(ev)
+    return entry
+
+
 def winograd_filter(wp: torch.Tensor, cin: int, cout: int, col0: int = 0, cols_total: int = None) -> torch.Tensor:
     """The Winograd-domain form (G g G^T, MFMA fragment order) of the output channels [col0, col0 + cout) of a packed filter of
     pack_weight with cols_total output channels (ynet_winograd_filter)."""
@@ -413,7 +434,8 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 if ent is None or ent[0] is not wp or ent[2] != tuple(cs):
                     u = torch.empty(lib.ynet_winograd_filter_cat_floats(cs, len(srcs), 32), device=wp.device, dtype=torch.float32)
                     L.check(lib.ynet_winograd_filter_cat(wp.data_ptr(), u.data_ptr(), cs, len(srcs), 32, 0, 32, _stream()), lib)
-                    ent = cache[key] = (wp, u, tuple(cs))
+                    ent = cache[key] = _wino_made((wp, u, tuple(cs)))
+                _wino_ready(ent)
                 conv2d_winograd_cat_raw(srcs, ent[1], bias, (dsts[0][0], dsts[0][2]), B, H, W, relu, pool=pooled)
                 wino_stats["launches"] += 1
                 return "winograd_cat:2,3"
@@ -447,7 +469,8 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 key = "wino_%s_%d_%d" % (what, col0, n)
                 ent = cache.get(key)
                 if ent is None or ent[0] is not wp:
-                    ent = cache[key] = (wp, winograd_filter(wp, cin, n, col0, ctot))
+                    ent = cache[key] = _wino_made((wp, winograd_filter(wp, cin, n, col0, ctot)))
+                _wino_ready(ent)
                 conv2d_winograd_raw((srcs[0][0], srcs[0][2]), ent[1], None if bias is None else bias[col0:col0 + n], (ptr, bs), cin, n, B, H, W, relu,
                                     relu_of=relu_of)
                 wino_stats["launches"] += 1
@@ -475,7 +498,8 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                     u0 = winograd_filter(wp, 32, 32, 0, 32)
                     u1 = torch.empty(lib.ynet_winograd_filter_cat_floats(rc, len(rest_c), 32), device=wp.device, dtype=torch.float32)
                     L.check(lib.ynet_winograd_filter_cat(wp.data_ptr() + 4 * 32 * 9 * cols_pad, u1.data_ptr(), rc, len(rest_c), 32, 0, 32, _stream()), lib)
-                    ent = cache[key] = (wp, u0, u1, tuple(rest_c))
+                    ent = cache[key] = _wino_made((wp, u0, u1, tuple(rest_c)))
+                _wino_ready(ent)
                 HW = H * W
                 conv2d_winograd_raw((first[0], first[2]), ent[1], None, (want[0][0], want[0][2]), 32, 32, B, H, W, False)
                 rsrcs = ([(first[0] + 4 * 32 * HW, first[1] - 32, first[2])] if first[1] > 32 else []) + list(srcs[1:])
@@ -489,7 +513,8 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 if ent is None or ent[0] is not wp or ent[2] != tuple(cs):
                     u = torch.empty(lib.ynet_winograd_filter_cat_floats(cs, len(srcs), 32), device=wp.device, dtype=torch.float32)
                     L.check(lib.ynet_winograd_filter_cat(wp.data_ptr(), u.data_ptr(), cs, len(srcs), 32, 0, 32, _stream()), lib)
-                    ent = cache[key] = (wp, u, tuple(cs))
+                    ent = cache[key] = _wino_made((wp, u, tuple(cs)))
+                _wino_ready(ent)
                 conv2d_winograd_cat_raw(srcs, ent[1], bias, (want[0][0], want[0][2]), B, H, W, relu)
                 wino_stats["launches"] += 1
                 return "winograd_cat:2,0"
