@@ -18,7 +18,13 @@
 //               pitch 640 bytes = 128 (mod 256): conflict-free.  Addresses are a static per-lane offset + a scalar offset.
 //   scheduling  the two waves of a SIMD are served oldest-first, so a workgroup hands its row pairs out from a counter in LDS, one
 //               ahead of the pair being computed (a static split left the younger four waves 25 % behind).
-//   epilogue    Y = A^T M A packed over channel pairs, bias through M[1][1], ReLU, 8-byte stores.
+//   epilogue    Y = A^T M A packed over channel pairs, bias through M[1][1], ReLU, 8-byte stores; variants: through the ReLU backward of
+//               the layer below (the activation fetched at the store addresses), + a precomputed additive term, + the 2x2 max-pooled copy
+//               (a lane holds exactly the block it pools).
+//   kernels     conv_wino_kernel<NCB, NCH, EM, NW>: one source, Cin = 8 NCH in {16, 32}, Cout = 16 NCB in {16, 32}, chunks of 8 channels;
+//               conv_wino_cat_kernel<2, EPI>: up to three concatenated sources padded to multiples of 4 channels (<= 56), chunks of 4.
+//               Wider convolutions are composed by the caller (ops.conv2d_raw): output-channel slices, or a second launch that adds onto
+//               the first one's output.
 #include "ynet_common.h"
 #include <math.h>
 #include <stdlib.h>
