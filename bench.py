@@ -19,6 +19,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   cpu_baseline : the CPU oracle (torch-CPU restatement of the reference, "port") on a bounded sample.
 """
 import argparse
+import glob
 import importlib
 import json
 import os
@@ -221,21 +222,24 @@ class ConvTimer:
         self.ops.conv2d_winograd_cat_raw = self.orig_cat
 
     def layers(self, steps):
-        """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, TFLOP/s]."""
+        """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, direct-form TFLOP/s,
+        direct-form GFLOP (2 * K^2 * Cin * Cout per pixel; a conv_wino launch EXECUTES 16 / 36 of it), algorithmic bytes]."""
         torch.cuda.synchronize()
         per = len(self.rec) // steps
         out = []
         for i in range(per):
             us = sorted(self.rec[i + s * per][1].elapsed_time(self.rec[i + s * per][2]) * 1e3 for s in range(steps))[steps // 2]
-            name, _, _, fl, _, shape = self.rec[i]
-            out.append([name, list(shape), round(us, 2), round(fl / us / 1e6, 2)])
+            name, _, _, fl, by, shape = self.rec[i]
+            out.append([name, list(shape), round(us, 2), round(fl / us / 1e6, 2), round(fl / 1e9, 5), int(by)])
         return out
 
-    def summary(self):
+    def summary(self, by_shape=False):
+        """Totals per kernel name, or per LAUNCH SHAPE (kernel name, (B, H, W, cin, cout, K, masked)): one instantiation serves layers
+        of very different sizes, so a roofline fraction belongs to a shape, not to a name."""
         torch.cuda.synchronize()
         agg = {}
-        for name, e0, e1, fl, by, _shape in self.rec:
-            d = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for name, e0, e1, fl, by, shape in self.rec:
+            d = agg.setdefault((name, tuple(shape)) if by_shape else name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
@@ -669,8 +673,37 @@ def main():
             for name, e0, e1, fl, by, shape in ct.rec:
                 ms = e0.elapsed_time(e1)
                 print(f"LAYER B,H,W,cin,cout,K,mask={shape} {ms * 1e3:8.1f} us {fl / ms / 1e9:7.2f} TF/s", file=sys.stderr)
-        name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
-        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # The dominant LAUNCH SHAPE (kernel instantiation + (B, H, W, cin, cout)), not a name that mixes 27 launches of different sizes.
+        # `achieved` / `frac` count the FLOPs the matrix pipes EXECUTE (a Winograd F(2x2, 3x3) launch: 16 / 36 of the direct form's
+        # 2 * 9 * Cin * Cout per pixel), so frac <= 1 by construction; the direct-form figure (SURVEY 8d's per-unit work, what the
+        # reference computes) is kept as `direct_equiv_*`.
+        shapes = ct.summary(by_shape=True)
+        for v in shapes.values():
+            for k in ("launches", "ms", "flops", "bytes"):
+                v[k] = v[k] / n_inst
+
+        def executed_factor(kernel):
+            return 16.0 / 36.0 if kernel.startswith("conv_wino") else 1.0
+
+        def shape_entry(key, v):
+            kernel, shp = key
+            us = v["ms"] * 1e3 / v["launches"]
+            direct_tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            ex_tf = direct_tf * executed_factor(kernel)
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            return {"kernel": kernel, "shape": dict(zip(("B", "H", "W", "cin", "cout", "K", "input_masked"), shp)),
+                    "launches_per_step": int(round(v["launches"])), "avg_launch_us": round(us, 2), "ms_per_step": round(v["ms"], 4),
+                    "executed_gflop_per_launch": round(v["flops"] * executed_factor(kernel) / v["launches"] / 1e9, 4),
+                    "achieved": round(ex_tf, 2), "frac": round(ex_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "direct_equiv_gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 4),
+                    "direct_equiv_achieved": round(direct_tf, 2), "direct_equiv_frac": round(direct_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "algorithmic_mb_per_launch": round(v["bytes"] / v["launches"] / 1e6, 3), "algorithmic_hbm_gbs": round(gbs, 1),
+                    "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
+
+        ranked = sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])
+        top = [shape_entry(k_, v_) for k_, v_ in ranked[:3]]
+        (name, dom_shape), d = ranked[0]
+        dom = top[0]
         # what a HIP-event pair reads around a ~1 us kernel: the marker / dispatch latency that every per-launch figure here
         # contains and rocprofv3's kernel durations do not (reported, NOT subtracted)
         floor = []
@@ -683,43 +716,42 @@ def main():
             floor.append((f0, f1))
         torch.cuda.synchronize()
         floor_us = sorted(a.elapsed_time(b) * 1e3 for a, b in floor)[len(floor) // 2]
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                entry = json.load(f).get(name)
-            if entry:       # measured with rocprofv3 --pmc in separate passes, committed under profiles/
-                # LDS-DMA (buffer_load ... lds) reads are tallied at half their bytes on gfx950 (MI355X_MICROARCH.md,
-                # HBM section): the doubled-FETCH figure applies to conv_dma_kernel, the raw one to register staging
-                traffic = entry["hbm_bytes_per_launch_fetch_x2" if name.startswith(("conv_dma", "conv_wino")) else "hbm_bytes_per_launch"]
-        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                           "profile": "profiles/r04_bench_C2_serial_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command "
-                                      "with YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1: the same isolated launches); "
-                                      "profiles/r04_bench_C2_kernel_stats.csv is the default command (captured step, concurrent branches)",
+        # HBM traffic of this launch shape from the counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, joined with
+        # the launch order of one eager serial step by tools/conv_shapes.py; committed under profiles/)
+        traffic, traffic_src = None, None
+        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_shapes_C2.json")), reverse=True):
+            with open(fn) as f:
+                for e in json.load(f).get("shapes", []):
+                    if e.get("kernel") == name and [e["shape"].get(k_) for k_ in ("B", "H", "W", "cin", "cout", "K")] == list(dom_shape[:6]) \
+                            and e.get("pmc_hbm_bytes_per_launch") is not None:
+                        traffic, traffic_src = e["pmc_hbm_bytes_per_launch"], os.path.relpath(fn, ROOT)
+            if traffic is not None:
+                break
+        out["roofline"] = {"bound": "mfma", "kernel": name, "shape": dom["shape"], "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                           "flops_counted": "EXECUTED by the matrix pipes" + (": Winograd F(2x2, 3x3) on the fp32 matrix cores (csrc/conv_wino.hip), 16 multiplies per "
+                                            "2x2 output block and channel pair instead of the direct form's 36" if name.startswith("conv_wino") else ""),
+                           "direct_equiv_achieved": dom["direct_equiv_achieved"], "direct_equiv_frac": dom["direct_equiv_frac"],
+                           "direct_equiv_note": "SURVEY 8d's algorithmic work (2 * 9 * Cin * Cout per pixel, what the reference computes) over the same time: "
+                                                "above 1.0 of the peak is the algorithmic saving of the Winograd form, not a roofline fraction",
                            "traffic_source": None if traffic is None else
-                           "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
-                           "earlier run of the same build; NOT measured in this run)",
-                           "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                           f"{traffic_src} (2 x FETCH_SIZE + WRITE_SIZE of this launch shape, rocprofv3 --pmc passes of this command on an earlier run "
+                           "of the same build; NOT measured in this run)",
+                           "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                            "event_pair_floor_us": floor_us,
-                           "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-                           "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
-                           "note": "per-kernel HIP-event timing of 3 instrumented EAGER steps on one stream, run before the "
-                                   "warm-up of the timed region (YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1 reproduces the condition under "
-                                   "rocprofv3: profiles/r04_bench_C2_serial_kernel_stats.csv; a HIP-event pair also reads the marker / dispatch "
-                                   "latency around the kernel -- `event_pair_floor_us` is what it reads around a 1-element fill -- so "
-                                   "`avg_launch_us` sits that much above rocprofv3's kernel-only average and `frac` below "
-                                   "the fraction computed from the profile).  The timed region itself "
-                                   "replays the captured step, whose decoder branches run CONCURRENTLY: per-kernel durations "
-                                   "inside it are inflated by sharing the GPU (profiles/r04_bench_C2_kernel_stats.csv) and "
-                                   "are not a kernel-quality measure; `value` and `step_roofline` are."}
-        if name.startswith("conv_wino"):
-            # a Winograd launch executes 16 / 36 of the convolution's FLOPs: `achieved` / `frac` count what the reference computes
-            # (SURVEY 8d's per-unit figure), the `executed_*` pair what the matrix pipes do
-            out["roofline"]["executed_achieved"] = tf / 2.25
-            out["roofline"]["executed_frac"] = tf / 2.25 / PEAK_FP32_MFMA_TFLOPS
-            out["roofline"]["form"] = ("Winograd F(2x2, 3x3) on the fp32 matrix cores (csrc/conv_wino.hip): 16 multiplies per 2x2 output block and "
-                                       "channel pair instead of 36 -- `frac` above 1 is the algorithmic saving, not a measurement error")
+                           "executed_gflop_per_launch": dom["executed_gflop_per_launch"],
+                           "algorithmic_mb_per_launch": dom["algorithmic_mb_per_launch"], "algorithmic_hbm_gbs": dom["algorithmic_hbm_gbs"],
+                           "hbm_frac": dom["hbm_frac"],
+                           "top_shapes": top,
+                           "profile": "profiles/r05_conv_shapes_C2.json: every launch shape of one step with rocprofv3's kernel-only duration "
+                                      "(--kernel-trace of this command with YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1), its executed FLOPs and counter "
+                                      "traffic; profiles/r05_bench_C2_serial_kernel_stats.csv is the --stats table of the same trace",
+                           "note": "per-launch HIP-event timing of 3 instrumented EAGER steps on one stream, run before the warm-up of the timed "
+                                   "region; a HIP-event pair also reads the marker / dispatch latency around the kernel (`event_pair_floor_us` "
+                                   "around a 1-element fill), so `avg_launch_us` sits that much above rocprofv3's kernel-only duration and "
+                                   "`frac` below the fraction computed from the profile.  The timed region itself replays the captured step, "
+                                   "whose decoder branches run CONCURRENTLY: per-kernel durations inside it are not a kernel-quality measure; "
+                                   "`value` and `step_roofline` are."}
         out["conv_kernels"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in agg.items()}
         for k, v in out["conv_kernels"].items():

@@ -15,6 +15,7 @@
 //       1. every workgroup copies its part of buf into slot[e & 1]; the last one to finish publishes flag[e & 1] = e
 //       2. every workgroup waits until each peer's flag[e & 1] == e (system-scope acquire), then adds the peers' parts to
 //          its own in rank order and writes buf
+//   (the 32-bit call number wraps 0xFFFFFFFF -> 2, which keeps the slots alternating)
 //   Slot reuse is safe with two slots: a rank enters call e only after call e - 1 returned on its stream, call e - 1
 //   needed every peer's flag e - 1, and a peer publishes flag e - 1 only after ITS call e - 2 finished reading.
 // A peer that never arrives (a crashed rank) would spin forever: the wait gives up after ~20 s of s_memrealtime (every
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const AllreduceA
     // the call number: read by every workgroup before it publishes; advanced by the last workgroup to publish (below), i.e.
     // after all of them have read it (0 is the flags' initial value and is skipped)
     unsigned epoch = __hip_atomic_load(a.done_counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (epoch == 0u) epoch = 1u;
+    if (epoch == 0u) epoch = 2u;      // (wrap after 2^32 - 1 calls: 0 is the flags' initial value; 2, not 1 -- call 0xFFFFFFFF used slot 1, and two consecutive calls must not share a slot)
     epoch = __builtin_amdgcn_readfirstlane(epoch);
     const int slot = (int)(epoch & 1u);
     unsigned* my_flags = reinterpret_cast<unsigned*>(a.mbox[a.rank]);

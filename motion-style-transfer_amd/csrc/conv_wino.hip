@@ -108,8 +108,9 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                     row0 += __builtin_bit_cast(f32x2, mk[h][k][0]);
                     row1 += __builtin_bit_cast(f32x2, mk[h][k][1]);
                 }
-                row0 = f32x2{fmaxf(row0[0], floor_v), fmaxf(row0[1], floor_v)};
-                row1 = f32x2{fmaxf(row1[0], floor_v), fmaxf(row1[1], floor_v)};
+                // (v < floor ? floor : v -- a NaN stays a NaN as in torch's relu; fmaxf would return the floor)
+                row0 = f32x2{row0[0] < floor_v ? floor_v : row0[0], row0[1] < floor_v ? floor_v : row0[1]};
+                row1 = f32x2{row1[0] < floor_v ? floor_v : row1[0], row1[1] < floor_v ? floor_v : row1[1]};
                 if constexpr (EPI == 1) {
                     const f32x2 m0 = __builtin_bit_cast(f32x2, mk[h][k][0]), m1 = __builtin_bit_cast(f32x2, mk[h][k][1]);
                     row0 = f32x2{m0[0] > 0.f ? row0[0] : 0.f, m0[1] > 0.f ? row0[1] : 0.f};
@@ -184,16 +185,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
     // the input descriptor starts one row and one unit BEFORE the tensor: the scalar offset of a chunk (its first output row and
     // column) is then never negative, and the lanes that would read in front of / behind a plane are exactly the edge lanes
     // (sent to an offset beyond the descriptor: zero fill)
+    // (every descriptor spans ONE image -- base + b * batch stride in scalar registers, built where the image is known: a tensor of any
+    //  size is addressed, and with fewer than 2^31 bytes per image the zero-fill offset 0x80000000 is beyond every descriptor whether
+    //  or not the hardware adds the scalar offset before the range check)
     const unsigned lead = (unsigned)((W + 4) * 4);
-    const unsigned x_bytes = (unsigned)(((long long)(a.B - 1) * a.x_bs + (long long)NCH * 8 * HW) * 4);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x) - lead),
-                                                                        0, x_bytes + lead, 0x00020000);
+    const unsigned x_img = (unsigned)(NCH * 8 * HW * 4) + lead, y_img = (unsigned)(NCB * 16 * HW * 4);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u), 0, (unsigned)(NCH * WQ * 16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(((long long)(a.B - 1) * a.y_bs + (long long)NCB * 16 * HW) * 4),
-                                                                        0x00020000);
-
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EM ? a.emask : a.y), 0,
-                                                                        (unsigned)(((long long)(a.B - 1) * (EM ? a.emask_bs : a.y_bs) + (long long)NCB * 16 * HW) * 4), 0x00020000);
 
     // XCD-aware walk (workgroups are dealt round-robin over the 8 XCDs): each XCD sweeps its own contiguous eighth of the tiles
     const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
@@ -243,7 +240,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
         const int y0 = ty * WN_TH + 2 * (unit & 7), x0 = tx * WN_TW;
         const unsigned em = (y0 == 0 ? 1u : 0u) | (y0 + 2 == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + WN_TW == W ? 8u : 0u);
-        const unsigned so = (unsigned)(((long long)b * a.x_bs + (long long)c * 8 * HW + y0 * W + x0) * 4);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x + (long long)b * a.x_bs) - lead), 0, x_img, 0x00020000);
+        const unsigned so = (unsigned)((c * 8 * HW + y0 * W + x0) * 4);
         const unsigned sb = ring0 + (unsigned)(slot * WN_SLOT_BYTES) + 4u;
         if (em == 0) {
 #pragma unroll
@@ -324,9 +323,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
         {
             const int t = tile_first + (cur >> 3) * gstride;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-            const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
-            const unsigned sm_t = (unsigned)(((long long)b * a.emask_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
-            wino_epilogue<NCB, EM ? 1 : 0>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, sm_t, HW);
+            const unsigned so_t = (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EM ? a.emask + (long long)b * a.emask_bs : a.y), 0, y_img, 0x00020000);
+            wino_epilogue<NCB, EM ? 1 : 0>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, so_t, HW);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -384,12 +385,7 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
     }
     const unsigned lead = (unsigned)((W + 4) * 4);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u), 0, wbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(((long long)(a.B - 1) * a.y_bs + (long long)NCB * 16 * HW) * 4), 0x00020000);
-    const int add_images = a.addend_bmod > 0 ? a.addend_bmod : a.B;
-    const __amdgpu_buffer_rsrc_t ra =
-        EPI == 3 ? __builtin_amdgcn_make_buffer_rsrc(a.pool, 0, (unsigned)(((long long)(a.B - 1) * a.pool_bs + (long long)NCB * 16 * (HW >> 2)) * 4), 0x00020000)
-                 : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? a.addend : a.y), 0,
-                                                     (unsigned)(((long long)(add_images - 1) * (ADD ? a.addend_bs : a.y_bs) + (long long)NCB * 16 * HW) * 4), 0x00020000);
+    const unsigned y_img = (unsigned)(NCB * 16 * HW * 4);      // (one image per descriptor, as in conv_wino_kernel)
 
     const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
     const int per_xcd = (a.ntiles + 7) >> 3;
@@ -443,10 +439,10 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
             ++s;
         }
         const unsigned nvalid = (unsigned)min(4, a.x_c[s] - ch);
-        const unsigned bytes = (unsigned)(((long long)(a.B - 1) * a.x_bs[s] + (long long)a.x_c[s] * HW) * 4);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x[s]) - lead), 0, bytes + lead, 0x00020000);
-        const unsigned so = (unsigned)(((long long)b * a.x_bs[s] + (long long)ch * HW + y0 * W + x0) * 4);
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x[s] + (long long)b * a.x_bs[s]) - lead), 0,
+            (unsigned)(a.x_c[s] * HW * 4) + lead, 0x00020000);
+        const unsigned so = (unsigned)((ch * HW + y0 * W + x0) * 4);
         const unsigned sb = ring0 + (unsigned)(slot * WC_SLOT_BYTES) + 4u;
         if (em == 0 && nvalid == 4) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)sb, 16, rel[0], so, 0, 0);
@@ -494,10 +490,13 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
         {
             const int t = tile_first + (cur >> 3) * gstride;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-            const unsigned so_t = (unsigned)(((long long)b * a.y_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            const unsigned so_t = (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
             const int ab = a.addend_bmod > 0 ? b % a.addend_bmod : b;
-            const unsigned sa_t = EPI == 3 ? (unsigned)(((long long)b * a.pool_bs + (ty * (WN_TH / 2) + (cur & 7)) * (W >> 1) + tx * (WN_TW / 2)) * 4)
-                                           : (unsigned)(((long long)ab * a.addend_bs + (ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            const unsigned sa_t = EPI == 3 ? (unsigned)(((ty * (WN_TH / 2) + (cur & 7)) * (W >> 1) + tx * (WN_TW / 2)) * 4) : so_t;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ra =
+                EPI == 3 ? __builtin_amdgcn_make_buffer_rsrc(a.pool + (long long)b * a.pool_bs, 0, y_img >> 2, 0x00020000)
+                         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? a.addend + (long long)ab * a.addend_bs : a.y), 0, y_img, 0x00020000);
             wino_epilogue<NCB, EPI>(acc, bias2, floor_v, ry, ra, st0, st1, so_t, sa_t, HW, stp);
         }
         cur = nxt;
@@ -553,6 +552,7 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
     if (!on || K != 3 || B <= 0) return false;
     if (H % WN_TH || W % WN_TW || H < WN_TH || W < WN_TW) return false;
     if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return false;
+    if (32ll * H * W * 4 + (W + 4) * 4 >= (1ll << 31)) return false;      // one image per buffer descriptor, below 2 GB (the batch is unbounded)
     static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 8;      // (round 4: 16 -> 8 -- batch 10 at 128^2 is 320 tiles: 3.15 -> 3.00 ms per step there, nothing lost at batch 32)
     return (long long)B * H * W >= min_pixels;      // (one workgroup of eight waves per CU: small launches stay with the direct tiles)
 }
@@ -625,6 +625,7 @@ static bool wino_cat_ok(int B, int H, int W, const int* src_c, int nsrc, int cou
     for (int i = 0; i < nsrc; ++i)
         if (src_c[i] <= 0) return false;
     const int nch = wino_cat_padded(src_c, nsrc) / 4;
+    if (56ll * H * W * 4 + (W + 4) * 4 >= (1ll << 31)) return false;      // one image of one source per buffer descriptor, below 2 GB
     if (nch < 2 || nch > 14) return false;          // 14 chunks of 8 KB of filters + eight 5 KB rings: 156 KB of LDS
     static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 8;      // (round 4: 16 -> 8 -- batch 10 at 128^2 is 320 tiles: 3.15 -> 3.00 ms per step there, nothing lost at batch 32)
     return (long long)B * H * W >= min_pixels;
@@ -662,23 +663,19 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
     for (int i = 0; i < nsrc; ++i) {
         YNET_REQUIRE(src[i] != nullptr && (reinterpret_cast<uintptr_t>(src[i]) & 15) == 0 && (src_bs[i] & 3) == 0 && (src_bs[i] == 0 || src_bs[i] >= src_c[i] * HW),
                      "%s: source %d must be 16-byte aligned with a batch stride of 0 (one image for the batch) or not smaller than its image", what, i);
-        YNET_REQUIRE(((long long)(B - 1) * src_bs[i] + src_c[i] * HW) * 4 + (W + 4) * 4 < (1ll << 32), "%s: source %d is beyond 4 GB", what, i);
         a.x[i] = src[i];
         a.x_bs[i] = src_bs[i];
         a.x_c[i] = src_c[i];
     }
-    YNET_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 && (dst_bs & 1) == 0 && dst_bs >= cout * HW &&
-                     ((long long)(B - 1) * dst_bs + cout * HW) * 4 < (1ll << 32),
-                 "%s: the output must be 8-byte aligned, its batch stride not smaller than the image, below 4 GB", what);
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 && (dst_bs & 1) == 0 && dst_bs >= cout * HW,
+                 "%s: the output must be 8-byte aligned, its batch stride not smaller than the image", what);
     if (addend != nullptr) {
-        const int images = addend_bmod > 0 ? addend_bmod : B;
-        YNET_REQUIRE(addend_bmod >= 0 && (reinterpret_cast<uintptr_t>(addend) & 7) == 0 && (addend_bs & 1) == 0 && addend_bs >= cout * HW &&
-                         ((long long)(images - 1) * addend_bs + cout * HW) * 4 < (1ll << 32),
-                     "%s: the additive term must be 8-byte aligned, its image stride not smaller than the image, below 4 GB, its modulus not negative", what);
+        YNET_REQUIRE(addend_bmod >= 0 && (reinterpret_cast<uintptr_t>(addend) & 7) == 0 && (addend_bs & 1) == 0 && addend_bs >= cout * HW,
+                     "%s: the additive term must be 8-byte aligned, its image stride not smaller than the image, its modulus not negative", what);
     }
     if (pool != nullptr)
-        YNET_REQUIRE(addend == nullptr && (reinterpret_cast<uintptr_t>(pool) & 3) == 0 && pool_bs >= cout * (HW / 4) && ((long long)(B - 1) * pool_bs + cout * (HW / 4)) * 4 < (1ll << 32),
-                     "%s: the pooled copy must have a batch stride not smaller than its image, below 4 GB, and excludes an additive term", what);
+        YNET_REQUIRE(addend == nullptr && (reinterpret_cast<uintptr_t>(pool) & 3) == 0 && pool_bs >= cout * (HW / 4),
+                     "%s: the pooled copy must have a batch stride not smaller than its image, and excludes an additive term", what);
     a.pool = pool;
     a.pool_bs = pool_bs;
     a.nsrc = nsrc;
@@ -742,12 +739,9 @@ static int wino_launch_any(const float* src, long long src_bs, const float* u, c
                  "%s: planes must be 16-byte (input, filters) / 8-byte (output) aligned", what);
     const long long HW = (long long)H * W;
     YNET_REQUIRE((src_bs == 0 || src_bs >= cin * HW) && dst_bs >= cout * HW, "%s: batch strides smaller than the images (input: 0 = one image for the batch)", what);
-    YNET_REQUIRE(((long long)(B - 1) * src_bs + cin * HW) * 4 + (W + 4) * 4 < (1ll << 32) && ((long long)(B - 1) * dst_bs + cout * HW) * 4 < (1ll << 32),
-                 "%s: tensors beyond 4 GB are not addressed by one buffer descriptor", what);
     if (emask != nullptr)
-        YNET_REQUIRE((reinterpret_cast<uintptr_t>(emask) & 7) == 0 && (emask_bs & 1) == 0 && emask_bs >= cout * HW &&
-                         ((long long)(B - 1) * emask_bs + cout * HW) * 4 < (1ll << 32),
-                     "%s: the activation must be 8-byte aligned, its batch stride not smaller than the image, below 4 GB", what);
+        YNET_REQUIRE((reinterpret_cast<uintptr_t>(emask) & 7) == 0 && (emask_bs & 1) == 0 && emask_bs >= cout * HW,
+                     "%s: the activation must be 8-byte aligned, its batch stride not smaller than the image", what);
     WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW), emask, emask_bs};
     hipStream_t st = (hipStream_t)stream;
     if (emask != nullptr) {

@@ -334,6 +334,10 @@ def join_wgrad_branch():
 _wino_allowed = _os.environ.get("YNET_WINOGRAD", "1") != "0"     # YNET_WINOGRAD=0: every convolution takes the implicit-GEMM kernels
 _wino_eval = _os.environ.get("YNET_WINOGRAD_EVAL", "1") != "0"  # YNET_WINOGRAD_EVAL=0: only under autograd (training steps) -- see conv2d's note
 wino_stats = {"launches": 0}
+# development switches of tests/wino_fp64.py (which launch family carries a deviation of evaluate()'s sweep): under no_grad only
+_wino_eval_min_hw = 0        # smallest H * W of a map that takes a Winograd launch
+_wino_cat_eval = True        # the concatenated-source / shared-term launches
+_wino_plain_eval = True      # the one-source launches
 
 
 def _wino_made(entry):
@@ -408,6 +412,9 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
     conv_wino_kernel) or "winograd_cat:2,<epilogue>" then, None otherwise."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
+    if wino is not None and not torch.is_grad_enabled() and (
+            H * W < _wino_eval_min_hw or not (_wino_plain_eval if len(srcs) == 1 and srcs[0][1] in (16, 32) else _wino_cat_eval)):
+        wino = None
     if bits_out is not None:
         if len(dsts) != 1 or mask is not None or relu_of is not None or pooled is not None or not relu or _bmods(srcs) is not None:
             raise ValueError("conv2d_raw: bits_out is for a forward ReLU convolution with one destination")
@@ -567,7 +574,7 @@ def conv2d_shared_term(x, x_times: int, rest, weight, bias, relu: bool, cache: d
     sp, sc, sb = _arrays(descs)
     ent = cache.get("wino_rest")
     if (ent is not None and ent[0] is cache["rest_wp"] and ent[2] == tuple(d[1] for d in descs) and _wino_allowed and _wino_eval and k == 3
-            and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs) and term.data_ptr() % 8 == 0
+            and _wino_cat_eval and H * W >= _wino_eval_min_hw and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs) and term.data_ptr() % 8 == 0
             and lib.ynet_conv2d_winograd_cat_supported(B, H, W, (ctypes.c_int * len(descs))(*ent[2]), len(descs), cout, k)):
         # the Winograd form of the same launch (its filter was transformed by rest_filter_winograd, before the sweep's streams fork)
         conv2d_winograd_cat_raw(descs, ent[1], bias.detach() if bias is not None else None, (y.data_ptr(), cout * H * W), B, H, W, relu,

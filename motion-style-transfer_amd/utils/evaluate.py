@@ -107,9 +107,12 @@ _sweep_graphs = weakref.WeakKeyDictionary()      # model -> {"token": weights to
 
 
 def _weights_token(model):
-    """Any in-place change of a parameter (an optimizer step, load_state_dict) changes it: a captured sweep reads packed filters
-    written before the capture, so it belongs to one state of the weights."""
-    return sum(p._version for p in model.parameters()), sum(1 for _ in model.parameters())
+    """A captured sweep bakes in the addresses of the packed / Winograd-domain filters written before the capture (and of the buffers
+    a torch op of it reads in place), so it belongs to ONE state of the weights: per parameter and buffer its identity, its storage
+    address and its in-place version -- an optimizer step or load_state_dict bumps the version, `p.data = ...`,
+    load_state_dict(assign=True), model.to(...) or a replaced Parameter changes the address / identity (a sum of versions
+    misses those, and can collide across parameters)."""
+    return tuple((id(t), t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
 
 
 class _CapturedSweep:

@@ -115,13 +115,9 @@ def model_state_token(model):
     """Part of a step's key: which tensors train, and the in-place history of the frozen ones.  A captured step reads the
     packed filters of frozen layers from buffers written once; if frozen weights are replaced (load_state_dict between
     two train() calls) or the freeze policy changes, the step must be captured again."""
-    flags, frozen = 0, 0
-    for i, p in enumerate(model.parameters()):
-        if p.requires_grad:
-            flags ^= hash((i, True))
-        else:
-            frozen += p._version
-    return flags, frozen
+    # per tensor, not a sum: (index, trains, identity, storage address[, version of a frozen one]) -- `p.data = ...`,
+    # load_state_dict(assign=True) or a replaced Parameter keeps every version and still invalidates the addresses a graph holds
+    return tuple((i, p.requires_grad, id(p), p.data_ptr(), 0 if p.requires_grad else p._version) for i, p in enumerate(model.parameters()))
 
 
 def _make_capturable(optimizer, fused: bool = True) -> bool:

@@ -316,6 +316,111 @@ def ttst_cws_case(tag, cfg, H, W, B, seed, n_goal, n_traj, use_ttst, use_cws, cw
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def trained_case(tag, cfg, H, W, B, seed, steps, lr, step_cfg=None, n_goal=20):
+    """fixtures on TRAINED weights.  Default-initialised weights decode diffuse heat-maps; SURVEY section 7 measured the
+    reference's own fp32-vs-fp64 soft-argmax gap at 1.7e-5 px on flat maps and 3.0e-4 px on peaky ones (utils/softargmax.py:55-81).  The
+    REFERENCE's train_epoch (utils/train_epoch.py:44-126, every weight trainable, models/trainer.py:222-235) runs `steps` Adam steps of
+    batch B on the synthetic scene; from the resulting state dict: one more training step in `step_cfg`'s mode (default: cfg's own) and
+    one K-sample evaluation sweep, both by the reference, both reproduced by the oracle, stored with the weights."""
+    if ONLY and not any(o in tag for o in ONLY):
+        return
+    import time
+    print(f"[{tag}] {steps} reference Adam steps of batch {B} at {H}x{W}, lr {lr}")
+    store = {}
+    sd0 = O.make_state_dict(cfg, seed=seed)
+    scene = O.synthetic_scene(cfg, H, W, seed)
+    images = {"scene0": scene[0].clone()}
+    S = cfg.template_size
+    in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+    names0 = O.trainable_names(cfg, sd0)
+    model = fresh_reference(cfg, sd0, B, lr, names0)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    t0 = time.time()
+    traj_all = O.synthetic_trajectories(cfg, steps * B, H, W, seed + 50)
+    ade, fde, loss = ref_train_epoch(
+        model, loader_for(traj_all), images, opt, torch.nn.BCEWithLogitsLoss(), cfg.loss_scale, torch.device("cpu"), "sdd", None,
+        gt_t, in_t, list(cfg.waypoints), 0, cfg.obs_len, cfg.pred_len, B, 10000, cfg.resize_factor, cfg.network, False)
+    print(f"  trained in {time.time() - t0:.0f} s: mean loss per step {float(loss) / steps:.3f}, ADE {float(ade):.3f}, FDE {float(fde):.3f}")
+    trained = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("semantic_segmentation")}
+    assert set(trained) == set(sd0)
+    # ---- the step fixture (step_cfg's adapters on top of the trained base weights)
+    scfg = step_cfg or cfg
+    sd1 = O.make_state_dict(scfg, seed=seed + 1, lora_b_std=0.05)
+    for k, v in trained.items():
+        assert sd1[k].shape == v.shape, k
+        sd1[k] = v.clone()
+    traj = O.synthetic_trajectories(scfg, B, H, W, seed + 60)
+    names = O.trainable_names(scfg, sd1)
+    meta = dict(obs_len=scfg.obs_len, pred_len=scfg.pred_len, waypoints=list(scfg.waypoints), enc=list(scfg.enc), dec=list(scfg.dec),
+                network=scfg.network, n_fusion=scfg.n_fusion or 0, train_net=scfg.train_net, position=list(scfg.position),
+                resize_factor=scfg.resize_factor, temperature=scfg.temperature, loss_scale=scfg.loss_scale, H=H, W=W, B=B, seed=seed,
+                lr=lr, n_goal=n_goal, adapter_std=0.0, trained_steps=steps, trained_mode=cfg.train_net,
+                lora_source="oracle/_stubs/loralib (restated 0.1.1, PARITY UNPINNED)")
+    store["meta"] = np.array(repr(meta))
+    for k, v in sd1.items():
+        store["sd/" + k] = v.numpy()
+    store["scene"], store["traj"] = scene.numpy(), traj.numpy()
+    m1 = fresh_reference(scfg, sd1, B, lr, names)
+    cap = Capture(m1)
+    opt1 = torch.optim.SGD(m1.parameters(), lr=0.0)          # (gradients only: the weights stay the fixture's)
+    ade, fde, loss = ref_train_epoch(
+        m1, loader_for(traj), images, opt1, torch.nn.BCEWithLogitsLoss(), scfg.loss_scale, torch.device("cpu"), "sdd", None,
+        gt_t, in_t, list(scfg.waypoints), 0, scfg.obs_len, scfg.pred_len, B, 10000, scfg.resize_factor, scfg.network, False)
+    cap.close()
+    st = O.train_step(sd1, scfg, scene, traj, in_t, gt_t, names, keep_maps=True)
+    check("step loss", st["loss"], loss, rtol=1e-6)
+    check("step ADE", st["ade"].mean(), ade, rtol=1e-6)
+    check("step FDE", st["fde"].mean(), fde, rtol=1e-6)
+    check("goal_map", st["goal_map"], cap.data["goal_map"], rtol=1e-5, atol=1e-5)
+    check("traj_map", st["traj_map"], cap.data["traj_map"], rtol=1e-5, atol=1e-5)
+    check("softargmax(traj)", st["pred_traj"], cap.soft[0], rtol=1e-6, atol=1e-4)
+    check("softargmax(goal)", st["pred_goal"], cap.soft[1], rtol=1e-6, atol=1e-4)
+    for i, b in enumerate(cap.data["features"]):
+        pack(store, f"step/features{i}", b)
+    pack(store, "step/goal_map", cap.data["goal_map"])
+    pack(store, "step/traj_map", cap.data["traj_map"])
+    store["step/pred_traj"], store["step/pred_goal"] = cap.soft[0].numpy(), cap.soft[1].numpy()
+    named = dict(m1.named_parameters())
+    for n in names:
+        check("grad " + n, st["grads"][n], named[n].grad, rtol=1e-4, atol=1e-5 * float(named[n].grad.abs().max()) + 1e-7)
+        if sd1[n].numel() <= FULL_LIMIT:
+            store["step/grad/" + n] = named[n].grad.numpy()
+    store["step/trainable"] = np.array(names)
+    store["step/loss"], store["step/ade"], store["step/fde"] = np.array(loss), np.array(ade), np.array(fde)
+    store["step/ade_per_traj"], store["step/fde_per_traj"] = st["ade"].numpy(), st["fde"].numpy()
+    # how peaked the decoded maps are: the largest soft-max probability of every plane (a flat 256^2 map has 1.5e-5)
+    tm = cap.data["traj_map"]
+    pk = torch.softmax(tm.flatten(2), dim=2).max(dim=2)[0]
+    store["step/peak_prob"] = pk.numpy()
+    print(f"  largest soft-max probability per plane: median {float(pk.median()):.4f}, max {float(pk.max()):.4f} (flat: {1.0 / (H * W):.2e})")
+    # ---- the sweep fixture on the trained weights of cfg itself
+    m2 = fresh_reference(cfg, trained, B, lr, names0)
+    cap = Capture(m2)
+    torch.manual_seed(seed + 3)
+    ade, fde, df, td = ref_evaluate(
+        m2, loader_for(traj), images, torch.device("cpu"), "sdd", None, in_t, list(cfg.waypoints), "test", n_goal, 1, cfg.obs_len, B,
+        cfg.resize_factor, cfg.temperature, False, False, 0.01, None, return_preds=True, return_samples=True, network=cfg.network)
+    cap.close()
+    wps = torch.from_numpy(td["waypoint_sample"]).permute(2, 0, 1, 3).contiguous()
+    ev = O.eval_batch(trained, cfg, scene, traj, in_t, n_goal=n_goal, waypoint_samples=wps)
+    check("eval goal_map", ev["goal_map"], td["goal_map"], rtol=1e-5, atol=1e-5)
+    check("eval trajs", ev["trajs"], torch.stack(cap.soft), rtol=1e-6, atol=1e-4)
+    check("eval ade/traj", ev["ade"], df["ade"].to_numpy(), rtol=1e-5, atol=1e-4)
+    check("eval fde/traj", ev["fde"], df["fde"].to_numpy(), rtol=1e-5, atol=1e-4)
+    torch.manual_seed(seed + 3)
+    ev2 = O.eval_batch(trained, cfg, scene, traj, in_t, n_goal=n_goal)
+    assert torch.equal(ev2["waypoint_samples"], wps), "sampling restatement diverges from the reference"
+    store["eval/waypoint_samples"] = wps.numpy()
+    pack(store, "eval/goal_map", torch.from_numpy(td["goal_map"]))
+    store["eval/trajs"] = torch.stack(cap.soft).numpy()
+    store["eval/ade_per_traj"], store["eval/fde_per_traj"] = df["ade"].to_numpy(), df["fde"].to_numpy()
+    store["eval/ade"], store["eval/fde"] = np.array(ade), np.array(fde)
+    store["eval/seed"] = np.array(seed + 3)
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def fresh_reference(cfg, sd0, B, lr, trainable):
     with contextlib.redirect_stdout(io.StringIO()):
         t = YNetTrainer(ref_params(cfg, B, lr), device=torch.device("cpu"))
@@ -452,6 +557,10 @@ def main():
               use_ttst=False, use_cws=True, cws_params={"sigma_factor": 6.0, "ratio": 2.0, "rot": True})
     make_eval("tiny_long_ttst_cws_ntraj2", O.sdd_long(train_net="train", **tiny), 32, 32, 2, seed=23, n_goal=3, n_traj=2,
               use_ttst=True, use_cws=True, cws_params={"sigma_factor": 6.0, "ratio": 2.0, "rot": False})
+    # trained (peaky-map) weights: the reference trains, then one step + one K = 20 sweep
+    trained_case("trained_tiny_long", O.sdd_long(train_net="train", **tiny), 64, 64, 4, seed=31, steps=300, lr=2e-3)
+    trained_case("trained_short_full", O.sdd_short(train_net="train"), 256, 256, 4, seed=32, steps=200, lr=1e-3,
+                 step_cfg=O.sdd_short(train_net="mosa_1", position=pos5))
     if not ONLY or "fullsize" in ONLY:
         fullsize_scalars()
 

@@ -788,6 +788,102 @@ def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     close(outs[0][0], ref, rtol=1e-4, scale_rel=2e-6, msg="forward vs torch")
 
 
+@pytest.mark.parametrize("case", [("plain", 520), ("dgrad_relu", 264), ("cat", 264), ("cat_add", 264)], ids=str)
+def test_winograd_tensors_beyond_2_and_4_gib(dev, case):
+    """the Winograd kernels address ONE image per buffer descriptor (base + b * batch stride in scalar registers), so a
+    [B, 32, 256, 256] tensor of 2.2 GB (B = 264: the zero-fill offset 0x80000000 must stay out of range) or 4.4 GB (B = 520: beyond one
+    32-bit descriptor) -- what evaluate() folds its K samples into on a real scene -- is served, borders included: every image against
+    the implicit GEMM (per-image descriptors since round 1), the first / the 2-GiB-straddling / the last image against torch."""
+    ops = pkg("ops")
+    kind, B = case
+    H = W = 256
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(B, 32, H, W, device=dev, generator=g).relu_()
+    assert x.numel() * 4 >= (1 << 31)
+    w = rnd(32, 49 if kind.startswith("cat") else 32, 3, 3, seed=2, scale=0.2).to(dev)
+    bias = rnd(32, seed=3).to(dev)
+    got, direct = torch.full((B, 32, H, W), float("nan"), device=dev), torch.empty(B, 32, H, W, device=dev)
+    dst = lambda t: [(t.data_ptr(), 32, 32 * H * W)]
+    picks = [0, (1 << 31) // (32 * H * W * 4), B - 1]
+    if kind == "plain":
+        wp = ops.pack_weight(w, 0)
+        assert ops.conv2d_raw([(x.data_ptr(), 32, 32 * H * W)], None, wp, bias, dst(got), B, H, W, 3, True, wino=({}, "fwd")).startswith("winograd")
+        assert ops.conv2d_raw([(x.data_ptr(), 32, 32 * H * W)], None, wp, bias, dst(direct), B, H, W, 3, True) is None
+        ref = lambda b: torch.relu(F.conv2d(x[b:b + 1], w, bias, padding=1))
+    elif kind == "dgrad_relu":
+        act = torch.randn(B, 32, H, W, device=dev, generator=g).relu_()
+        wp = ops.pack_weight(w, 1)
+        ro = (act.data_ptr(), 32 * H * W)
+        assert ops.conv2d_raw([(x.data_ptr(), 32, 32 * H * W)], None, wp, None, dst(got), B, H, W, 3, False, relu_of=ro, wino=({}, "dgrad")).startswith("winograd")
+        assert ops.conv2d_raw([(x.data_ptr(), 32, 32 * H * W)], None, wp, None, dst(direct), B, H, W, 3, False, relu_of=ro) is None
+        ref = lambda b: F.conv_transpose2d(x[b:b + 1], w, padding=1) * (act[b:b + 1] > 0)
+    else:
+        skip = torch.randn(B if kind == "cat" else 4, 16, H, W, device=dev, generator=g).relu_()
+        wmap = torch.rand(B, 1, H, W, device=dev, generator=g)
+        if kind == "cat":
+            wp = ops.pack_weight(w, 0)
+            srcs = [(x.data_ptr(), 32, 32 * H * W), (skip.data_ptr(), 16, 16 * H * W), (wmap.data_ptr(), 1, H * W)]
+            assert ops.conv2d_raw(srcs, None, wp, bias, dst(got), B, H, W, 3, True, wino=({}, "fwd")) == "winograd_cat:2,0"
+            assert ops.conv2d_raw(srcs, None, wp, bias, dst(direct), B, H, W, 3, True) is None
+            ref = lambda b: torch.relu(F.conv2d(torch.cat([x[b:b + 1], skip[b:b + 1], wmap[b:b + 1]], 1), w, bias, padding=1))
+        else:       # evaluate()'s shared-skip-term launch: the term of image b % 4 added in front of the ReLU
+            outs = []
+            for allowed in (True, False):
+                old, cache = ops._wino_allowed, {}
+                ops._wino_allowed = allowed
+                try:
+                    with torch.no_grad():
+                        term = ops.shared_conv_term(skip, w, 32, 48, cache)
+                        ops.rest_filter(w, 32, 48, cache)
+                        ops.rest_filter_winograd(w, 32, 48, cache, (32, 1), 4, H, W)
+                        n1 = ops.wino_stats["launches"]
+                        outs.append(ops.conv2d_shared_term(None, B // 4, [x, wmap], w, bias, True, cache, term, 32, 48))
+                        assert ops.wino_stats["launches"] - n1 == (1 if allowed else 0)
+                finally:
+                    ops._wino_allowed = old
+            got, direct = outs
+            ref = lambda b: torch.relu(F.conv2d(torch.cat([x[b:b + 1], skip[b % 4:b % 4 + 1], wmap[b:b + 1]], 1), w, bias, padding=1))
+    assert not bool(torch.isnan(got).any())
+    scale = float(direct.abs().max())
+    err = (got - direct).abs_()
+    assert float(err.max()) <= 2e-6 * scale + 2e-5, (float(err.max()), scale)
+    # the border rows / columns of every image (zero padding by the out-of-range offset) on their own
+    for sl in (err[:, :, 0], err[:, :, -1], err[:, :, :, 0], err[:, :, :, -1]):
+        assert float(sl.max()) <= 2e-6 * scale + 2e-5
+    for b in picks:
+        close(got[b:b + 1], ref(b), rtol=1e-4, scale_rel=2e-6, msg=f"image {b} vs torch")
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_winograd_epilogue_propagates_nan(dev, relu):
+    """a NaN convolution result stays a NaN through the epilogue's ReLU (torch: relu(NaN) = NaN), it is not turned into
+    0 / -inf by a max against the floor.  One NaN input pixel: every output torch makes NaN is NaN here (the Winograd transforms spread
+    it over the 2 x 2 blocks whose 4 x 4 patch holds the pixel, a superset), everything else finite and equal to the clean run's; the
+    pooled copy carries it too."""
+    ops = pkg("ops")
+    B, H, W = 8, 128, 128
+    x = torch.relu(rnd(B, 32, H, W, seed=1)).to(dev)
+    w, bias = rnd(32, 32, 3, 3, seed=2, scale=0.2).to(dev), rnd(32, seed=3).to(dev)
+    wp = ops.pack_weight(w, 0)
+    clean = torch.empty(B, 32, H, W, device=dev)
+    cache = {}
+    ops.conv2d_raw([(x.data_ptr(), 32, 32 * H * W)], None, wp, bias, [(clean.data_ptr(), 32, 32 * H * W)], B, H, W, 3, relu, wino=(cache, "fwd"))
+    x[3, 5, 40, 77] = float("nan")
+    got = torch.empty(B, 32, H, W, device=dev)
+    assert ops.conv2d_raw([(x.data_ptr(), 32, 32 * H * W)], None, wp, bias, [(got.data_ptr(), 32, 32 * H * W)], B, H, W, 3, relu, wino=(cache, "fwd")).startswith("winograd")
+    want = F.conv2d(x, w, bias, padding=1)
+    want = torch.relu(want) if relu else want
+    nan_w, nan_g = torch.isnan(want), torch.isnan(got)
+    assert int(nan_w.sum()) == 9 * 32 and bool((nan_g | ~nan_w).all()), "a NaN of the reference is missing"
+    assert int(nan_g.sum()) <= 16 * 32 and bool(nan_g[3, :, 38:44, 74:80].any()) and not bool(torch.isinf(got).any())
+    assert torch.equal(got[~nan_g], clean[~nan_g])
+    if relu:       # the pooled copy of the same launch family (ynet_conv2d_winograd_cat_pool)
+        y, yp = torch.empty(B, 32, H, W, device=dev), torch.empty(B, 32, H // 2, W // 2, device=dev)
+        assert ops.conv2d_raw([(x.data_ptr(), 32, 32 * H * W)], None, wp, bias, [(y.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True,
+                              pooled=(yp.data_ptr(), 32 * (H // 2) * (W // 2)), wino=({}, "fwd")).startswith("winograd_cat")
+        assert bool(torch.isnan(y)[nan_w].all()) and torch.equal(torch.isnan(yp), torch.isnan(F.max_pool2d(y, 2, 2)))
+
+
 # B, H, W, channels of the first layer's output (= of dx), channels of dy, dy masked too, input channels of the first layer
 RELU_BITS_CASES = [
     (8, 128, 128, 32, 16, False, 14),     # two 16-channel tiles x 4 rows: 64 mask bits per lane

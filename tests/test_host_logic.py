@@ -216,6 +216,18 @@ def test_step_graph_keys():
     t1 = sg.model_state_token(model)
     frozen[1].requires_grad = True                # a different freeze policy
     assert sg.model_state_token(model) != t1
+    # swapped storage keeps every version but not the addresses a graph holds -- both tokens must notice
+    t2 = sg.model_state_token(model)
+    ev = pkg("utils.evaluate")
+    w0 = ev._weights_token(model)
+    versions = [p._version for p in model.parameters()]
+    frozen[2].data = frozen[2].data.clone()
+    assert [p._version for p in model.parameters()] == versions
+    assert sg.model_state_token(model) != t2 and ev._weights_token(model) != w0
+    w1 = ev._weights_token(model)
+    with torch.no_grad():
+        trainable[0].add_(1.0)                     # the sweep's token follows trainable weights too (an optimizer step)
+    assert ev._weights_token(model) != w1
     assert not sg.enabled(None, torch.device("cpu")) and not sg.enabled(True, "cpu")
     assert sg.waypoint_index("cpu", [14, 29]).tolist() == [14, 29]
 

@@ -81,6 +81,43 @@ def test_eval_sweep(case):
     assert torch.equal(ev2["waypoint_samples"], g.t("eval/waypoint_samples"))
 
 
+TRAINED_CASES = ["trained_tiny_long", "trained_short_full"]
+
+
+@pytest.mark.parametrize("case", TRAINED_CASES)
+def test_trained_weights_step_and_sweep(case):
+    """weights after a few hundred Adam steps OF THE REFERENCE (peaked heat-maps: the largest soft-max probability
+    of a decoded plane is 20-1000x a flat map's) -- one training step and one K = 20 sweep by the reference, reproduced by the oracle."""
+    g = Golden(case)
+    cfg, m = g.cfg(), g.meta
+    sd = g.state_dict()
+    H, W = m["H"], m["W"]
+    S = cfg.template_size
+    in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+    names = O.trainable_names(cfg, sd)
+    assert names == [str(s) for s in g.z["step/trainable"]]
+    st = O.train_step(sd, cfg, g.t("scene"), g.t("traj"), in_t, gt_t, names, keep_maps=True)
+    assert float(np.median(g.z["step/peak_prob"])) >= 10.0 / (H * W)          # the maps ARE peaked
+    g.compare("step/goal_map", st["goal_map"], rtol=1e-5, atol=1e-5)
+    g.compare("step/traj_map", st["traj_map"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(st["pred_traj"].numpy(), g.z["step/pred_traj"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(st["pred_goal"].numpy(), g.z["step/pred_goal"], rtol=0, atol=1e-4)
+    assert abs(float(st["loss"]) - float(g.z["step/loss"])) <= 1e-6 * abs(float(g.z["step/loss"]))
+    np.testing.assert_allclose(st["ade"].numpy(), g.z["step/ade_per_traj"], rtol=0, atol=1e-4)
+    for n in g.keys("step/grad/"):
+        g.compare("step/grad/" + n, st["grads"][n], rtol=1e-4, atol=1e-5 * float(np.abs(g.z["step/grad/" + n]).max()) + 1e-7)
+    # the sweep runs on the base weights (the step fixture may carry adapters on top of them)
+    ecfg = O.Cfg(**{**cfg.__dict__, "train_net": m["trained_mode"], "position": []})
+    esd = {k: v for k, v in sd.items() if "lora_" not in k}
+    ev = O.eval_batch(esd, ecfg, g.t("scene"), g.t("traj"), in_t, n_goal=m["n_goal"], waypoint_samples=g.t("eval/waypoint_samples"))
+    np.testing.assert_allclose(ev["trajs"].numpy(), g.z["eval/trajs"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(ev["ade"].numpy(), g.z["eval/ade_per_traj"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(ev["fde"].numpy(), g.z["eval/fde_per_traj"], rtol=0, atol=1e-4)
+    torch.manual_seed(int(g.z["eval/seed"]))
+    ev2 = O.eval_batch(esd, ecfg, g.t("scene"), g.t("traj"), in_t, n_goal=m["n_goal"])
+    assert torch.equal(ev2["waypoint_samples"], g.t("eval/waypoint_samples"))
+
+
 TTST_CWS_CASES = ["tiny_short_ttst", "tiny_long_cws", "tiny_long_ttst_cws_ntraj2"]
 
 

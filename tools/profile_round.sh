@@ -29,6 +29,11 @@ echo "fetch rc=$?"
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o c2 -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-c5 --no-legs --no-sustained --no-repeats > "$OUT/write.log" 2>&1
 echo "write rc=$?"
 python3 "$R/tools/pmc_aggregate.py" "$TAG" --to "$OUT"      # per-kernel HBM bytes -> $OUT/pmc_traffic.json; the counter databases stay on the box
+# 3b. the per-LAUNCH-SHAPE table (round 5): bench.py's launch order of one eager serial step joined with the serial trace's kernel-only
+#     durations and the two counter passes -> ${TAG}_conv_shapes_C2.json (every per-shape roofline fraction reproducible from profiles/)
+$B --steps 3 --warmup 1 --no-cpu-baseline --no-c5 --no-legs --no-sustained --no-repeats --conv-layers "$OUT/${TAG}_conv_layers_C2.json" > /dev/null 2> "$OUT/conv_layers.err"
+python3 "$R/tools/conv_shapes.py" "$OUT/${TAG}_conv_layers_C2.json" /tmp/tr_serial "$OUT/${TAG}_conv_shapes_C2.json" --fetch "$OUT/fetch" --write "$OUT/write" > "$OUT/conv_shapes.txt" 2>&1
+echo "conv shapes rc=$?"; head -14 "$OUT/conv_shapes.txt"
 rm -rf "$OUT/fetch" "$OUT/write"
 unset YNET_STEP_GRAPH YNET_SERIAL_DECODERS
 cd "$R"
