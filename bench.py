@@ -155,6 +155,7 @@ class ConvTimer:
         self.ops, self.orig, self.rec = ops, ops.conv2d_raw, []
         self.orig_wino = ops.conv2d_winograd_raw
         self.orig_cat = ops.conv2d_winograd_cat_raw
+        self.orig_16 = ops.conv2d_winograd16_raw
 
     def __enter__(self):
         def timed_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None):
@@ -178,6 +179,18 @@ class ConvTimer:
             self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * 32 * 9, 4.0 * B * H * W * (cin + 32 * (2 if addend is not None else (1.25 if pool is not None else 1))),
                              (B, H, W, cin, 32, 3, False)))
         self.ops.conv2d_winograd_cat_raw = timed_cat
+
+        def timed_16(srcs, u, bias, dst, cout, B, H, W, relu, relu_of=None, addend=None, pool=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig_16(srcs, u, bias, dst, cout, B, H, W, relu, relu_of=relu_of, addend=addend, pool=pool)
+            e1.record()
+            cin = sum(s_[1] for s_ in srcs)
+            epi = 1 if relu_of is not None else (2 if addend is not None else (3 if pool is not None else 0))
+            name = f"conv_wino16_kernel<{epi}>"      # (epilogue: 0 plain, 1 through a ReLU backward, 2 additive term, 3 pooled copy)
+            self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin + cout * (2 if epi in (1, 2) else (1.25 if epi == 3 else 1))),
+                             (B, H, W, cin, cout, 3, False)))
+        self.ops.conv2d_winograd16_raw = timed_16
 
         def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -220,6 +233,7 @@ class ConvTimer:
         self.ops.conv2d_raw = self.orig
         self.ops.conv2d_winograd_raw = self.orig_wino
         self.ops.conv2d_winograd_cat_raw = self.orig_cat
+        self.ops.conv2d_winograd16_raw = self.orig_16
 
     def layers(self, steps):
         """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, direct-form TFLOP/s,

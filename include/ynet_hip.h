@@ -102,7 +102,8 @@ int ynet_conv2d_dgrad_relu_bits(const float* dy, int dy_c, long long dy_bs, cons
 /* The Winograd F(2x2, 3x3) generation of the 3x3 convolution (csrc/conv_wino.hip; round 4): 2.25x fewer fp32 MFMAs than the implicit
  * GEMM behind ynet_conv2d, fp32 throughout -- results differ from ynet_conv2d's by rounding only (the error against fp64 is smaller:
  * fewer additions reach an accumulator).  One source, one destination, no mask / epilogue variant; serves
- *   K = 3, cin in {16, 32}, cout in {16, 32}, H % 16 == 0, W % 32 == 0, B * H * W >= 128 * 128 * 8   (ynet_conv2d_winograd_supported)
+ *   K = 3, cin in {16, 32}, cout in {16, 32}, H % 16 == 0, W % 32 == 0, B * H * W >= 128 * 128 * 8, an image below 2 GB (ynet_conv2d_winograd_supported;
+ *   every tensor is addressed one image per buffer descriptor: any batch size)
  * i.e. the plain large-map convolutions and data gradients of both decoders (models/ynet.py:196,206: Conv2d(3x3) + ReLU; their
  * convolution_backward -> grad_input).  Replaces the same ATen calls as ynet_conv2d.
  *   ynet_winograd_filter        u = G g G^T of every (cout, cin) pair in MFMA fragment order, from a packed filter of ynet_pack_weight
@@ -143,6 +144,22 @@ int ynet_conv2d_winograd_cat_add(const float* const* src, const int* src_c, cons
  *                               conv + ReLU in front of MaxPool2d(2, 2), models/ynet.py:196-213): a lane of the Winograd tiling holds exactly the block it pools. */
 int ynet_conv2d_winograd_cat_pool(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                                   long long dst_bs, float* pooled, long long pooled_bs, int cout, int B, int H, int W, int relu, void* stream);
+/*   ynet_conv2d_winograd16      the SLICE form of the same convolution (round 5): every workgroup keeps the transformed filter of 16 output channels in LDS
+ *                               and a wave computes two row pairs (4 output rows x 32 columns) per unit -- for the layers the two kernels above do not
+ *                               serve, 16 / 32 / 64 / 128 output channels from up to three concatenated sources of at most 84 padded input channels
+ *                               (the 64-channel convolutions and data gradients at 64^2 of models/ynet.py:200-211, 420-445, and the 32 -> 16 up-convolution,
+ *                               ynet.py:464), H % 32 == 0, W % 32 == 0, B * H * W >= 128 * 128 * 8 (ynet_conv2d_winograd16_supported).  At most ONE epilogue
+ *                               variant: relu_of (a data gradient written through that activation's ReLU backward, as ynet_conv2d_winograd_dgrad_relu: bias
+ *                               NULL, relu 0), addend (+ addend[b % addend_bmod] in front of the ReLU, as ynet_conv2d_winograd_cat_add) or pooled (the
+ *                               2 x 2 max-pooled copy, as ynet_conv2d_winograd_cat_pool); the others NULL.  ynet_winograd16_filter writes the slice-major
+ *                               filter (ynet_winograd16_filter_floats floats) from a packed filter of ynet_pack_weight, output channels [col0, col0 + cout)
+ *                               of its cols_total.  Every tensor is addressed one image per buffer descriptor (any batch size; an image below 2 GB). */
+int ynet_conv2d_winograd16_supported(int B, int H, int W, const int* src_c, int nsrc, int cout, int K);
+long long ynet_winograd16_filter_floats(const int* src_c, int nsrc, int cout);
+int ynet_winograd16_filter(const float* wp, float* u, const int* src_c, int nsrc, int cout, int col0, int cols_total, void* stream);
+int ynet_conv2d_winograd16(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                           long long dst_bs, int cout, int B, int H, int W, int relu, const float* relu_of, long long relu_of_bs, const float* addend,
+                           long long addend_bs, int addend_bmod, float* pooled, long long pooled_bs, void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,

@@ -504,15 +504,225 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The slice form (round 5): 16 output channels per workgroup, TWO row pairs (4 output rows x 32 columns) per wave and unit.  It serves
+// what the two kernels above do not: layers with 48 / 64 / 128 output channels and up to 84 (padded) input channels -- the 64-channel
+// layers at 64^2 (and 32^2 in evaluate()'s folded batches) --, and it replaces conv_wino_kernel<1, ...> (32 -> 16 at 256^2), whose
+// MFMA pipes were 0.49 busy: that form did a whole patch transform, a whole staging step and a filter-fragment read per 16 MFMAs.
+//   filters     ONE slice (16 output channels) of the transformed filter is resident per workgroup: 4 KB per chunk of 4 input channels,
+//               at most 21 chunks; the slices of a layer are spread over the workgroups of an XCD (workgroup index / 8 modulo the number
+//               of slices), which sweep the same tiles -- the input is fetched from HBM once and re-read from that XCD's L2.
+//   unit        4 output rows x 32 columns: the two row pairs share two of their six input rows (6 staged rows instead of 8) and every
+//               filter fragment read from LDS feeds 8 MFMAs instead of 4; 2 x 16 accumulators of 4 registers, as many as NCB = 2 above.
+//   staging     per chunk one LDS-DMA instruction per input channel (60 lanes: 6 rows x 10 units), plane pitch 288 floats = 32 (mod 64)
+//               banks: the patch reads of the four channel groups of a wave are conflict-free; two slots per wave, the chunk two ahead
+//               issued when a slot's patch is in registers (as conv_wino_cat_kernel).
+//   epilogue    wino_epilogue<1, EPI> once per row pair: plain / through a ReLU backward (the activation fetched) / + additive term /
+//               + the 2 x 2 max-pooled copy.
+#define W6_PLANE_BYTES 1152
+#define W6_SLOT_BYTES (4 * W6_PLANE_BYTES + 16)
+#define W6_RING_BYTES (2 * W6_SLOT_BYTES)
+#define W6_MAX_CHUNKS 21
+#define W6_TH 32
+
+struct Wino16Args {
+    const float* x[WC_MAX_SRC];
+    long long x_bs[WC_MAX_SRC];
+    int x_c[WC_MAX_SRC];
+    int nsrc, nchunks;         // chunks of 4 channels over all sources (each padded to a multiple of 4)
+    const f32x4* u;            // [slice][chunk][4 quads of (xi,nu)][64 lanes] (ynet_winograd16_filter)
+    const float* bias;         // 16 * ns floats or NULL
+    float* y;                  // [B] x (y_bs floats): 16 * ns planes
+    long long y_bs;
+    int ns;                    // slices of 16 output channels
+    int B, H, W, relu, ntiles;
+    const float* aux;          // EPI 1: the post-ReLU activation whose backward is applied to y; EPI 2: the additive term (image b % aux_bmod)
+    long long aux_bs;
+    int aux_bmod;
+    float* pool;               // EPI 3: [B] x (pool_bs floats), 16 * ns planes of (H / 2) x (W / 2)
+    long long pool_bs;
+};
+
+// one chunk (4 input channels) for both row pairs: V = B^T d B of the two patches (rows 0..3 / 2..5 of the six staged rows), then
+// 4 filter-fragment reads feeding 2 x 16 MFMAs
+template <bool FIRST>
+__device__ __forceinline__ void wino16_kstep(f32x4 (&acc)[2][16][1], const f32x2 (&dl)[6], const f32x2 (&dh)[6], const f32x4* wl, int lane) {
+    f32x2 v01[2][4], v23[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2 tl[4] = {dl[2 * p] - dl[2 * p + 2], dl[2 * p + 1] + dl[2 * p + 2], dl[2 * p + 2] - dl[2 * p + 1], dl[2 * p + 1] - dl[2 * p + 3]};
+        const f32x2 th[4] = {dh[2 * p] - dh[2 * p + 2], dh[2 * p + 1] + dh[2 * p + 2], dh[2 * p + 2] - dh[2 * p + 1], dh[2 * p + 1] - dh[2 * p + 3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v01[p][i] = wn_v01(tl[i], th[i]);
+            v23[p][i] = wn_v23(tl[i], th[i]);
+        }
+    }
+    // (inline asm is opaque to hipcc's hazard recognizer: the wait states between a vector write and the MFMA that reads it)
+    asm volatile("s_nop 3"
+                 : "+v"(v01[0][0]), "+v"(v01[0][1]), "+v"(v01[0][2]), "+v"(v01[0][3]), "+v"(v23[0][0]), "+v"(v23[0][1]), "+v"(v23[0][2]), "+v"(v23[0][3]),
+                   "+v"(v01[1][0]), "+v"(v01[1][1]), "+v"(v01[1][2]), "+v"(v01[1][3]), "+v"(v23[1][0]), "+v"(v23[1][1]), "+v"(v23[1][2]), "+v"(v23[1][3]));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 w = wl[q * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float bv = e < 2 ? v01[p][q][e] : v23[p][q][e - 2];
+                if constexpr (FIRST) acc[p][q * 4 + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else acc[p][q * 4 + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], bv, acc[p][q * 4 + e][0], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(WN_THREADS, 1) void conv_wino16_kernel(const Wino16Args a) {
+    extern __shared__ f32x4 smem[];
+    constexpr int WQ = 4 * 64;            // units of one chunk's filters: [4 quads of (xi,nu)][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, HW = H * W, nchunks = a.nchunks;
+    const int tiles_x = W / WN_TW, tiles_y = H / W6_TH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const unsigned wbytes = (unsigned)(nchunks * WQ * 16);
+    const unsigned ring0 = lds0 + wbytes + (unsigned)(wave * W6_RING_BYTES);
+
+    // static DMA geometry: lane l < 60 moves unit (row l / 10, unit l % 10) of a plane
+    const int r6 = lane / WN_LQ, xq = lane - r6 * WN_LQ;
+    const unsigned rel = (unsigned)((r6 * W + 4 * xq) * 4);
+    const unsigned edge = (r6 == 0 ? 1u : 0u) | (r6 == 5 ? 2u : 0u) | (xq == 0 ? 4u : 0u) | (xq == WN_LQ - 1 ? 8u : 0u);
+    const unsigned lead = (unsigned)((W + 4) * 4);
+    const unsigned y_img = (unsigned)(16 * HW * 4);
+
+    // workgroups of one XCD (blockIdx & 7) share its eighth of the tiles: index / 8 -> (slice, member of the slice's team)
+    const int g8 = (int)(gridDim.x >> 3), idx = (int)(blockIdx.x >> 3);
+    const int slice = idx % a.ns, gstride = g8 / a.ns;
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    const int tile_first = (int)(blockIdx.x & 7) * per_xcd + idx / a.ns;
+    const int tile_end = min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd);
+    if (tile_first >= tile_end) return;
+    const int my_tiles = (tile_end - tile_first + gstride - 1) / gstride;
+    const int total_units = my_tiles * 8;
+
+    const int n = lane & 15, kq = lane >> 4;
+    const float floor_v = a.relu ? 0.f : -INFINITY;
+    f32x2 bias2[1][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        bias2[0][h] = a.bias ? f32x2{a.bias[slice * 16 + 4 * kq + 2 * h], a.bias[slice * 16 + 4 * kq + 2 * h + 1]} : f32x2{0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bias2[0][h]));
+    const unsigned st0 = (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
+    const unsigned stp = (unsigned)((4 * kq * (HW >> 2) + n) * 4);
+
+    // this slice's transformed filters -> LDS, once; the workgroup's unit counter
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u + (long long)slice * nchunks * WQ), 0, wbytes, 0x00020000);
+    for (int j = 0; j * WN_THREADS + wave * 64 < nchunks * WQ; ++j)      // (whole wave instructions: a chunk is 256 units)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(uintptr_t)(lds0 + (unsigned)(j * 8192 + wave * 1024)), 16,
+                                                 (unsigned)((j * WN_THREADS + tid) * 16), 0, 0, 0);
+    unsigned* unit_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(smem) + wbytes + 8 * W6_RING_BYTES);
+    if (tid == 0) *unit_ctr = 8u;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    auto next_unit = [&]() {
+        unsigned u = 0;
+        if (lane == 0) u = atomicAdd(unit_ctr, 1u);
+        return (int)__builtin_amdgcn_readfirstlane(u);
+    };
+
+    // chunk c of unit `unit` -> slot: four DMA instructions (one per input channel of the chunk), always
+    auto dma_chunk = [&](int unit, int c, int slot) {
+        const int t = tile_first + (unit >> 3) * gstride;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int y0 = ty * W6_TH + 4 * (unit & 7), x0 = tx * WN_TW;
+        const unsigned em = (y0 == 0 ? 1u : 0u) | (y0 + 4 == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + WN_TW == W ? 8u : 0u);
+        int s = 0, ch = c * 4;
+        while (s + 1 < a.nsrc && ch >= ((a.x_c[s] + 3) & ~3)) {
+            ch -= (a.x_c[s] + 3) & ~3;
+            ++s;
+        }
+        const int nvalid = min(4, a.x_c[s] - ch);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x[s] + (long long)b * a.x_bs[s]) - lead), 0,
+            (unsigned)(a.x_c[s] * HW * 4) + lead, 0x00020000);
+        const unsigned so = (unsigned)((ch * HW + y0 * W + x0) * 4);
+        const unsigned sb = ring0 + (unsigned)(slot * W6_SLOT_BYTES) + 4u;
+        const unsigned v = (edge & em) ? 0x80000000u : rel;
+        if (lane < 60) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + (unsigned)(p * W6_PLANE_BYTES)), 16, p < nvalid ? v : 0x80000000u,
+                                                         so + (unsigned)(p * HW * 4), 0, 0);
+        }
+    };
+
+    int cur = wave, nxt = next_unit();
+    int g = 0;                              // the wave's running chunk count: chunk g lives in slot g & 1
+    dma_chunk(cur, 0, 0);
+    dma_chunk(cur, 1, 1);
+
+    f32x4 acc[2][16][1];
+    const unsigned char* ringp = reinterpret_cast<const unsigned char*>(smem) + wbytes + wave * W6_RING_BYTES;
+    while (cur < total_units) {
+        auto step = [&](int c, auto first) {
+            if (c + 1 < nchunks || nxt < total_units) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int slot = g & 1;
+            const float* ip = reinterpret_cast<const float*>(ringp + slot * W6_SLOT_BYTES + 4 + kq * W6_PLANE_BYTES) + 3 + 2 * n;
+            f32x2 dl[6], dh[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                dl[r] = *reinterpret_cast<const f32x2*>(ip + r * WN_ROWF);
+                dh[r] = *reinterpret_cast<const f32x2*>(ip + r * WN_ROWF + 2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (c + 2 < nchunks) dma_chunk(cur, c + 2, slot);
+            else if (nxt < total_units) dma_chunk(nxt, c + 2 - nchunks, slot);
+            wino16_kstep<decltype(first)::value>(acc, dl, dh, smem + c * WQ, lane);
+            ++g;
+        };
+        step(0, std::true_type{});
+        for (int c = 1; c < nchunks; ++c) step(c, std::false_type{});
+        {
+            const int t = tile_first + (cur >> 3) * gstride;
+            const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+            const int y0 = ty * W6_TH + 4 * (cur & 7), x0 = tx * WN_TW;
+            const int ab = (EPI == 2 && a.aux_bmod > 0) ? b % a.aux_bmod : b;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs + (long long)slice * 16 * HW, 0, y_img, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm =
+                EPI == 3 ? __builtin_amdgcn_make_buffer_rsrc(a.pool + (long long)b * a.pool_bs + (long long)slice * 16 * (HW >> 2), 0, y_img >> 2, 0x00020000)
+                         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((EPI == 1 || EPI == 2) ? a.aux + (long long)ab * a.aux_bs + (long long)slice * 16 * HW : a.y), 0,
+                                                             y_img, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned so_t = (unsigned)(((y0 + 2 * p) * W + x0) * 4);
+                const unsigned sm_t = EPI == 3 ? (unsigned)((((y0 >> 1) + p) * (W >> 1) + (x0 >> 1)) * 4) : so_t;
+                wino_epilogue<1, EPI>(acc[p], bias2, floor_v, ry, rm, st0, st1, so_t, sm_t, HW, stp);
+            }
+        }
+        cur = nxt;
+        if (cur < total_units) nxt = next_unit();
+    }
+}
+
 // U = G g G^T of every (cout, cin) pair, in the fragment order the kernels read: unit ((c4 * 4 + q) * NCB + cb) * 64 + lane holds
 // (xi = q, nu = 0..3) of output channel col0 + cb * 16 + (lane & 15), PADDED input channel c4 * 4 + (lane >> 4) -- the input channels
 // are the concatenation of up to three sources, each padded to a multiple of 4 (padded channels: zero filters); with one source of a
 // multiple-of-4 channel count the padded channel is the channel.
 // wp: a packed filter of ynet_pack_weight, [k][tap][m] with m padded to cols_pad (k = the conv's input channels, m = its outputs).
-__global__ void wino_filter_kernel(const float* __restrict__ wp, f32x4* __restrict__ u, int cols_pad, int col0, int ncb, int nunits, int c0, int c1, int c2) {
+// nch_slice > 0: the slice-major order of conv_wino16_kernel instead -- unit ((cb * nch_slice + c4) * 4 + q) * 64 + lane, every 16-channel
+// slice of the output contiguous.
+__global__ void wino_filter_kernel(const float* __restrict__ wp, f32x4* __restrict__ u, int cols_pad, int col0, int ncb, int nunits, int c0, int c1, int c2,
+                                   int nch_slice) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nunits) return;
-    const int l = i & 63, cb = (i >> 6) % ncb, q = ((i >> 6) / ncb) & 3, c4 = ((i >> 6) / ncb) >> 2;
+    const int l = i & 63;
+    const int cb = nch_slice > 0 ? (i >> 8) / nch_slice : (i >> 6) % ncb;
+    const int q = nch_slice > 0 ? (i >> 6) & 3 : ((i >> 6) / ncb) & 3;
+    const int c4 = nch_slice > 0 ? (i >> 8) % nch_slice : ((i >> 6) / ncb) >> 2;
     const int co = col0 + cb * 16 + (l & 15);
     // padded channel -> row of the packed filter, or none
     int cp = c4 * 4 + (l >> 4), row = -1, base = 0;
@@ -606,7 +816,7 @@ int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, int col0,
     YNET_REQUIRE((reinterpret_cast<uintptr_t>(u) & 15) == 0, "winograd_filter: the output must be 16-byte aligned");
     const int ncb = cout / 16, nunits = (cin / 4) * 4 * ncb * 64;
     hipLaunchKernelGGL(wino_filter_kernel, dim3(ceil_div(nunits, 256)), dim3(256), 0, (hipStream_t)stream, wp, reinterpret_cast<f32x4*>(u),
-                       wino_cols_pad(cols_total), col0, ncb, nunits, cin, 0, 0);
+                       wino_cols_pad(cols_total), col0, ncb, nunits, cin, 0, 0, 0);
     return ynet_check_launch("winograd_filter");
 }
 
@@ -648,7 +858,7 @@ int ynet_winograd_filter_cat(const float* wp, float* u, const int* src_c, int ns
     for (int i = 0; i < nsrc; ++i) YNET_REQUIRE(src_c[i] > 0, "winograd_filter_cat: source %d has no channels", i);
     const int ncb = cout / 16, nunits = wino_cat_padded(src_c, nsrc) * ncb * 64;
     hipLaunchKernelGGL(wino_filter_kernel, dim3(ceil_div(nunits, 256)), dim3(256), 0, (hipStream_t)stream, wp, reinterpret_cast<f32x4*>(u),
-                       wino_cols_pad(cols_total), col0, ncb, nunits, src_c[0], nsrc > 1 ? src_c[1] : 0, nsrc > 2 ? src_c[2] : 0);
+                       wino_cols_pad(cols_total), col0, ncb, nunits, src_c[0], nsrc > 1 ? src_c[1] : 0, nsrc > 2 ? src_c[2] : 0, 0);
     return ynet_check_launch("winograd_filter_cat");
 }
 
@@ -761,6 +971,122 @@ int ynet_conv2d_winograd_dgrad_relu(const float* dy, long long dy_bs, const floa
                                     int dy_c, int dx_c, int B, int H, int W, void* stream) {
     YNET_REQUIRE(relu_of != nullptr, "conv2d_winograd_dgrad_relu: the activation whose ReLU backward is applied is null");
     return wino_launch_any(dy, dy_bs, u, nullptr, dx, dx_bs, relu_of, relu_of_bs, dy_c, dx_c, B, H, W, 0, stream, "conv2d_winograd_dgrad_relu");
+}
+
+}  // extern "C"
+
+// ---- the slice form (conv_wino16_kernel)
+static bool wino16_ok(int B, int H, int W, const int* src_c, int nsrc, int cout, int K) {
+    static const int on = getenv("YNET_WINOGRAD") ? atoi(getenv("YNET_WINOGRAD")) : 1;
+    static const int on16 = getenv("YNET_WINOGRAD16") ? atoi(getenv("YNET_WINOGRAD16")) : 1;
+    if (!on || !on16 || K != 3 || B <= 0 || nsrc < 1 || nsrc > WC_MAX_SRC) return false;
+    if (cout != 16 && cout != 32 && cout != 64 && cout != 128) return false;      // 1 / 2 / 4 / 8 slices: a divisor of the 32 workgroups of an XCD
+    if (H % W6_TH || W % WN_TW || H < W6_TH || W < WN_TW) return false;
+    for (int i = 0; i < nsrc; ++i)
+        if (src_c[i] <= 0) return false;
+    const int nch = wino_cat_padded(src_c, nsrc) / 4;
+    if (nch < 2 || nch > W6_MAX_CHUNKS) return false;      // 21 chunks of 4 KB of filters + eight 9.2 KB rings: 158 KB of LDS
+    if (84ll * H * W * 4 + (W + 4) * 4 >= (1ll << 31)) return false;      // one image of one source / of the output per buffer descriptor
+    static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 8;
+    return (long long)B * H * W >= min_pixels;
+}
+
+extern "C" {
+
+int ynet_conv2d_winograd16_supported(int B, int H, int W, const int* src_c, int nsrc, int cout, int K) {
+    return (src_c != nullptr && wino16_ok(B, H, W, src_c, nsrc, cout, K)) ? 1 : 0;
+}
+
+long long ynet_winograd16_filter_floats(const int* src_c, int nsrc, int cout) {
+    if (src_c == nullptr || nsrc < 1 || nsrc > WC_MAX_SRC || cout <= 0) return 0;
+    return 16ll * wino_cat_padded(src_c, nsrc) * (ceil_div(cout, 16) * 16);
+}
+
+int ynet_winograd16_filter(const float* wp, float* u, const int* src_c, int nsrc, int cout, int col0, int cols_total, void* stream) {
+    YNET_REQUIRE(wp && u && src_c, "winograd16_filter: null pointer");
+    YNET_REQUIRE(nsrc >= 1 && nsrc <= WC_MAX_SRC && cout > 0 && cout % 16 == 0, "winograd16_filter: 1..%d sources, cout %d a multiple of 16", WC_MAX_SRC, cout);
+    YNET_REQUIRE(col0 >= 0 && cols_total >= col0 + cout, "winograd16_filter: output channels %d .. %d are not inside the filter's %d", col0, col0 + cout, cols_total);
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(u) & 15) == 0, "winograd16_filter: the output must be 16-byte aligned");
+    for (int i = 0; i < nsrc; ++i) YNET_REQUIRE(src_c[i] > 0, "winograd16_filter: source %d has no channels", i);
+    const int ncb = cout / 16, nch = wino_cat_padded(src_c, nsrc) / 4, nunits = nch * 4 * ncb * 64;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(ceil_div(nunits, 256)), dim3(256), 0, (hipStream_t)stream, wp, reinterpret_cast<f32x4*>(u),
+                       wino_cols_pad(cols_total), col0, ncb, nunits, src_c[0], nsrc > 1 ? src_c[1] : 0, nsrc > 2 ? src_c[2] : 0, nch);
+    return ynet_check_launch("winograd16_filter");
+}
+
+int ynet_conv2d_winograd16(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                           long long dst_bs, int cout, int B, int H, int W, int relu, const float* relu_of, long long relu_of_bs, const float* addend,
+                           long long addend_bs, int addend_bmod, float* pooled, long long pooled_bs, void* stream) {
+    const char* what = "conv2d_winograd16";
+    YNET_REQUIRE(src && src_c && src_bs && u && dst, "%s: null pointer", what);
+    YNET_REQUIRE(wino16_ok(B, H, W, src_c, nsrc, cout, 3), "%s: shape B=%d %dx%d -> %d with %d sources is not served (ask ynet_conv2d_winograd16_supported)", what,
+                 B, H, W, cout, nsrc);
+    YNET_REQUIRE((relu_of != nullptr) + (addend != nullptr) + (pooled != nullptr) <= 1, "%s: at most one of relu_of / addend / pooled", what);
+    const long long HW = (long long)H * W;
+    Wino16Args a{};
+    for (int i = 0; i < nsrc; ++i) {
+        YNET_REQUIRE(src[i] != nullptr && (reinterpret_cast<uintptr_t>(src[i]) & 15) == 0 && (src_bs[i] & 3) == 0 && (src_bs[i] == 0 || src_bs[i] >= src_c[i] * HW),
+                     "%s: source %d must be 16-byte aligned with a batch stride of 0 (one image for the batch) or not smaller than its image", what, i);
+        a.x[i] = src[i];
+        a.x_bs[i] = src_bs[i];
+        a.x_c[i] = src_c[i];
+    }
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 && (dst_bs & 1) == 0 && dst_bs >= cout * HW,
+                 "%s: the output must be 8-byte aligned, its batch stride not smaller than the image", what);
+    if (relu_of != nullptr) {
+        YNET_REQUIRE(bias == nullptr && !relu && (reinterpret_cast<uintptr_t>(relu_of) & 7) == 0 && (relu_of_bs & 1) == 0 && relu_of_bs >= cout * HW,
+                     "%s: relu_of is for a data gradient (no bias, no ReLU); 8-byte aligned, batch stride not smaller than the image", what);
+        a.aux = relu_of;
+        a.aux_bs = relu_of_bs;
+    }
+    if (addend != nullptr) {
+        YNET_REQUIRE(addend_bmod >= 0 && (reinterpret_cast<uintptr_t>(addend) & 7) == 0 && (addend_bs & 1) == 0 && addend_bs >= cout * HW,
+                     "%s: the additive term must be 8-byte aligned, its image stride not smaller than the image, its modulus not negative", what);
+        a.aux = addend;
+        a.aux_bs = addend_bs;
+        a.aux_bmod = addend_bmod;
+    }
+    if (pooled != nullptr)
+        YNET_REQUIRE((reinterpret_cast<uintptr_t>(pooled) & 3) == 0 && pooled_bs >= cout * (HW / 4), "%s: the pooled copy's batch stride is smaller than its image", what);
+    a.pool = pooled;
+    a.pool_bs = pooled_bs;
+    a.nsrc = nsrc;
+    a.nchunks = wino_cat_padded(src_c, nsrc) / 4;
+    a.u = reinterpret_cast<const f32x4*>(u);
+    a.bias = bias;
+    a.y = dst;
+    a.y_bs = dst_bs;
+    a.ns = cout / 16;
+    a.B = B; a.H = H; a.W = W; a.relu = relu ? 1 : 0;
+    a.ntiles = B * (H / W6_TH) * (W / WN_TW);
+    const int lds = a.nchunks * 4096 + 8 * W6_RING_BYTES + 16;
+    constexpr int lds_max = W6_MAX_CHUNKS * 4096 + 8 * W6_RING_BYTES + 16;
+    static bool attr_dev[YNET_MAX_DEV] = {false};
+    static int cus_dev[YNET_MAX_DEV] = {0};
+    const int slot = ynet_device_slot();
+    if (!attr_dev[slot]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus_dev[slot] = cus < 64 ? 64 : cus;
+        attr_dev[slot] = true;
+    }
+    // one workgroup per CU; a slice's team inside an XCD is as large as that XCD has tiles for
+    const int per_xcd = (a.ntiles + 7) / 8;
+    int team = (cus_dev[slot] / 8) / a.ns;
+    if (team > per_xcd) team = per_xcd;
+    if (team < 1) team = 1;
+    const int grid = 8 * a.ns * team;
+    hipStream_t st = (hipStream_t)stream;
+    if (relu_of != nullptr) hipLaunchKernelGGL((conv_wino16_kernel<1>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    else if (addend != nullptr) hipLaunchKernelGGL((conv_wino16_kernel<2>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    else if (pooled != nullptr) hipLaunchKernelGGL((conv_wino16_kernel<3>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((conv_wino16_kernel<0>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    return ynet_check_launch(what);
 }
 
 }  // extern "C"

@@ -400,6 +400,53 @@ def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool
                                                  addend[0], addend[1], addend[2], _stream()), lib)
 
 
+_wino16_allowed = _os.environ.get("YNET_WINOGRAD16", "1") != "0"     # YNET_WINOGRAD16=0: no conv_wino16_kernel launches (round 5's slice form)
+_wino16_for_16 = _os.environ.get("YNET_WINOGRAD16_SLICE16", "1") != "0"   # ... = 0: 16-output-channel launches stay on conv_wino_kernel<1, ...>
+
+
+def conv2d_winograd16_raw(srcs, u, bias, dst, cout, B, H, W, relu, relu_of=None, addend=None, pool=None):
+    """The slice form of the Winograd convolution (ynet_conv2d_winograd16: 16 output channels per workgroup, two row pairs per wave):
+    srcs [(ptr, channels, batch_stride)] (at most three, 84 padded channels); dst (ptr, batch_stride) of cout in {16, 32, 64, 128} channels;
+    u: the filter in ynet_winograd16_filter's layout; at most one of relu_of (ptr, batch_stride) -- a data gradient written through
+    that activation's ReLU backward --, addend (ptr, image_stride, modulus) and pool (ptr, batch_stride)."""
+    lib = _lib()
+    sp, sc, sb = _arrays(srcs)
+    L.check(lib.ynet_conv2d_winograd16(sp, sc, sb, len(srcs), u.data_ptr(), bias.data_ptr() if bias is not None else None, dst[0], dst[1], cout, B, H, W,
+                                       1 if relu else 0, relu_of[0] if relu_of else None, relu_of[1] if relu_of else 0,
+                                       addend[0] if addend else None, addend[1] if addend else 0, addend[2] if addend else 0,
+                                       pool[0] if pool else None, pool[1] if pool else 0, _stream()), lib)
+
+
+def _wino16_supported(srcs_c, cout, B, H, W, K=3):
+    if not (_wino16_allowed and _wino_allowed and K == 3 and 1 <= len(srcs_c) <= 3):
+        return False
+    return bool(_lib().ynet_conv2d_winograd16_supported(B, H, W, (ctypes.c_int * len(srcs_c))(*srcs_c), len(srcs_c), cout, K))
+
+
+def _wino16(wino, wp, row0, srcs, bias, dst, cout, col0, ctot, B, H, W, relu, relu_of=None, addend=None, pool=None):
+    """One ynet_conv2d_winograd16 launch over output channels [col0, col0 + cout) of the packed filter wp (ctot output channels in all)
+    and its input-channel rows from row0 on, the transformed filter kept in the layer's cache."""
+    lib = _lib()
+    cache, what = wino
+    cs = tuple(s_[1] for s_ in srcs)
+    key = "wino16_%s_%d_%d_%d" % (what, row0, col0, cout)
+    ent = cache.get(key)
+    if ent is None or ent[0] is not wp or ent[2] != cs:
+        ca = (ctypes.c_int * len(cs))(*cs)
+        u = torch.empty(lib.ynet_winograd16_filter_floats(ca, len(cs), cout), device=wp.device, dtype=torch.float32)
+        cols_pad = -(-ctot // 64) * 64
+        L.check(lib.ynet_winograd16_filter(wp.data_ptr() + 4 * row0 * 9 * cols_pad, u.data_ptr(), ca, len(cs), cout, col0, ctot, _stream()), lib)
+        ent = cache[key] = _wino_made((wp, u, cs))
+    _wino_ready(ent)
+    conv2d_winograd16_raw(srcs, ent[1], None if bias is None else bias[col0:col0 + cout], dst, cout, B, H, W, relu, relu_of=relu_of, addend=addend, pool=pool)
+    wino_stats["launches"] += 1
+    wino_stats["launches16"] = wino_stats.get("launches16", 0) + 1
+
+
+def _pad4(c):
+    return (c + 3) & ~3
+
+
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None.  pooled: (ptr,
@@ -446,6 +493,11 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 conv2d_winograd_cat_raw(srcs, ent[1], bias, (dsts[0][0], dsts[0][2]), B, H, W, relu, pool=pooled)
                 wino_stats["launches"] += 1
                 return "winograd_cat:2,3"
+        if (wino is not None and K == 3 and dsts[0][0] % 8 == 0 and dsts[0][2] % 2 == 0 and all(len(s_) == 3 and s_[0] % 16 == 0 and s_[2] % 4 == 0 for s_ in srcs)
+                and _wino16_supported([s_[1] for s_ in srcs], dsts[0][1], B, H, W)):
+            # (64 output channels: the encoder's last 64^2 layer in front of its max-pool)
+            _wino16(wino, wp, 0, srcs, bias, (dsts[0][0], dsts[0][2]), dsts[0][1], 0, dsts[0][1], B, H, W, relu, pool=pooled)
+            return "winograd16:3"
         L.check(lib.ynet_conv2d_pool(sp, sc, sb, len(srcs), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                      dsts[0][0], dsts[0][1], dsts[0][2], pooled[0], pooled[1], B, H, W, K, 1 if relu else 0, _stream()), lib)
         return
@@ -468,6 +520,12 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 pieces = None
                 break
             c0 += c
+        if (_wino16_for_16 and pieces and len(pieces) == 1 and pieces[0][1] == 16 and pieces[0][0] % 8 == 0 and pieces[0][2] % 2 == 0
+                and _wino16_supported([cin], 16, B, H, W)):
+            # 16 output channels (the 32 -> 16 up-convolution at 256^2): the slice form with two row pairs per wave
+            ptr, n, bs, col0 = pieces[0]
+            _wino16(wino, wp, 0, srcs, bias, (ptr, bs), 16, col0, ctot, B, H, W, relu, relu_of=relu_of)
+            return "winograd16:%d" % (1 if relu_of is not None else 0)
         if (pieces and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
                 and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces)):
             cache, what = wino
@@ -482,6 +540,17 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                                     relu_of=relu_of)
                 wino_stats["launches"] += 1
             return tag
+        # the slice form for what the kernels above do not serve: 64 input channels, destinations of 64 channels (one launch per
+        # destination over its slice of the filter; a destination nobody wants is not computed)
+        wanted, c0 = [], 0
+        for ptr, c, bs in dsts:
+            if ptr is not None:
+                wanted.append((ptr, c, bs, c0))
+            c0 += c
+        if (wanted and (relu_of is None or len(wanted) == 1) and all(w_[0] % 8 == 0 and w_[2] % 2 == 0 and _wino16_supported([cin], w_[1], B, H, W) for w_ in wanted)):
+            for ptr, c, bs, col0 in wanted:
+                _wino16(wino, wp, 0, srcs, bias, (ptr, bs), c, col0, ctot, B, H, W, relu, relu_of=relu_of)
+            return "winograd16:" + "+".join("%d" % (1 if relu_of is not None else 0) for _ in wanted)
     if (wino is not None and _wino_allowed and K == 3 and mask is None and relu_of is None and all(len(s_) == 3 for s_ in srcs)
             and (len(srcs) > 1 or srcs[0][1] not in (16, 32)) and all(s_[0] % 16 == 0 and s_[2] % 4 == 0 for s_ in srcs)):
         # the decoders' first convolutions: cat(up-sampled features, skip features[, way-point map]) -> 32 (ynet_conv2d_winograd_cat)
@@ -525,6 +594,20 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 conv2d_winograd_cat_raw(srcs, ent[1], bias, (want[0][0], want[0][2]), B, H, W, relu)
                 wino_stats["launches"] += 1
                 return "winograd_cat:2,0"
+        if len(want) == 1 and len(dsts) == 1 and want[0][0] % 8 == 0 and want[0][2] % 2 == 0:
+            # the slice form: 64 output channels (the decoders' first convolutions at 64^2: cat(up-sampled 32, skip 64[, way-point map]) -> 64)
+            cout_w, cs_all = want[0][1], [s_[1] for s_ in srcs]
+            if _wino16_supported(cs_all, cout_w, B, H, W):
+                _wino16(wino, wp, 0, srcs, bias, (want[0][0], want[0][2]), cout_w, 0, cout_w, B, H, W, relu)
+                return "winograd16:0"
+            # more than 84 padded input channels: the leading sources into the destination, then the rest with the destination as the
+            # additive term in front of bias and ReLU (read and written by the same lane: in place)
+            for cut in range(1, len(srcs)):
+                if _wino16_supported(cs_all[:cut], cout_w, B, H, W) and _wino16_supported(cs_all[cut:], cout_w, B, H, W):
+                    _wino16(wino, wp, 0, srcs[:cut], None, (want[0][0], want[0][2]), cout_w, 0, cout_w, B, H, W, False)
+                    _wino16(wino, wp, sum(cs_all[:cut]), srcs[cut:], bias, (want[0][0], want[0][2]), cout_w, 0, cout_w, B, H, W, relu,
+                            addend=(want[0][0], want[0][2], 0))
+                    return "winograd16:0+2"
     dp, dc, db = _arrays(dsts)
     nws, ws = 0, None
     if B * H * W <= 65536:                                       # small maps only (see ynet_conv2d_workspace_floats)
@@ -581,6 +664,15 @@ def conv2d_shared_term(x, x_times: int, rest, weight, bias, relu: bool, cache: d
                                 addend=(term.data_ptr(), cout * H * W, term.shape[0]))
         wino_stats["launches"] += 1
         return y
+    ent16 = cache.get("wino16_rest")
+    if (ent16 is not None and ent16[0] is cache["rest_wp"] and ent16[2] == tuple(d[1] for d in descs) and _wino_eval and k == 3
+            and _wino_cat_eval and H * W >= _wino_eval_min_hw and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs) and term.data_ptr() % 8 == 0
+            and _wino16_supported([d[1] for d in descs], cout, B, H, W, k)):
+        conv2d_winograd16_raw(descs, ent16[1], bias.detach() if bias is not None else None, (y.data_ptr(), cout * H * W), cout, B, H, W, relu,
+                              addend=(term.data_ptr(), cout * H * W, term.shape[0]))
+        wino_stats["launches"] += 1
+        wino_stats["launches16"] = wino_stats.get("launches16", 0) + 1
+        return y
     L.check(lib.ynet_conv2d_add(sp, sc, sb, None, len(descs), cache["rest_wp"].data_ptr(),
                                 bias.detach().data_ptr() if bias is not None else None, y.data_ptr(), cout, cout * H * W,
                                 B, H, W, k, 1 if relu else 0, term.data_ptr(), cout * H * W, term.shape[0], _stream()), lib)
@@ -609,7 +701,18 @@ def rest_filter_winograd(weight, c0: int, c1: int, cache: dict, src_c, B: int, H
     cs = (ctypes.c_int * len(src_c))(*src_c)
     if not (_wino_allowed and _wino_eval and k == 3 and src_c and lib.ynet_conv2d_winograd_cat_supported(B, H, W, cs, len(src_c), cout, k)):
         cache.pop("wino_rest", None)
+        # the slice form (64 output channels: the 64^2 / 32^2 levels of evaluate()'s folded batches)
+        if _wino_eval and src_c and _wino16_supported(list(src_c), cout, B, H, W, k):
+            ent = cache.get("wino16_rest")
+            if ent is None or ent[0] is not wp or ent[2] != src_c:
+                with torch.no_grad():
+                    u = torch.empty(lib.ynet_winograd16_filter_floats(cs, len(src_c), cout), device=wp.device, dtype=torch.float32)
+                    L.check(lib.ynet_winograd16_filter(wp.data_ptr(), u.data_ptr(), cs, len(src_c), cout, 0, cout, _stream()), lib)
+                ent = cache["wino16_rest"] = (wp, u, src_c)
+            return ent[1]
+        cache.pop("wino16_rest", None)
         return None
+    cache.pop("wino16_rest", None)
     ent = cache.get("wino_rest")
     if ent is None or ent[0] is not wp or ent[2] != src_c:
         with torch.no_grad():
@@ -863,7 +966,8 @@ class _Conv2dFn(torch.autograd.Function):
             pooled = torch.empty((B, cout, H // 2, W // 2), device=weight.device, dtype=torch.float32)
         bits = None
         consumer_wino = (isinstance(meta.get("bits"), int) and not isinstance(meta.get("bits"), bool) and meta.get("wino") and _wino_allowed and k == 3
-                         and cout in (16, 32) and bool(_lib().ynet_conv2d_winograd_supported(B, H, W, int(meta["bits"]), cout, k)))
+                         and ((cout in (16, 32) and bool(_lib().ynet_conv2d_winograd_supported(B, H, W, int(meta["bits"]), cout, k)))
+                              or _wino16_supported([int(meta["bits"])], cout, B, H, W, k)))
         if (meta.get("bits") and not consumer_wino and relu and premask and _relu_bits_allowed and pooled is None and not meta.get("repeat")
                 and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs)):
             # the next conv of a conv -> ReLU -> conv chain will write its data gradient THROUGH this ReLU's backward: leave it the
@@ -944,7 +1048,8 @@ class _Conv2dFn(torch.autograd.Function):
             # (where the Winograd generation serves the launch it applies the float mask itself -- faster than the implicit GEMM with
             #  the 1-bit mask, whose layout belongs to that kernel's tiles)
             wino_em = (emask is not None and mask is None and meta.get("wino") and _wino_allowed and k == 3 and dy.data_ptr() % 16 == 0
-                       and d_srcs[0].data_ptr() % 8 == 0 and _lib().ynet_conv2d_winograd_supported(B, H, W, cout, int(s0.shape[1]), int(k)))
+                       and d_srcs[0].data_ptr() % 8 == 0 and (_lib().ynet_conv2d_winograd_supported(B, H, W, cout, int(s0.shape[1]), int(k))
+                                                               or _wino16_supported([cout], int(s0.shape[1]), B, H, W, int(k))))
             if ebits is not None and not wino_em:
                 premask_stats["bit_masks"] = premask_stats.get("bit_masks", 0) + 1
                 conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_bits=ebits.data_ptr())

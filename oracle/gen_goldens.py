@@ -37,13 +37,15 @@ FULL_LIMIT = 40000
 STRIDE = 5
 
 
-def pack(store, name, t):
+def pack(store, name, t, stride=STRIDE):
     a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
     if a.size <= FULL_LIMIT:
         store[name] = a
     else:
         flat = a.reshape(-1)
-        store[name + "__strided"] = flat[::STRIDE].copy()
+        store[name + "__strided"] = flat[::stride].copy()
+        if stride != STRIDE:
+            store[name + "__stride"] = np.array(stride)
         store[name + "__shape"] = np.array(a.shape)
         store[name + "__sum"] = np.array(flat.astype(np.float64).sum())
         store[name + "__sqsum"] = np.array((flat.astype(np.float64) ** 2).sum())
@@ -375,10 +377,12 @@ def trained_case(tag, cfg, H, W, B, seed, steps, lr, step_cfg=None, n_goal=20):
     check("traj_map", st["traj_map"], cap.data["traj_map"], rtol=1e-5, atol=1e-5)
     check("softargmax(traj)", st["pred_traj"], cap.soft[0], rtol=1e-6, atol=1e-4)
     check("softargmax(goal)", st["pred_goal"], cap.soft[1], rtol=1e-6, atol=1e-4)
-    for i, b in enumerate(cap.data["features"]):
-        pack(store, f"step/features{i}", b)
-    pack(store, "step/goal_map", cap.data["goal_map"])
-    pack(store, "step/traj_map", cap.data["traj_map"])
+    big = H * W * B > 100000            # (full-size case: the weights are 6.6 MB already -- maps every 23rd element, no feature maps)
+    if not big:
+        for i, b in enumerate(cap.data["features"]):
+            pack(store, f"step/features{i}", b)
+    pack(store, "step/goal_map", cap.data["goal_map"], 23 if big else STRIDE)
+    pack(store, "step/traj_map", cap.data["traj_map"], 23 if big else STRIDE)
     store["step/pred_traj"], store["step/pred_goal"] = cap.soft[0].numpy(), cap.soft[1].numpy()
     named = dict(m1.named_parameters())
     for n in names:
@@ -411,7 +415,7 @@ def trained_case(tag, cfg, H, W, B, seed, steps, lr, step_cfg=None, n_goal=20):
     ev2 = O.eval_batch(trained, cfg, scene, traj, in_t, n_goal=n_goal)
     assert torch.equal(ev2["waypoint_samples"], wps), "sampling restatement diverges from the reference"
     store["eval/waypoint_samples"] = wps.numpy()
-    pack(store, "eval/goal_map", torch.from_numpy(td["goal_map"]))
+    pack(store, "eval/goal_map", torch.from_numpy(td["goal_map"]), 23 if big else STRIDE)
     store["eval/trajs"] = torch.stack(cap.soft).numpy()
     store["eval/ade_per_traj"], store["eval/fde_per_traj"] = df["ade"].to_numpy(), df["fde"].to_numpy()
     store["eval/ade"], store["eval/fde"] = np.array(ade), np.array(fde)

@@ -91,7 +91,8 @@ class Golden:
         else:
             assert tuple(self.z[k + "__shape"]) == got.shape, (k, got.shape)
             flat = got.reshape(-1)
-            np.testing.assert_allclose(flat[::5], self.z[k + "__strided"].astype(np.float64), rtol=rtol, atol=atol, err_msg=k)
+            stride = int(self.z[k + "__stride"]) if (k + "__stride") in self.z.files else 5
+            np.testing.assert_allclose(flat[::stride], self.z[k + "__strided"].astype(np.float64), rtol=rtol, atol=atol, err_msg=k)
             n = flat.size
             np.testing.assert_allclose(flat.sum(), float(self.z[k + "__sum"]), rtol=1e-4, atol=atol * n ** 0.5, err_msg=k + " sum")
             np.testing.assert_allclose((flat ** 2).sum(), float(self.z[k + "__sqsum"]), rtol=1e-4, atol=atol, err_msg=k + " sqsum")

@@ -163,7 +163,19 @@ def test_eval_sweep_at_headline_batch_matches_oracle(dev, K):
     """C5 shape at B = 128: the K decoder passes run folded into the batch, G = max_effective_batch // B = 2 goal samples
     per pass (256 virtual batch items, encoder features read in place through the batch modulus).  K = 20 is BASELINE.json's
     configs[4] itself -- ten folded passes alternating between the two sweep streams, the full B = 128 batch against the host
-    oracle (its cost is linear in K: about a minute on the box's host) --, K = 4 the quick form of it."""
+    oracle (its cost is linear in K: about a minute on the box's host) --, K = 4 the quick form of it.
+
+    Bounds (VERDICT r4 item 1 -- round 4 had loosened the per-coordinate bound to "1 % beyond 1e-4, none beyond 2e-2 px" for the
+    Winograd launches; the fp64 adjudication, tests/wino_fp64.py -> profiles/r05_wino_fp64.log, showed that was not rounding but a
+    defect: all 487 outliers sat in virtual image 0 of a folded pass, whose 256 x 32 x 256^2 tensor is exactly 2 GiB, so the zero-fill
+    offset 0x80000000 of conv_wino_kernel was INSIDE its whole-tensor buffer descriptor and the top padding row read real memory.  With
+    one image per descriptor the Winograd path is within the reference's own fp32 noise: |HIP - fp64| max 2.6e-5 px against
+    |oracle32 - fp64| 3.8e-5):
+      * every coordinate of every goal sample within 1e-4 px of the fp32 oracle, whichever convolution kernels ran;
+      * every SAMPLE's ADE [K, B] (before the best-of-K minimum) and every trajectory's ADE / FDE within 1e-4;
+      * against the oracle run in fp64 (the exact value of the same function of the same fp32 weights and inputs; sixteen of the 128
+        trajectories incl. the first and the last virtual image, fp64 convolutions on the host being ~8x slower):
+        |HIP - fp64| <= max(1e-4, 3 |oracle32 - fp64|) per coordinate -- the HIP path is inside the reference's own rounding noise."""
     cfg = O.sdd_long(train_net="train")
     H = W = 256
     B = 128
@@ -172,39 +184,44 @@ def test_eval_sweep_at_headline_batch_matches_oracle(dev, K):
     in_t = O.dist_template(cfg.template_size)
     gen = torch.Generator().manual_seed(5)
     want = O.eval_batch(sd, cfg, scene, traj, in_t, n_goal=K, n_traj=1, generator=gen)
+    sub = list(range(8)) + list(range(B - 8, B))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    want64 = O.eval_batch(sd64, cfg, scene.double(), traj[sub], in_t.double(), n_goal=K, n_traj=1,
+                          waypoint_samples=want["waypoint_samples"][:, sub].double())["trajs"]
     model = build_model(cfg, sd, dev)
     ev = pkg("utils.evaluate")
-    caught = []
-    h = model.softargmax_.register_forward_hook(lambda m, i, o: caught.append(o.detach().cpu()))
-    ade, fde, df, _ = ev.evaluate(
-        model, loader_for(traj), {"scene0": scene[0]}, dev, "sdd", None, in_t.to(dev), list(cfg.waypoints), "test", K, 1,
-        cfg.obs_len, B, cfg.resize_factor, cfg.temperature, forced_samples={0: want["waypoint_samples"]})
-    h.remove()
-    assert len(caught) == K // 2 and caught[0].shape[0] == 256, [c.shape for c in caught]      # K / 2 folded passes of 2 x 128
-    got = torch.cat(caught).view(K, B, cfg.pred_len, 2)
-    # ADE / FDE of every trajectory and their means: the north star's 1e-4, whichever convolution kernels ran
-    np.testing.assert_allclose(df["ade"].to_numpy(), want["ade"].numpy(), rtol=0, atol=1e-4)
-    np.testing.assert_allclose(df["fde"].to_numpy(), want["fde"].numpy(), rtol=0, atol=1e-4)
-    assert abs(ade - float(want["ade"].mean())) <= 1e-4 and abs(fde - float(want["fde"].mean())) <= 1e-4
-    # every coordinate of every goal sample.  With the Winograd convolutions (14 launches per pass; fp32 rounding uncorrelated with
-    # the reference's own summation order) single coordinates of single samples move further than with the implicit GEMM, where a
-    # sample's decoded heat-map is diffuse: measured 97 of 30,720 beyond 1e-4, the largest 5.3e-3 px, ADE / FDE above untouched.
-    # Bounds: 1 % of the coordinates beyond 1e-4, none beyond 2e-2 px; with the implicit GEMM (below) all within 1e-4 as before.
-    dc = (got - want["trajs"]).abs()
-    assert float(dc.max()) <= 2e-2 and int((dc > 1e-4).sum()) <= dc.numel() // 100, (float(dc.max()), int((dc > 1e-4).sum()))
+    ops = pkg("ops")
+    fut = traj[:, cfg.obs_len:]
+
+    def run():
+        caught = []
+        h = model.softargmax_.register_forward_hook(lambda m, i, o: caught.append(o.detach().cpu()))
+        ade, fde, df, _ = ev.evaluate(
+            model, loader_for(traj), {"scene0": scene[0]}, dev, "sdd", None, in_t.to(dev), list(cfg.waypoints), "test", K, 1,
+            cfg.obs_len, B, cfg.resize_factor, cfg.temperature, forced_samples={0: want["waypoint_samples"]})
+        h.remove()
+        assert len(caught) == K // 2 and caught[0].shape[0] == 256, [c.shape for c in caught]      # K / 2 folded passes of 2 x 128
+        return torch.cat(caught).view(K, B, cfg.pred_len, 2), ade, fde, df
+
+    def check(got, ade, fde, df, what):
+        np.testing.assert_allclose(df["ade"].to_numpy(), want["ade"].numpy(), rtol=0, atol=1e-4, err_msg=what)
+        np.testing.assert_allclose(df["fde"].to_numpy(), want["fde"].numpy(), rtol=0, atol=1e-4, err_msg=what)
+        assert abs(ade - float(want["ade"].mean())) <= 1e-4 and abs(fde - float(want["fde"].mean())) <= 1e-4, what
+        np.testing.assert_allclose(got.numpy(), want["trajs"].numpy(), rtol=0, atol=1e-4, err_msg=what + ": coordinates vs the fp32 oracle")
+        ade_k = O.displacement_error(fut, got, cfg.resize_factor).mean(dim=2)             # [K, B]: every sample, not the best of K
+        np.testing.assert_allclose(ade_k.numpy(), want["ade_k"].numpy(), rtol=0, atol=1e-4, err_msg=what + ": per-sample ADE")
+        e32 = (want["trajs"][:, sub].double() - want64).abs()
+        d64 = (got[:, sub].double() - want64).abs()
+        bad = d64 > torch.clamp(3.0 * e32, min=1e-4)
+        assert not bool(bad.any()), (what, float(d64.max()), float(e32.max()), int(bad.sum()))
+
+    n0 = ops.wino_stats["launches"]
+    check(*run(), "default kernels")
+    assert ops.wino_stats["launches"] > n0 or not ops._wino_allowed          # (the Winograd launches ARE what ran)
     if K == 4:
-        ops = pkg("ops")
         old = ops._wino_allowed
         ops._wino_allowed = False
         try:
-            caught.clear()
-            h = model.softargmax_.register_forward_hook(lambda m, i, o: caught.append(o.detach().cpu()))
-            ade2, fde2, df2, _ = ev.evaluate(
-                model, loader_for(traj), {"scene0": scene[0]}, dev, "sdd", None, in_t.to(dev), list(cfg.waypoints), "test", K, 1,
-                cfg.obs_len, B, cfg.resize_factor, cfg.temperature, forced_samples={0: want["waypoint_samples"]})
-            h.remove()
+            check(*run(), "implicit GEMM only")
         finally:
             ops._wino_allowed = old
-        np.testing.assert_allclose(torch.cat(caught).view(K, B, cfg.pred_len, 2).numpy(), want["trajs"].numpy(), rtol=0, atol=1e-4)
-        np.testing.assert_allclose(df2["ade"].to_numpy(), want["ade"].numpy(), rtol=0, atol=1e-4)
-        np.testing.assert_allclose(df2["fde"].to_numpy(), want["fde"].numpy(), rtol=0, atol=1e-4)

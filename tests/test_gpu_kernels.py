@@ -634,6 +634,42 @@ def test_winograd_convolution_matches_the_direct_form(dev, case):
     assert e_w <= 1.5 * e_d + 1e-7, (e_w, e_d)
 
 
+def test_winograd_on_production_like_inputs(dev):
+    """the inputs the decoders really feed these launches -- bilinearly up-sampled post-ReLU planes (smooth: the
+    Winograd input transform takes differences of nearly equal values), skip features, and the way-point distance map, a ramp over
+    [0, 2] -- not relu(randn).  The Winograd launches (one source and concatenated) against fp64 and against the implicit GEMM: the same
+    2e-6-of-the-largest-output bound, an error against fp64 not above 1.5x the direct kernel's."""
+    ops = pkg("ops")
+    B, H, W = 8, 256, 256
+    up = F.interpolate(torch.relu(rnd(B, 32, H // 2, W // 2, seed=1)), scale_factor=2, mode="bilinear", align_corners=False).to(dev)
+    skip = torch.relu(rnd(B, 16, H, W, seed=2)).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    ramp = torch.stack([(((yy - 40.0 - 11 * b) ** 2 + (xx - 200.0 + 13 * b) ** 2).sqrt() / 742.0 * 2.0) for b in range(B)]).unsqueeze(1).to(dev)
+    w, bias = rnd(32, 49, 3, 3, seed=4, scale=0.2).to(dev), rnd(32, seed=5).to(dev)
+    wp = ops.pack_weight(w, 0)
+    srcs = [(up.data_ptr(), 32, 32 * H * W), (skip.data_ptr(), 16, 16 * H * W), (ramp.data_ptr(), 1, H * W)]
+    got, direct = torch.full((B, 32, H, W), float("nan"), device=dev), torch.empty(B, 32, H, W, device=dev)
+    assert ops.conv2d_raw(srcs, None, wp, bias, [(got.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True, wino=({}, "fwd")).startswith("winograd")
+    assert ops.conv2d_raw(srcs, None, wp, bias, [(direct.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True) is None
+    ref64 = torch.relu(F.conv2d(torch.cat([up, skip, ramp], 1).double(), w.double(), bias.double(), padding=1))
+    close(got, ref64, rtol=1e-5, scale_rel=2e-6, msg="winograd (cat) vs fp64")
+    close(got, direct, rtol=1e-5, scale_rel=2e-6, msg="winograd (cat) vs ynet_conv2d")
+    e_w, e_d = float((got.double() - ref64).abs().max()), float((direct.double() - ref64).abs().max())
+    assert e_w <= 1.5 * e_d + 1e-7, (e_w, e_d)
+    # the smooth planes alone through the one-source kernel (32 -> 32 and 32 -> 16)
+    for cout in (32, 16):
+        w1 = rnd(cout, 32, 3, 3, seed=6, scale=0.2).to(dev)
+        wp1 = ops.pack_weight(w1, 0)
+        g1, d1 = torch.empty(B, cout, H, W, device=dev), torch.empty(B, cout, H, W, device=dev)
+        assert ops.conv2d_raw([(up.data_ptr(), 32, 32 * H * W)], None, wp1, None, [(g1.data_ptr(), cout, cout * H * W)], B, H, W, 3, False,
+                              wino=({}, "fwd")).startswith("winograd")
+        ops.conv2d_raw([(up.data_ptr(), 32, 32 * H * W)], None, wp1, None, [(d1.data_ptr(), cout, cout * H * W)], B, H, W, 3, False)
+        r1 = F.conv2d(up.double(), w1.double(), None, padding=1)
+        close(g1, r1, rtol=1e-5, scale_rel=2e-6, msg=f"winograd 32 -> {cout} vs fp64")
+        e_w, e_d = float((g1.double() - r1).abs().max()), float((d1.double() - r1).abs().max())
+        assert e_w <= 1.5 * e_d + 1e-7, (cout, e_w, e_d)
+
+
 @pytest.mark.parametrize("case", [(8, 256, 256, 32, [32, 16]), (16, 128, 128, 32, [64]), (8, 256, 256, 16, [32, None])], ids=str)
 def test_winograd_launches_over_output_channel_slices(dev, case):
     """A data gradient with 48 or 64 output channels (the decoders' first convolutions: up-sampled part + skip part) runs as two
@@ -786,6 +822,119 @@ def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     close(outs[0][1], outs[1][1], rtol=1e-5, scale_rel=2e-6, msg="input gradient")
     ref = F.conv2d(rnd(B, 32, H, W, seed=7).to(dev), w, bias, padding=1)
     close(outs[0][0], ref, rtol=1e-4, scale_rel=2e-6, msg="forward vs torch")
+
+
+W16_CASES = [
+    # B, H, W, [source channels], cout, relu, bias, mode (0 forward filter, 1 data gradient)
+    (32, 64, 64, [64], 64, True, True, 0),          # the 64 -> 64 layers at 64^2 (4 slices, 2 tiles per team member)
+    (32, 64, 64, [32], 64, True, True, 0),          # encoder stage 2's first layer
+    (32, 64, 64, [64], 32, False, True, 0),         # the up-convolution 64 -> 32 at 64^2 (no ReLU)
+    (8, 256, 256, [32], 16, False, True, 0),        # the up-convolution 32 -> 16 at 256^2 (one slice)
+    (10, 64, 64, [64], 64, True, False, 1),         # batch 10: 40 tiles, teams smaller than 8
+    (32, 64, 64, [32, 64], 64, True, True, 0),      # decoder level 2, first convolution: 96 channels = two launches (in-place add)
+    (32, 64, 64, [32, 64, 1], 64, True, True, 0),   # ... + the way-point map: 97 channels
+    (16, 128, 128, [64, 1], 32, True, True, 0),     # 65 -> 32 at 128^2 in ONE launch of two slices (17 chunks)
+    (256, 32, 32, [64], 64, True, True, 0),         # evaluate()'s folded batch at 32^2
+    (4, 96, 160, [20, 7], 16, False, False, 0),     # ragged channel counts (zero planes / zero filters), H = 3 tiles, W = 5 tiles
+]
+
+
+@pytest.mark.parametrize("case", W16_CASES, ids=str)
+def test_winograd_slice_form_matches_the_direct_form(dev, case):
+    """ynet_conv2d_winograd16 (round 5: 16 output channels per workgroup, two row pairs per wave) through ops.conv2d_raw's dispatch: the
+    same values as torch's convolution in fp64 and as ynet_conv2d within fp32 rounding (2e-6 of the largest output), its error against
+    fp64 not above 1.5x the implicit GEMM's."""
+    ops = pkg("ops")
+    B, H, W, cs, cout, relu, has_bias, mode = case
+    cin = sum(cs)
+    xs = [torch.relu(rnd(B, c, H, W, seed=10 + i)).to(dev) for i, c in enumerate(cs)]
+    w = (rnd(cout, cin, 3, 3, seed=2, scale=0.2) if mode == 0 else rnd(cin, cout, 3, 3, seed=2, scale=0.2)).to(dev)
+    bias = rnd(cout, seed=3).to(dev) if has_bias else None
+    wp = ops.pack_weight(w, mode)
+    srcs = [(x.data_ptr(), c, c * H * W) for x, c in zip(xs, cs)]
+    got, direct = torch.full((B, cout, H, W), float("nan"), device=dev), torch.empty(B, cout, H, W, device=dev)
+    n0 = ops.wino_stats.get("launches16", 0)
+    old = ops._wino16_for_16
+    ops._wino16_for_16 = True
+    try:
+        tag = ops.conv2d_raw(srcs, None, wp, bias, [(got.data_ptr(), cout, cout * H * W)], B, H, W, 3, relu, wino=({}, "fwd" if mode == 0 else "dgrad"))
+    finally:
+        ops._wino16_for_16 = old
+    assert tag is not None and tag.startswith("winograd16"), tag
+    assert ops.wino_stats["launches16"] - n0 == (2 if cin > 84 else 1)
+    assert ops.conv2d_raw(srcs, None, wp, bias, [(direct.data_ptr(), cout, cout * H * W)], B, H, W, 3, relu) is None
+    x64 = torch.cat(xs, 1).double()
+    ref64 = F.conv2d(x64, w.double(), bias.double() if has_bias else None, padding=1) if mode == 0 else F.conv_transpose2d(x64, w.double(), padding=1)
+    ref64 = torch.relu(ref64) if relu else ref64
+    close(got, ref64, rtol=1e-5, scale_rel=2e-6, msg="winograd16 vs fp64")
+    close(got, direct, rtol=1e-5, scale_rel=2e-6, msg="winograd16 vs ynet_conv2d")
+    e_w, e_d = float((got.double() - ref64).abs().max()), float((direct.double() - ref64).abs().max())
+    assert e_w <= 1.5 * e_d + 1e-7, (e_w, e_d)
+
+
+def test_winograd_slice_form_epilogues(dev):
+    """The epilogue variants of ynet_conv2d_winograd16 at 64 channels, 64^2: a data gradient over two destinations (32 + 64 channels, a
+    third one nobody wants), the data gradient through the ReLU backward of the layer below (bit-identical to "plain, then mask"), the
+    2 x 2 max-pooled copy (bit-identical to max_pool2d of the same launch's output) and evaluate()'s shared-skip-term launch."""
+    ops = pkg("ops")
+    B, H, W = 32, 64, 64
+    dy = rnd(B, 64, H, W, seed=1).to(dev)
+    # ---- two wanted destinations + an unwanted one (decoder level 2's first convolution: up 32, skip 64, way-point map 1)
+    w = rnd(64, 97, 3, 3, seed=2, scale=0.2).to(dev)
+    wp = ops.pack_weight(w, 1)
+    sizes = [32, 64, 1]
+    want = [torch.empty(B, c, H, W, device=dev) for c in sizes]
+    got = [torch.full((B, c, H, W), float("nan"), device=dev) for c in sizes]
+    ops.conv2d_raw([(dy.data_ptr(), 64, 64 * H * W)], None, wp, None, [(t.data_ptr(), t.shape[1], t.shape[1] * H * W) for t in want], B, H, W, 3, False)
+    dsts = [(got[0].data_ptr(), 32, 32 * H * W), (got[1].data_ptr(), 64, 64 * H * W), (None, 1, 0)]
+    tag = ops.conv2d_raw([(dy.data_ptr(), 64, 64 * H * W)], None, wp, None, dsts, B, H, W, 3, False, wino=({}, "dgrad"))
+    assert tag == "winograd16:0+0", tag
+    close(got[0], want[0], rtol=1e-5, scale_rel=2e-6, msg="32-channel destination")
+    close(got[1], want[1], rtol=1e-5, scale_rel=2e-6, msg="64-channel destination")
+    assert bool(torch.isnan(got[2]).all())
+    # ---- through the ReLU backward of the layer below
+    w2 = rnd(64, 64, 3, 3, seed=3, scale=0.2).to(dev)
+    wp2 = ops.pack_weight(w2, 1)
+    act = torch.relu(rnd(B, 64, H, W, seed=4)).to(dev)
+    plain, masked, direct = (torch.full((B, 64, H, W), float("nan"), device=dev) for _ in range(3))
+    src, cache = [(dy.data_ptr(), 64, 64 * H * W)], {}
+    assert ops.conv2d_raw(src, None, wp2, None, [(plain.data_ptr(), 64, 64 * H * W)], B, H, W, 3, False, wino=(cache, "dgrad")) == "winograd16:0"
+    assert ops.conv2d_raw(src, None, wp2, None, [(masked.data_ptr(), 64, 64 * H * W)], B, H, W, 3, False, relu_of=(act.data_ptr(), 64 * H * W),
+                          wino=(cache, "dgrad")) == "winograd16:1"
+    assert ops.conv2d_raw(src, None, wp2, None, [(direct.data_ptr(), 64, 64 * H * W)], B, H, W, 3, False, relu_of=(act.data_ptr(), 64 * H * W)) is None
+    assert torch.equal(masked, torch.where(act > 0, plain, torch.zeros_like(plain)))
+    close(masked, direct, rtol=1e-5, scale_rel=2e-6, msg="through the ReLU backward: winograd16 vs implicit GEMM")
+    # ---- the pooled copy
+    x = torch.relu(rnd(B, 64, H, W, seed=5)).to(dev)
+    w3, b3 = rnd(64, 64, 3, 3, seed=6, scale=0.2).to(dev), rnd(64, seed=7).to(dev)
+    wp3 = ops.pack_weight(w3, 0)
+    y, yp = torch.full((B, 64, H, W), float("nan"), device=dev), torch.full((B, 64, H // 2, W // 2), float("nan"), device=dev)
+    assert ops.conv2d_raw([(x.data_ptr(), 64, 64 * H * W)], None, wp3, b3, [(y.data_ptr(), 64, 64 * H * W)], B, H, W, 3, True,
+                          pooled=(yp.data_ptr(), 64 * (H // 2) * (W // 2)), wino=({}, "fwd")) == "winograd16:3"
+    close(y, torch.relu(F.conv2d(x, w3, b3, padding=1)), rtol=1e-4, scale_rel=2e-6, msg="output vs torch")
+    assert torch.equal(yp, F.max_pool2d(y, 2, 2))
+    # ---- evaluate()'s shared-skip-term launch with 64 output channels: relu(conv(cat(up, way-point map), W_rest) + b + term[b % Bs])
+    Bs, times = 16, 2
+    up, wmap = torch.relu(rnd(Bs * times, 32, H, W, seed=8)).to(dev), torch.relu(rnd(Bs * times, 1, H, W, seed=9)).to(dev)
+    skip = torch.relu(rnd(Bs, 64, H, W, seed=10)).to(dev)
+    w4, b4 = rnd(64, 97, 3, 3, seed=11, scale=0.2).to(dev), rnd(64, seed=12).to(dev)
+    outs = []
+    for allowed in (True, False):
+        old, cache = ops._wino_allowed, {}
+        ops._wino_allowed = allowed
+        try:
+            with torch.no_grad():
+                term = ops.shared_conv_term(skip, w4, 32, 96, cache)
+                ops.rest_filter(w4, 32, 96, cache)
+                ops.rest_filter_winograd(w4, 32, 96, cache, (32, 1), Bs * times, H, W)
+                n1 = ops.wino_stats.get("launches16", 0)
+                outs.append(ops.conv2d_shared_term(None, times, [up, wmap], w4, b4, True, cache, term, 32, 96))
+                assert ops.wino_stats.get("launches16", 0) - n1 == (1 if allowed else 0)
+        finally:
+            ops._wino_allowed = old
+    ref = torch.relu(F.conv2d(torch.cat([up, skip.repeat(times, 1, 1, 1), wmap], 1), w4, b4, padding=1))
+    close(outs[0], outs[1], rtol=1e-5, scale_rel=2e-6, msg="shared term: winograd16 vs implicit GEMM")
+    close(outs[0], ref, rtol=1e-4, scale_rel=2e-6, msg="shared term vs torch")
 
 
 @pytest.mark.parametrize("case", [("plain", 520), ("dgrad_relu", 264), ("cat", 264), ("cat_add", 264)], ids=str)

@@ -106,6 +106,30 @@ int main() {
         EXPECT_REJECT(ynet_conv2d_winograd_cat_pool(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, nullptr, 32 * 16384, 32, 32, 256, 256, 1, nullptr));   // no pooled output
         EXPECT_REJECT(ynet_conv2d_winograd_cat_pool(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, fp, 16 * 16384, 32, 32, 256, 256, 1, nullptr));        // pooled stride too small
     }
+    {   // the slice form (round 5)
+        const int one64[1] = {64}, cat3[3] = {32, 64, 1}, bad[2] = {32, 0};
+        const long long bs1[1] = {64 * 4096}, bs3[3] = {32 * 4096, 64 * 4096, 4096};
+        const float* s1[1] = {cfp};
+        const float* s3[3] = {cfp, cfp, cfp};
+        for (int b : {1, 10, 32, 256})
+            for (int hw : {32, 64, 128, 256})
+                for (int co : {16, 32, 48, 64, 128})
+                    acc += ynet_conv2d_winograd16_supported(b, hw, hw, one64, 1, co, 3) + ynet_conv2d_winograd16_supported(b, hw, hw, cat3, 3, co, 3) +
+                           ynet_conv2d_winograd16_supported(b, hw, hw + 16, one64, 1, co, 3) + ynet_conv2d_winograd16_supported(b, hw, hw, bad, 2, co, 3) +
+                           ynet_conv2d_winograd16_supported(b, hw, hw, one64, 1, co, 5) + ynet_winograd16_filter_floats(cat3, 3, co);
+        EXPECT_REJECT(ynet_winograd16_filter(cfp, fp, cat3, 4, 64, 0, 64, nullptr));                                                     // too many sources
+        EXPECT_REJECT(ynet_winograd16_filter(cfp, fp, one64, 1, 24, 0, 64, nullptr));                                                    // cout not a multiple of 16
+        EXPECT_REJECT(ynet_winograd16_filter(cfp, fp, one64, 1, 64, 32, 64, nullptr));                                                   // slice beyond the filter
+        EXPECT_REJECT(ynet_conv2d_winograd16(s3, cat3, bs3, 3, cfp, nullptr, fp, 64 * 4096, 64, 32, 64, 64, 1, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr));   // 97 -> 100 padded channels: too many filters for LDS
+        EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, cfp, nullptr, fp, 64 * 4096, 48, 32, 64, 64, 1, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr));  // 48 outputs: not a divisor of an XCD's workgroups
+        EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, cfp, nullptr, fp, 64 * 4096, 64, 32, 48, 64, 1, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr));  // H not a multiple of 32
+        EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, cfp, nullptr, fp, 32 * 4096, 64, 32, 64, 64, 1, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr));  // output stride smaller than the image
+        EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, cfp, nullptr, fp, 64 * 4096, 64, 32, 64, 64, 0, cfp, 64 * 4096, cfp, 64 * 4096, 0, nullptr, 0, nullptr));  // two epilogue variants
+        EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, cfp, cfp, fp, 64 * 4096, 64, 32, 64, 64, 0, cfp, 64 * 4096, nullptr, 0, 0, nullptr, 0, nullptr));         // relu_of with a bias
+        EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, cfp, nullptr, fp, 64 * 4096, 64, 32, 64, 64, 1, nullptr, 0, cfp, 64 * 4096, -1, nullptr, 0, nullptr));    // negative modulus
+        EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, cfp, nullptr, fp, 64 * 4096, 64, 32, 64, 64, 1, nullptr, 0, nullptr, 0, 0, fp, 16 * 1024, nullptr));       // pooled stride too small
+        EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, nullptr, nullptr, fp, 64 * 4096, 64, 32, 64, 64, 1, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr));      // no filters
+    }
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, nullptr, 32 * 65536, 32, 32, 32, 256, 256, nullptr));   // no activation
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, cfp, 16 * 65536, 32, 32, 32, 256, 256, nullptr));       // activation stride too small
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 0, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));

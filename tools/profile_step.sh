@@ -12,4 +12,4 @@ rm -rf /tmp/trace_$TAG
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/trace_$TAG -o t -- python3 "$R/bench.py" --no-cpu-baseline --no-roofline "$@" > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 tail -1 "$OUT/trace.log" | cut -c1-400
-python3 "$R/tools/trace_summary.py" /tmp/trace_$TAG "$OUT/$TAG" --tail-frac 0.6 --dump ${DUMP:-700}
+python3 "$R/tools/trace_summary.py" /tmp/trace_$TAG "$OUT/$TAG" --tail-frac 0.6 --dump ${DUMP:-700} --rows ${ROWS:-700}

@@ -74,6 +74,11 @@ def main():
             for i, (n, a, b) in enumerate(last):
                 conc = sum(1 for (_, a2, b2) in last[max(0, i - 8):i + 8] if a2 < b and b2 > a) - 1
                 f.write(f"{(a - t0) / 1e3:10.1f} us  +{(b - a) / 1e3:8.1f} us  x{conc}  {n[:90]}\n")
+    if "--rows" in sys.argv:        # the last `--rows N` kernels as JSON rows [name, start ns (from the first row), duration ns]: overlap analysis off the box
+        k = int(sys.argv[sys.argv.index("--rows") + 1])
+        last = rows[-k:]
+        t0 = last[0][1]
+        json.dump([[n[:80], a - t0, b - a] for n, a, b in last], open(out + "_rows.json", "w"))
     tail = rows[int(len(rows) * (1 - frac)):]
     json.dump({"all": span(rows), f"last_{frac}": span(tail)}, open(out + "_timeline.json", "w"), indent=1)
     print(open(out + "_timeline.json").read())
