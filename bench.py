@@ -501,7 +501,6 @@ def main():
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
-        import glob
         import tempfile
         logs = tempfile.mkdtemp(prefix="ynet_bench_ranks_")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",

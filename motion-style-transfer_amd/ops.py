@@ -401,7 +401,9 @@ def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool
 
 
 _wino16_allowed = _os.environ.get("YNET_WINOGRAD16", "1") != "0"     # YNET_WINOGRAD16=0: no conv_wino16_kernel launches (round 5's slice form)
-_wino16_for_16 = _os.environ.get("YNET_WINOGRAD16_SLICE16", "1") != "0"   # ... = 0: 16-output-channel launches stay on conv_wino_kernel<1, ...>
+# YNET_WINOGRAD16_SLICE16=1: 16-output-channel launches (32 -> 16 at 256^2) on the slice form too -- measured SLOWER there than
+# conv_wino_kernel<1, 4> (141 against 134 us at B 32: the launch streams 402 MB, and six staged rows per unit do not pay for one slice)
+_wino16_for_16 = _os.environ.get("YNET_WINOGRAD16_SLICE16", "0") != "0"
 
 
 def conv2d_winograd16_raw(srcs, u, bias, dst, cout, B, H, W, relu, relu_of=None, addend=None, pool=None):
