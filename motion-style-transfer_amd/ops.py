@@ -528,7 +528,8 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
             ptr, n, bs, col0 = pieces[0]
             _wino16(wino, wp, 0, srcs, bias, (ptr, bs), 16, col0, ctot, B, H, W, relu, relu_of=relu_of)
             return "winograd16:%d" % (1 if relu_of is not None else 0)
-        if (pieces and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
+        wide = any(d_[0] is not None and d_[1] >= 64 for d_ in dsts)      # (a 64-channel destination: one launch of the slice form, below)
+        if (pieces and not wide and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
                 and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces)):
             cache, what = wino
             tag = "winograd:" + "+".join("%d,%d,%s" % (p_[1] // 16, cin // 8, "true" if relu_of is not None else "false") for p_ in pieces)
@@ -553,6 +554,20 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
             for ptr, c, bs, col0 in wanted:
                 _wino16(wino, wp, 0, srcs, bias, (ptr, bs), c, col0, ctot, B, H, W, relu, relu_of=relu_of)
             return "winograd16:" + "+".join("%d" % (1 if relu_of is not None else 0) for _ in wanted)
+        if (pieces and wide and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
+                and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces)):      # (YNET_WINOGRAD16=0)
+            cache, what = wino
+            tag = "winograd:" + "+".join("%d,%d,%s" % (p_[1] // 16, cin // 8, "true" if relu_of is not None else "false") for p_ in pieces)
+            for ptr, n, bs, col0 in pieces:
+                key = "wino_%s_%d_%d" % (what, col0, n)
+                ent = cache.get(key)
+                if ent is None or ent[0] is not wp:
+                    ent = cache[key] = _wino_made((wp, winograd_filter(wp, cin, n, col0, ctot)))
+                _wino_ready(ent)
+                conv2d_winograd_raw((srcs[0][0], srcs[0][2]), ent[1], None if bias is None else bias[col0:col0 + n], (ptr, bs), cin, n, B, H, W, relu,
+                                    relu_of=relu_of)
+                wino_stats["launches"] += 1
+            return tag
     if (wino is not None and _wino_allowed and K == 3 and mask is None and relu_of is None and all(len(s_) == 3 for s_ in srcs)
             and (len(srcs) > 1 or srcs[0][1] not in (16, 32)) and all(s_[0] % 16 == 0 and s_[2] % 4 == 0 for s_ in srcs)):
         # the decoders' first convolutions: cat(up-sampled features, skip features[, way-point map]) -> 32 (ynet_conv2d_winograd_cat)
