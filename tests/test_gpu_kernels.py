@@ -688,7 +688,8 @@ def test_winograd_launches_over_output_channel_slices(dev, case):
     dsts = [(t.data_ptr() if c is not None else None, t.shape[1], t.shape[1] * H * W if c is not None else 0) for t, c in zip(got, couts)]
     n0 = ops.wino_stats["launches"]
     assert ops.conv2d_raw([(dy.data_ptr(), cin, cin * H * W)], None, wp, None, dsts, B, H, W, 3, False, wino=({}, "dgrad")).startswith("winograd")
-    assert ops.wino_stats["launches"] - n0 == (2 if None not in couts else 1)
+    # (round 5: a destination of 64 channels is ONE launch of the slice form, ynet_conv2d_winograd16, not two 32-channel launches)
+    assert ops.wino_stats["launches"] - n0 == (1 if None in couts or (64 in couts and ops._wino16_allowed) else 2)
     for g, t, c in zip(got, want, couts):
         if c is None:
             assert bool(torch.isnan(g).all())
