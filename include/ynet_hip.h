@@ -10,7 +10,14 @@
  *  - every pointer is a DEVICE pointer into caller-owned memory (PyTorch allocations); fp32, NCHW,
  *    contiguous inside one image plane; batch strides are explicit where concatenation is fused;
  *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); calls only enqueue
- *    work: no allocation, no synchronisation, no host<->device copies, no global state;
+ *    work: no allocation, no synchronisation, no host<->device copies;
+ *  - process state the library DOES keep (and nothing else): (1) per HIP device, set on first use -- the > 64 KB dynamic-LDS
+ *    attribute of its kernels and the CU count its persistent grids are sized for; (2) the DEVELOPMENT switches YNET_* read from
+ *    the environment ONCE, at the first call that consults them (function-local statics in csrc/conv_mfma.hip, conv_wino.hip,
+ *    wgrad_mfma.hip, lora_wgrad.hip: dispatch overrides such as YNET_WINOGRAD, YNET_WINOGRAD16, YNET_WINOGRAD_MIN, YNET_CONV_R,
+ *    YNET_KSPLIT_ITEMS -- the full table is DESIGN.md section 9).  A process that changes one of them after that first call keeps the
+ *    old value: set them before loading the library; the defaults are what is tested and measured, no entry point's result depends
+ *    on them beyond fp32 rounding (which kernel serves a shape), and the *_supported / *_plan queries report the dispatch in force;
  *  - return 0 on success, non-zero on error; ynet_last_error() returns the message (thread local);
  *  - results are bitwise reproducible run to run (no float atomics anywhere).
  */

@@ -290,32 +290,26 @@ class YNetEncoderB(YNetEncoder):
             self.adapters = nn.ModuleList([AdapterBlock(train_net, par_channels_in[i], channels[i]) for i in self.position])
 
     def forward(self, x):
-        features = []
-        j = 0
+        """The feature pyramid (one map per stage).  Adapter blocks sit at the stages listed in ``position``: a serial block
+        transforms its stage's OUTPUT; a parallel block sees what the stage's convolutions see -- the stage input behind the
+        stage's own leading max-pool, if it has one -- and is added to the stage output (reference models/ynet.py:258-283)."""
+        serial, parallel = "serial" in self.train_net, "parallel" in self.train_net
+        blocks = iter(self.adapters) if (serial or parallel) else iter(())
+        pyramid = []
         for i, stage in enumerate(self.stages):
-            if "serial" in self.train_net:
+            adapted = i in self.position
+            if serial:
                 x = stage(x)
-                if i in self.position:
-                    x = self.adapters[j](x)
-                    j += 1
-            elif "parallel" in self.train_net:
-                if isinstance(stage[0], nn.MaxPool2d):
-                    y = stage[0](x)
-                    x = stage(x)
-                    if i in self.position:
-                        x = x + self.adapters[j](y)
-                        j += 1
-                else:
-                    y = stage(x)
-                    if i in self.position:
-                        y = y + self.adapters[j](x)
-                        j += 1
-                    x = y
+                x = next(blocks)(x) if adapted else x
+            elif parallel:
+                seen = stage[0](x) if isinstance(stage[0], nn.MaxPool2d) else x      # (pooled twice: once here, once inside the stage -- as the reference)
+                x = stage(x)
+                x = x + next(blocks)(seen) if adapted else x
             else:
-                nxt = self.stages[i + 1] if i + 1 < len(self.stages) else None
-                x = stage(x, pool_next=nxt is not None and isinstance(nxt[0], HipMaxPool2d))
-            features.append(x)
-        return features
+                following = self.stages[i + 1] if i + 1 < len(self.stages) else None
+                x = stage(x, pool_next=following is not None and isinstance(following[0], HipMaxPool2d))
+            pyramid.append(x)
+        return pyramid
 
 
 class YNetEncoderFusion(nn.Module):
