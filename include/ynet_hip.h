@@ -155,7 +155,7 @@ int ynet_conv2d_winograd_cat_pool(const float* const* src, const int* src_c, con
  *                               and a wave computes two row pairs (4 output rows x 32 columns) per unit -- for the layers the two kernels above do not
  *                               serve, 16 / 32 / 64 / 128 output channels from up to three concatenated sources of at most 84 padded input channels
  *                               (the 64-channel convolutions and data gradients at 64^2 of models/ynet.py:200-211, 420-445, and the 32 -> 16 up-convolution,
- *                               ynet.py:464), H % 32 == 0, W % 32 == 0, B * H * W >= 64 * 64 * 8 (ynet_conv2d_winograd16_supported).  At most ONE epilogue
+ *                               ynet.py:464), H % 32 == 0, W % 32 == 0, B * H * W >= 64 * 64 * 10 (ynet_conv2d_winograd16_supported).  At most ONE epilogue
  *                               variant: relu_of (a data gradient written through that activation's ReLU backward, as ynet_conv2d_winograd_dgrad_relu: bias
  *                               NULL, relu 0), addend (+ addend[b % addend_bmod] in front of the ReLU, as ynet_conv2d_winograd_cat_add) or pooled (the
  *                               2 x 2 max-pooled copy, as ynet_conv2d_winograd_cat_pool); the others NULL.  ynet_winograd16_filter writes the slice-major

@@ -987,8 +987,9 @@ static bool wino16_ok(int B, int H, int W, const int* src_c, int nsrc, int cout,
     const int nch = wino_cat_padded(src_c, nsrc) / 4;
     if (nch < 2 || nch > W6_MAX_CHUNKS) return false;      // 21 chunks of 4 KB of filters + eight 9.2 KB rings: 158 KB of LDS
     if (84ll * H * W * 4 + (W + 4) * 4 >= (1ll << 31)) return false;      // one image of one source / of the output per buffer descriptor
-    // (32 K pixels: batch 10 at 64^2 is served -- 3.02 -> 2.92 ms per step there; batch 32 at 32^2 measures the same either way)
-    static const int min_pixels = getenv("YNET_WINOGRAD16_MIN") ? atoi(getenv("YNET_WINOGRAD16_MIN")) : (getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 64 * 64 * 8);
+    // (40 K pixels: batch 10 at 64^2 is served -- 3.02 -> 2.92 ms per step there --, batch 32 at 32^2 is not: one 8-unit tile per workgroup on
+    //  half the CUs takes 30-37 us per launch where the direct tiles take 27-30, and the 96 / 97-channel layers would be two launches)
+    static const int min_pixels = getenv("YNET_WINOGRAD16_MIN") ? atoi(getenv("YNET_WINOGRAD16_MIN")) : (getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 64 * 64 * 10);
     return (long long)B * H * W >= min_pixels;
 }
 

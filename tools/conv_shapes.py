@@ -18,7 +18,7 @@ import sqlite3
 import sys
 
 PEAK_TF, PEAK_GBS = 157.3, 8000.0
-CONV = ("conv_dma_", "conv_mfma_kernel", "conv_wino_")
+CONV = ("conv_dma_", "conv_mfma_kernel", "conv_wino")
 
 
 def short(name):
