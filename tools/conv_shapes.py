@@ -89,13 +89,13 @@ def main():
     for e in shapes.values():
         us = sum(e["us"]) / len(e["us"])
         ex = e["direct_gflop"] * (16.0 / 36.0 if e["kernel"].startswith("conv_wino") else 1.0)
-        tf = ex / us / 1e3
+        tf = ex / us * 1e3          # GFLOP per microsecond = 1e15 FLOP/s
         gbs = e["bytes"] / us / 1e3
         r = dict(kernel=e["kernel"], shape=e["shape"], launches_per_step=e["launches_per_step"], rocprof_avg_us=round(us, 2),
                  rocprof_min_us=round(min(e["us"]), 2), rocprof_max_us=round(max(e["us"]), 2), ms_per_step=round(us * e["launches_per_step"] / 1e3, 4),
                  hip_event_us=round(sum(e["event_us"]) / len(e["event_us"]), 2), direct_gflop_per_launch=e["direct_gflop"],
                  executed_gflop_per_launch=round(ex, 5), executed_tflops=round(tf, 2), frac_of_fp32_mfma_peak=round(tf / PEAK_TF, 4),
-                 direct_equiv_tflops=round(e["direct_gflop"] / us / 1e3, 2), algorithmic_mb_per_launch=round(e["bytes"] / 1e6, 3),
+                 direct_equiv_tflops=round(e["direct_gflop"] / us * 1e3, 2), algorithmic_mb_per_launch=round(e["bytes"] / 1e6, 3),
                  algorithmic_gbs=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK_GBS, 4), pmc_hbm_bytes_per_launch=None)
         if e["fetch"] and e["write"]:
             f, w = sum(e["fetch"]) / len(e["fetch"]), sum(e["write"]) / len(e["write"])
