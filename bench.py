@@ -156,6 +156,7 @@ class ConvTimer:
         self.orig_wino = ops.conv2d_winograd_raw
         self.orig_cat = ops.conv2d_winograd_cat_raw
         self.orig_16 = ops.conv2d_winograd16_raw
+        self.orig_up = ops.upsample2x_conv2d_raw
 
     def __enter__(self):
         def timed_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None):
@@ -191,6 +192,16 @@ class ConvTimer:
             self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin + cout * (2 if epi in (1, 2) else (1.25 if epi == 3 else 1))),
                              (B, H, W, cin, cout, 3, False)))
         self.ops.conv2d_winograd16_raw = timed_16
+
+        def timed_up(src, u, bias, dst, cin, cout, B, H, W, relu=False):
+            # the up-convolution with its bilinear x2 inside: the convolution's FLOPs at the up-sampled size; bytes = the LOW-resolution input + the output
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig_up(src, u, bias, dst, cin, cout, B, H, W, relu)
+            e1.record()
+            self.rec.append((f"conv_wino_up_kernel<{cin // 8}>", e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin / 4.0 + cout),
+                             (B, H, W, cin, cout, 3, False)))
+        self.ops.upsample2x_conv2d_raw = timed_up
 
         def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -234,6 +245,7 @@ class ConvTimer:
         self.ops.conv2d_winograd_raw = self.orig_wino
         self.ops.conv2d_winograd_cat_raw = self.orig_cat
         self.ops.conv2d_winograd16_raw = self.orig_16
+        self.ops.upsample2x_conv2d_raw = self.orig_up
 
     def layers(self, steps):
         """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, direct-form TFLOP/s,
@@ -272,7 +284,7 @@ class FlopCounter:
 
     def __enter__(self):
         ops, me = self.ops, self
-        names = ("conv2d_raw", "conv2d_wgrad_raw", "lora_conv2d_wgrad_raw", "conv2d_shared_term", "pred_bce", "pred_softargmax")
+        names = ("conv2d_raw", "conv2d_wgrad_raw", "lora_conv2d_wgrad_raw", "conv2d_shared_term", "pred_bce", "pred_softargmax", "upsample2x_conv2d_raw")
         self.saved = {n: getattr(ops, n) for n in names}
 
         def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, **kw):
@@ -318,8 +330,12 @@ class FlopCounter:
             me.flops += 2.0 * B * H * W * cin * weight.shape[0]
             return me.saved["pred_softargmax"](x, weight, bias)
 
+        def upsample2x_conv2d_raw(src, u, bias, dst, cin, cout, B, H, W, relu=False):
+            me.flops += 2.0 * B * H * W * cin * cout * 9 * (16.0 / 36.0)      # (a Winograd launch)
+            return me.saved["upsample2x_conv2d_raw"](src, u, bias, dst, cin, cout, B, H, W, relu)
+
         for n, f in (("conv2d_raw", conv2d_raw), ("conv2d_wgrad_raw", conv2d_wgrad_raw), ("lora_conv2d_wgrad_raw", lora_conv2d_wgrad_raw),
-                     ("conv2d_shared_term", conv2d_shared_term),
+                     ("conv2d_shared_term", conv2d_shared_term), ("upsample2x_conv2d_raw", upsample2x_conv2d_raw),
                      ("pred_bce", pred_bce), ("pred_softargmax", pred_softargmax)):
             setattr(ops, n, f)
         return self

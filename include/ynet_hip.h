@@ -167,6 +167,16 @@ int ynet_winograd16_filter(const float* wp, float* u, const int* src_c, int nsrc
 int ynet_conv2d_winograd16(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                            long long dst_bs, int cout, int B, int H, int W, int relu, const float* relu_of, long long relu_of_bs, const float* addend,
                            long long addend_bs, int addend_bmod, float* pooled, long long pooled_bs, void* stream);
+/*   ynet_upsample2x_conv2d_winograd   dst = [relu](conv3x3(upsample_bilinear2d(src, scale 2, align_corners = false)) + bias): the decoders'
+ *                               `F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)` followed by `upsample_conv[i]` (models/ynet.py:463-464) as
+ *                               ONE launch -- the up-sampled tensor (4x the input) is never written: every lane builds its 4 x 4 patch of it from the 3 x 3
+ *                               low-resolution patch underneath (the bilinear phase is the same for every 2 x 2 output block), clamping at the image border as
+ *                               ATen does and zero-padding the UP-SAMPLED image for the convolution.  src: cin planes of (H / 2) x (W / 2) per image, dst: cout
+ *                               planes of H x W; u = ynet_winograd_filter(wp, u, cin, cout, 0, cout); serves cin 32 -> cout 16, H % 16 == 0, W % 32 == 0,
+ *                               B * H * W >= 128 * 128 * 8 (ynet_upsample2x_conv2d_winograd_supported; H, W are the up-sampled size). */
+int ynet_upsample2x_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K);
+int ynet_upsample2x_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout, int B,
+                                    int H, int W, int relu, void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,

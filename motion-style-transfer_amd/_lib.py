@@ -46,6 +46,8 @@ SIGNATURES = {
     "ynet_conv2d_winograd_cat": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_cat_add": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp]),
     "ynet_conv2d_winograd_cat_pool": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_upsample2x_conv2d_winograd_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "ynet_upsample2x_conv2d_winograd": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd16_supported": (c_i, [c_i, c_i, c_i, PI, c_i, c_i, c_i]),
     "ynet_winograd16_filter_floats": (c_ll, [PI, c_i, c_i]),
     "ynet_winograd16_filter": (c_i, [c_fp, c_fp, PI, c_i, c_i, c_i, c_i, c_fp]),

@@ -708,6 +708,201 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino16_kernel(const Wino16
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The up-convolution with its bilinear x2 inside (round 5): y = conv3x3(upsample_bilinear2d(x, 2, align_corners = false)) + bias, the
+// decoders' `F.interpolate(x, scale_factor=2, mode='bilinear')` + `upsample_conv[i]` (models/ynet.py:463-464), for 32 -> 16 channels.
+// The up-sampled tensor (4x the input) is never written: a wave stages the THREE low-resolution rows under its row pair (8 channels x 3
+// rows x 6 units = 144 units per chunk: 2.25 LDS-DMA instructions instead of 5) and every lane builds its 4 x 4 high-resolution patch from
+// its 3 x 3 low-resolution patch -- a 2 x 2 output block starts at an odd column / row of the up-sampled image, so the bilinear phase is the
+// same for every block: rows (y0 - 1, y0) = (0.75, 0.25) L[i-1] + (0.25, 0.75) L[i], (y0 + 1, y0 + 2) = (0.75, 0.25) L[i] + (0.25, 0.75) L[i+1],
+// columns alike.  Borders: the bilinear clamp (L[-1] = L[0]) happens in staging (rows: the lane's offset; columns: a select in
+// registers), the convolution's zero padding of the UP-SAMPLED image is applied to the finished patch (row -1 / H, column -1 / W).
+// Measured motive (tools/probe_up.py): 32 -> 16 at 256^2 sits under both roofs -- 144 us at B 32, 122 with its input in L2 -- and the
+// bilinear pass in front of it takes another 74.
+#define WU_LQ 6
+#define WU_ROWF 24
+#define WU_PLANE_F 72
+#define WU_SLOT_BYTES (144 * 16)
+#define WU_RING_BYTES (2 * WU_SLOT_BYTES)
+
+struct WinoUpArgs {
+    const float* x;        // [B] x (x_bs floats): 8 NCH planes of (H / 2) x (W / 2)
+    const f32x4* u;        // transformed filters (ynet_winograd_filter, 16 output channels)
+    const float* bias;     // 16 floats or NULL
+    float* y;              // [B] x (y_bs floats): 16 planes of H x W
+    long long x_bs, y_bs;
+    int B, H, W, relu, ntiles;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_up_kernel(const WinoUpArgs a) {
+    extern __shared__ f32x4 smem[];
+    constexpr int NCB = 1, WQ = 8 * NCB * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, HW = H * W, Hl = H >> 1, Wl = W >> 1, HWl = Hl * Wl;
+    const int tiles_x = W / WN_TW, tiles_y = H / WN_TH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const unsigned ring0 = lds0 + (unsigned)(NCH * WQ * 16) + (unsigned)(wave * WU_RING_BYTES);
+
+    // static DMA geometry: unit j * 64 + lane -> (channel of the chunk, low-resolution row 0..2, unit of the row); the third instruction has 16 lanes
+    unsigned rel[3], edge[3];             // edge bits: 1 row above, 2 row below, 4 left unit, 8 right unit
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int u = j * 64 + lane, plane = u / 18, rem = u - plane * 18, r = rem / WU_LQ, xq = rem - r * WU_LQ;
+        rel[j] = (unsigned)((plane * HWl + r * Wl + 4 * xq) * 4);
+        edge[j] = (r == 0 ? 1u : 0u) | (r == 2 ? 2u : 0u) | (xq == 0 ? 4u : 0u) | (xq == WU_LQ - 1 ? 8u : 0u);
+    }
+    const unsigned lead = (unsigned)((Wl + 4) * 4);
+    const unsigned x_img = (unsigned)(NCH * 8 * HWl * 4) + lead, y_img = (unsigned)(NCB * 16 * HW * 4);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u), 0, (unsigned)(NCH * WQ * 16), 0x00020000);
+
+    const bool xcd_walk = (gridDim.x & 7) == 0 && a.ntiles >= (int)gridDim.x;
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    const int gstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int tile_first = xcd_walk ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int tile_end = xcd_walk ? min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : a.ntiles;
+    if (tile_first >= tile_end) return;
+    const int my_tiles = (tile_end - tile_first + gstride - 1) / gstride;
+    const int total_units = my_tiles * 8;
+
+    const int n = lane & 15, kq = lane >> 4;
+    const float floor_v = a.relu ? 0.f : -INFINITY;
+    f32x2 bias2[NCB][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bias2[0][h] = a.bias ? f32x2{a.bias[4 * kq + 2 * h], a.bias[4 * kq + 2 * h + 1]} : f32x2{0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bias2[0][h]));
+    const unsigned st0 = (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
+
+#pragma unroll
+    for (int j = 0; j < (NCH * WQ + WN_THREADS - 1) / WN_THREADS; ++j)
+        if (j * WN_THREADS + wave * 64 < NCH * WQ)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(uintptr_t)(lds0 + (unsigned)((j * WN_THREADS + wave * 64) * 16)), 16,
+                                                     (unsigned)((j * WN_THREADS + tid) * 16), 0, 0, 0);
+    unsigned* unit_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(smem) + NCH * WQ * 16 + 8 * WU_RING_BYTES);
+    if (tid == 0) *unit_ctr = 8u;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    auto next_unit = [&]() {
+        unsigned u = 0;
+        if (lane == 0) u = atomicAdd(unit_ctr, 1u);
+        return (int)__builtin_amdgcn_readfirstlane(u);
+    };
+
+    auto dma_chunk = [&](int unit, int c) {       // the three low-resolution rows under row pair `unit`, chunk c -> slot c & 1
+        const int t = tile_first + (unit >> 3) * gstride, slot = c & 1;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int i = (ty * WN_TH >> 1) + (unit & 7), j0 = tx * (WN_TW / 2);
+        const unsigned em = (i == 0 ? 1u : 0u) | (i + 1 == Hl ? 2u : 0u) | (j0 == 0 ? 4u : 0u) | (j0 + WN_TW / 2 == Wl ? 8u : 0u);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x + (long long)b * a.x_bs) - lead), 0, x_img, 0x00020000);
+        const unsigned so = (unsigned)((c * 8 * HWl + i * Wl + j0) * 4);
+        const unsigned sb = ring0 + (unsigned)(slot * WU_SLOT_BYTES);
+        unsigned v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // the row above the image is row 0, the row below it the last row (bilinear clamp); units left / right of the image: zero
+            // (their one float that matters, column -1 / W_low, is replaced by the clamp in registers)
+            unsigned o = rel[j];
+            if (edge[j] & em & 1u) o += (unsigned)(Wl * 4);
+            if (edge[j] & em & 2u) o -= (unsigned)(Wl * 4);
+            v[j] = (edge[j] & em & 12u) ? 0x80000000u : o;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)sb, 16, v[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + 1024u), 16, v[1], so, 0, 0);
+        if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + 2048u), 16, v[2], so, 0, 0);
+    };
+
+    int cur = wave, nxt = next_unit();
+    dma_chunk(cur, 0);
+    dma_chunk(cur, 1);
+
+    const f32x2 c7525 = {0.75f, 0.25f}, c2575 = {0.25f, 0.75f};
+    f32x4 acc[16][NCB];
+    while (cur < total_units) {
+        // this unit's place in the image: which of the patch's border rows / columns lie outside the up-sampled image
+        const int t = tile_first + (cur >> 3) * gstride;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int y0 = ty * WN_TH + 2 * (cur & 7), x0 = tx * WN_TW;
+        const bool top = y0 == 0, bottom = y0 + 2 == H;
+        const bool left = x0 == 0 && n == 0, right = x0 + WN_TW == W && n == 15;      // (per lane)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH || nxt < total_units) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const f32x4* wl = smem + c * WQ;
+            const float* il = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(smem) + NCH * WQ * 16 + wave * WU_RING_BYTES + (c & 1) * WU_SLOT_BYTES);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // the lane's 3 x 3 low-resolution patch of channel s * 4 + kq: staged rows 0 .. 2, floats 3 + n .. 5 + n of the row
+                const float* ip = il + (s * 4 + kq) * WU_PLANE_F + 3 + n;
+                float x[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) x[r][m] = ip[r * WU_ROWF + m];
+                if (s == 1) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (c + 2 < NCH) dma_chunk(cur, c + 2);
+                    else if (nxt < total_units) dma_chunk(nxt, c + 2 - NCH);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {      // bilinear clamp of the columns left / right of the image
+                    x[r][0] = left ? x[r][1] : x[r][0];
+                    x[r][2] = right ? x[r][1] : x[r][2];
+                }
+                // rows: (y0 - 1, y0) and (y0 + 1, y0 + 2) of the up-sampled image at the three low-resolution columns
+                f32x2 va[3], vb[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    va[m] = c7525 * x[0][m] + c2575 * x[1][m];
+                    vb[m] = c7525 * x[1][m] + c2575 * x[2][m];
+                    if (top) va[m][0] = 0.f;          // (the convolution's zero padding: row -1 / row H of the up-sampled image)
+                    if (bottom) vb[m][1] = 0.f;
+                }
+                // columns: dl[R] = up-sampled columns (x0 + 2n - 1, x0 + 2n), dh[R] = (x0 + 2n + 1, x0 + 2n + 2) of patch row R
+                f32x2 dl[4], dh[4];
+#pragma unroll
+                for (int R = 0; R < 4; ++R) {
+                    const float v0 = R < 2 ? va[0][R] : vb[0][R - 2], v1 = R < 2 ? va[1][R] : vb[1][R - 2], v2 = R < 2 ? va[2][R] : vb[2][R - 2];
+                    dl[R] = c7525 * v0 + c2575 * v1;
+                    dh[R] = c7525 * v1 + c2575 * v2;
+                    dl[R][0] = left ? 0.f : dl[R][0];       // (column -1 / column W of the up-sampled image)
+                    dh[R][1] = right ? 0.f : dh[R][1];
+                }
+                const f32x2 tl[4] = {dl[0] - dl[2], dl[1] + dl[2], dl[2] - dl[1], dl[1] - dl[3]};
+                const f32x2 th[4] = {dh[0] - dh[2], dh[1] + dh[2], dh[2] - dh[1], dh[1] - dh[3]};
+                f32x2 v01[4], v23[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v01[q] = wn_v01(tl[q], th[q]);
+                    v23[q] = wn_v23(tl[q], th[q]);
+                }
+                asm volatile("s_nop 3" : "+v"(v01[0]), "+v"(v01[1]), "+v"(v01[2]), "+v"(v01[3]), "+v"(v23[0]), "+v"(v23[1]), "+v"(v23[2]), "+v"(v23[3]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = wl[((s * 4 + q) * NCB) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bv = e < 2 ? v01[q][e] : v23[q][e - 2];
+                        if (c == 0 && s == 0) acc[q * 4 + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else acc[q * 4 + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], bv, acc[q * 4 + e][0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        {
+            const unsigned so_t = (unsigned)((y0 * W + x0) * 4);
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
+            wino_epilogue<NCB, 0>(acc, bias2, floor_v, ry, ry, st0, st1, so_t, so_t, HW);
+        }
+        cur = nxt;
+        if (cur < total_units) nxt = next_unit();
+    }
+}
+
 // U = G g G^T of every (cout, cin) pair, in the fragment order the kernels read: unit ((c4 * 4 + q) * NCB + cb) * 64 + lane holds
 // (xi = q, nu = 0..3) of output channel col0 + cb * 16 + (lane & 15), PADDED input channel c4 * 4 + (lane >> 4) -- the input channels
 // are the concatenation of up to three sources, each padded to a multiple of 4 (padded channels: zero filters); with one source of a
@@ -1088,6 +1283,53 @@ int ynet_conv2d_winograd16(const float* const* src, const int* src_c, const long
     else if (addend != nullptr) hipLaunchKernelGGL((conv_wino16_kernel<2>), dim3(grid), dim3(WN_THREADS), lds, st, a);
     else if (pooled != nullptr) hipLaunchKernelGGL((conv_wino16_kernel<3>), dim3(grid), dim3(WN_THREADS), lds, st, a);
     else hipLaunchKernelGGL((conv_wino16_kernel<0>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    return ynet_check_launch(what);
+}
+
+}  // extern "C"
+
+// ---- the up-convolution with its bilinear x2 inside (conv_wino_up_kernel)
+static bool wino_up_ok(int B, int H, int W, int cin, int cout, int K) {
+    static const int on = getenv("YNET_WINOGRAD") ? atoi(getenv("YNET_WINOGRAD")) : 1;
+    static const int up_on = getenv("YNET_WINOGRAD_UP") ? atoi(getenv("YNET_WINOGRAD_UP")) : 1;
+    if (!on || !up_on || K != 3 || B <= 0 || cin != 32 || cout != 16) return false;
+    if (H % WN_TH || W % WN_TW || H < WN_TH || W < WN_TW) return false;      // (H, W: the UP-SAMPLED size; the input is H / 2 x W / 2)
+    if (32ll * H * W * 4 + (W + 4) * 4 >= (1ll << 31)) return false;
+    static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 8;
+    return (long long)B * H * W >= min_pixels;
+}
+
+extern "C" {
+
+int ynet_upsample2x_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K) { return wino_up_ok(B, H, W, cin, cout, K) ? 1 : 0; }
+
+int ynet_upsample2x_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout, int B,
+                                    int H, int W, int relu, void* stream) {
+    const char* what = "upsample2x_conv2d_winograd";
+    YNET_REQUIRE(src && u && dst, "%s: null pointer", what);
+    YNET_REQUIRE(wino_up_ok(B, H, W, cin, cout, 3), "%s: shape B=%d %dx%d (up-sampled) %d -> %d is not served (ask ynet_upsample2x_conv2d_winograd_supported)", what,
+                 B, H, W, cin, cout);
+    const long long HW = (long long)H * W;
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 &&
+                     (src_bs & 3) == 0 && (dst_bs & 1) == 0,
+                 "%s: planes must be 16-byte (input, filters) / 8-byte (output) aligned", what);
+    YNET_REQUIRE((src_bs == 0 || src_bs >= cin * (HW / 4)) && dst_bs >= cout * HW, "%s: batch strides smaller than the images (input: 0 = one image for the batch)", what);
+    WinoUpArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW)};
+    constexpr int lds = 4 * 8 * 64 * 16 + 8 * WU_RING_BYTES + 16;
+    static bool attr_dev[YNET_MAX_DEV] = {false};
+    static int cus_dev[YNET_MAX_DEV] = {0};
+    const int slot = ynet_device_slot();
+    if (!attr_dev[slot]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_up_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus_dev[slot] = cus < 8 ? 8 : cus;
+        attr_dev[slot] = true;
+    }
+    int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
+    if (grid >= 8) grid &= ~7;
+    hipLaunchKernelGGL((conv_wino_up_kernel<4>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     return ynet_check_launch(what);
 }
 

@@ -438,8 +438,9 @@ class YNetDecoder(nn.Module):
         features = features[::-1]
         x = self.center(features[0])
         for lvl, (f, d, up) in enumerate(zip(features[1:], self.decoder, self.upsample_conv)):
-            x = ops.upsample2x(x)
-            x = up(x)
+            # (F.interpolate(x, scale_factor=2, mode='bilinear') + upsample_conv[lvl], reference models/ynet.py:463-464: one launch where
+            #  the shape is served and the filter is frozen -- the up-sampled tensor is never written, ops.upsample2x_conv2d)
+            x = ops.upsample2x_conv2d(x, up) if type(up) is HipConv2d else up(ops.upsample2x(x))
             y = self._first_conv_shared(lvl, d, x, f)
             x = d[2](y, relu=True) if y is not None else d(ops.lazy_cat([x, f]))
         if readout:

@@ -1298,6 +1298,80 @@ def upsample2x(x):
     return _Upsample2xFn.apply(x)
 
 
+_upconv_allowed = _os.environ.get("YNET_WINOGRAD_UP", "1") != "0"      # YNET_WINOGRAD_UP=0: the bilinear x2 stays a pass of its own in front of the up-convolution
+upconv_stats = {"fused": 0}
+
+
+def upsample2x_conv2d_raw(src, u, bias, dst, cin, cout, B, H, W, relu=False):
+    """dst = [relu](conv3x3(bilinear x2 of src) + bias) in one launch (ynet_upsample2x_conv2d_winograd): src (ptr, batch_stride) of cin planes
+    of (H / 2) x (W / 2), dst (ptr, batch_stride) of cout planes of H x W, u = winograd_filter(packed filter, cin, cout)."""
+    lib = _lib()
+    L.check(lib.ynet_upsample2x_conv2d_winograd(src[0], src[1], u.data_ptr(), bias.data_ptr() if bias is not None else None, dst[0], dst[1], cin, cout, B, H, W,
+                                                1 if relu else 0, _stream()), lib)
+
+
+class _UpConvFn(torch.autograd.Function):
+    """y = conv3x3(upsample2x(x), W) + b without the up-sampled tensor (models/ynet.py:463-464 as one launch).  The filter is frozen (no
+    filter gradient needs the up-sampled input); backward = the convolution's data gradient at the up-sampled size, then the bilinear
+    backward -- through the ReLU backward of the layer that produced x, exactly as _Upsample2xFn does."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        _need_gpu(x, "upsample2x_conv2d")
+        x = x.contiguous()
+        B, cin, Hl, Wl = x.shape
+        cout = weight.shape[0]
+        H, W = 2 * Hl, 2 * Wl
+        wp = _cached(cache, weight, None, None, 1.0, "fwd")
+        key = "wino_fwd_0_%d" % cout      # (the entry ops.conv2d_raw keeps for the unfused launch of the same layer)
+        ent = cache.get(key)
+        if ent is None or ent[0] is not wp:
+            ent = cache[key] = _wino_made((wp, winograd_filter(wp, cin, cout, 0, cout)))
+        _wino_ready(ent)
+        y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+        upsample2x_conv2d_raw((x.data_ptr(), cin * Hl * Wl), ent[1], bias.detach() if bias is not None else None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W)
+        wino_stats["launches"] += 1
+        upconv_stats["fused"] += 1
+        ctx.cache, ctx.shape, ctx.cout = cache, (B, cin, Hl, Wl), cout
+        ctx.w_key = _weight_key(weight, None, None)
+        ctx.premask = bool(premask and ctx.needs_input_grad[0] and _is_relu_output(x))
+        ctx.save_for_backward(weight, x if ctx.premask else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, x = ctx.saved_tensors
+        B, cin, Hl, Wl = ctx.shape
+        H, W, cout = 2 * Hl, 2 * Wl, ctx.cout
+        if ctx.w_key != _weight_key(weight, None, None):
+            raise RuntimeError("upsample2x_conv2d backward: the filter was modified in place between forward and backward")
+        dy = dy.contiguous()
+        wp_d = _cached(ctx.cache, weight, None, None, 1.0, "dgrad")
+        d_up = torch.empty((B, cin, H, W), device=dy.device, dtype=torch.float32)
+        conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], None, wp_d, None, [(d_up.data_ptr(), cin, cin * H * W)], B, H, W, 3, False, wino=(ctx.cache, "dgrad"))
+        dx = torch.empty((B, cin, Hl, Wl), device=dy.device, dtype=torch.float32)
+        lib = _lib()
+        if ctx.premask and premask and x is not None:
+            L.check(lib.ynet_upsample2x_bwd_relu(d_up.data_ptr(), dx.data_ptr(), x.data_ptr(), B * cin, Hl, Wl, _stream()), lib)
+            _premasked[dx.data_ptr()] = (x.data_ptr(), dx._version, tuple(dx.shape))
+        else:
+            L.check(lib.ynet_upsample2x_bwd(d_up.data_ptr(), dx.data_ptr(), B * cin, Hl, Wl, _stream()), lib)
+        return dx, None, None, None
+
+
+def upsample2x_conv2d(x, conv):
+    """conv(upsample2x(x)) for a decoder's up-convolution `conv` (a plain HipConv2d, 3 x 3, no ReLU): ONE launch where the shape is served, the
+    filter is frozen and nobody hooks the module; the two modules otherwise."""
+    w, b = conv.weight, conv.bias
+    if (_upconv_allowed and _wino_allowed and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
+            and (torch.is_grad_enabled() or _wino_eval) and not w.requires_grad and (b is None or not b.requires_grad)
+            and not conv._forward_hooks and not conv._forward_pre_hooks and not conv._backward_hooks
+            and tuple(w.shape[1:]) == (x.shape[1], 3, 3) and x.data_ptr() % 16 == 0
+            and _lib().ynet_upsample2x_conv2d_winograd_supported(int(x.shape[0]), 2 * int(x.shape[2]), 2 * int(x.shape[3]), int(x.shape[1]), int(w.shape[0]), 3)):
+        return _UpConvFn.apply(x, w, b, conv._packed)
+    return conv(upsample2x(x))
+
+
 def avgpool_pyramid(x: torch.Tensor, n_levels: int) -> List[torch.Tensor]:
     """[x, AvgPool2d(2)(x), ..., AvgPool2d(2**(n_levels-1))(x)] in one pass (no gradient)."""
     _need_gpu(x, "avgpool_pyramid")

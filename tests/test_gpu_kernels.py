@@ -834,6 +834,61 @@ def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     close(outs[0][0], ref, rtol=1e-4, scale_rel=2e-6, msg="forward vs torch")
 
 
+@pytest.mark.parametrize("case", [(8, 256, 256, True), (16, 128, 128, False), (4, 64, 96, True), (10, 256, 256, False)], ids=str)
+def test_upsample_and_up_convolution_in_one_launch(dev, case):
+    """ynet_upsample2x_conv2d_winograd (round 5): conv3x3(bilinear x2 of x) + bias for 32 -> 16 channels without the up-sampled tensor --
+    against torch's interpolate + conv2d in fp64 (2e-6 of the largest output) and against the two launches it replaces (ynet_upsample2x_fwd,
+    then ynet_conv2d_winograd: the same values within fp32 rounding, the image borders -- bilinear clamp inside, the convolution's zero
+    padding outside -- checked on their own); through autograd (ops.upsample2x_conv2d on a frozen HipConv2d): the input gradient equals
+    the unfused graph's."""
+    ops, ynet = pkg("ops"), pkg("models.ynet")
+    B, H, W, has_bias = case
+    Hl, Wl = H // 2, W // 2
+    assert ops._lib().ynet_upsample2x_conv2d_winograd_supported(B, H, W, 32, 16, 3)
+    x = torch.relu(rnd(B, 32, Hl, Wl, seed=1)).to(dev)
+    w = rnd(16, 32, 3, 3, seed=2, scale=0.2).to(dev)
+    bias = rnd(16, seed=3).to(dev) if has_bias else None
+    wp = ops.pack_weight(w, 0)
+    u = ops.winograd_filter(wp, 32, 16)
+    got = torch.full((B, 16, H, W), float("nan"), device=dev)
+    ops.upsample2x_conv2d_raw((x.data_ptr(), 32 * Hl * Wl), u, bias, (got.data_ptr(), 16 * H * W), 32, 16, B, H, W)
+    up = ops.upsample2x(x)
+    two = torch.empty(B, 16, H, W, device=dev)
+    ops.conv2d_winograd_raw((up.data_ptr(), 32 * H * W), u, bias, (two.data_ptr(), 16 * H * W), 32, 16, B, H, W, False)
+    ref64 = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False), w.double(), bias.double() if has_bias else None, padding=1)
+    assert not bool(torch.isnan(got).any())
+    close(got, ref64, rtol=1e-5, scale_rel=2e-6, msg="fused vs fp64")
+    close(got, two, rtol=1e-5, scale_rel=2e-6, msg="fused vs up-sample + convolution")
+    scale = float(ref64.abs().max())
+    for name, sl in (("top", (slice(None), slice(None), 0)), ("bottom", (slice(None), slice(None), -1)), ("left", (slice(None), slice(None), slice(None), 0)),
+                     ("right", (slice(None), slice(None), slice(None), -1))):
+        assert float((got[sl].double() - ref64[sl]).abs().max()) <= 2e-6 * scale + 2e-5, name
+    e_f, e_t = float((got.double() - ref64).abs().max()), float((two.double() - ref64).abs().max())
+    assert e_f <= 1.5 * e_t + 1e-7, (e_f, e_t)
+    # autograd: a frozen up-convolution module
+    conv = ynet.HipConv2d(32, 16, kernel_size=3).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(bias if has_bias else torch.zeros(16, device=dev))
+    conv.weight.requires_grad_(False)
+    conv.bias.requires_grad_(False)
+    g = rnd(B, 16, H, W, seed=5).to(dev)
+    grads = []
+    for fused in (True, False):
+        old, n0 = ops._upconv_allowed, ops.upconv_stats["fused"]
+        ops._upconv_allowed = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = ops.upsample2x_conv2d(xi, conv)
+            (y * g).sum().backward()
+        finally:
+            ops._upconv_allowed = old
+        assert ops.upconv_stats["fused"] - n0 == (1 if fused else 0)
+        grads.append((y.detach(), xi.grad))
+    close(grads[0][0], grads[1][0], rtol=1e-5, scale_rel=2e-6, msg="module forward")
+    close(grads[0][1], grads[1][1], rtol=1e-5, scale_rel=2e-6, msg="input gradient")
+
+
 W16_CASES = [
     # B, H, W, [source channels], cout, relu, bias, mode (0 forward filter, 1 data gradient)
     (32, 64, 64, [64], 64, True, True, 0),          # the 64 -> 64 layers at 64^2 (4 slices, 2 tiles per team member)
