@@ -1360,11 +1360,12 @@ class _UpConvFn(torch.autograd.Function):
 
 
 def upsample2x_conv2d(x, conv):
-    """conv(upsample2x(x)) for a decoder's up-convolution `conv` (a plain HipConv2d, 3 x 3, no ReLU): ONE launch where the shape is served, the
-    filter is frozen and nobody hooks the module; the two modules otherwise."""
+    """conv(upsample2x(x)) for a decoder's up-convolution `conv` (a plain HipConv2d, 3 x 3, no ReLU): ONE launch where the shape is served, no
+    filter gradient is wanted (inference, or a frozen filter: the filter gradient would need the up-sampled input) and nobody hooks the
+    module; the two modules otherwise."""
     w, b = conv.weight, conv.bias
     if (_upconv_allowed and _wino_allowed and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
-            and (torch.is_grad_enabled() or _wino_eval) and not w.requires_grad and (b is None or not b.requires_grad)
+            and ((not torch.is_grad_enabled() and _wino_eval) or (torch.is_grad_enabled() and not w.requires_grad and (b is None or not b.requires_grad)))
             and not conv._forward_hooks and not conv._forward_pre_hooks and not conv._backward_hooks
             and tuple(w.shape[1:]) == (x.shape[1], 3, 3) and x.data_ptr() % 16 == 0
             and _lib().ynet_upsample2x_conv2d_winograd_supported(int(x.shape[0]), 2 * int(x.shape[2]), 2 * int(x.shape[3]), int(x.shape[1]), int(w.shape[0]), 3)):

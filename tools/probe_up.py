@@ -1,4 +1,5 @@
-import sys, torch, time
+"""Development probe: the up-convolution 32 -> 16 with and without the bilinear x2 inside (tools, not tests)."""
+import sys, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from conftest import pkg
 ops = pkg("ops")
@@ -11,17 +12,15 @@ def bench(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
-for (B, H, W, cin, cout) in [(32, 256, 256, 32, 16), (32, 256, 256, 16, 32), (32, 256, 256, 32, 32), (256, 256, 256, 32, 16)]:
-    x = torch.relu(torch.randn(B, cin, H, W, device=dev))
+for (B, H, W) in [(32, 256, 256), (256, 256, 256), (16, 512, 512), (32, 128, 128)]:
+    cin, cout = 32, 16
+    xl = torch.relu(torch.randn(B, cin, H // 2, W // 2, device=dev))
     w = torch.randn(cout, cin, 3, 3, device=dev) * 0.2
     wp = ops.pack_weight(w, 0)
     u = ops.winograd_filter(wp, cin, cout)
     y = torch.empty(B, cout, H, W, device=dev)
-    t_full = bench(lambda: ops.conv2d_winograd_raw((x.data_ptr(), cin * H * W), u, None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W, False))
-    t_in0 = bench(lambda: ops.conv2d_winograd_raw((x.data_ptr(), 0), u, None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W, False))
-    # quarter of the input bytes: every image reads one of B/4 images
-    print(f"B={B} {H}x{W} {cin}->{cout}: full {t_full:.1f} us, input batch-stride 0 (L2-resident input) {t_in0:.1f} us")
-    # upsample kernel alone
-    xl = torch.relu(torch.randn(B, cin, H // 2, W // 2, device=dev))
+    up = ops.upsample2x(xl)
     t_up = bench(lambda: ops.upsample2x(xl))
-    print(f"   upsample2x {cin}ch {H//2}->{H}: {t_up:.1f} us")
+    t_conv = bench(lambda: ops.conv2d_winograd_raw((up.data_ptr(), cin * H * W), u, None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W, False))
+    t_fused = bench(lambda: ops.upsample2x_conv2d_raw((xl.data_ptr(), cin * H * W // 4), u, None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W))
+    print(f"B={B} {H}x{W}: upsample {t_up:.1f} + conv {t_conv:.1f} = {t_up + t_conv:.1f} us; fused {t_fused:.1f} us")
