@@ -199,7 +199,8 @@ class ConvTimer:
             e0.record()
             self.orig_up(src, u, bias, dst, cin, cout, B, H, W, relu)
             e1.record()
-            self.rec.append((f"conv_wino_up_kernel<{cin // 8}>", e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin / 4.0 + cout),
+            kind = self.ops._lib().ynet_upsample2x_conv2d_winograd_supported(B, H, W, cin, cout, 3)
+            self.rec.append(("conv_wino16_up_kernel" if kind == 2 else f"conv_wino_up_kernel<{cin // 8}>", e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin / 4.0 + cout),
                              (B, H, W, cin, cout, 3, False)))
         self.ops.upsample2x_conv2d_raw = timed_up
 

@@ -173,7 +173,8 @@ int ynet_conv2d_winograd16(const float* const* src, const int* src_c, const long
  *                               low-resolution patch underneath (the bilinear phase is the same for every 2 x 2 output block), clamping at the image border as
  *                               ATen does and zero-padding the UP-SAMPLED image for the convolution.  src: cin planes of (H / 2) x (W / 2) per image, dst: cout
  *                               planes of H x W; u = ynet_winograd_filter(wp, u, cin, cout, 0, cout); serves cin 32 -> cout 16, H % 16 == 0, W % 32 == 0,
- *                               B * H * W >= 128 * 128 * 8 (ynet_upsample2x_conv2d_winograd_supported; H, W are the up-sampled size). */
+ *                               B * H * W >= 128 * 128 * 8 -- ynet_upsample2x_conv2d_winograd_supported returns 1 --, and in the SLICE form (it returns 2: u = ynet_winograd16_filter of the one source) cin a multiple of 4 up to 84,
+ *                               cout in {16, 32, 64}, H % 32 == 0, B * H * W >= 64 * 64 * 10: the 64 -> 32 up-convolutions at 128^2 and 64^2.  H, W are the up-sampled size. */
 int ynet_upsample2x_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K);
 int ynet_upsample2x_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout, int B,
                                     int H, int W, int relu, void* stream);

@@ -903,6 +903,171 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_up_kernel(const WinoU
     }
 }
 
+// ... and in the slice form (64 -> 32 at 128^2, 64 -> 32 at 64^2: the decoders' levels 3 and 2): a unit of 4 up-sampled rows sits on FOUR
+// low-resolution rows (4 channels x 4 rows x 6 units = 96 units per chunk: 1.5 LDS-DMA instructions instead of 4), the lane's 4 x 3 patch
+// becomes the six up-sampled rows of its two 4 x 4 patches.  (The contiguous LDS image puts the four channel groups of a wave 96 floats
+// apart: 2-way bank conflicts on its twelve 4-byte reads per chunk -- 24 LDS cycles on 1024 of MFMAs.)
+#define WV_SLOT_BYTES (96 * 16)
+#define WV_RING_BYTES (2 * WV_SLOT_BYTES)
+
+struct Wino16UpArgs {
+    const float* x;        // [B] x (x_bs floats): 4 nchunks planes of (H / 2) x (W / 2)
+    const f32x4* u;        // [slice][chunk][4 quads][64 lanes] (ynet_winograd16_filter)
+    const float* bias;     // 16 ns floats or NULL
+    float* y;              // [B] x (y_bs floats): 16 ns planes of H x W
+    long long x_bs, y_bs;
+    int nchunks, ns, B, H, W, relu, ntiles;
+};
+
+__global__ __launch_bounds__(WN_THREADS, 1) void conv_wino16_up_kernel(const Wino16UpArgs a) {
+    extern __shared__ f32x4 smem[];
+    constexpr int WQ = 4 * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, HW = H * W, Hl = H >> 1, Wl = W >> 1, HWl = Hl * Wl, nchunks = a.nchunks;
+    const int tiles_x = W / WN_TW, tiles_y = H / W6_TH;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const unsigned wbytes = (unsigned)(nchunks * WQ * 16);
+    const unsigned ring0 = lds0 + wbytes + (unsigned)(wave * WV_RING_BYTES);
+
+    // static DMA geometry: unit j * 64 + lane (j = 1: 32 lanes) -> (channel of the chunk, low-resolution row 0..3, unit of the row)
+    unsigned rel[2], edge[2];             // edge bits: 1 row above, 2 row below, 4 left unit, 8 right unit
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = j * 64 + lane, plane = u / 24, rem = u - plane * 24, r = rem / WU_LQ, xq = rem - r * WU_LQ;
+        rel[j] = (unsigned)((plane * HWl + r * Wl + 4 * xq) * 4);
+        edge[j] = (r == 0 ? 1u : 0u) | (r == 3 ? 2u : 0u) | (xq == 0 ? 4u : 0u) | (xq == WU_LQ - 1 ? 8u : 0u);
+    }
+    const unsigned lead = (unsigned)((Wl + 4) * 4);
+    const unsigned x_img = (unsigned)(nchunks * 4 * HWl * 4) + lead, y_img = (unsigned)(16 * HW * 4);
+
+    const int g8 = (int)(gridDim.x >> 3), idx = (int)(blockIdx.x >> 3);
+    const int slice = idx % a.ns, gstride = g8 / a.ns;
+    const int per_xcd = (a.ntiles + 7) >> 3;
+    const int tile_first = (int)(blockIdx.x & 7) * per_xcd + idx / a.ns;
+    const int tile_end = min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd);
+    if (tile_first >= tile_end) return;
+    const int my_tiles = (tile_end - tile_first + gstride - 1) / gstride;
+    const int total_units = my_tiles * 8;
+
+    const int n = lane & 15, kq = lane >> 4;
+    const float floor_v = a.relu ? 0.f : -INFINITY;
+    f32x2 bias2[1][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        bias2[0][h] = a.bias ? f32x2{a.bias[slice * 16 + 4 * kq + 2 * h], a.bias[slice * 16 + 4 * kq + 2 * h + 1]} : f32x2{0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bias2[0][h]));
+    const unsigned st0 = (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
+
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(a.u + (long long)slice * nchunks * WQ), 0, wbytes, 0x00020000);
+    for (int j = 0; j * WN_THREADS + wave * 64 < nchunks * WQ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (lds_ptr_t)(uintptr_t)(lds0 + (unsigned)(j * 8192 + wave * 1024)), 16,
+                                                 (unsigned)((j * WN_THREADS + tid) * 16), 0, 0, 0);
+    unsigned* unit_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(smem) + wbytes + 8 * WV_RING_BYTES);
+    if (tid == 0) *unit_ctr = 8u;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    auto next_unit = [&]() {
+        unsigned u = 0;
+        if (lane == 0) u = atomicAdd(unit_ctr, 1u);
+        return (int)__builtin_amdgcn_readfirstlane(u);
+    };
+
+    auto dma_chunk = [&](int unit, int c, int slot) {       // the four low-resolution rows under unit `unit`, chunk c (4 channels) -> slot
+        const int t = tile_first + (unit >> 3) * gstride;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int i = (ty * W6_TH >> 1) + 2 * (unit & 7), j0 = tx * (WN_TW / 2);
+        const unsigned em = (i == 0 ? 1u : 0u) | (i + 2 == Hl ? 2u : 0u) | (j0 == 0 ? 4u : 0u) | (j0 + WN_TW / 2 == Wl ? 8u : 0u);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x + (long long)b * a.x_bs) - lead), 0, x_img, 0x00020000);
+        const unsigned so = (unsigned)((c * 4 * HWl + i * Wl + j0) * 4);
+        const unsigned sb = ring0 + (unsigned)(slot * WV_SLOT_BYTES);
+        unsigned v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned o = rel[j];
+            if (edge[j] & em & 1u) o += (unsigned)(Wl * 4);       // (bilinear clamp: the row above the image is row 0, the row below it the last row)
+            if (edge[j] & em & 2u) o -= (unsigned)(Wl * 4);
+            v[j] = (edge[j] & em & 12u) ? 0x80000000u : o;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)sb, 16, v[0], so, 0, 0);
+        if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(sb + 1024u), 16, v[1], so, 0, 0);
+    };
+
+    int cur = wave, nxt = next_unit();
+    int g = 0;
+    dma_chunk(cur, 0, 0);
+    dma_chunk(cur, 1, 1);
+
+    const f32x2 c7525 = {0.75f, 0.25f}, c2575 = {0.25f, 0.75f};
+    f32x4 acc[2][16][1];
+    const unsigned char* ringp = reinterpret_cast<const unsigned char*>(smem) + wbytes + wave * WV_RING_BYTES;
+    while (cur < total_units) {
+        const int t = tile_first + (cur >> 3) * gstride;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int y0 = ty * W6_TH + 4 * (cur & 7), x0 = tx * WN_TW;
+        const bool top = y0 == 0, bottom = y0 + 4 == H;
+        const bool left = x0 == 0 && n == 0, right = x0 + WN_TW == W && n == 15;
+        auto step = [&](int c, auto first) {
+            if (c + 1 < nchunks || nxt < total_units) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int slot = g & 1;
+            const float* ip = reinterpret_cast<const float*>(ringp + slot * WV_SLOT_BYTES) + kq * 96 + 3 + n;
+            float x[4][3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) x[r][m] = ip[r * WU_ROWF + m];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (c + 2 < nchunks) dma_chunk(cur, c + 2, slot);
+            else if (nxt < total_units) dma_chunk(nxt, c + 2 - nchunks, slot);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x[r][0] = left ? x[r][1] : x[r][0];
+                x[r][2] = right ? x[r][1] : x[r][2];
+            }
+            f32x2 pv[3][3];      // pv[k][m]: up-sampled rows (y0 - 1 + 2k, y0 + 2k) at low-resolution column m
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) pv[k][m] = c7525 * x[k][m] + c2575 * x[k + 1][m];
+            if (top) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) pv[0][m][0] = 0.f;
+            }
+            if (bottom) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) pv[2][m][1] = 0.f;
+            }
+            f32x2 dl[6], dh[6];
+#pragma unroll
+            for (int R = 0; R < 6; ++R) {
+                const float v0 = pv[R >> 1][0][R & 1], v1 = pv[R >> 1][1][R & 1], v2 = pv[R >> 1][2][R & 1];
+                dl[R] = c7525 * v0 + c2575 * v1;
+                dh[R] = c7525 * v1 + c2575 * v2;
+                dl[R][0] = left ? 0.f : dl[R][0];
+                dh[R][1] = right ? 0.f : dh[R][1];
+            }
+            wino16_kstep<decltype(first)::value>(acc, dl, dh, smem + c * WQ, lane);
+            ++g;
+        };
+        step(0, std::true_type{});
+        for (int c = 1; c < nchunks; ++c) step(c, std::false_type{});
+        {
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs + (long long)slice * 16 * HW, 0, y_img, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned so_t = (unsigned)(((y0 + 2 * p) * W + x0) * 4);
+                wino_epilogue<1, 0>(acc[p], bias2, floor_v, ry, ry, st0, st1, so_t, so_t, HW);
+            }
+        }
+        cur = nxt;
+        if (cur < total_units) nxt = next_unit();
+    }
+}
+
 // U = G g G^T of every (cout, cin) pair, in the fragment order the kernels read: unit ((c4 * 4 + q) * NCB + cb) * 64 + lane holds
 // (xi = q, nu = 0..3) of output channel col0 + cb * 16 + (lane & 15), PADDED input channel c4 * 4 + (lane >> 4) -- the input channels
 // are the concatenation of up to three sources, each padded to a multiple of 4 (padded channels: zero filters); with one source of a
@@ -1289,6 +1454,19 @@ int ynet_conv2d_winograd16(const float* const* src, const int* src_c, const long
 }  // extern "C"
 
 // ---- the up-convolution with its bilinear x2 inside (conv_wino_up_kernel)
+// (the slice form of it: cin a multiple of 4 up to 84, 16 / 32 / 64 outputs, 32-row tiles)
+static bool wino16_up_ok(int B, int H, int W, int cin, int cout, int K) {
+    static const int on = getenv("YNET_WINOGRAD") ? atoi(getenv("YNET_WINOGRAD")) : 1;
+    static const int up_on = getenv("YNET_WINOGRAD_UP") ? atoi(getenv("YNET_WINOGRAD_UP")) : 1;
+    static const int on16 = getenv("YNET_WINOGRAD16") ? atoi(getenv("YNET_WINOGRAD16")) : 1;
+    if (!on || !up_on || !on16 || K != 3 || B <= 0 || cin < 8 || cin % 4 || cin / 4 > W6_MAX_CHUNKS) return false;
+    if (cout != 16 && cout != 32 && cout != 64) return false;
+    if (H % W6_TH || W % WN_TW || H < W6_TH || W < WN_TW) return false;
+    if (84ll * H * W * 4 + (W + 4) * 4 >= (1ll << 31)) return false;
+    static const int min_pixels = getenv("YNET_WINOGRAD16_MIN") ? atoi(getenv("YNET_WINOGRAD16_MIN")) : (getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 64 * 64 * 10);
+    return (long long)B * H * W >= min_pixels;
+}
+
 static bool wino_up_ok(int B, int H, int W, int cin, int cout, int K) {
     static const int on = getenv("YNET_WINOGRAD") ? atoi(getenv("YNET_WINOGRAD")) : 1;
     static const int up_on = getenv("YNET_WINOGRAD_UP") ? atoi(getenv("YNET_WINOGRAD_UP")) : 1;
@@ -1301,32 +1479,47 @@ static bool wino_up_ok(int B, int H, int W, int cin, int cout, int K) {
 
 extern "C" {
 
-int ynet_upsample2x_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K) { return wino_up_ok(B, H, W, cin, cout, K) ? 1 : 0; }
+// 0: not served; 1: served, filter in ynet_winograd_filter's layout (32 -> 16); 2: served by the slice form, filter in ynet_winograd16_filter's layout
+int ynet_upsample2x_conv2d_winograd_supported(int B, int H, int W, int cin, int cout, int K) {
+    return wino_up_ok(B, H, W, cin, cout, K) ? 1 : (wino16_up_ok(B, H, W, cin, cout, K) ? 2 : 0);
+}
 
 int ynet_upsample2x_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout, int B,
                                     int H, int W, int relu, void* stream) {
     const char* what = "upsample2x_conv2d_winograd";
     YNET_REQUIRE(src && u && dst, "%s: null pointer", what);
-    YNET_REQUIRE(wino_up_ok(B, H, W, cin, cout, 3), "%s: shape B=%d %dx%d (up-sampled) %d -> %d is not served (ask ynet_upsample2x_conv2d_winograd_supported)", what,
-                 B, H, W, cin, cout);
+    const bool plain = wino_up_ok(B, H, W, cin, cout, 3);
+    YNET_REQUIRE(plain || wino16_up_ok(B, H, W, cin, cout, 3), "%s: shape B=%d %dx%d (up-sampled) %d -> %d is not served (ask ynet_upsample2x_conv2d_winograd_supported)",
+                 what, B, H, W, cin, cout);
     const long long HW = (long long)H * W;
     YNET_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 &&
                      (src_bs & 3) == 0 && (dst_bs & 1) == 0,
                  "%s: planes must be 16-byte (input, filters) / 8-byte (output) aligned", what);
     YNET_REQUIRE((src_bs == 0 || src_bs >= cin * (HW / 4)) && dst_bs >= cout * HW, "%s: batch strides smaller than the images (input: 0 = one image for the batch)", what);
-    WinoUpArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW)};
-    constexpr int lds = 4 * 8 * 64 * 16 + 8 * WU_RING_BYTES + 16;
     static bool attr_dev[YNET_MAX_DEV] = {false};
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
+    constexpr int lds = 4 * 8 * 64 * 16 + 8 * WU_RING_BYTES + 16;
     if (!attr_dev[slot]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_up_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino16_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  W6_MAX_CHUNKS * 4096 + 8 * WV_RING_BYTES + 16);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         cus_dev[slot] = cus < 8 ? 8 : cus;
         attr_dev[slot] = true;
     }
+    if (!plain) {      // the slice form: one slice of the filter per workgroup, the slices of a tile inside one XCD (as ynet_conv2d_winograd16)
+        Wino16UpArgs w{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, cin / 4, cout / 16, B, H, W, relu ? 1 : 0, B * (H / W6_TH) * (W / WN_TW)};
+        const int per_xcd = (w.ntiles + 7) / 8;
+        int team = ((cus_dev[slot] < 64 ? 64 : cus_dev[slot]) / 8) / w.ns;
+        if (team > per_xcd) team = per_xcd;
+        if (team < 1) team = 1;
+        hipLaunchKernelGGL(conv_wino16_up_kernel, dim3(8 * w.ns * team), dim3(WN_THREADS), w.nchunks * 4096 + 8 * WV_RING_BYTES + 16, (hipStream_t)stream, w);
+        return ynet_check_launch(what);
+    }
+    WinoUpArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW)};
     int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
     if (grid >= 8) grid &= ~7;
     hipLaunchKernelGGL((conv_wino_up_kernel<4>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);

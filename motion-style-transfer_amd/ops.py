@@ -425,12 +425,11 @@ def _wino16_supported(srcs_c, cout, B, H, W, K=3):
     return bool(_lib().ynet_conv2d_winograd16_supported(B, H, W, (ctypes.c_int * len(srcs_c))(*srcs_c), len(srcs_c), cout, K))
 
 
-def _wino16(wino, wp, row0, srcs, bias, dst, cout, col0, ctot, B, H, W, relu, relu_of=None, addend=None, pool=None):
-    """One ynet_conv2d_winograd16 launch over output channels [col0, col0 + cout) of the packed filter wp (ctot output channels in all)
-    and its input-channel rows from row0 on, the transformed filter kept in the layer's cache."""
+def _wino16_filter(wino, wp, row0, cs, cout, col0, ctot):
+    """The slice-major Winograd filter (ynet_winograd16_filter) of output channels [col0, col0 + cout) of the packed filter wp for sources of
+    cs channels each, from the filter's input-channel row row0 on; kept in the layer's cache."""
     lib = _lib()
     cache, what = wino
-    cs = tuple(s_[1] for s_ in srcs)
     key = "wino16_%s_%d_%d_%d" % (what, row0, col0, cout)
     ent = cache.get(key)
     if ent is None or ent[0] is not wp or ent[2] != cs:
@@ -440,6 +439,13 @@ def _wino16(wino, wp, row0, srcs, bias, dst, cout, col0, ctot, B, H, W, relu, re
         L.check(lib.ynet_winograd16_filter(wp.data_ptr() + 4 * row0 * 9 * cols_pad, u.data_ptr(), ca, len(cs), cout, col0, ctot, _stream()), lib)
         ent = cache[key] = _wino_made((wp, u, cs))
     _wino_ready(ent)
+    return ent
+
+
+def _wino16(wino, wp, row0, srcs, bias, dst, cout, col0, ctot, B, H, W, relu, relu_of=None, addend=None, pool=None):
+    """One ynet_conv2d_winograd16 launch over output channels [col0, col0 + cout) of the packed filter wp (ctot output channels in all)
+    and its input-channel rows from row0 on, the transformed filter kept in the layer's cache."""
+    ent = _wino16_filter(wino, wp, row0, tuple(s_[1] for s_ in srcs), cout, col0, ctot)
     conv2d_winograd16_raw(srcs, ent[1], None if bias is None else bias[col0:col0 + cout], dst, cout, B, H, W, relu, relu_of=relu_of, addend=addend, pool=pool)
     wino_stats["launches"] += 1
     wino_stats["launches16"] = wino_stats.get("launches16", 0) + 1
@@ -1323,11 +1329,14 @@ class _UpConvFn(torch.autograd.Function):
         cout = weight.shape[0]
         H, W = 2 * Hl, 2 * Wl
         wp = _cached(cache, weight, None, None, 1.0, "fwd")
-        key = "wino_fwd_0_%d" % cout      # (the entry ops.conv2d_raw keeps for the unfused launch of the same layer)
-        ent = cache.get(key)
-        if ent is None or ent[0] is not wp:
-            ent = cache[key] = _wino_made((wp, winograd_filter(wp, cin, cout, 0, cout)))
-        _wino_ready(ent)
+        if _lib().ynet_upsample2x_conv2d_winograd_supported(B, H, W, cin, cout, 3) == 2:      # the slice form: its own filter layout
+            ent = _wino16_filter((cache, "fwd"), wp, 0, (cin,), cout, 0, cout)
+        else:
+            key = "wino_fwd_0_%d" % cout      # (the entry ops.conv2d_raw keeps for the unfused launch of the same layer)
+            ent = cache.get(key)
+            if ent is None or ent[0] is not wp:
+                ent = cache[key] = _wino_made((wp, winograd_filter(wp, cin, cout, 0, cout)))
+            _wino_ready(ent)
         y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
         upsample2x_conv2d_raw((x.data_ptr(), cin * Hl * Wl), ent[1], bias.detach() if bias is not None else None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W)
         wino_stats["launches"] += 1

@@ -834,7 +834,9 @@ def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     close(outs[0][0], ref, rtol=1e-4, scale_rel=2e-6, msg="forward vs torch")
 
 
-@pytest.mark.parametrize("case", [(8, 256, 256, True), (16, 128, 128, False), (12, 96, 160, True), (10, 256, 256, False)], ids=str)
+@pytest.mark.parametrize("case", [(8, 256, 256, 32, 16, True), (16, 128, 128, 32, 16, False), (12, 96, 160, 32, 16, True), (10, 256, 256, 32, 16, False),
+                                  # the slice form (ynet_upsample2x_conv2d_winograd_supported == 2): the decoders' levels 3 and 2, and a ragged map
+                                  (16, 128, 128, 64, 32, True), (32, 64, 64, 64, 32, False), (6, 96, 160, 64, 32, True), (256, 32, 32, 64, 32, True)], ids=str)
 def test_upsample_and_up_convolution_in_one_launch(dev, case):
     """ynet_upsample2x_conv2d_winograd (round 5): conv3x3(bilinear x2 of x) + bias for 32 -> 16 channels without the up-sampled tensor --
     against torch's interpolate + conv2d in fp64 (2e-6 of the largest output) and against the two launches it replaces (ynet_upsample2x_fwd,
@@ -842,19 +844,20 @@ def test_upsample_and_up_convolution_in_one_launch(dev, case):
     padding outside -- checked on their own); through autograd (ops.upsample2x_conv2d on a frozen HipConv2d): the input gradient equals
     the unfused graph's."""
     ops, ynet = pkg("ops"), pkg("models.ynet")
-    B, H, W, has_bias = case
+    B, H, W, cin, cout, has_bias = case
     Hl, Wl = H // 2, W // 2
-    assert ops._lib().ynet_upsample2x_conv2d_winograd_supported(B, H, W, 32, 16, 3)
-    x = torch.relu(rnd(B, 32, Hl, Wl, seed=1)).to(dev)
-    w = rnd(16, 32, 3, 3, seed=2, scale=0.2).to(dev)
-    bias = rnd(16, seed=3).to(dev) if has_bias else None
+    kind = ops._lib().ynet_upsample2x_conv2d_winograd_supported(B, H, W, cin, cout, 3)
+    assert kind == (1 if (cin, cout) == (32, 16) else 2)
+    x = torch.relu(rnd(B, cin, Hl, Wl, seed=1)).to(dev)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=0.2).to(dev)
+    bias = rnd(cout, seed=3).to(dev) if has_bias else None
     wp = ops.pack_weight(w, 0)
-    u = ops.winograd_filter(wp, 32, 16)
-    got = torch.full((B, 16, H, W), float("nan"), device=dev)
-    ops.upsample2x_conv2d_raw((x.data_ptr(), 32 * Hl * Wl), u, bias, (got.data_ptr(), 16 * H * W), 32, 16, B, H, W)
+    u = ops.winograd_filter(wp, cin, cout) if kind == 1 else ops._wino16_filter(({}, "fwd"), wp, 0, (cin,), cout, 0, cout)[1]
+    got = torch.full((B, cout, H, W), float("nan"), device=dev)
+    ops.upsample2x_conv2d_raw((x.data_ptr(), cin * Hl * Wl), u, bias, (got.data_ptr(), cout * H * W), cin, cout, B, H, W)
     up = ops.upsample2x(x)
-    two = torch.empty(B, 16, H, W, device=dev)
-    ops.conv2d_winograd_raw((up.data_ptr(), 32 * H * W), u, bias, (two.data_ptr(), 16 * H * W), 32, 16, B, H, W, False)
+    two = torch.empty(B, cout, H, W, device=dev)
+    assert ops.conv2d_raw([(up.data_ptr(), cin, cin * H * W)], None, wp, bias, [(two.data_ptr(), cout, cout * H * W)], B, H, W, 3, False, wino=({}, "fwd")).startswith("winograd")
     ref64 = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False), w.double(), bias.double() if has_bias else None, padding=1)
     assert not bool(torch.isnan(got).any())
     close(got, ref64, rtol=1e-5, scale_rel=2e-6, msg="fused vs fp64")
@@ -866,13 +869,13 @@ def test_upsample_and_up_convolution_in_one_launch(dev, case):
     e_f, e_t = float((got.double() - ref64).abs().max()), float((two.double() - ref64).abs().max())
     assert e_f <= 1.5 * e_t + 1e-7, (e_f, e_t)
     # autograd: a frozen up-convolution module
-    conv = ynet.HipConv2d(32, 16, kernel_size=3).to(dev)
+    conv = ynet.HipConv2d(cin, cout, kernel_size=3).to(dev)
     with torch.no_grad():
         conv.weight.copy_(w)
-        conv.bias.copy_(bias if has_bias else torch.zeros(16, device=dev))
+        conv.bias.copy_(bias if has_bias else torch.zeros(cout, device=dev))
     conv.weight.requires_grad_(False)
     conv.bias.requires_grad_(False)
-    g = rnd(B, 16, H, W, seed=5).to(dev)
+    g = rnd(B, cout, H, W, seed=5).to(dev)
     grads = []
     for fused in (True, False):
         old, n0 = ops._upconv_allowed, ops.upconv_stats["fused"]

@@ -130,6 +130,14 @@ int main() {
         EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, cfp, nullptr, fp, 64 * 4096, 64, 32, 64, 64, 1, nullptr, 0, nullptr, 0, 0, fp, 16 * 1024, nullptr));       // pooled stride too small
         EXPECT_REJECT(ynet_conv2d_winograd16(s1, one64, bs1, 1, nullptr, nullptr, fp, 64 * 4096, 64, 32, 64, 64, 1, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr));      // no filters
     }
+    for (int b : {1, 10, 32})
+        for (int hw : {32, 128, 256})
+            for (int c : {16, 32, 64}) acc += ynet_upsample2x_conv2d_winograd_supported(b, hw, hw, c, 16, 3) + ynet_upsample2x_conv2d_winograd_supported(b, hw, hw + 8, 32, c, 3);
+    EXPECT_REJECT(ynet_upsample2x_conv2d_winograd(cfp, 32 * 16384, cfp, nullptr, fp, 16 * 65536, 32, 32, 32, 256, 256, 0, nullptr));     // 32 outputs: not served
+    EXPECT_REJECT(ynet_upsample2x_conv2d_winograd(cfp, 32 * 16384, cfp, nullptr, fp, 16 * 65536, 32, 16, 32, 250, 256, 0, nullptr));     // H not a multiple of 16
+    EXPECT_REJECT(ynet_upsample2x_conv2d_winograd(cfp, 16 * 16384, cfp, nullptr, fp, 16 * 65536, 32, 16, 32, 256, 256, 0, nullptr));     // input stride smaller than the low-resolution image
+    EXPECT_REJECT(ynet_upsample2x_conv2d_winograd(cfp, 32 * 16384, cfp, nullptr, fp, 8 * 65536, 32, 16, 32, 256, 256, 0, nullptr));      // output stride smaller than the image
+    EXPECT_REJECT(ynet_upsample2x_conv2d_winograd(nullptr, 32 * 16384, cfp, nullptr, fp, 16 * 65536, 32, 16, 32, 256, 256, 0, nullptr));
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, nullptr, 32 * 65536, 32, 32, 32, 256, 256, nullptr));   // no activation
     EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu(cfp, 32 * 65536, cfp, fp, 32 * 65536, cfp, 16 * 65536, 32, 32, 32, 256, 256, nullptr));       // activation stride too small
     EXPECT_REJECT(ynet_conv2d_wgrad(srcs, &one, &bs, 1, nullptr, 0, nullptr, 0, fp, nullptr, fp, 1, 4, 4, 1, 3, nullptr));

@@ -23,7 +23,7 @@ CONV = ("conv_dma_", "conv_mfma_kernel", "conv_wino")
 
 def short(name):
     name = re.sub(r"^void ", "", name.strip())
-    return re.sub(r"\((ConvArgs|WgradArgs|WinoArgs|WinoCatArgs|Wino16Args|WinoUpArgs)\)$", "", name)
+    return re.sub(r"\((ConvArgs|WgradArgs|WinoArgs|WinoCatArgs|Wino16Args|WinoUpArgs|Wino16UpArgs)\)$", "", name)
 
 
 def kernel_rows(d):

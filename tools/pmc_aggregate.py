@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = re.sub(r"^void ", "", name.strip())
-    return re.sub(r"\((ConvArgs|WgradArgs|WinoArgs|WinoCatArgs|Wino16Args|WinoUpArgs)\)$", "", name)
+    return re.sub(r"\((ConvArgs|WgradArgs|WinoArgs|WinoCatArgs|Wino16Args|WinoUpArgs|Wino16UpArgs)\)$", "", name)
 
 
 def db_of(d):

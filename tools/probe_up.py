@@ -24,3 +24,15 @@ for (B, H, W) in [(32, 256, 256), (256, 256, 256), (16, 512, 512), (32, 128, 128
     t_conv = bench(lambda: ops.conv2d_winograd_raw((up.data_ptr(), cin * H * W), u, None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W, False))
     t_fused = bench(lambda: ops.upsample2x_conv2d_raw((xl.data_ptr(), cin * H * W // 4), u, None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W))
     print(f"B={B} {H}x{W}: upsample {t_up:.1f} + conv {t_conv:.1f} = {t_up + t_conv:.1f} us; fused {t_fused:.1f} us")
+for (B, H, W, cin, cout) in [(32, 128, 128, 64, 32), (256, 128, 128, 64, 32), (32, 64, 64, 64, 32), (256, 64, 64, 64, 32)]:
+    xl = torch.relu(torch.randn(B, cin, H // 2, W // 2, device=dev))
+    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.2
+    wp = ops.pack_weight(w, 0)
+    u = ops._wino16_filter(({}, "fwd"), wp, 0, (cin,), cout, 0, cout)[1]
+    y = torch.empty(B, cout, H, W, device=dev)
+    up = ops.upsample2x(xl)
+    cache = {}
+    t_up = bench(lambda: ops.upsample2x(xl))
+    t_conv = bench(lambda: ops.conv2d_raw([(up.data_ptr(), cin, cin * H * W)], None, wp, None, [(y.data_ptr(), cout, cout * H * W)], B, H, W, 3, False, wino=(cache, "fwd")))
+    t_fused = bench(lambda: ops.upsample2x_conv2d_raw((xl.data_ptr(), cin * H * W // 4), u, None, (y.data_ptr(), cout * H * W), cin, cout, B, H, W))
+    print(f"B={B} {H}x{W} {cin}->{cout}: upsample {t_up:.1f} + conv {t_conv:.1f} = {t_up + t_conv:.1f} us; fused (slice form) {t_fused:.1f} us")
