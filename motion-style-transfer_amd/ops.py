@@ -314,19 +314,11 @@ wgrad_branch = False
 _wgrad_branch_allowed = _os.environ.get("YNET_WGRAD_BRANCH", "1") != "0"
 _wgrad_streams = {}
 _wgrad_pending = {}
-# Round 5: consecutive layers' adapter gradients alternate between TWO side streams.  On one stream the chains [filter gradient -> reduce ->
-# rank-r projections] of the nine layers ran strictly one after the other, the small layers' latency-bound launches in front of the three large
-# layers': in the captured C2 step the last filter gradient started 200 us after its input was ready and the branch was the tail of the step
-# (profiles/r05_bench_C2_overlap.txt: 0.33 ms with nothing else on the chip).  YNET_WGRAD_STREAMS=1 restores the single branch.
-_wgrad_nstreams = max(1, int(_os.environ.get("YNET_WGRAD_STREAMS", "2")))
-_wgrad_turn = {}
 
 
 def _wgrad_stream(device):
     dev = torch.device(device)
-    dkey = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-    turn = _wgrad_turn[dkey] = (_wgrad_turn.get(dkey, -1) + 1) % _wgrad_nstreams
-    key = dkey + (turn,)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _wgrad_streams:
         _wgrad_streams[key] = torch.cuda.Stream(device=dev)
     return key, _wgrad_streams[key]
@@ -337,7 +329,6 @@ def join_wgrad_branch():
     for key, side in list(_wgrad_pending.items()):
         torch.cuda.current_stream(torch.device(key[0], key[1])).wait_stream(side)
     _wgrad_pending.clear()
-    _wgrad_turn.clear()
 
 
 _wino_allowed = _os.environ.get("YNET_WINOGRAD", "1") != "0"     # YNET_WINOGRAD=0: every convolution takes the implicit-GEMM kernels
