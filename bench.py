@@ -159,24 +159,27 @@ class ConvTimer:
         self.orig_up = ops.upsample2x_conv2d_raw
 
     def __enter__(self):
-        def timed_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None):
+        def timed_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None, wbits_out=None, relu_wbits=None):
             # one Winograd launch (a convolution with 48 / 64 outputs is two of them): its own event pair, rocprof's kernel name
+            # (third template argument: 0 plain, 1 through a ReLU backward with the float activation, 2 with the 1-bit mask, 3 plain + mask written)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=relu_of)
+            self.orig_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=relu_of, wbits_out=wbits_out, relu_wbits=relu_wbits)
             e1.record()
-            name = f"conv_wino_kernel<{cout // 16}, {cin // 8}, {'true' if relu_of is not None else 'false'}, 8>"
-            self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin + cout * (2 if relu_of is not None else 1)),
+            em = 3 if wbits_out is not None else (2 if relu_wbits is not None else (1 if relu_of is not None else 0))
+            name = f"conv_wino_kernel<{cout // 16}, {cin // 8}, {em}, 8>"
+            self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin + cout * (2 if em == 1 else (1 + 1 / 32 if em >= 2 else 1))),
                              (B, H, W, cin, cout, 3, False)))
         self.ops.conv2d_winograd_raw = timed_wino
 
-        def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None):
+        def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig_cat(srcs, u, bias, dst, B, H, W, relu, addend=addend, pool=pool)
+            self.orig_cat(srcs, u, bias, dst, B, H, W, relu, addend=addend, pool=pool, wbits_out=wbits_out)
             e1.record()
             cin = sum(s_[1] for s_ in srcs)
-            name = f"conv_wino_cat_kernel<2, {2 if addend is not None else (3 if pool is not None else 0)}>"      # (epilogue: 0 plain, 2 additive term, 3 pooled copy)
+            epi = 2 if addend is not None else (3 if pool is not None else 0)      # (epilogue: 0 plain, 2 additive term, 3 pooled copy; + 4: 1-bit mask written = 4 / 5)
+            name = f"conv_wino_cat_kernel<2, {epi + 4 if wbits_out is not None and epi != 3 else epi}>"
             self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * 32 * 9, 4.0 * B * H * W * (cin + 32 * (2 if addend is not None else (1.25 if pool is not None else 1))),
                              (B, H, W, cin, 32, 3, False)))
         self.ops.conv2d_winograd_cat_raw = timed_cat

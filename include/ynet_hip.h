@@ -151,6 +151,20 @@ int ynet_conv2d_winograd_cat_add(const float* const* src, const int* src_c, cons
  *                               conv + ReLU in front of MaxPool2d(2, 2), models/ynet.py:196-213): a lane of the Winograd tiling holds exactly the block it pools. */
 int ynet_conv2d_winograd_cat_pool(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                                   long long dst_bs, float* pooled, long long pooled_bs, int cout, int B, int H, int W, int relu, void* stream);
+/*   The Winograd-native 1-bit ReLU mask (round 5), the counterpart of ynet_conv2d_relu_bits / ynet_conv2d_dgrad_relu_bits for conv -> ReLU -> conv chains whose
+ *   launches are Winograd ones with 32 channels in between: the FORWARD launch of the first convolution also writes one bit per output element (y > 0) -- one 32-bit
+ *   word per lane and unit of the tiling both launches share, ynet_winograd_relu_bits_words(B, H, W) words --, and the data gradient of the second convolution
+ *   (ynet_conv2d_winograd_dgrad_relu_bits) is gated by it instead of fetching the float activation (ynet_conv2d_winograd_dgrad_relu): bit-identical results,
+ *   1 / 32 of the mask traffic.  ynet_conv2d_winograd_relu_bits = ynet_conv2d_winograd with relu 1 and 32 outputs; ynet_conv2d_winograd_cat_relu_bits =
+ *   ynet_conv2d_winograd_cat (addend NULL) or ynet_conv2d_winograd_cat_add with relu 1. */
+long long ynet_winograd_relu_bits_words(int B, int H, int W);
+int ynet_conv2d_winograd_relu_bits(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int B, int H, int W,
+                                   unsigned* bits_out, void* stream);
+int ynet_conv2d_winograd_cat_relu_bits(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                                       long long dst_bs, int B, int H, int W, const float* addend, long long addend_bs, int addend_bmod, unsigned* bits_out,
+                                       void* stream);
+int ynet_conv2d_winograd_dgrad_relu_bits(const float* dy, long long dy_bs, const float* u, float* dx, long long dx_bs, const unsigned* bits, int dy_c, int B, int H,
+                                         int W, void* stream);
 /*   ynet_conv2d_winograd16      the SLICE form of the same convolution (round 5): every workgroup keeps the transformed filter of 16 output channels in LDS
  *                               and a wave computes two row pairs (4 output rows x 32 columns) per unit -- for the layers the two kernels above do not
  *                               serve, 16 / 32 / 64 / 128 output channels from up to three concatenated sources of at most 84 padded input channels

@@ -46,6 +46,10 @@ SIGNATURES = {
     "ynet_conv2d_winograd_cat": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_cat_add": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp]),
     "ynet_conv2d_winograd_cat_pool": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_winograd_relu_bits_words": (c_ll, [c_i, c_i, c_i]),
+    "ynet_conv2d_winograd_relu_bits": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "ynet_conv2d_winograd_cat_relu_bits": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp, c_fp]),
+    "ynet_conv2d_winograd_dgrad_relu_bits": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_upsample2x_conv2d_winograd_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "ynet_upsample2x_conv2d_winograd": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd16_supported": (c_i, [c_i, c_i, c_i, PI, c_i, c_i, c_i]),

@@ -52,6 +52,7 @@ struct WinoArgs {
     int B, H, W, relu, ntiles;
     const float* emask;    // EM: [B] x (emask_bs floats), cout planes -- the post-ReLU activation whose backward is applied to y (y = emask > 0 ? y : 0)
     long long emask_bs;
+    unsigned* wbits;       // the Winograd-native 1-bit mask [B][H / 2][W / 32][64 lanes] (NCB = 2): written (EM 3) or applied (EM 2)
 };
 
 __device__ __forceinline__ f32x2 wn_v01(f32x2 tl, f32x2 th) {      // (t0 - t2, t1 + t2)
@@ -70,9 +71,16 @@ __device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, 
 // precomputed term is fetched the same way and added in front of the ReLU (y = relu(conv + bias + addend)); EPI 3: the 2 x 2 max-pooled
 // copy of the output is written too -- a lane holds exactly the 2 x 2 block it pools (rm / sm_t: the pooled tensor, stp: the lane's
 // static offset there, HW / 4 pixels per plane)
-template <int NCB, int EPI>
+// BITS (round 5, the Winograd-native 1-bit ReLU mask: one 32-bit word per lane and unit at NCB = 2, bit ((cb * 2 + h) * 2 + k) * 4 + 2 * row + column
+// = "output channel cb * 16 + 4 kq + 2 h + k of this lane's 2 x 2 block is positive"): 1 -- the forward launch of a conv -> ReLU -> conv chain returns
+// the word of its outputs in *wbits; 2 -- the data gradient of the chain's second convolution is gated by that word (*wbits) instead of fetching
+// the 16 activation quads of EPI 1 (268 MB less traffic and no fetch latency in front of the stores of a 32-channel launch at 256^2, B 32).
+template <int NCB, int EPI, int BITS = 0>
 __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2 (&bias2)[NCB][2], float floor_v, __amdgpu_buffer_rsrc_t ry,
-                                              __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW, unsigned stp = 0) {
+                                              __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW, unsigned stp = 0,
+                                              unsigned* wbits = nullptr) {
+    unsigned word = 0u;
+    if constexpr (BITS == 2) word = *wbits;
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         u32x2 mk[2][2][2];
@@ -116,6 +124,13 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                     row0 = f32x2{m0[0] > 0.f ? row0[0] : 0.f, m0[1] > 0.f ? row0[1] : 0.f};
                     row1 = f32x2{m1[0] > 0.f ? row1[0] : 0.f, m1[1] > 0.f ? row1[1] : 0.f};
                 }
+                const int bit0 = ((cb * 2 + h) * 2 + k) * 4;
+                if constexpr (BITS == 2) {
+                    row0 = f32x2{(word >> bit0) & 1u ? row0[0] : 0.f, (word >> (bit0 + 1)) & 1u ? row0[1] : 0.f};
+                    row1 = f32x2{(word >> (bit0 + 2)) & 1u ? row1[0] : 0.f, (word >> (bit0 + 3)) & 1u ? row1[1] : 0.f};
+                }
+                if constexpr (BITS == 1)      // (v > 0: NaN and -0 count as "not positive", as the float comparison of EPI 1 does)
+                    word |= (row0[0] > 0.f ? 1u << bit0 : 0u) | (row0[1] > 0.f ? 2u << bit0 : 0u) | (row1[0] > 0.f ? 4u << bit0 : 0u) | (row1[1] > 0.f ? 8u << bit0 : 0u);
                 const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), ry, st0, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), ry, st1, so, 0);
@@ -127,6 +142,7 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
             }
         }
     }
+    if constexpr (BITS == 1) *wbits = word;
 }
 
 // one k-step of 4 input channels: V = B^T d B of the lane's patch (rows dl / dh), then 16 NCB MFMAs against the filter fragments at wl
@@ -162,7 +178,7 @@ __device__ __forceinline__ void wino_kstep(f32x4 (&acc)[16][NCB], const f32x2 (&
 
 // NCB: 16-channel output blocks (cout = 16 NCB), NCH: chunks of 8 input channels (cin = 8 NCH; even: chunk c lives in slot c & 1 of the
 // wave's ring, and the chunk two ahead -- of this pair or the next -- takes the slot just read)
-template <int NCB, int NCH, bool EM, int NW>
+template <int NCB, int NCH, int EM, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a) {
     extern __shared__ f32x4 smem[];
     constexpr int WQ = 8 * NCB * 64;      // units of one chunk's filters: [2 k-steps][4 quads of (xi,nu)][NCB][64 lanes]
@@ -326,8 +342,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
             const unsigned so_t = (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
             const __amdgpu_buffer_rsrc_t rm =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EM ? a.emask + (long long)b * a.emask_bs : a.y), 0, y_img, 0x00020000);
-            wino_epilogue<NCB, EM ? 1 : 0>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, so_t, HW);
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EM == 1 ? a.emask + (long long)b * a.emask_bs : a.y), 0, y_img, 0x00020000);
+            unsigned* wb = EM >= 2 ? a.wbits + (((long long)b * (H >> 1) + (ty * (WN_TH / 2) + (cur & 7))) * tiles_x + tx) * 64 + lane : nullptr;
+            wino_epilogue<NCB, EM == 1 ? 1 : 0, EM == 2 ? 2 : (EM == 3 ? 1 : 0)>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, so_t, HW, 0, wb);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -359,10 +376,13 @@ struct WinoCatArgs {
     int addend_bmod;
     float* pool;               // EPI 3: [B] x (pool_bs floats), cout planes of (H / 2) x (W / 2): the 2 x 2 max-pooled copy of y
     long long pool_bs;
+    unsigned* wbits;           // EPI 4 / 5 (= 0 / 2 + the Winograd-native 1-bit mask of the output written, see wino_epilogue)
 };
 
-template <int NCB, int EPI>
+template <int NCB, int EPI_>
 __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const WinoCatArgs a) {
+    constexpr int EPI = EPI_ == 4 ? 0 : (EPI_ == 5 ? 2 : EPI_);
+    constexpr int BITS = EPI_ >= 4 ? 1 : 0;
     constexpr bool ADD = EPI == 2;
     extern __shared__ f32x4 smem[];
     constexpr int WQ = 4 * NCB * 64;      // units of one chunk's filters: [4 quads of (xi,nu)][NCB][64 lanes]
@@ -497,7 +517,8 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
             const __amdgpu_buffer_rsrc_t ra =
                 EPI == 3 ? __builtin_amdgcn_make_buffer_rsrc(a.pool + (long long)b * a.pool_bs, 0, y_img >> 2, 0x00020000)
                          : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? a.addend + (long long)ab * a.addend_bs : a.y), 0, y_img, 0x00020000);
-            wino_epilogue<NCB, EPI>(acc, bias2, floor_v, ry, ra, st0, st1, so_t, sa_t, HW, stp);
+            unsigned* wb = BITS ? a.wbits + (((long long)b * (H >> 1) + (ty * (WN_TH / 2) + (cur & 7))) * tiles_x + tx) * 64 + lane : nullptr;
+            wino_epilogue<NCB, EPI, BITS>(acc, bias2, floor_v, ry, ra, st0, st1, so_t, sa_t, HW, stp, wb);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -1127,7 +1148,7 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
     return (long long)B * H * W >= min_pixels;      // (one workgroup of eight waves per CU: small launches stay with the direct tiles)
 }
 
-template <int NCB, int NCH, bool EM, int NW>
+template <int NCB, int NCH, int EM, int NW>
 static int launch_wino_nw(WinoArgs& a, hipStream_t st) {
     constexpr int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16;
     static bool attr_dev[YNET_MAX_DEV] = {false};
@@ -1151,7 +1172,7 @@ static int launch_wino_nw(WinoArgs& a, hipStream_t st) {
 // (32 -> 16 @ 256^2, B 32: 123.5 against 130.5 TFLOP/s direct-equivalent, the captured C2 step 7.73 against 7.65 ms): the 16-channel form does
 // the same patch reads, input transform and staging per k-step for half the MFMAs, and a third wave adds to that contention, not to the
 // pipes' work.  Left as a switch (YNET_WINOGRAD_W12=1).
-template <int NCB, int NCH, bool EM>
+template <int NCB, int NCH, int EM>
 static int launch_wino(WinoArgs& a, hipStream_t st) {
     static const int w12 = getenv("YNET_WINOGRAD_W12") ? atoi(getenv("YNET_WINOGRAD_W12")) : 0;
     if constexpr (NCB == 1) {
@@ -1224,7 +1245,7 @@ int ynet_winograd_filter_cat(const float* wp, float* u, const int* src_c, int ns
 
 static int wino_cat_launch(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                            long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod, float* pool,
-                           long long pool_bs, void* stream, const char* what) {
+                           long long pool_bs, void* stream, const char* what, unsigned* wbits = nullptr) {
     YNET_REQUIRE(src && src_c && src_bs && u && dst, "%s: null pointer", what);
     YNET_REQUIRE(wino_cat_ok(B, H, W, src_c, nsrc, cout, 3), "%s: shape B=%d %dx%d -> %d with %d sources is not served (ask ynet_conv2d_winograd_cat_supported)", what,
                  B, H, W, cout, nsrc);
@@ -1246,6 +1267,9 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
     if (pool != nullptr)
         YNET_REQUIRE(addend == nullptr && (reinterpret_cast<uintptr_t>(pool) & 3) == 0 && pool_bs >= cout * (HW / 4),
                      "%s: the pooled copy must have a batch stride not smaller than its image, and excludes an additive term", what);
+    if (wbits != nullptr)
+        YNET_REQUIRE(pool == nullptr && (reinterpret_cast<uintptr_t>(wbits) & 3) == 0, "%s: the 1-bit mask excludes the pooled copy and must be 4-byte aligned", what);
+    a.wbits = wbits;
     a.pool = pool;
     a.pool_bs = pool_bs;
     a.nsrc = nsrc;
@@ -1267,6 +1291,8 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1275,7 +1301,9 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
     }
     int grid = a.ntiles < cus_dev[slot] ? a.ntiles : cus_dev[slot];
     if (grid >= 8) grid &= ~7;
-    if (addend != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 2>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    if (wbits != nullptr && addend != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 5>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    else if (wbits != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 4>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    else if (addend != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 2>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     else if (pool != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 3>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_wino_cat_kernel<2, 0>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     return ynet_check_launch(what);
@@ -1300,7 +1328,8 @@ int ynet_conv2d_winograd_cat_pool(const float* const* src, const int* src_c, con
 }
 
 static int wino_launch_any(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, const float* emask,
-                           long long emask_bs, int cin, int cout, int B, int H, int W, int relu, void* stream, const char* what) {
+                           long long emask_bs, int cin, int cout, int B, int H, int W, int relu, void* stream, const char* what, unsigned* wbits = nullptr,
+                           bool wbits_apply = false) {
     YNET_REQUIRE(src && u && dst, "%s: null pointer", what);
     YNET_REQUIRE(wino_shape_ok(B, H, W, cin, cout, 3), "%s: shape B=%d %dx%d %d -> %d is not served (ask ynet_conv2d_winograd_supported)", what, B, H, W, cin,
                  cout);
@@ -1312,19 +1341,50 @@ static int wino_launch_any(const float* src, long long src_bs, const float* u, c
     if (emask != nullptr)
         YNET_REQUIRE((reinterpret_cast<uintptr_t>(emask) & 7) == 0 && (emask_bs & 1) == 0 && emask_bs >= cout * HW,
                      "%s: the activation must be 8-byte aligned, its batch stride not smaller than the image", what);
-    WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW), emask, emask_bs};
+    WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW), emask, emask_bs, wbits};
     hipStream_t st = (hipStream_t)stream;
-    if (emask != nullptr) {
-        if (cout == 32) return cin == 32 ? launch_wino<2, 4, true>(a, st) : launch_wino<2, 2, true>(a, st);
-        return cin == 32 ? launch_wino<1, 4, true>(a, st) : launch_wino<1, 2, true>(a, st);
+    if (wbits != nullptr) {          // the 1-bit mask: 32 output channels only (one word per lane and unit)
+        YNET_REQUIRE(cout == 32 && emask == nullptr && (reinterpret_cast<uintptr_t>(wbits) & 3) == 0, "%s: the 1-bit mask serves 32 output channels and excludes the float mask", what);
+        if (wbits_apply) return cin == 32 ? launch_wino<2, 4, 2>(a, st) : launch_wino<2, 2, 2>(a, st);
+        return cin == 32 ? launch_wino<2, 4, 3>(a, st) : launch_wino<2, 2, 3>(a, st);
     }
-    if (cout == 32) return cin == 32 ? launch_wino<2, 4, false>(a, st) : launch_wino<2, 2, false>(a, st);
-    return cin == 32 ? launch_wino<1, 4, false>(a, st) : launch_wino<1, 2, false>(a, st);
+    if (emask != nullptr) {
+        if (cout == 32) return cin == 32 ? launch_wino<2, 4, 1>(a, st) : launch_wino<2, 2, 1>(a, st);
+        return cin == 32 ? launch_wino<1, 4, 1>(a, st) : launch_wino<1, 2, 1>(a, st);
+    }
+    if (cout == 32) return cin == 32 ? launch_wino<2, 4, 0>(a, st) : launch_wino<2, 2, 0>(a, st);
+    return cin == 32 ? launch_wino<1, 4, 0>(a, st) : launch_wino<1, 2, 0>(a, st);
 }
 
 int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
                          int B, int H, int W, int relu, void* stream) {
     return wino_launch_any(src, src_bs, u, bias, dst, dst_bs, nullptr, 0, cin, cout, B, H, W, relu, stream, "conv2d_winograd");
+}
+
+// ---- the Winograd-native 1-bit ReLU mask (round 5): one 32-bit word per lane and unit of the NCB = 2 tiling, i.e. per (image, row pair, 32-column tile, lane)
+long long ynet_winograd_relu_bits_words(int B, int H, int W) {
+    if (B <= 0 || H % WN_TH || W % WN_TW) return 0;
+    return (long long)B * (H / 2) * (W / WN_TW) * 64;
+}
+
+int ynet_conv2d_winograd_relu_bits(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int B, int H,
+                                   int W, unsigned* bits_out, void* stream) {
+    YNET_REQUIRE(bits_out != nullptr, "conv2d_winograd_relu_bits: the mask output is null");
+    return wino_launch_any(src, src_bs, u, bias, dst, dst_bs, nullptr, 0, cin, 32, B, H, W, 1, stream, "conv2d_winograd_relu_bits", bits_out, false);
+}
+
+int ynet_conv2d_winograd_cat_relu_bits(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                                       long long dst_bs, int B, int H, int W, const float* addend, long long addend_bs, int addend_bmod, unsigned* bits_out,
+                                       void* stream) {
+    YNET_REQUIRE(bits_out != nullptr, "conv2d_winograd_cat_relu_bits: the mask output is null");
+    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, 32, B, H, W, 1, addend, addend_bs, addend_bmod, nullptr, 0, stream,
+                           "conv2d_winograd_cat_relu_bits", bits_out);
+}
+
+int ynet_conv2d_winograd_dgrad_relu_bits(const float* dy, long long dy_bs, const float* u, float* dx, long long dx_bs, const unsigned* bits, int dy_c, int B, int H,
+                                         int W, void* stream) {
+    YNET_REQUIRE(bits != nullptr, "conv2d_winograd_dgrad_relu_bits: the mask is null");
+    return wino_launch_any(dy, dy_bs, u, nullptr, dx, dx_bs, nullptr, 0, dy_c, 32, B, H, W, 0, stream, "conv2d_winograd_dgrad_relu_bits", const_cast<unsigned*>(bits), true);
 }
 
 int ynet_conv2d_winograd_dgrad_relu(const float* dy, long long dy_bs, const float* u, float* dx, long long dx_bs, const float* relu_of, long long relu_of_bs,

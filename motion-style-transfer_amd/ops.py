@@ -370,10 +370,23 @@ def winograd_filter(wp: torch.Tensor, cin: int, cout: int, col0: int = 0, cols_t
     return u
 
 
-def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None):
+def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None, wbits_out=None, relu_wbits=None):
     """src / dst: (ptr, batch_stride in floats); u: winograd_filter(...) of the layer's packed filter; relu_of: (ptr, batch_stride) of the
-    post-ReLU activation whose backward is applied to dst (ynet_conv2d_winograd_dgrad_relu: a data gradient, no bias / ReLU)."""
+    post-ReLU activation whose backward is applied to dst (ynet_conv2d_winograd_dgrad_relu: a data gradient, no bias / ReLU).  wbits_out: an
+    int32 tensor of ynet_winograd_relu_bits_words(B, H, W) words that receives the 1-bit mask of the (ReLU, 32-channel) output; relu_wbits:
+    such a mask, applied to a data gradient in place of relu_of's activation fetch."""
     lib = _lib()
+    if wbits_out is not None:
+        if cout != 32 or not relu or relu_of is not None or relu_wbits is not None:
+            raise ValueError("conv2d_winograd_raw: wbits_out is for a forward ReLU launch with 32 outputs")
+        L.check(lib.ynet_conv2d_winograd_relu_bits(src[0], src[1], u.data_ptr(), bias.data_ptr() if bias is not None else None, dst[0], dst[1], cin, B, H, W,
+                                                   wbits_out.data_ptr(), _stream()), lib)
+        return
+    if relu_wbits is not None:
+        if cout != 32 or bias is not None or relu or relu_of is not None:
+            raise ValueError("conv2d_winograd_raw: relu_wbits is for a data gradient with 32 outputs")
+        L.check(lib.ynet_conv2d_winograd_dgrad_relu_bits(src[0], src[1], u.data_ptr(), dst[0], dst[1], relu_wbits.data_ptr(), cin, B, H, W, _stream()), lib)
+        return
     if relu_of is not None:
         if bias is not None or relu:
             raise ValueError("conv2d_winograd_raw: relu_of is for a data gradient")
@@ -383,13 +396,20 @@ def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=Non
                                      cin, cout, B, H, W, 1 if relu else 0, _stream()), lib)
 
 
-def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None):
+def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None):
     """srcs: [(ptr, channels, batch_stride)] (at most three, 56 padded channels); dst: (ptr, batch_stride), 32 channels; u: the filter in
     ynet_winograd_filter_cat's layout for these sources; addend: (ptr, image_stride, modulus) of a term added in front of the ReLU;
-    pool: (ptr, batch_stride) of the 2 x 2 max-pooled copy of the output, written by the same launch."""
+    pool: (ptr, batch_stride) of the 2 x 2 max-pooled copy of the output, written by the same launch; wbits_out: receives the 1-bit mask of
+    the (ReLU) output (see conv2d_winograd_raw)."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
     b = bias.data_ptr() if bias is not None else None
+    if wbits_out is not None:
+        if pool is not None or not relu:
+            raise ValueError("conv2d_winograd_cat_raw: wbits_out is for a ReLU launch without the pooled copy")
+        L.check(lib.ynet_conv2d_winograd_cat_relu_bits(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], B, H, W, addend[0] if addend else None,
+                                                       addend[1] if addend else 0, addend[2] if addend else 0, wbits_out.data_ptr(), _stream()), lib)
+        return
     if pool is not None:
         L.check(lib.ynet_conv2d_winograd_cat_pool(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], pool[0], pool[1], 32, B, H, W,
                                                   1 if relu else 0, _stream()), lib)
@@ -400,6 +420,7 @@ def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool
                                                  addend[0], addend[1], addend[2], _stream()), lib)
 
 
+_wino_relu_bits_allowed = _os.environ.get("YNET_WINOGRAD_RELU_BITS", "1") != "0"      # YNET_WINOGRAD_RELU_BITS=0: the Winograd data gradients fetch the float activation (no 1-bit mask in their tiling)
 _wino16_allowed = _os.environ.get("YNET_WINOGRAD16", "1") != "0"     # YNET_WINOGRAD16=0: no conv_wino16_kernel launches (round 5's slice form)
 # YNET_WINOGRAD16_SLICE16=1: 16-output-channel launches (32 -> 16 at 256^2) on the slice form too -- measured SLOWER there than
 # conv_wino_kernel<1, 4> (141 against 134 us at B 32: the launch streams 402 MB, and six staged rows per unit do not pay for one slice)
@@ -455,7 +476,8 @@ def _pad4(c):
     return (c + 3) & ~3
 
 
-def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
+def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
+               relu_wbits=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None.  pooled: (ptr,
     batch_stride) of a second output, the 2 x 2 max-pooled copy of the single destination (ynet_conv2d_pool), or None.
@@ -464,7 +486,10 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
     wino: (the layer's filter cache, "fwd" | "dgrad") -- a plain launch (one source, one destination, no mask, no epilogue variant)
     of a shape ynet_conv2d_winograd_supported admits takes the Winograd F(2x2, 3x3) kernel, its transformed filter kept in that
     cache next to the packed one; returns "winograd:<NCB>,<NCH>,<EM>[+...]" (one group per launch: the template arguments of
-    conv_wino_kernel) or "winograd_cat:2,<epilogue>" then, None otherwise."""
+    conv_wino_kernel) or "winograd_cat:2,<epilogue>" then, None otherwise.
+    wbits_out / relu_wbits: the Winograd-native 1-bit ReLU mask (int32 tensors of ynet_winograd_relu_bits_words words) -- wbits_out is
+    WRITTEN only if the launch taken is a 32-output Winograd one (the returned tag then ends in "|wbits": the caller keeps the tensor
+    only in that case); relu_wbits gates a 32-channel data gradient in place of relu_of's activation fetch."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
     if wino is not None and not torch.is_grad_enabled() and (
@@ -538,7 +563,11 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
         if (pieces and not wide and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
                 and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces)):
             cache, what = wino
-            tag = "winograd:" + "+".join("%d,%d,%s" % (p_[1] // 16, cin // 8, "true" if relu_of is not None else "false") for p_ in pieces)
+            one32 = len(pieces) == 1 and pieces[0][1] == 32
+            wb_out = wbits_out if (one32 and relu and relu_of is None) else None      # the forward launch of a conv -> ReLU -> conv chain writes the mask word
+            wb_in = relu_wbits if (one32 and relu_of is not None and not relu and bias is None) else None      # ... and the chain's data gradient applies it
+            em = 3 if wb_out is not None else (2 if wb_in is not None else (1 if relu_of is not None else 0))
+            tag = "winograd:" + "+".join("%d,%d,%d" % (p_[1] // 16, cin // 8, em) for p_ in pieces) + ("|wbits" if wb_out is not None else "")
             for ptr, n, bs, col0 in pieces:
                 key = "wino_%s_%d_%d" % (what, col0, n)
                 ent = cache.get(key)
@@ -546,7 +575,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                     ent = cache[key] = _wino_made((wp, winograd_filter(wp, cin, n, col0, ctot)))
                 _wino_ready(ent)
                 conv2d_winograd_raw((srcs[0][0], srcs[0][2]), ent[1], None if bias is None else bias[col0:col0 + n], (ptr, bs), cin, n, B, H, W, relu,
-                                    relu_of=relu_of)
+                                    relu_of=None if wb_in is not None else relu_of, wbits_out=wb_out, relu_wbits=wb_in)
                 wino_stats["launches"] += 1
             return tag
         # the slice form for what the kernels above do not serve: 64 input channels, destinations of 64 channels (one launch per
@@ -563,7 +592,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
         if (pieces and wide and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
                 and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces)):      # (YNET_WINOGRAD16=0)
             cache, what = wino
-            tag = "winograd:" + "+".join("%d,%d,%s" % (p_[1] // 16, cin // 8, "true" if relu_of is not None else "false") for p_ in pieces)
+            tag = "winograd:" + "+".join("%d,%d,%d" % (p_[1] // 16, cin // 8, 1 if relu_of is not None else 0) for p_ in pieces)
             for ptr, n, bs, col0 in pieces:
                 key = "wino_%s_%d_%d" % (what, col0, n)
                 ent = cache.get(key)
@@ -602,9 +631,10 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                 HW = H * W
                 conv2d_winograd_raw((first[0], first[2]), ent[1], None, (want[0][0], want[0][2]), 32, 32, B, H, W, False)
                 rsrcs = ([(first[0] + 4 * 32 * HW, first[1] - 32, first[2])] if first[1] > 32 else []) + list(srcs[1:])
-                conv2d_winograd_cat_raw(rsrcs, ent[2], bias, (want[0][0], want[0][2]), B, H, W, relu, addend=(want[0][0], want[0][2], 0))
+                wb_out = wbits_out if relu else None
+                conv2d_winograd_cat_raw(rsrcs, ent[2], bias, (want[0][0], want[0][2]), B, H, W, relu, addend=(want[0][0], want[0][2], 0), wbits_out=wb_out)
                 wino_stats["launches"] += 2
-                return "winograd_cat:2,2"
+                return "winograd_cat:2,5|wbits" if wb_out is not None else "winograd_cat:2,2"
             if lib.ynet_conv2d_winograd_cat_supported(B, H, W, cs, len(srcs), 32, K):
                 cache, what = wino
                 key = "wino_cat_" + what
@@ -614,9 +644,10 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                     L.check(lib.ynet_winograd_filter_cat(wp.data_ptr(), u.data_ptr(), cs, len(srcs), 32, 0, 32, _stream()), lib)
                     ent = cache[key] = _wino_made((wp, u, tuple(cs)))
                 _wino_ready(ent)
-                conv2d_winograd_cat_raw(srcs, ent[1], bias, (want[0][0], want[0][2]), B, H, W, relu)
+                wb_out = wbits_out if relu else None
+                conv2d_winograd_cat_raw(srcs, ent[1], bias, (want[0][0], want[0][2]), B, H, W, relu, wbits_out=wb_out)
                 wino_stats["launches"] += 1
-                return "winograd_cat:2,0"
+                return "winograd_cat:2,4|wbits" if wb_out is not None else "winograd_cat:2,0"
         if len(want) == 1 and len(dsts) == 1 and want[0][0] % 8 == 0 and want[0][2] % 2 == 0:
             # the slice form: 64 output channels (the decoders' first convolutions at 64^2: cat(up-sampled 32, skip 64[, way-point map]) -> 64)
             cout_w, cs_all = want[0][1], [s_[1] for s_ in srcs]
@@ -998,9 +1029,19 @@ class _Conv2dFn(torch.autograd.Function):
             n_words = _lib().ynet_conv2d_relu_bits_words(B, H, W, cout, k)
             if n_words > 0:
                 bits = torch.empty(n_words, device=weight.device, dtype=torch.int32)
-        conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu,
-                   pooled=None if pooled is None else (pooled.data_ptr(), cout * (H // 2) * (W // 2)),
-                   bits_out=None if bits is None else bits.data_ptr(), wino=(cache, "fwd") if meta.get("wino") else None)
+        # ... and where that data gradient will be the 32-channel Winograd launch, this (Winograd) launch leaves it the mask in THAT tiling's
+        # register layout: one word per lane and unit (ynet_conv2d_winograd_*_relu_bits; kept only if the launch taken did write it)
+        wbits = None
+        if (consumer_wino and cout == 32 and relu and premask and _wino_relu_bits_allowed and pooled is None and not meta.get("repeat")
+                and int(meta["bits"]) in (16, 32) and bool(_lib().ynet_conv2d_winograd_supported(B, H, W, int(meta["bits"]), 32, k))):
+            n_words = _lib().ynet_winograd_relu_bits_words(B, H, W)
+            if n_words > 0:
+                wbits = torch.empty(n_words, device=weight.device, dtype=torch.int32)
+        took = conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu,
+                          pooled=None if pooled is None else (pooled.data_ptr(), cout * (H // 2) * (W // 2)),
+                          bits_out=None if bits is None else bits.data_ptr(), wino=(cache, "fwd") if meta.get("wino") else None, wbits_out=wbits)
+        if not (isinstance(took, str) and took.endswith("|wbits")):
+            wbits = None
         if pooled is not None:
             for k_ in [k_ for k_, e_ in _pooled_outputs.items() if e_[0]() is None]:      # (a pool that never followed)
                 del _pooled_outputs[k_]
@@ -1012,7 +1053,7 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(weight, lora_a, lora_b, y if relu else None, *keep)
         ctx.w_key = _weight_key(weight, lora_a, lora_b)
         if relu and premask:
-            _relu_outputs[y.data_ptr()] = (weakref.ref(y), tuple(y.shape), bits, k)
+            _relu_outputs[y.data_ptr()] = (weakref.ref(y), tuple(y.shape), bits, k, wbits)
         return y
 
     @staticmethod
@@ -1073,12 +1114,20 @@ class _Conv2dFn(torch.autograd.Function):
             wino_em = (emask is not None and mask is None and meta.get("wino") and _wino_allowed and k == 3 and dy.data_ptr() % 16 == 0
                        and d_srcs[0].data_ptr() % 8 == 0 and (_lib().ynet_conv2d_winograd_supported(B, H, W, cout, int(s0.shape[1]), int(k))
                                                                or _wino16_supported([cout], int(s0.shape[1]), B, H, W, int(k))))
+            ewbits = None
+            if wino_em and _wino_relu_bits_allowed and int(s0.shape[1]) == 32:
+                e0 = _relu_outputs.get(s0.data_ptr())
+                if (e0 is not None and len(e0) > 4 and e0[4] is not None and e0[4].numel() == _lib().ynet_winograd_relu_bits_words(B, H, W)
+                        and _lib().ynet_conv2d_winograd_supported(B, H, W, cout, 32, int(k))):
+                    ewbits = e0[4]         # (written by s0's own Winograd forward launch: the 1-bit mask in this launch's tiling)
             if ebits is not None and not wino_em:
                 premask_stats["bit_masks"] = premask_stats.get("bit_masks", 0) + 1
                 conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_bits=ebits.data_ptr())
             else:
+                if ewbits is not None:
+                    premask_stats["wino_bit_masks"] = premask_stats.get("wino_bit_masks", 0) + 1
                 conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_of=emask,
-                           wino=(cache, "dgrad") if meta.get("wino") else None)
+                           wino=(cache, "dgrad") if meta.get("wino") else None, relu_wbits=ewbits)
             if emask is not None:
                 _premasked[d_srcs[0].data_ptr()] = (s0.data_ptr(), d_srcs[0]._version, tuple(d_srcs[0].shape))
             if skip_fold:

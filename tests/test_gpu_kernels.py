@@ -834,6 +834,52 @@ def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     close(outs[0][0], ref, rtol=1e-4, scale_rel=2e-6, msg="forward vs torch")
 
 
+@pytest.mark.parametrize("case", [(8, 256, 256, "plain", 32), (16, 128, 128, "plain", 16), (8, 256, 256, "cat", 32), (16, 128, 128, "split", 32), (6, 96, 160, "cat", 16)], ids=str)
+def test_winograd_native_one_bit_relu_mask(dev, case):
+    """Round 5: conv -> ReLU -> conv with 32 channels in between, both launches Winograd ones.  The first convolution's FORWARD launch (one source,
+    concatenated sources, or the two-launch form for 57..88 channels) also writes one bit per output element in the register layout of the tiling
+    the second convolution's data gradient shares -- one 32-bit word per lane and unit --, and that data gradient is gated by it
+    (ynet_conv2d_winograd_dgrad_relu_bits) instead of fetching the float activation: the forward output is unchanged (bit-identical to the
+    launch without the mask), the masked gradient bit-identical to ynet_conv2d_winograd_dgrad_relu's, a NaN / -0 activation counts as not positive."""
+    ops = pkg("ops")
+    lib = ops._lib()
+    B, H, W, kind, dyc = case
+    cs = {"plain": [32], "cat": [32, 16, 1], "split": [64, 1]}[kind]
+    cin = sum(cs)
+    xs = [rnd(B, c, H, W, seed=10 + i).to(dev) for i, c in enumerate(cs)]
+    w, bias = rnd(32, cin, 3, 3, seed=2, scale=0.2).to(dev), rnd(32, seed=3).to(dev)
+    wp = ops.pack_weight(w, 0)
+    srcs = [(x.data_ptr(), c, c * H * W) for x, c in zip(xs, cs)]
+    n_words = lib.ynet_winograd_relu_bits_words(B, H, W)
+    assert n_words == B * (H // 2) * (W // 32) * 64
+    y0, y1 = torch.empty(B, 32, H, W, device=dev), torch.empty(B, 32, H, W, device=dev)
+    wbits = torch.full((n_words,), -1, device=dev, dtype=torch.int32)
+    t0 = ops.conv2d_raw(srcs, None, wp, bias, [(y0.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True, wino=({}, "fwd"))
+    t1 = ops.conv2d_raw(srcs, None, wp, bias, [(y1.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True, wino=({}, "fwd"), wbits_out=wbits)
+    assert t0.startswith("winograd") and t1.endswith("|wbits") and not t0.endswith("|wbits"), (t0, t1)
+    assert torch.equal(y0, y1)
+    assert not bool((wbits == -1).all())
+    # a NaN and a -0 in the activation: "not positive" either way
+    y1[0, 3, 5, 7] = float("nan")
+    y1[1, 4, 9, 11] = -0.0
+    dy = rnd(B, dyc, H, W, seed=5).to(dev)
+    w2 = rnd(dyc, 32, 3, 3, seed=6, scale=0.2).to(dev)          # the second layer's filter [Cout = dyc][Cin = 32]
+    wp2 = ops.pack_weight(w2, 1)
+    src, cache = [(dy.data_ptr(), dyc, dyc * H * W)], {}
+    g_float, g_bits = torch.full((B, 32, H, W), float("nan"), device=dev), torch.full((B, 32, H, W), float("nan"), device=dev)
+    ta = ops.conv2d_raw(src, None, wp2, None, [(g_float.data_ptr(), 32, 32 * H * W)], B, H, W, 3, False, relu_of=(y1.data_ptr(), 32 * H * W), wino=(cache, "dgrad"))
+    tb = ops.conv2d_raw(src, None, wp2, None, [(g_bits.data_ptr(), 32, 32 * H * W)], B, H, W, 3, False, relu_of=(y1.data_ptr(), 32 * H * W), wino=(cache, "dgrad"),
+                        relu_wbits=wbits)
+    assert ta == "winograd:2,%d,1" % (dyc // 8) and tb == "winograd:2,%d,2" % (dyc // 8), (ta, tb)
+    # the mask was written from the launch's own output, before the NaN / -0 were planted: those two elements may differ, nothing else
+    same = torch.ones_like(g_float, dtype=torch.bool)
+    same[0, 3, 5, 7] = False
+    same[1, 4, 9, 11] = False
+    assert torch.equal(g_float[same], g_bits[same])
+    assert float(g_float[0, 3, 5, 7]) == 0.0 and float(g_float[1, 4, 9, 11]) == 0.0
+    assert int((g_bits == 0).sum()) >= int((y0 <= 0).sum())
+
+
 @pytest.mark.parametrize("case", [(8, 256, 256, 32, 16, True), (16, 128, 128, 32, 16, False), (12, 96, 160, 32, 16, True), (10, 256, 256, 32, 16, False),
                                   # the slice form (ynet_upsample2x_conv2d_winograd_supported == 2): the decoders' levels 3 and 2, and a ragged map
                                   (16, 128, 128, 64, 32, True), (32, 64, 64, 64, 32, False), (6, 96, 160, 64, 32, True), (256, 32, 32, 64, 32, True)], ids=str)
