@@ -207,11 +207,12 @@ class ConvTimer:
                              (B, H, W, cin, cout, 3, False)))
         self.ops.upsample2x_conv2d_raw = timed_up
 
-        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None):
+        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
+                  relu_wbits=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             took = self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits,
-                             wino=wino)
+                             wino=wino, wbits_out=wbits_out, relu_wbits=relu_wbits)
             e1.record()
             cin = sum(s[1] for s in srcs)
             dl = list(dsts)
@@ -225,7 +226,7 @@ class ConvTimer:
             rows, tiles, m16, dma = plan & 255, (plan >> 8) & 255, (plan >> 16) & 1, (plan >> 17) & 1
             cc = plan >> 21                       # input channels per staged chunk (the kernel's CC template argument)
             if took is not None and str(took).startswith("winograd"):
-                return                            # (timed launch by launch in timed_wino / timed_cat, under rocprof's kernel names)
+                return took                       # (timed launch by launch in timed_wino / timed_cat, under rocprof's kernel names)
             if dma:
                 if cc > 8:                        # launch_dma_small: the deep chunks are for plain launches with enough input channels
                     if relu_of or pooled or bits_out or relu_bits:
@@ -241,6 +242,7 @@ class ConvTimer:
                 name = (f"conv_mfma_kernel<{K}, {tiles}, {rows}, {cc}, {'true' if mask else 'false'}, "
                         f"{'true' if m16 else 'false'}>")
             self.rec.append((name, e0, e1, flops, byts, (B, H, W, cin, cout, K, bool(mask))))
+            return took
         self.ops.conv2d_raw = timed
         return self
 

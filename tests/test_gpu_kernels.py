@@ -834,7 +834,7 @@ def test_winograd_path_of_the_model_layer_and_its_switch(dev):
     close(outs[0][0], ref, rtol=1e-4, scale_rel=2e-6, msg="forward vs torch")
 
 
-@pytest.mark.parametrize("case", [(8, 256, 256, "plain", 32), (16, 128, 128, "plain", 16), (8, 256, 256, "cat", 32), (16, 128, 128, "split", 32), (6, 96, 160, "cat", 16)], ids=str)
+@pytest.mark.parametrize("case", [(8, 256, 256, "plain", 32), (16, 128, 128, "plain", 16), (8, 256, 256, "cat", 32), (16, 128, 128, "split", 32), (10, 96, 160, "cat", 16)], ids=str)
 def test_winograd_native_one_bit_relu_mask(dev, case):
     """Round 5: conv -> ReLU -> conv with 32 channels in between, both launches Winograd ones.  The first convolution's FORWARD launch (one source,
     concatenated sources, or the two-launch form for 57..88 channels) also writes one bit per output element in the register layout of the tiling

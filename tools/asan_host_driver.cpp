@@ -87,6 +87,15 @@ int main() {
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 250, 256, 1, nullptr));               // H not a multiple of 16
     EXPECT_REJECT(ynet_conv2d_winograd(cfp, 16 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));               // batch stride smaller than the image
     EXPECT_REJECT(ynet_conv2d_winograd(nullptr, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 32, 256, 256, 1, nullptr));
+    // the Winograd-native 1-bit ReLU mask
+    for (int b : {0, 1, 10, 32})
+        for (int hw : {8, 32, 250, 256}) acc += ynet_winograd_relu_bits_words(b, hw, hw) + ynet_winograd_relu_bits_words(b, hw, hw + 16);
+    EXPECT_REJECT(ynet_conv2d_winograd_relu_bits(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, nullptr, nullptr));                    // no mask words
+    EXPECT_REJECT(ynet_conv2d_winograd_relu_bits(cfp, 32 * 65536, cfp, nullptr, fp, 32 * 65536, 12, 32, 256, 256, (unsigned*)dummy, nullptr));           // cin not a multiple of 8
+    EXPECT_REJECT(ynet_conv2d_winograd_relu_bits(cfp, 32 * 65536, cfp, nullptr, fp, 16 * 65536, 32, 32, 256, 256, (unsigned*)dummy, nullptr));           // output stride smaller than the image
+    EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu_bits(cfp, 32 * 65536, cfp, fp, 32 * 65536, nullptr, 32, 32, 256, 256, nullptr));                      // no mask words
+    EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu_bits(cfp, 32 * 65536, cfp, fp, 32 * 65536, (const unsigned*)dummy, 32, 32, 250, 256, nullptr));       // H not a multiple of 16
+    EXPECT_REJECT(ynet_conv2d_winograd_dgrad_relu_bits(cfp, 32 * 65536, nullptr, fp, 32 * 65536, (const unsigned*)dummy, 32, 32, 256, 256, nullptr));   // no filters
     {
         const int cat3[3] = {32, 16, 1}, cat2[2] = {32, 32}, bad[2] = {32, 0};
         const long long bs3[3] = {32 * 65536, 16 * 65536, 65536};
@@ -103,6 +112,9 @@ int main() {
         EXPECT_REJECT(ynet_conv2d_winograd_cat(s3, cat3, bs3, 3, nullptr, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr));          // no filters
         EXPECT_REJECT(ynet_conv2d_winograd_cat_add(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, nullptr, 32 * 65536, 4, nullptr));   // no additive term
         EXPECT_REJECT(ynet_conv2d_winograd_cat_add(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 32, 256, 256, 1, cfp, 32 * 65536, -1, nullptr));      // negative modulus
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_relu_bits(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 256, 256, nullptr, 0, 0, nullptr, nullptr));              // no mask words
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_relu_bits(s3, cat2, bs3, 2, cfp, nullptr, fp, 32 * 65536, 32, 256, 256, nullptr, 0, 0, (unsigned*)dummy, nullptr));     // 64 inputs: too many filters for LDS
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_relu_bits(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 256, 256, cfp, 32 * 65536, -1, (unsigned*)dummy, nullptr)); // negative modulus
         EXPECT_REJECT(ynet_conv2d_winograd_cat_pool(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, nullptr, 32 * 16384, 32, 32, 256, 256, 1, nullptr));   // no pooled output
         EXPECT_REJECT(ynet_conv2d_winograd_cat_pool(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, fp, 16 * 16384, 32, 32, 256, 256, 1, nullptr));        // pooled stride too small
     }
