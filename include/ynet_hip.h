@@ -300,6 +300,14 @@ long long ynet_pred_bce_workspace_bytes(void);
 int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target,
                   float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, long long HW,
                   float expected_grad, int dx_relu_mask, void* stream);
+/* The same pass with the target given by POSITION (round 5): plane (b, co) of the target is the H x W window of the S x S Gaussian template
+ * around (x, y) = target_xy[2 * (b * cout + co) ..], i.e. what get_patch(gt_template, gt_future, H, W) holds (utils/train_epoch.py:68-72,
+ * utils/image_utils.py:15-27,40-63) and ynet_heatmap_analytic(kind 1) writes: the kernlen x kernlen `blob` placed at the rounded position, zero
+ * elsewhere, all zero when the window would leave the template.  The 12 target planes are computed, not read (88 -> 76 planes of traffic per pixel);
+ * results bit-identical to ynet_pred_bce on the materialised target.  W % 4 == 0, kernlen <= S, S >= H, W. */
+int ynet_pred_bce_blob(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target_xy, const float* blob, int kernlen,
+                       int S, int H, int W, float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, float expected_grad,
+                       int dx_relu_mask, void* stream);
 
 /* ---- goal / trajectory read-out -------------------------------------------------------------- */
 /* SoftArgmax2D.forward (utils/softargmax.py:55-81; models/ynet.py:582-583): x [B][C][H][W] with

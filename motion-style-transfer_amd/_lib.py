@@ -88,6 +88,7 @@ SIGNATURES = {
     "ynet_bce_grad_rescale": (c_i, [c_fp, c_fp, c_f, c_ll, c_fp]),
     "ynet_pred_bce_workspace_bytes": (c_ll, []),
     "ynet_pred_bce": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_ll, c_f, c_i, c_fp]),
+    "ynet_pred_bce_blob": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_f, c_i, c_fp]),
     "ynet_softargmax2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, c_i, c_i, c_fp]),
     "ynet_train_readout": (c_i, [c_fp, c_ll, c_fp, c_ll, c_i, c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_fp]),
     "ynet_pred_softargmax_supported": (c_i, [c_i, c_i, c_i, c_i]),

@@ -543,6 +543,9 @@ struct PredBceArgs {
     const float* wp;        // packed [cin_pad][cout_pad] (forward layout of a 1x1 filter)
     const float* bias;
     const float* t;         // [B][cout][HW]
+    const float* t_xy;      // BLOB form of the target: plane (b, co) is the window of the Gaussian template around (x, y) = t_xy[2 * (b * cout + co) ..]
+    const float* t_blob;    //   (heatmap_analytic_kernel kind 1: the m x m blob placed at the rounded position, zero elsewhere, all zero when the
+    int t_m, t_S, t_W, t_H; //    H x W window would leave the S x S template) -- t is not read
     float* y;               // [B][cout][HW] logits
     float* dx;              // [B][cin][HW] or NULL
     int relu_mask;          // dx is zeroed where x <= 0 (x = post-ReLU output of the conv that receives dx: see maxpool2_bwd_add_kernel)
@@ -559,7 +562,7 @@ typedef const __attribute__((address_space(4))) float* glue_const_f32_ptr;      
 
 // (4 workgroups per CU = 4 waves per SIMD: <= 128 VGPRs.  Left alone hipcc hoists the loads of both loops and takes 175
 // registers -- 2 waves per SIMD, too few to hide the HBM latency of a streaming kernel: 213 -> see DESIGN.md)
-template <int CT, int PX>
+template <int CT, int PX, bool BLOB = false>
 __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2))) void pred_bce_kernel(const PredBceArgs a) {
     typedef float vec_t __attribute__((ext_vector_type(PX)));
     __shared__ double ws[4];
@@ -613,10 +616,31 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
         }
         const long long obase = (long long)b * a.cout * hwv + p;
         float s = 0.f;
+        int py = 0, px0 = 0;
+        if (BLOB) {         // this thread's PX pixels: row py, columns px0 .. px0 + PX - 1 (W % PX == 0)
+            const int pix = (int)p * PX;
+            py = pix / a.t_W;
+            px0 = pix - py * a.t_W;
+        }
 #pragma unroll
         for (int co = 0; co < CT; ++co) {
             if (co < a.cout) {
-                const vec_t tv = reinterpret_cast<const vec_t*>(a.t)[obase + (long long)co * hwv];
+                vec_t tv;
+                if (BLOB) {
+                    const float* pos = a.t_xy + 2ll * ((long long)b * a.cout + co);
+                    const int rx = (int)rintf(pos[0]), ry = (int)rintf(pos[1]);
+                    const int ox = a.t_S / 2 - rx, oy = a.t_S / 2 - ry;
+                    const bool inside = !(ox < 0 || oy < 0 || ox + a.t_W > a.t_S || oy + a.t_H > a.t_S);
+                    const int by = py - ry + a.t_m / 2, bx0 = px0 - rx + a.t_m / 2;
+                    const bool row_in = inside && by >= 0 && by < a.t_m;
+#pragma unroll
+                    for (int e = 0; e < PX; ++e) {
+                        const int bx = bx0 + e;
+                        tv[e] = (row_in && bx >= 0 && bx < a.t_m) ? a.t_blob[by * a.t_m + bx] : 0.f;
+                    }
+                } else {
+                    tv = reinterpret_cast<const vec_t*>(a.t)[obase + (long long)co * hwv];
+                }
                 reinterpret_cast<vec_t*>(a.y)[obase + (long long)co * hwv] = acc[co];
                 vec_t d;
 #pragma unroll
@@ -1438,20 +1462,30 @@ long long ynet_bce_workspace_bytes(void) { return YNET_BCE_PARTS * (long long)si
 /* workspace: [YNET_BCE_PARTS] doubles + a ticket counter that must be ZERO before the first launch (the kernel resets it) */
 long long ynet_pred_bce_workspace_bytes(void) { return YNET_BCE_PARTS * (long long)sizeof(double) + 16; }
 
-int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target,
-                  float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, long long HW,
-                  float expected_grad, int dx_relu_mask, void* stream) {
-    YNET_REQUIRE(x && wp && target && y && loss && workspace, "pred_bce: null pointer");
+static int pred_bce_launch(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target, const float* t_xy,
+                           const float* t_blob, int t_m, int t_S, int t_H, int t_W, float* y, float* loss, float* dx, float* dy, void* workspace, int B,
+                           int cin, int cout, long long HW, float expected_grad, int dx_relu_mask, void* stream) {
+    YNET_REQUIRE(x && wp && (target || t_xy) && y && loss && workspace, "pred_bce: null pointer");
+    YNET_REQUIRE(!t_xy || (t_blob && t_m > 0 && t_m <= t_S && t_H > 0 && t_W > 0 && (long long)t_H * t_W == HW && (t_W & 3) == 0 && t_S >= t_H && t_S >= t_W),
+                 "pred_bce_blob: the target needs a blob table, 0 < kernlen <= S, H * W == HW, W %% 4 == 0 and S >= H, W (got kernlen %d, S %d, %dx%d, HW %lld)", t_m,
+                 t_S, t_H, t_W, HW);
     YNET_REQUIRE(!dx_relu_mask || (dx != nullptr && cin <= 32), "pred_bce: the ReLU mask of dx needs dx and cin <= 32 (got cin = %d)", cin);
     YNET_REQUIRE(B > 0 && cin > 0 && cout > 0 && cout <= 32 && HW > 0 && (HW & 3) == 0, "pred_bce: bad shape B=%d cin=%d cout=%d HW=%lld (cout <= 32, HW %% 4 == 0)", B, cin, cout, HW);
     YNET_REQUIRE((((uintptr_t)x | (uintptr_t)target | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)dy) & 15) == 0 && (x_batch_stride & 3) == 0,
                  "pred_bce: tensors must be 16-byte aligned");
+    YNET_REQUIRE(t_xy == nullptr || HW < (1ll << 31), "pred_bce_blob: H * W must stay below 2^31");
     PredBceArgs a{};
     a.x = x;
     a.x_bs = x_batch_stride;
     a.wp = wp;
     a.bias = bias;
     a.t = target;
+    a.t_xy = t_xy;
+    a.t_blob = t_blob;
+    a.t_m = t_m;
+    a.t_S = t_S;
+    a.t_H = t_H;
+    a.t_W = t_W;
     a.y = y;
     a.dx = dx;
     a.relu_mask = dx_relu_mask ? 1 : 0;
@@ -1468,11 +1502,34 @@ int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, con
     a.gs = expected_grad / (float)a.n;
     // exact channel counts for the two prediction horizons of the shipped configs (12 and 30 steps): no padded FMAs
     const int parts4 = grid_for((long long)B * a.hw4, 256, YNET_BCE_PARTS), parts2 = grid_for((long long)B * a.hw4 * 2, 256, YNET_BCE_PARTS);
+    if (t_xy != nullptr) {
+        if (cout == 12) hipLaunchKernelGGL((pred_bce_kernel<12, 4, true>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);
+        else if (cout <= 16) hipLaunchKernelGGL((pred_bce_kernel<16, 4, true>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);
+        else if (cout == 30) hipLaunchKernelGGL((pred_bce_kernel<30, 2, true>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((pred_bce_kernel<32, 2, true>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
+        return ynet_check_launch("pred_bce_blob");
+    }
     if (cout == 12) hipLaunchKernelGGL((pred_bce_kernel<12, 4>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);      // (2 pixels per thread: measured equal)
     else if (cout <= 16) hipLaunchKernelGGL((pred_bce_kernel<16, 4>), dim3(parts4), dim3(256), 0, (hipStream_t)stream, a);
     else if (cout == 30) hipLaunchKernelGGL((pred_bce_kernel<30, 2>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((pred_bce_kernel<32, 2>), dim3(parts2), dim3(256), 0, (hipStream_t)stream, a);
     return ynet_check_launch("pred_bce");
+}
+
+int ynet_pred_bce(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target,
+                  float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, long long HW,
+                  float expected_grad, int dx_relu_mask, void* stream) {
+    YNET_REQUIRE(target != nullptr, "pred_bce: null pointer");
+    return pred_bce_launch(x, x_batch_stride, wp, bias, target, nullptr, nullptr, 0, 0, 0, 0, y, loss, dx, dy, workspace, B, cin, cout, HW, expected_grad,
+                           dx_relu_mask, stream);
+}
+
+int ynet_pred_bce_blob(const float* x, long long x_batch_stride, const float* wp, const float* bias, const float* target_xy, const float* blob, int kernlen,
+                       int S, int H, int W, float* y, float* loss, float* dx, float* dy, void* workspace, int B, int cin, int cout, float expected_grad,
+                       int dx_relu_mask, void* stream) {
+    YNET_REQUIRE(target_xy != nullptr && blob != nullptr, "pred_bce_blob: null pointer");
+    return pred_bce_launch(x, x_batch_stride, wp, bias, nullptr, target_xy, blob, kernlen, S, H, W, y, loss, dx, dy, workspace, B, cin, cout,
+                           (long long)H * W, expected_grad, dx_relu_mask, stream);
 }
 
 int ynet_bce_logits_fwd(const float* x, const float* t, long long n, float* loss, void* workspace, void* stream) {

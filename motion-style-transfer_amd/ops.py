@@ -1526,11 +1526,22 @@ class _PredBCEFn(torch.autograd.Function):
         ctx.dy = torch.empty_like(y) if need_w else None
         # x is the post-ReLU output of decoder[4][2]: the kernel writes dx with that ReLU's backward applied
         ctx.premask_y = x.data_ptr() if (need_x and premask and cin <= 32 and _is_relu_output(x)) else None
-        L.check(lib.ynet_pred_bce(x.data_ptr(), cin * H * W, wp.data_ptr(), bias.detach().data_ptr() if bias is not None else None,
-                                  target.data_ptr(), y.data_ptr(), loss.data_ptr(),
-                                  ctx.dx.data_ptr() if need_x else None, ctx.dy.data_ptr() if need_w else None,
-                                  ws.data_ptr(), B, cin, cout, H * W, expected_grad, 1 if ctx.premask_y is not None else 0,
-                                  _stream()), lib)
+        blob_t = _blob_target(target, B, cout, H, W)
+        if blob_t is not None:      # the target is a Gaussian blob per plane: computed from the positions, its planes are not read
+            pos, tmpl = blob_t
+            pos.record_stream(torch.cuda.current_stream(x.device))
+            bce_blob_stats["launches"] += 1
+            L.check(lib.ynet_pred_bce_blob(x.data_ptr(), cin * H * W, wp.data_ptr(), bias.detach().data_ptr() if bias is not None else None,
+                                           pos.data_ptr(), tmpl.blob.data_ptr(), tmpl.blob.shape[0], tmpl.size, H, W, y.data_ptr(), loss.data_ptr(),
+                                           ctx.dx.data_ptr() if need_x else None, ctx.dy.data_ptr() if need_w else None,
+                                           ws.data_ptr(), B, cin, cout, expected_grad, 1 if ctx.premask_y is not None else 0, _stream()), lib)
+            ctx.blob_keep = (pos, tmpl)
+        else:
+            L.check(lib.ynet_pred_bce(x.data_ptr(), cin * H * W, wp.data_ptr(), bias.detach().data_ptr() if bias is not None else None,
+                                      target.data_ptr(), y.data_ptr(), loss.data_ptr(),
+                                      ctx.dx.data_ptr() if need_x else None, ctx.dy.data_ptr() if need_w else None,
+                                      ws.data_ptr(), B, cin, cout, H * W, expected_grad, 1 if ctx.premask_y is not None else 0,
+                                      _stream()), lib)
         ctx.expected = expected_grad
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight)
@@ -1795,7 +1806,30 @@ def _analytic_patches(t: AnalyticTemplate, xy, H: int, W: int) -> torch.Tensor:
     L.check(lib.ynet_heatmap_analytic(coords.data_ptr(), out.data_ptr(), n, H, W, t.size, 0 if t.kind == "dist" else 1, t.dmax,
                                       t.blob.data_ptr() if t.blob is not None else None,
                                       t.blob.shape[0] if t.blob is not None else 0, st.data_ptr(), _stream()), lib)
+    if t.kind == "gaussian" and _bce_blob_allowed:
+        # the fused predictor + criterion computes such a target from the positions instead of reading its planes (ynet_pred_bce_blob):
+        # remembered by storage, size and version -- a tensor somebody wrote into since is read as the tensor it is
+        for k_ in [k_ for k_, e_ in _blob_targets.items() if e_[0]() is None]:
+            del _blob_targets[k_]
+        _blob_targets[out.data_ptr()] = (weakref.ref(out), out._version, n, H, W, coords, t, coords._version)
     return out
+
+
+_bce_blob_allowed = _os.environ.get("YNET_BCE_BLOB_TARGET", "1") != "0"      # (development switch)
+_blob_targets = {}
+bce_blob_stats = {"launches": 0}
+
+
+def _blob_target(target, B, cout, H, W):
+    """(positions [B * cout, 2], AnalyticTemplate) if `target` [B, cout, H, W] is, untouched, what gather_patches wrote for a Gaussian template."""
+    e = _blob_targets.get(target.data_ptr()) if _bce_blob_allowed else None
+    if (e is None or e[0]() is None or not target.is_contiguous() or target._version != e[1] or (e[2], e[3], e[4]) != (B * cout, H, W) or W % 4 != 0
+            or e[5]._version != e[7]):
+        return None
+    base = e[0]()
+    if base.untyped_storage().data_ptr() != target.untyped_storage().data_ptr() or target.numel() != base.numel():
+        return None
+    return e[5], e[6]
 
 
 def pad_planes(x: torch.Tensor, division_factor: int = 32) -> torch.Tensor:

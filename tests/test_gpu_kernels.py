@@ -1601,6 +1601,60 @@ def test_fused_predictor_and_bce(dev, B, cin, cout, H, W, train_pred, scale, up)
     assert torch.equal(y2, yd) and float(l2) == float(ld)
 
 
+@pytest.mark.parametrize("B,cout,H,W,S,device_xy", [(4, 12, 64, 96, 400, False), (3, 12, 128, 128, 300, True), (2, 30, 32, 64, 200, True), (2, 5, 64, 64, 160, False)])
+def test_fused_predictor_and_bce_with_the_target_given_by_position(dev, B, cout, H, W, S, device_xy):
+    """ynet_pred_bce_blob (round 5): the BCE target of a training step is get_patch(gt_template, gt_future, H, W) (utils/train_epoch.py:68-72) -- per plane
+    the 31 x 31 Gaussian blob at the rounded position, zero elsewhere.  The fused predictor + criterion is handed such a tensor, recognises it (same storage,
+    size, version as gather_patches left it) and computes the target from the positions instead of reading its planes: logits, loss, dx, dlogits
+    bit-identical to the pass over the materialised target.  A target somebody wrote into, or a clone, is read as the tensor it is."""
+    ops, iu = pkg("ops"), pkg("utils.image_utils")
+    lib = ops._lib()
+    tmpl = iu.analytic_gaussian_template(S, 31, 4, True, dev)
+    gen = torch.Generator().manual_seed(B + cout)
+    xy = torch.rand(B * cout, 2, generator=gen) * torch.tensor([W * 1.0, H * 1.0])
+    xy[0] = torch.tensor([0.5, 1.5])                       # blobs cut by the window's corners, round-half-even
+    xy[1] = torch.tensor([W - 0.5, H - 1.49])
+    xy[2] = torch.tensor([W / 2.0, 0.0])
+    if device_xy:
+        xy[3] = torch.tensor([W + S * 1.0, 3.0])           # (device-side positions are not checked on the host: the window leaves the template -> an all-zero plane)
+    x = rnd(B, 32, H, W, seed=1).relu().to(dev)
+    w, b = rnd(cout, 32, 1, 1, seed=2, scale=0.3).to(dev), rnd(cout, seed=3, scale=0.1).to(dev)
+    target = ops.gather_patches(tmpl, xy.to(dev) if device_xy else xy, H, W).view(B, cout, H, W)
+    if device_xy:
+        assert float(target[0, 3].abs().max()) == 0.0 and float(target[0, 2].max()) > 0.5
+        with pytest.raises(ValueError, match="left the template"):      # (flagged by the heat-map kernel, raised -- and cleared -- at the next check)
+            ops.check_patch_status()
+    outs = []
+    for how in ("blob", "tensor", "written"):
+        t_in = target if how == "blob" else target.clone()
+        if how == "written":
+            t_in = target
+            target[0, 0, 0, 0] += 0.0                          # (an in-place write, whatever it wrote: the version moved -> the planes are read)
+        n0 = ops.bce_blob_stats["launches"]
+        xd, wd, bd = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y, loss = ops.pred_bce(xd, wd, bd, t_in, 1000.0, {})
+        (loss * 1000.0).backward()
+        assert ops.bce_blob_stats["launches"] - n0 == (1 if how == "blob" else 0), how
+        outs.append((y, loss.detach().clone(), xd.grad, wd.grad, bd.grad))
+    for o in outs[1:]:
+        for got, want, name in zip(outs[0], o, ("logits", "loss", "dx", "dW", "db")):
+            assert torch.equal(got, want), name
+    assert float(outs[0][1]) > 0 and float(outs[0][2].abs().max()) > 0
+    # the C ABI's argument checks
+    ws = torch.zeros(lib.ynet_pred_bce_workspace_bytes() // 8 + 1, device=dev, dtype=torch.float64)
+    yb, lb = torch.empty(B, cout, H, W, device=dev), torch.empty((), device=dev)
+    wp = ops.pack_weight(w, 0)
+    pos = xy.to(dev)
+    assert lib.ynet_pred_bce_blob(x.data_ptr(), 32 * H * W, wp.data_ptr(), b.data_ptr(), pos.data_ptr(), tmpl.blob.data_ptr(), 31, 16, H, W, yb.data_ptr(),
+                                  lb.data_ptr(), None, None, ws.data_ptr(), B, 32, cout, 1.0, 0, None) != 0          # template smaller than the window
+    assert lib.ynet_pred_bce_blob(x.data_ptr(), 32 * H * W, wp.data_ptr(), b.data_ptr(), pos.data_ptr(), None, 31, S, H, W, yb.data_ptr(),
+                                  lb.data_ptr(), None, None, ws.data_ptr(), B, 32, cout, 1.0, 0, None) != 0          # no blob table
+    assert lib.ynet_pred_bce_blob(x.data_ptr(), 32 * H * W, wp.data_ptr(), b.data_ptr(), pos.data_ptr(), tmpl.blob.data_ptr(), 31, S, H, W, yb.data_ptr(),
+                                  lb.data_ptr(), None, None, ws.data_ptr(), B, 32, cout, 1000.0, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(yb, outs[0][0]) and float(lb) == float(outs[0][1])
+
+
 def test_scene_padding_and_label_one_hot_known_answers(dev):
     """SURVEY 8(f)-4, the part that needs neither OpenCV nor the segmentation backbone (utils/image_utils.py:74-81, 95-107):
     zero border at the bottom / right up to a multiple of 32, and the one-hot planes of a label map -- padded BEFORE the

@@ -181,6 +181,12 @@ int main() {
     EXPECT_REJECT(ynet_bce_logits_fwd_grad(cfp, nullptr, 4, 1.f, fp, fp, fp, nullptr));
     EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 33, 4, 1.f, 0, nullptr));   // cout 33
     EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 6, 1.f, 0, nullptr));   // HW % 4
+    EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, nullptr, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 4, 1.f, 0, nullptr));                            // no target
+    EXPECT_REJECT(ynet_pred_bce_blob(cfp, 4096, cfp, nullptr, nullptr, cfp, 31, 400, 64, 64, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 1.f, 0, nullptr));    // no positions
+    EXPECT_REJECT(ynet_pred_bce_blob(cfp, 4096, cfp, nullptr, cfp, nullptr, 31, 400, 64, 64, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 1.f, 0, nullptr));    // no blob table
+    EXPECT_REJECT(ynet_pred_bce_blob(cfp, 4096, cfp, nullptr, cfp, cfp, 31, 16, 64, 64, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 1.f, 0, nullptr));         // template smaller than the window
+    EXPECT_REJECT(ynet_pred_bce_blob(cfp, 4096, cfp, nullptr, cfp, cfp, 31, 400, 64, 62, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 1.f, 0, nullptr));        // W % 4
+    EXPECT_REJECT(ynet_pred_bce_blob(cfp, 4096, cfp, nullptr, cfp, cfp, 0, 400, 64, 64, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 1.f, 0, nullptr));         // empty blob
     EXPECT_REJECT(ynet_softargmax2d(nullptr, fp, 1, 1, 4, 2, 2, nullptr));
     EXPECT_REJECT(ynet_pred_softargmax(nullptr, 0, nullptr, nullptr, nullptr, nullptr, 1, 32, 12, 16, 32, nullptr));
     EXPECT_REJECT(ynet_pred_softargmax(fp, 32 * 17 * 23, fp, nullptr, fp, fp, 1, 32, 12, 17, 23, nullptr));      /* H*W % 128 != 0 */
