@@ -172,14 +172,14 @@ class ConvTimer:
                              (B, H, W, cin, cout, 3, False)))
         self.ops.conv2d_winograd_raw = timed_wino
 
-        def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None):
+        def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None, pool_code=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig_cat(srcs, u, bias, dst, B, H, W, relu, addend=addend, pool=pool, wbits_out=wbits_out)
+            self.orig_cat(srcs, u, bias, dst, B, H, W, relu, addend=addend, pool=pool, wbits_out=wbits_out, pool_code=pool_code)
             e1.record()
             cin = sum(s_[1] for s_ in srcs)
-            epi = 2 if addend is not None else (3 if pool is not None else 0)      # (epilogue: 0 plain, 2 additive term, 3 pooled copy; + 4: 1-bit mask written = 4 / 5)
-            name = f"conv_wino_cat_kernel<2, {epi + 4 if wbits_out is not None and epi != 3 else epi}>"
+            epi = 2 if addend is not None else (3 if pool is not None else 0)      # (epilogue: 0 plain, 2 additive term, 3 pooled copy; + 4: 1-bit mask written = 4 / 5; 6: pooled copy + code bytes)
+            name = f"conv_wino_cat_kernel<2, {6 if (epi == 3 and pool_code is not None) else (epi + 4 if wbits_out is not None and epi != 3 else epi)}>"
             self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * 32 * 9, 4.0 * B * H * W * (cin + 32 * (2 if addend is not None else (1.25 if pool is not None else 1))),
                              (B, H, W, cin, 32, 3, False)))
         self.ops.conv2d_winograd_cat_raw = timed_cat
@@ -207,12 +207,11 @@ class ConvTimer:
                              (B, H, W, cin, cout, 3, False)))
         self.ops.upsample2x_conv2d_raw = timed_up
 
-        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
-                  relu_wbits=None):
+        def timed(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, **more):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             took = self.orig(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits,
-                             wino=wino, wbits_out=wbits_out, relu_wbits=relu_wbits)
+                             wino=wino, **more)
             e1.record()
             cin = sum(s[1] for s in srcs)
             dl = list(dsts)

@@ -151,6 +151,12 @@ int ynet_conv2d_winograd_cat_add(const float* const* src, const int* src_c, cons
  *                               conv + ReLU in front of MaxPool2d(2, 2), models/ynet.py:196-213): a lane of the Winograd tiling holds exactly the block it pools. */
 int ynet_conv2d_winograd_cat_pool(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                                   long long dst_bs, float* pooled, long long pooled_bs, int cout, int B, int H, int W, int relu, void* stream);
+/*   ynet_conv2d_winograd_cat_pool_code  (round 5) the same launch for a 32-channel ReLU output, which also leaves what the pool's BACKWARD needs of every 2 x 2 block in one
+ *                               byte, code [B][32][H/2][W/2]: bits 0..1 the arg-max (first maximum in window scan order, a NaN wins: ynet_maxpool2_bwd's rule), bits 2..5
+ *                               "element is positive" in scan order (the ReLU backward ynet_maxpool2_bwd_add applies with relu_mask) -- ynet_maxpool2_bwd_add_code then
+ *                               routes the pooled gradient without reading the full-resolution activation again. */
+int ynet_conv2d_winograd_cat_pool_code(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                                       long long dst_bs, float* pooled, long long pooled_bs, unsigned char* code, int B, int H, int W, void* stream);
 /*   The Winograd-native 1-bit ReLU mask (round 5), the counterpart of ynet_conv2d_relu_bits / ynet_conv2d_dgrad_relu_bits for conv -> ReLU -> conv chains whose
  *   launches are Winograd ones with 32 channels in between: the FORWARD launch of the first convolution also writes one bit per output element (y > 0) -- one 32-bit
  *   word per lane and unit of the tiling both launches share, ynet_winograd_relu_bits_words(B, H, W) words --, and the data gradient of the second convolution
@@ -261,6 +267,9 @@ int ynet_maxpool2_bwd(const float* x, const float* dy, float* dx, long long N, i
  * would apply by reading x again is applied here, where x is in registers anyway. */
 int ynet_maxpool2_bwd_add(const float* x, const float* dy, const float* add0, const float* add1, float* dx, long long N,
                           int H, int W, int relu_mask, void* stream);
+/* The same with the activation replaced by the code plane of ynet_conv2d_winograd_cat_pool_code ([N][H/2][W/2] bytes): bit-identical dx, x is not read. */
+int ynet_maxpool2_bwd_add_code(const unsigned char* code, const float* dy, const float* add0, const float* add1, float* dx, long long N, int H, int W,
+                               int relu_mask, void* stream);
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) (models/ynet.py:463);
  * H, W are the LOW-resolution sizes in both directions. */
 int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream);

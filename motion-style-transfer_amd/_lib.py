@@ -46,6 +46,7 @@ SIGNATURES = {
     "ynet_conv2d_winograd_cat": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_cat_add": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp]),
     "ynet_conv2d_winograd_cat_pool": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_conv2d_winograd_cat_pool_code": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_fp, c_ll, c_fp, c_i, c_i, c_i, c_fp]),
     "ynet_winograd_relu_bits_words": (c_ll, [c_i, c_i, c_i]),
     "ynet_conv2d_winograd_relu_bits": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "ynet_conv2d_winograd_cat_relu_bits": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp, c_fp]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "ynet_maxpool2_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_maxpool2_bwd": (c_i, [c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_maxpool2_bwd_add": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_fp]),
+    "ynet_maxpool2_bwd_add_code": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_fp]),
     "ynet_upsample2x_fwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_upsample2x_bwd": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_fp]),
     "ynet_upsample2x_bwd_relu": (c_i, [c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_fp]),

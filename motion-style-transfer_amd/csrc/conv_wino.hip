@@ -78,7 +78,7 @@ __device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, 
 template <int NCB, int EPI, int BITS = 0>
 __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2 (&bias2)[NCB][2], float floor_v, __amdgpu_buffer_rsrc_t ry,
                                               __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW, unsigned stp = 0,
-                                              unsigned* wbits = nullptr) {
+                                              unsigned* wbits = nullptr, unsigned char* pcode = nullptr) {
     unsigned word = 0u;
     if constexpr (BITS == 2) word = *wbits;
 #pragma unroll
@@ -138,6 +138,15 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                     float pm = fmaxf(fmaxf(row0[0], row0[1]), fmaxf(row1[0], row1[1]));
                     if (__builtin_isunordered(row0[0], row0[1]) || __builtin_isunordered(row1[0], row1[1])) pm = __builtin_nanf("");
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pm), rm, stp, sm_t + (unsigned)((cb * 16 + 2 * h + k) * (HW >> 2) * 4), 0);
+                    if constexpr (BITS == 3) {      // what the pool's backward needs of this block, in one byte: bits 0..1 the arg-max (first maximum in scan
+                        float mx = row0[0];         // order, a NaN wins: maxpool2_bwd_add_kernel's rule), bits 2..5 "element is positive" (the ReLU backward)
+                        unsigned arg = 0u;
+                        if (row0[1] > mx || row0[1] != row0[1]) { mx = row0[1]; arg = 1u; }
+                        if (row1[0] > mx || row1[0] != row1[0]) { mx = row1[0]; arg = 2u; }
+                        if (row1[1] > mx || row1[1] != row1[1]) { mx = row1[1]; arg = 3u; }
+                        const unsigned code = arg | (row0[0] > 0.f ? 4u : 0u) | (row0[1] > 0.f ? 8u : 0u) | (row1[0] > 0.f ? 16u : 0u) | (row1[1] > 0.f ? 32u : 0u);
+                        pcode[(cb * 16 + 2 * h + k) * (HW >> 2)] = (unsigned char)code;
+                    }
                 }
             }
         }
@@ -376,13 +385,14 @@ struct WinoCatArgs {
     int addend_bmod;
     float* pool;               // EPI 3: [B] x (pool_bs floats), cout planes of (H / 2) x (W / 2): the 2 x 2 max-pooled copy of y
     long long pool_bs;
+    unsigned char* pcode;      // EPI_ 6: [B][cout][H / 2][W / 2] bytes: arg-max and ReLU bits of every pooled block (see wino_epilogue)
     unsigned* wbits;           // EPI 4 / 5 (= 0 / 2 + the Winograd-native 1-bit mask of the output written, see wino_epilogue)
 };
 
 template <int NCB, int EPI_>
 __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const WinoCatArgs a) {
-    constexpr int EPI = EPI_ == 4 ? 0 : (EPI_ == 5 ? 2 : EPI_);
-    constexpr int BITS = EPI_ >= 4 ? 1 : 0;
+    constexpr int EPI = EPI_ == 4 ? 0 : (EPI_ == 5 ? 2 : (EPI_ == 6 ? 3 : EPI_));
+    constexpr int BITS = EPI_ == 6 ? 3 : (EPI_ >= 4 ? 1 : 0);
     constexpr bool ADD = EPI == 2;
     extern __shared__ f32x4 smem[];
     constexpr int WQ = 4 * NCB * 64;      // units of one chunk's filters: [4 quads of (xi,nu)][NCB][64 lanes]
@@ -517,8 +527,9 @@ __global__ __launch_bounds__(WN_THREADS, 1) void conv_wino_cat_kernel(const Wino
             const __amdgpu_buffer_rsrc_t ra =
                 EPI == 3 ? __builtin_amdgcn_make_buffer_rsrc(a.pool + (long long)b * a.pool_bs, 0, y_img >> 2, 0x00020000)
                          : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? a.addend + (long long)ab * a.addend_bs : a.y), 0, y_img, 0x00020000);
-            unsigned* wb = BITS ? a.wbits + (((long long)b * (H >> 1) + (ty * (WN_TH / 2) + (cur & 7))) * tiles_x + tx) * 64 + lane : nullptr;
-            wino_epilogue<NCB, EPI, BITS>(acc, bias2, floor_v, ry, ra, st0, st1, so_t, sa_t, HW, stp, wb);
+            unsigned* wb = BITS == 1 ? a.wbits + (((long long)b * (H >> 1) + (ty * (WN_TH / 2) + (cur & 7))) * tiles_x + tx) * 64 + lane : nullptr;
+            unsigned char* pc = BITS == 3 ? a.pcode + ((long long)b * (16 * NCB) * (HW >> 2) + ((stp + sa_t) >> 2)) : nullptr;      // (the pooled copy's element index)
+            wino_epilogue<NCB, EPI, BITS>(acc, bias2, floor_v, ry, ra, st0, st1, so_t, sa_t, HW, stp, wb, pc);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -1245,7 +1256,7 @@ int ynet_winograd_filter_cat(const float* wp, float* u, const int* src_c, int ns
 
 static int wino_cat_launch(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
                            long long dst_bs, int cout, int B, int H, int W, int relu, const float* addend, long long addend_bs, int addend_bmod, float* pool,
-                           long long pool_bs, void* stream, const char* what, unsigned* wbits = nullptr) {
+                           long long pool_bs, void* stream, const char* what, unsigned* wbits = nullptr, unsigned char* pcode = nullptr) {
     YNET_REQUIRE(src && src_c && src_bs && u && dst, "%s: null pointer", what);
     YNET_REQUIRE(wino_cat_ok(B, H, W, src_c, nsrc, cout, 3), "%s: shape B=%d %dx%d -> %d with %d sources is not served (ask ynet_conv2d_winograd_cat_supported)", what,
                  B, H, W, cout, nsrc);
@@ -1269,9 +1280,11 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
                      "%s: the pooled copy must have a batch stride not smaller than its image, and excludes an additive term", what);
     if (wbits != nullptr)
         YNET_REQUIRE(pool == nullptr && (reinterpret_cast<uintptr_t>(wbits) & 3) == 0, "%s: the 1-bit mask excludes the pooled copy and must be 4-byte aligned", what);
+    if (pcode != nullptr) YNET_REQUIRE(pool != nullptr && cout == 32 && relu, "%s: the arg-max / ReLU bytes come with the pooled copy of a 32-channel ReLU output", what);
     a.wbits = wbits;
     a.pool = pool;
     a.pool_bs = pool_bs;
+    a.pcode = pcode;
     a.nsrc = nsrc;
     a.nchunks = wino_cat_padded(src_c, nsrc) / 4;
     a.u = reinterpret_cast<const f32x4*>(u);
@@ -1293,6 +1306,7 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_cat_kernel<2, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 8192 + 8 * WC_RING_BYTES + 16);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1304,6 +1318,7 @@ static int wino_cat_launch(const float* const* src, const int* src_c, const long
     if (wbits != nullptr && addend != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 5>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     else if (wbits != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 4>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     else if (addend != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 2>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
+    else if (pcode != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 6>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     else if (pool != nullptr) hipLaunchKernelGGL((conv_wino_cat_kernel<2, 3>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_wino_cat_kernel<2, 0>), dim3(grid), dim3(WN_THREADS), lds, (hipStream_t)stream, a);
     return ynet_check_launch(what);
@@ -1325,6 +1340,13 @@ int ynet_conv2d_winograd_cat_pool(const float* const* src, const int* src_c, con
                                   long long dst_bs, float* pooled, long long pooled_bs, int cout, int B, int H, int W, int relu, void* stream) {
     YNET_REQUIRE(pooled != nullptr, "conv2d_winograd_cat_pool: the pooled output is null");
     return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, cout, B, H, W, relu, nullptr, 0, 0, pooled, pooled_bs, stream, "conv2d_winograd_cat_pool");
+}
+
+int ynet_conv2d_winograd_cat_pool_code(const float* const* src, const int* src_c, const long long* src_bs, int nsrc, const float* u, const float* bias, float* dst,
+                                       long long dst_bs, float* pooled, long long pooled_bs, unsigned char* code, int B, int H, int W, void* stream) {
+    YNET_REQUIRE(pooled != nullptr && code != nullptr, "conv2d_winograd_cat_pool_code: the pooled output or its code plane is null");
+    return wino_cat_launch(src, src_c, src_bs, nsrc, u, bias, dst, dst_bs, 32, B, H, W, 1, nullptr, 0, 0, pooled, pooled_bs, stream, "conv2d_winograd_cat_pool_code",
+                           nullptr, code);
 }
 
 static int wino_launch_any(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, const float* emask,

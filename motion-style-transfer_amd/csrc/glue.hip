@@ -50,7 +50,9 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
 // RELU: x is the post-ReLU output of the conv that receives dx as ITS output gradient; that conv's backward would zero
 // dx where x <= 0 (models/ynet.py: nn.ReLU after every encoder conv) by reading x once more next to dx -- x is in this
 // kernel's registers already, so the mask is applied here and the conv runs its unmasked dgrad / wgrad kernels.
-template <bool RELU>
+// CODE: x is not read -- the conv that produced it left one byte per 2 x 2 block (ynet_conv2d_winograd_cat_pool_code: bits 0..1 the arg-max by
+// the rule above, bits 2..5 "element is positive" in window scan order), a quarter of a float per element instead of a float.
+template <bool RELU, bool CODE = false>
 __global__ void maxpool2_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                         const float* __restrict__ add0, const float* __restrict__ add1,
                                         float* __restrict__ dx, long long N, int H, int W) {
@@ -61,12 +63,21 @@ __global__ void maxpool2_bwd_add_kernel(const float* __restrict__ x, const float
         const int yo = ip / Wo, xo = ip - yo * Wo;
         const long long i = n * per_plane + ip;
         const long long base = (n * H + 2 * yo) * W + 2 * xo;
-        const f2 t = *reinterpret_cast<const f2*>(x + base), b = *reinterpret_cast<const f2*>(x + base + W);
-        float m = t[0];
+        f2 t, b;
         int arg = 0;
-        if (t[1] > m || t[1] != t[1]) { m = t[1]; arg = 1; }
-        if (b[0] > m || b[0] != b[0]) { m = b[0]; arg = 2; }
-        if (b[1] > m || b[1] != b[1]) { m = b[1]; arg = 3; }
+        if (CODE) {
+            const unsigned code = reinterpret_cast<const unsigned char*>(x)[i];
+            arg = (int)(code & 3u);
+            t = f2{(code & 4u) ? 1.f : 0.f, (code & 8u) ? 1.f : 0.f};       // (only their sign is looked at below)
+            b = f2{(code & 16u) ? 1.f : 0.f, (code & 32u) ? 1.f : 0.f};
+        } else {
+            t = *reinterpret_cast<const f2*>(x + base);
+            b = *reinterpret_cast<const f2*>(x + base + W);
+            float m = t[0];
+            if (t[1] > m || t[1] != t[1]) { m = t[1]; arg = 1; }
+            if (b[0] > m || b[0] != b[0]) { m = b[0]; arg = 2; }
+            if (b[1] > m || b[1] != b[1]) { m = b[1]; arg = 3; }
+        }
         const float g = dy[i];
         f2 o0 = {arg == 0 ? g : 0.f, arg == 1 ? g : 0.f}, o1 = {arg == 2 ? g : 0.f, arg == 3 ? g : 0.f};
         if (add0) {
@@ -1310,6 +1321,20 @@ int ynet_maxpool2_bwd_add(const float* x, const float* dy, const float* add0, co
     else
         hipLaunchKernelGGL(maxpool2_bwd_add_kernel<false>, plane_grid(N, total / N), dim3(256), 0, (hipStream_t)stream, x, dy, add0, add1, dx, N, H, W);
     return ynet_check_launch("maxpool2_bwd_add");
+}
+
+int ynet_maxpool2_bwd_add_code(const unsigned char* code, const float* dy, const float* add0, const float* add1, float* dx, long long N, int H, int W,
+                               int relu_mask, void* stream) {
+    YNET_REQUIRE(code && dy && dx && N > 0 && H >= 2 && W >= 2, "maxpool2_bwd_add_code: bad arguments");
+    YNET_REQUIRE((H & 1) == 0 && (W & 1) == 0, "maxpool2_bwd_add_code: H and W must be even (got %dx%d)", H, W);
+    YNET_REQUIRE((((uintptr_t)dx | (uintptr_t)add0 | (uintptr_t)add1) & 7) == 0, "maxpool2_bwd_add_code: 8-byte aligned planes required");
+    const long long total = N * (H / 2) * (W / 2);
+    const float* c = reinterpret_cast<const float*>(code);
+    if (relu_mask)
+        hipLaunchKernelGGL((maxpool2_bwd_add_kernel<true, true>), plane_grid(N, total / N), dim3(256), 0, (hipStream_t)stream, c, dy, add0, add1, dx, N, H, W);
+    else
+        hipLaunchKernelGGL((maxpool2_bwd_add_kernel<false, true>), plane_grid(N, total / N), dim3(256), 0, (hipStream_t)stream, c, dy, add0, add1, dx, N, H, W);
+    return ynet_check_launch("maxpool2_bwd_add_code");
 }
 
 int ynet_upsample2x_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {

@@ -396,7 +396,7 @@ def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=Non
                                      cin, cout, B, H, W, 1 if relu else 0, _stream()), lib)
 
 
-def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None):
+def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None, pool_code=None):
     """srcs: [(ptr, channels, batch_stride)] (at most three, 56 padded channels); dst: (ptr, batch_stride), 32 channels; u: the filter in
     ynet_winograd_filter_cat's layout for these sources; addend: (ptr, image_stride, modulus) of a term added in front of the ReLU;
     pool: (ptr, batch_stride) of the 2 x 2 max-pooled copy of the output, written by the same launch; wbits_out: receives the 1-bit mask of
@@ -410,6 +410,12 @@ def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool
         L.check(lib.ynet_conv2d_winograd_cat_relu_bits(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], B, H, W, addend[0] if addend else None,
                                                        addend[1] if addend else 0, addend[2] if addend else 0, wbits_out.data_ptr(), _stream()), lib)
         return
+    if pool is not None and pool_code is not None:      # (+ one byte per pooled block for the pool's backward: ynet_maxpool2_bwd_add_code)
+        if not relu:
+            raise ValueError("conv2d_winograd_cat_raw: pool_code is for a ReLU launch")
+        L.check(lib.ynet_conv2d_winograd_cat_pool_code(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], pool[0], pool[1], pool_code.data_ptr(), B, H, W,
+                                                       _stream()), lib)
+        return
     if pool is not None:
         L.check(lib.ynet_conv2d_winograd_cat_pool(sp, sc, sb, len(srcs), u.data_ptr(), b, dst[0], dst[1], pool[0], pool[1], 32, B, H, W,
                                                   1 if relu else 0, _stream()), lib)
@@ -420,6 +426,7 @@ def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool
                                                  addend[0], addend[1], addend[2], _stream()), lib)
 
 
+_pool_code_allowed = _os.environ.get("YNET_POOL_CODE", "1") != "0"      # YNET_POOL_CODE=0: the max-pool's backward re-reads the full-resolution activation (no arg-max / ReLU byte per block)
 _wino_relu_bits_allowed = _os.environ.get("YNET_WINOGRAD_RELU_BITS", "1") != "0"      # YNET_WINOGRAD_RELU_BITS=0: the Winograd data gradients fetch the float activation (no 1-bit mask in their tiling)
 _wino16_allowed = _os.environ.get("YNET_WINOGRAD16", "1") != "0"     # YNET_WINOGRAD16=0: no conv_wino16_kernel launches (round 5's slice form)
 # YNET_WINOGRAD16_SLICE16=1: 16-output-channel launches (32 -> 16 at 256^2) on the slice form too -- measured SLOWER there than
@@ -477,7 +484,7 @@ def _pad4(c):
 
 
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
-               relu_wbits=None):
+               relu_wbits=None, pool_code=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None.  pooled: (ptr,
     batch_stride) of a second output, the 2 x 2 max-pooled copy of the single destination (ynet_conv2d_pool), or None.
@@ -489,7 +496,9 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
     conv_wino_kernel) or "winograd_cat:2,<epilogue>" then, None otherwise.
     wbits_out / relu_wbits: the Winograd-native 1-bit ReLU mask (int32 tensors of ynet_winograd_relu_bits_words words) -- wbits_out is
     WRITTEN only if the launch taken is a 32-output Winograd one (the returned tag then ends in "|wbits": the caller keeps the tensor
-    only in that case); relu_wbits gates a 32-channel data gradient in place of relu_of's activation fetch."""
+    only in that case); relu_wbits gates a 32-channel data gradient in place of relu_of's activation fetch.  pool_code (with pooled): a uint8
+    tensor [B, 32, H/2, W/2] that receives arg-max + ReLU bits of every pooled block when the launch taken is the Winograd one for
+    concatenated sources (tag "winograd_cat:2,6|code": the caller keeps the tensor only then)."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
     if wino is not None and not torch.is_grad_enabled() and (
@@ -523,9 +532,10 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
                     L.check(lib.ynet_winograd_filter_cat(wp.data_ptr(), u.data_ptr(), cs, len(srcs), 32, 0, 32, _stream()), lib)
                     ent = cache[key] = _wino_made((wp, u, tuple(cs)))
                 _wino_ready(ent)
-                conv2d_winograd_cat_raw(srcs, ent[1], bias, (dsts[0][0], dsts[0][2]), B, H, W, relu, pool=pooled)
+                code = pool_code if (relu and _pool_code_allowed) else None
+                conv2d_winograd_cat_raw(srcs, ent[1], bias, (dsts[0][0], dsts[0][2]), B, H, W, relu, pool=pooled, pool_code=code)
                 wino_stats["launches"] += 1
-                return "winograd_cat:2,3"
+                return "winograd_cat:2,6|code" if code is not None else "winograd_cat:2,3"
         if (wino is not None and K == 3 and dsts[0][0] % 8 == 0 and dsts[0][2] % 2 == 0 and all(len(s_) == 3 and s_[0] % 16 == 0 and s_[2] % 4 == 0 for s_ in srcs)
                 and _wino16_supported([s_[1] for s_ in srcs], dsts[0][1], B, H, W)):
             # (64 output channels: the encoder's last 64^2 layer in front of its max-pool)
@@ -1037,15 +1047,22 @@ class _Conv2dFn(torch.autograd.Function):
             n_words = _lib().ynet_winograd_relu_bits_words(B, H, W)
             if n_words > 0:
                 wbits = torch.empty(n_words, device=weight.device, dtype=torch.int32)
+        # (a pooled 32-channel ReLU output under autograd: the Winograd launch also leaves the pool's backward one byte per block -- kept if that launch was taken)
+        pcode = None
+        if pooled is not None and relu and cout == 32 and _pool_code_allowed and any(ctx.needs_input_grad) and meta.get("wino"):
+            pcode = torch.empty((B, cout, H // 2, W // 2), device=weight.device, dtype=torch.uint8)
         took = conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu,
                           pooled=None if pooled is None else (pooled.data_ptr(), cout * (H // 2) * (W // 2)),
-                          bits_out=None if bits is None else bits.data_ptr(), wino=(cache, "fwd") if meta.get("wino") else None, wbits_out=wbits)
+                          bits_out=None if bits is None else bits.data_ptr(), wino=(cache, "fwd") if meta.get("wino") else None, wbits_out=wbits,
+                          pool_code=pcode)
         if not (isinstance(took, str) and took.endswith("|wbits")):
             wbits = None
+        if not (isinstance(took, str) and took.endswith("|code")):
+            pcode = None
         if pooled is not None:
             for k_ in [k_ for k_, e_ in _pooled_outputs.items() if e_[0]() is None]:      # (a pool that never followed)
                 del _pooled_outputs[k_]
-            _pooled_outputs[y.data_ptr()] = (weakref.ref(y), tuple(y.shape), pooled)
+            _pooled_outputs[y.data_ptr()] = (weakref.ref(y), tuple(y.shape), pooled, pcode)
         ctx.meta = meta
         ctx.n_src = len(srcs)
         ctx.has_bias = bias is not None
@@ -1262,6 +1279,7 @@ def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, s
 # conv outputs whose 2 x 2 max-pooled copy was written by the conv's own epilogue (ops.conv2d(..., pool=True)):
 # address of y -> (weak reference to y, its shape, the pooled tensor); consumed by the max_pool2 call that follows
 _pooled_outputs = {}
+pool_code_stats = {"launches": 0}
 _pool_epilogue_allowed = _os.environ.get("YNET_POOL_EPILOGUE", "1") != "0"
 
 
@@ -1272,8 +1290,10 @@ class _MaxPool2Fn(torch.autograd.Function):
         x = x.contiguous()
         B, C, H, W = x.shape
         e = _pooled_outputs.pop(x.data_ptr(), None) if _pooled_outputs else None
+        ctx.code = None
         if e is not None and e[0]() is x and e[1] == tuple(x.shape) and x._version == 0:
             y = e[2]                 # written by the producing conv's epilogue: no pass over x here
+            ctx.code = e[3] if len(e) > 3 else None      # (... and, from a Winograd launch, arg-max + ReLU bits per block for backward)
         else:
             y = torch.empty((B, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
             lib = _lib()
@@ -1306,9 +1326,16 @@ class _MaxPool2Fn(torch.autograd.Function):
                 t.record_stream(cur)
             a0 = adds[0][0] if adds else None
             a1 = adds[1][0] if len(adds) > 1 else None
-            L.check(lib.ynet_maxpool2_bwd_add(x.data_ptr(), dy.contiguous().data_ptr(), a0.data_ptr() if a0 is not None else None,
-                                              a1.data_ptr() if a1 is not None else None, dx.data_ptr(), B * C, H, W,
-                                              1 if pm else 0, _stream()), lib)
+            code, ctx.code = ctx.code, None
+            if code is not None and _pool_code_allowed:      # x (saved: autograd has checked that nobody wrote into it) is not read again
+                pool_code_stats["launches"] += 1
+                L.check(lib.ynet_maxpool2_bwd_add_code(code.data_ptr(), dy.contiguous().data_ptr(), a0.data_ptr() if a0 is not None else None,
+                                                       a1.data_ptr() if a1 is not None else None, dx.data_ptr(), B * C, H, W,
+                                                       1 if pm else 0, _stream()), lib)
+            else:
+                L.check(lib.ynet_maxpool2_bwd_add(x.data_ptr(), dy.contiguous().data_ptr(), a0.data_ptr() if a0 is not None else None,
+                                                  a1.data_ptr() if a1 is not None else None, dx.data_ptr(), B * C, H, W,
+                                                  1 if pm else 0, _stream()), lib)
             if pm:
                 _premasked[dx.data_ptr()] = (x.data_ptr(), dx._version, tuple(dx.shape))
         else:

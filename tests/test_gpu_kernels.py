@@ -550,6 +550,70 @@ def test_conv2d_pool_epilogue(dev, B, H, W, cs, cout):
         close(a.grad, c.grad, rtol=1e-4, scale_rel=2e-6, msg="dx through the pooled epilogue")
 
 
+@pytest.mark.parametrize("B,H,W,cs,relu_mask,adds", [(8, 256, 256, [6, 8], True, 2), (16, 128, 128, [32], True, 1), (10, 96, 160, [32, 16, 1], False, 2), (8, 128, 256, [32], True, 0)], ids=str)
+def test_winograd_pool_epilogue_leaves_the_backward_its_arg_max_and_relu_bits(dev, B, H, W, cs, relu_mask, adds):
+    """Round 5: ynet_conv2d_winograd_cat_pool_code -- the Winograd launch in front of a MaxPool2d(2, 2) writes, besides the output and its pooled copy, one
+    byte per 2 x 2 block: bits 0..1 the arg-max by ynet_maxpool2_bwd's rule (first maximum in scan order, a NaN wins), bits 2..5 `element > 0`.
+    ynet_maxpool2_bwd_add_code routes the pooled gradient (+ the folded skip gradients, + the ReLU backward) from that byte alone: dx bit-identical to
+    ynet_maxpool2_bwd_add reading the full-resolution activation; output and pooled copy bit-identical to the launch without the code plane."""
+    ops, L = pkg("ops"), pkg("_lib")
+    lib = ops._lib()
+    cin = sum(cs)
+    xs = [rnd(B, c, H, W, seed=i + 1).to(dev) for i, c in enumerate(cs)]
+    xs[0][0, 0, 5, 7] = float("nan")                       # (a NaN spreads over a 3 x 3 neighbourhood of every output channel of image 0)
+    w, b = rnd(32, cin, 3, 3, seed=10, scale=1.0 / (cin * 9) ** 0.5).to(dev), rnd(32, seed=11, scale=0.1).to(dev)
+    wp = ops.pack_weight(w, 0)
+    descs = [(x.data_ptr(), x.shape[1], x.shape[1] * H * W) for x in xs]
+    y0, y1 = torch.empty(B, 32, H, W, device=dev), torch.empty(B, 32, H, W, device=dev)
+    p0, p1 = torch.empty(B, 32, H // 2, W // 2, device=dev), torch.empty(B, 32, H // 2, W // 2, device=dev)
+    code = torch.full((B, 32, H // 2, W // 2), 255, device=dev, dtype=torch.uint8)
+    pst = 32 * (H // 2) * (W // 2)
+    t0 = ops.conv2d_raw(descs, None, wp, b, [(y0.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True, pooled=(p0.data_ptr(), pst), wino=({}, "fwd"))
+    t1 = ops.conv2d_raw(descs, None, wp, b, [(y1.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True, pooled=(p1.data_ptr(), pst), wino=({}, "fwd"), pool_code=code)
+    assert t0 == "winograd_cat:2,3" and t1 == "winograd_cat:2,6|code", (t0, t1)
+    assert torch.equal(torch.nan_to_num(y0, nan=-1.0), torch.nan_to_num(y1, nan=-1.0)) and torch.equal(torch.nan_to_num(p0, nan=-1.0), torch.nan_to_num(p1, nan=-1.0))
+    assert bool(torch.isnan(y1).any())
+    # the byte, recomputed from the output: window scan order (0, 0), (0, 1), (1, 0), (1, 1)
+    blk = y1.view(B, 32, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, 32, H // 2, W // 2, 4)
+    m, arg = blk[..., 0].clone(), torch.zeros_like(blk[..., 0], dtype=torch.int64)
+    for e in (1, 2, 3):
+        v = blk[..., e]
+        take = (v > m) | torch.isnan(v)
+        m, arg = torch.where(take, v, m), torch.where(take, torch.full_like(arg, e), arg)
+    want = arg + sum(((blk[..., e] > 0).to(torch.int64) << (2 + e)) for e in range(4))
+    assert torch.equal(code.to(torch.int64), want)
+    assert int((code & 3 != 0).sum()) > 0 and int((code >> 2 == 0).sum()) > 0      # (every arg-max position occurs, and all-negative blocks do)
+    # backward: from the byte against from the activation
+    dy = rnd(B, 32, H // 2, W // 2, seed=20).to(dev)
+    a = [rnd(B, 32, H, W, seed=21 + i).to(dev) for i in range(adds)]
+    ap = [t.data_ptr() for t in a] + [None, None]
+    dx0, dx1 = torch.empty(B, 32, H, W, device=dev), torch.full((B, 32, H, W), float("nan"), device=dev)
+    L.check(lib.ynet_maxpool2_bwd_add(y1.data_ptr(), dy.data_ptr(), ap[0], ap[1], dx0.data_ptr(), B * 32, H, W, 1 if relu_mask else 0, ops._stream()), lib)
+    L.check(lib.ynet_maxpool2_bwd_add_code(code.data_ptr(), dy.data_ptr(), ap[0], ap[1], dx1.data_ptr(), B * 32, H, W, 1 if relu_mask else 0, ops._stream()), lib)
+    assert torch.equal(dx0, dx1)
+    assert lib.ynet_maxpool2_bwd_add_code(None, dy.data_ptr(), None, None, dx1.data_ptr(), B * 32, H, W, 0, ops._stream()) != 0
+    assert lib.ynet_maxpool2_bwd_add_code(code.data_ptr(), dy.data_ptr(), None, None, dx1.data_ptr(), B * 32, H + 1, W, 0, ops._stream()) != 0
+    # through autograd: conv2d(pool=True) -> max_pool2 -> backward uses the byte, and gives what the path without it gives
+    grads = []
+    for on in (True, False):
+        old, n0 = ops._pool_code_allowed, ops.pool_code_stats["launches"]
+        ops._pool_code_allowed = on
+        try:
+            xd = [x.detach().clone().nan_to_num(0.0).requires_grad_(True) for x in xs]
+            wd = w.clone().requires_grad_(True)
+            with ops.fold_skip_gradients():
+                yd = ops.conv2d(ops.lazy_cat(xd) if len(xd) > 1 else xd[0], wd, b, True, {}, pool=True)
+                ops.max_pool2(yd).square().sum().backward()
+        finally:
+            ops._pool_code_allowed = old
+        grads.append(([t.grad for t in xd], wd.grad, ops.pool_code_stats["launches"] - n0))
+    if grads[0][2] > 0:      # (the Winograd launch served the layer: the byte was used)
+        assert grads[1][2] == 0
+    for g0, g1 in zip(grads[0][0], grads[1][0]):
+        assert torch.equal(g0, g1)
+    assert torch.equal(grads[0][1], grads[1][1])
+
+
 def test_conv2d_pool_rejects_shapes_without_the_epilogue(dev):
     ops = pkg("ops")
     lib = ops._lib()
