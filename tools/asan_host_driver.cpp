@@ -116,6 +116,9 @@ int main() {
         EXPECT_REJECT(ynet_conv2d_winograd_cat_relu_bits(s3, cat2, bs3, 2, cfp, nullptr, fp, 32 * 65536, 32, 256, 256, nullptr, 0, 0, (unsigned*)dummy, nullptr));     // 64 inputs: too many filters for LDS
         EXPECT_REJECT(ynet_conv2d_winograd_cat_relu_bits(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, 32, 256, 256, cfp, 32 * 65536, -1, (unsigned*)dummy, nullptr)); // negative modulus
         EXPECT_REJECT(ynet_conv2d_winograd_cat_pool(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, nullptr, 32 * 16384, 32, 32, 256, 256, 1, nullptr));   // no pooled output
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_pool_code(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, fp, 32 * 16384, nullptr, 32, 256, 256, nullptr));   // no code plane
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_pool_code(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, nullptr, 32 * 16384, (unsigned char*)dummy, 32, 256, 256, nullptr));   // no pooled output
+        EXPECT_REJECT(ynet_conv2d_winograd_cat_pool_code(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, fp, 16 * 16384, (unsigned char*)dummy, 32, 256, 256, nullptr));     // pooled stride too small
         EXPECT_REJECT(ynet_conv2d_winograd_cat_pool(s3, cat3, bs3, 3, cfp, nullptr, fp, 32 * 65536, fp, 16 * 16384, 32, 32, 256, 256, 1, nullptr));        // pooled stride too small
     }
     {   // the slice form (round 5)
@@ -179,6 +182,8 @@ int main() {
     EXPECT_REJECT(ynet_avgpool_pyramid(cfp, dsts, 9, 1, 32, 32, nullptr));
     EXPECT_REJECT(ynet_bce_logits_fwd(cfp, cfp, 0, fp, fp, nullptr));
     EXPECT_REJECT(ynet_bce_logits_fwd_grad(cfp, nullptr, 4, 1.f, fp, fp, fp, nullptr));
+    EXPECT_REJECT(ynet_maxpool2_bwd_add_code(nullptr, cfp, nullptr, nullptr, fp, 4, 8, 8, 1, nullptr));                          // no code plane
+    EXPECT_REJECT(ynet_maxpool2_bwd_add_code((const unsigned char*)dummy, cfp, nullptr, nullptr, fp, 4, 7, 8, 1, nullptr));      // odd H
     EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 33, 4, 1.f, 0, nullptr));   // cout 33
     EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, cfp, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 6, 1.f, 0, nullptr));   // HW % 4
     EXPECT_REJECT(ynet_pred_bce(cfp, 4, cfp, nullptr, nullptr, fp, fp, nullptr, nullptr, fp, 1, 4, 12, 4, 1.f, 0, nullptr));                            // no target
