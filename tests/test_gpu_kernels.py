@@ -1662,7 +1662,7 @@ def test_fused_predictor_and_bce(dev, B, cin, cout, H, W, train_pred, scale, up)
     assert not yd.requires_grad
     # twice in a row on the same stream: the workspace ticket was reset by the kernel
     y2, l2 = ops.pred_bce(x.to(dev), w.to(dev), b.to(dev), t.to(dev), up, {})
-    assert torch.equal(y2, yd) and float(l2) == float(ld)
+    assert torch.equal(y2, yd) and float(l2.detach()) == float(ld.detach())
 
 
 @pytest.mark.parametrize("B,cout,H,W,S,device_xy", [(4, 12, 64, 96, 400, False), (3, 12, 128, 128, 300, True), (2, 30, 32, 64, 200, True), (2, 5, 64, 64, 160, False)])
