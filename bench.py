@@ -178,8 +178,12 @@ class ConvTimer:
             self.orig_cat(srcs, u, bias, dst, B, H, W, relu, addend=addend, pool=pool, wbits_out=wbits_out, pool_code=pool_code)
             e1.record()
             cin = sum(s_[1] for s_ in srcs)
-            epi = 2 if addend is not None else (3 if pool is not None else 0)      # (epilogue: 0 plain, 2 additive term, 3 pooled copy; + 4: 1-bit mask written = 4 / 5; 6: pooled copy + code bytes)
-            name = f"conv_wino_cat_kernel<2, {6 if (epi == 3 and pool_code is not None) else (epi + 4 if wbits_out is not None and epi != 3 else epi)}>"
+            epi = 2 if addend is not None else (3 if pool is not None else 0)      # (epilogue: 0 plain, 2 additive term, 3 pooled copy; 4 / 5: plain / additive term + 1-bit mask written; 6: pooled copy + code bytes)
+            if epi == 3 and pool_code is not None:
+                epi = 6
+            elif wbits_out is not None and epi != 3:
+                epi = 4 if epi == 0 else 5
+            name = f"conv_wino_cat_kernel<2, {epi}>"
             self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * 32 * 9, 4.0 * B * H * W * (cin + 32 * (2 if addend is not None else (1.25 if pool is not None else 1))),
                              (B, H, W, cin, 32, 3, False)))
         self.ops.conv2d_winograd_cat_raw = timed_cat

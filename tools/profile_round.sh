@@ -34,11 +34,13 @@ python3 "$R/tools/pmc_aggregate.py" "$TAG" --to "$OUT"      # per-kernel HBM byt
 $B --steps 3 --warmup 1 --no-cpu-baseline --no-c5 --no-legs --no-sustained --no-repeats --conv-layers "$OUT/${TAG}_conv_layers_C2.json" > /dev/null 2> "$OUT/conv_layers.err"
 python3 "$R/tools/conv_shapes.py" "$OUT/${TAG}_conv_layers_C2.json" /tmp/tr_serial "$OUT/${TAG}_conv_shapes_C2.json" --fetch "$OUT/fetch" --write "$OUT/write" > "$OUT/conv_shapes.txt" 2>&1
 echo "conv shapes rc=$?"; head -14 "$OUT/conv_shapes.txt"
+# (the bench line below reads its `roofline.traffic` from profiles/<tag>_conv_shapes_C2.json: this build's table, on the box's scratch copy of the repository too)
+[ -s "$OUT/${TAG}_conv_shapes_C2.json" ] && cp "$OUT/${TAG}_conv_shapes_C2.json" "$R/profiles/${TAG}_conv_shapes_C2.json"
 rm -rf "$OUT/fetch" "$OUT/write"
 unset YNET_STEP_GRAPH YNET_SERIAL_DECODERS
 cd "$R"
 $B --steps 30 --warmup 5 > "$OUT/${TAG}_bench_C2_line.json" 2> "$OUT/bench_C2.err"; echo "C2 rc=$?"
-$B --steps 30 --warmup 5 --batch 10 --no-cpu-baseline > "$OUT/${TAG}_bench_C2_batch10_line.json" 2> "$OUT/bench_C2_b10.err"; echo "C2 b10 rc=$?"
+$B --steps 30 --warmup 20 --batch 10 --no-cpu-baseline > "$OUT/${TAG}_bench_C2_batch10_line.json" 2> "$OUT/bench_C2_b10.err"; echo "C2 b10 rc=$?"
 YNET_STEP_GRAPH=0 $B --steps 30 --warmup 5 --batch 10 --no-cpu-baseline --no-roofline > "$OUT/${TAG}_bench_C2_batch10_eager_line.json" 2>/dev/null
 for c in C1 C3 C4 C5; do
   $B --steps 20 --warmup 5 --config $c --no-cpu-baseline > "$OUT/${TAG}_bench_${c}_line.json" 2> "$OUT/bench_$c.err"; echo "$c rc=$?"
