@@ -22,7 +22,11 @@
 //               the layer below (the activation fetched at the store addresses), + a precomputed additive term, + the 2x2 max-pooled copy
 //               (a lane holds exactly the block it pools).
 //   kernels     conv_wino_kernel<NCB, NCH, EM, NW>: one source, Cin = 8 NCH in {16, 32}, Cout = 16 NCB in {16, 32}, chunks of 8 channels;
-//               conv_wino_cat_kernel<2, EPI>: up to three concatenated sources padded to multiples of 4 channels (<= 56), chunks of 4.
+//               EM 0 plain, 1 through a ReLU backward (float activation fetched), 2 the same from the 1-bit mask, 3 plain + that mask written.
+//               conv_wino_cat_kernel<2, EPI>: up to three concatenated sources padded to multiples of 4 channels (<= 56), chunks of 4;
+//               EPI 0 plain, 2 + additive term, 3 + pooled copy, 4 / 5 = 0 / 2 + the 1-bit mask written, 6 = 3 + one byte per pooled block
+//               (arg-max and ReLU bits for the pool's backward).
+//               conv_wino16_kernel<EPI> (the slice form), conv_wino_up_kernel<NCH> / conv_wino16_up_kernel (bilinear x2 inside): further down.
 //               Wider convolutions are composed by the caller (ops.conv2d_raw): output-channel slices, or a second launch that adds onto
 //               the first one's output.
 #include "ynet_common.h"
