@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Development probe (GPU only): per-launch time of a chain of six dependent 32 -> 32 Winograd convolutions at 256^2, B 32.  Round 5 used it to price a tile walk that
+alternates direction from launch to launch (an experimental YNET_WINO_REV switch in conv_wino.hip, not kept: -2 % on this chain, nothing in the step -- DESIGN.md section 4.23)."""
 import importlib, os, sys
 sys.path.insert(0, "/root/repo")
 import torch
