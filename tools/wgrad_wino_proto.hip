@@ -17,11 +17,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int CI = 32, CO = 32;
-constexpr int PXB = 176, PDB = 144;                       // group pitches: 11 and 9 units of 16 bytes
-constexpr int XBYTES = 4 * CI * PXB + 16, DBYTES = 2 * CO * PDB;
-constexpr int UNIT_BYTES = XBYTES + DBYTES;               // one unit's operands
-constexpr int STAGE_BYTES = 2 * UNIT_BYTES;               // two units (the two tile groups)
-constexpr int NX = (4 * CI + 4) / 5, ND = (2 * CO + 6) / 7;   // DMA instructions per unit: 5 / 7 groups each
+constexpr int PXB = 176, PDB = 144;                       // pitches of a (row, channel) group: 11 / 9 units of 16 bytes (an odd count = conflict-free 8-byte reads)
+constexpr int XBYTES = 6 * CI * PXB + 16, DBYTES = 4 * CO * PDB;
+constexpr int STAGE_BYTES = XBYTES + DBYTES;              // a stage: FOUR output rows x 32 columns = six input rows + four rows of the output gradient
+constexpr int NBUF = 3;
+constexpr int NX = (6 * CI + 4) / 5, ND = (4 * CO + 6) / 7;   // DMA instructions per stage: 5 / 7 groups each
+constexpr int NDMA = NX + ND;
 
 struct Args {
     const float* x;     // [B][CI][H][W]
@@ -30,116 +31,121 @@ struct Args {
     int B, H, W;
 };
 
+// version 3: a stage is two vertically adjacent row pairs (they share two of their four input rows), everything arrives by LDS-DMA, three stages in flight,
+// one barrier per stage; the two tile groups of the workgroup take one row pair each.
 __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const Args a) {
     extern __shared__ unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = a.H, W = a.W, HW = H * W;
-    const int upr = W / 32, upi = (H / 2) * upr;            // units per row of units, per image
-    const int total_units = a.B * upi, stages = (total_units + 1) / 2;
+    const int upr = W / 32, upi = (H / 4) * upr;            // stages per row of stages, per image
+    const int stages = a.B * upi;
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     const unsigned lead = (unsigned)((W + 4) * 4);
     const unsigned x_img = (unsigned)(CI * HW * 4) + lead, d_img = (unsigned)(CO * HW * 4);
 
-    // one DMA instruction of a stage: i in [0, 2 * (NX + ND)): unit (i / (NX + ND)), then X instructions, then dY instructions
-    auto dma = [&](int stage, int i, int buf) {
-        const int g = i / (NX + ND), j = i - g * (NX + ND);
-        const int unit = stage * 2 + g;
-        if (unit >= total_units) return;
-        const int b = unit / upi, rem = unit - b * upi, p = rem / upr, tx = rem - p * upr;
-        const int y0 = 2 * p, x0 = 32 * tx;
-        const unsigned ub = lds0 + (unsigned)(buf * STAGE_BYTES + g * UNIT_BYTES);
-        if (j < NX) {
-            const int gi = lane / 11, u = lane - gi * 11, grp = 5 * j + gi;
-            if (lane < 55 && grp < 4 * CI) {
-                const int r = grp / CI, c = grp - r * CI;
-                const int yy = y0 - 1 + r;
-                const bool zero = u == 10 || yy < 0 || yy >= H || (u == 0 && x0 == 0) || (u == 9 && x0 + 32 == W);
-                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x + (long long)b * CI * HW) - lead), 0, x_img, 0x00020000);
-                const unsigned off = zero ? 0x80000000u : (unsigned)((c * HW + yy * W + x0 - 4 + 4 * u) * 4) + lead;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(ub + 4u + (unsigned)(5 * j * PXB)), 16, off, 0, 0, 0);
-            }
-        } else {
-            const int jd = j - NX;
-            const int gi = lane / 9, u = lane - gi * 9, grp = 7 * jd + gi;
-            if (lane < 63 && grp < 2 * CO) {
-                const int r = grp / CO, c = grp - r * CO;
-                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (long long)b * CO * HW), 0, d_img, 0x00020000);
-                const unsigned off = u == 8 ? 0x80000000u : (unsigned)((c * HW + (y0 + r) * W + x0 + 4 * u) * 4);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(uintptr_t)(ub + (unsigned)XBYTES + (unsigned)(7 * jd * PDB)), 16, off, 0, 0, 0);
+    const int gx = lane / 11, ux = lane - gx * 11, gd = lane / 9, ud = lane - gd * 9;
+    auto dma_stage = [&](int stage, int buf) {
+        const int b = stage / upi, rem = stage - b * upi, p = rem / upr, tx = rem - p * upr;
+        const int y0 = 4 * p, x0 = 32 * tx;
+        const unsigned ub = lds0 + (unsigned)(buf * STAGE_BYTES);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.x + (long long)b * CI * HW) - lead), 0, x_img, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (long long)b * CO * HW), 0, d_img, 0x00020000);
+        for (int i = wave; i < NDMA; i += 8) {
+            if (i < NX) {
+                const int grp = 5 * i + gx;
+                if (lane < 55 && grp < 6 * CI) {
+                    const int r = grp / CI, c = grp - r * CI;
+                    const int yy = y0 - 1 + r;
+                    const bool zero = ux == 10 || yy < 0 || yy >= H || (ux == 0 && x0 == 0) || (ux == 9 && x0 + 32 == W);
+                    const unsigned off = zero ? 0x80000000u : (unsigned)((c * HW + yy * W + x0 - 4 + 4 * ux) * 4) + lead;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(uintptr_t)(ub + 4u + (unsigned)(5 * i * PXB)), 16, off, 0, 0, 0);
+                }
+            } else {
+                const int jd = i - NX, grp = 7 * jd + gd;
+                if (lane < 63 && grp < 4 * CO) {
+                    const int r = grp / CO, c = grp - r * CO;
+                    const unsigned off = ud == 8 ? 0x80000000u : (unsigned)((c * HW + (y0 + r) * W + x0 + 4 * ud) * 4);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(uintptr_t)(ub + (unsigned)XBYTES + (unsigned)(7 * jd * PDB)), 16, off, 0, 0, 0);
+                }
             }
         }
     };
-    auto dma_stage = [&](int stage, int buf) {
-        for (int i = wave; i < 2 * (NX + ND); i += 8) dma(stage, i, buf);
-    };
+    const int ndma = (NDMA - wave + 7) / 8;                 // how many of a stage's instructions this wave issues
 
-    const int grp = wave >> 2, bo = (wave >> 1) & 1, bi = wave & 1, ch = lane & 15, tk = lane >> 4;
+    const int grp2 = wave >> 2, bo = (wave >> 1) & 1, bi = wave & 1, ch = lane & 15, tk = lane >> 4;
     f32x4 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const int G = gridDim.x;
     int s = blockIdx.x, it = 0;
     if (s < stages) dma_stage(s, 0);
-    for (; s < stages; s += gridDim.x, ++it) {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (s + G < stages) dma_stage(s + G, 1);
+    for (; s < stages; s += G, ++it) {
+        const int buf = it % NBUF;
+        // stage s has landed: what may still be in flight is this wave's share of stage s + G (issued after it)
+        if (s + G < stages) {
+            if (ndma == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         asm volatile("s_barrier" ::: "memory");
-        if (s + (int)gridDim.x < stages) dma_stage(s + gridDim.x, buf ^ 1);
-        if (s * 2 + grp < total_units) {
-            const unsigned char* ub = smem + buf * STAGE_BYTES + grp * UNIT_BYTES;
+        if (s + 2 * G < stages) dma_stage(s + 2 * G, (it + 2) % NBUF);
+        __builtin_amdgcn_sched_barrier(0);      // (the fetches are ISSUED here, not after the products hipcc would rather start with)
+        const unsigned char* ub = smem + buf * STAGE_BYTES;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int t = 4 * st + tk;
-                const unsigned char* xp = ub + 4 + (bi * 16 + ch) * PXB + (2 * t + 3) * 4;
-                f32x2 dl[4], dh[4];
+        for (int st = 0; st < 4; ++st) {
+            const int t = 4 * st + tk;
+            const unsigned char* xp = ub + 4 + ((2 * grp2) * CI + bi * 16 + ch) * PXB + (2 * t + 3) * 4;
+            f32x2 dl[4], dh[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dl[r] = *reinterpret_cast<const f32x2*>(xp + r * CI * PXB);
-                    dh[r] = *reinterpret_cast<const f32x2*>(xp + r * CI * PXB + 8);
-                }
-                const unsigned char* dp = ub + XBYTES + (bo * 16 + ch) * PDB + (2 * t) * 4;
-                const f32x2 e0 = *reinterpret_cast<const f32x2*>(dp), e1 = *reinterpret_cast<const f32x2*>(dp + CO * PDB);
-                // V = B^T d B
-                const f32x2 tl[4] = {dl[0] - dl[2], dl[1] + dl[2], dl[2] - dl[1], dl[1] - dl[3]};
-                const f32x2 th[4] = {dh[0] - dh[2], dh[1] + dh[2], dh[2] - dh[1], dh[1] - dh[3]};
-                float V[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    V[i][0] = tl[i][0] - th[i][0];
-                    V[i][1] = tl[i][1] + th[i][0];
-                    V[i][2] = th[i][0] - tl[i][1];
-                    V[i][3] = tl[i][1] - th[i][1];
-                }
-                // Z = A dY A^T
-                const f32x2 z[4] = {e0, e0 + e1, e0 - e1, -e1};
-                float Z[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    Z[i][0] = z[i][0];
-                    Z[i][1] = z[i][0] + z[i][1];
-                    Z[i][2] = z[i][0] - z[i][1];
-                    Z[i][3] = -z[i][1];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[4 * i + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Z[i][j], V[i][j], acc[4 * i + j], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                dl[r] = *reinterpret_cast<const f32x2*>(xp + r * CI * PXB);
+                dh[r] = *reinterpret_cast<const f32x2*>(xp + r * CI * PXB + 8);
             }
+            const unsigned char* dp = ub + XBYTES + ((2 * grp2) * CO + bo * 16 + ch) * PDB + (2 * t) * 4;
+            const f32x2 e0 = *reinterpret_cast<const f32x2*>(dp), e1 = *reinterpret_cast<const f32x2*>(dp + CO * PDB);
+            // V = B^T d B
+            const f32x2 tl[4] = {dl[0] - dl[2], dl[1] + dl[2], dl[2] - dl[1], dl[1] - dl[3]};
+            const f32x2 th[4] = {dh[0] - dh[2], dh[1] + dh[2], dh[2] - dh[1], dh[1] - dh[3]};
+            float V[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                V[i][0] = tl[i][0] - th[i][0];
+                V[i][1] = tl[i][1] + th[i][0];
+                V[i][2] = th[i][0] - tl[i][1];
+                V[i][3] = tl[i][1] - th[i][1];
+            }
+            // Z = A dY A^T
+            const f32x2 z[4] = {e0, e0 + e1, e0 - e1, -e1};
+            float Z[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Z[i][0] = z[i][0];
+                Z[i][1] = z[i][0] + z[i][1];
+                Z[i][2] = z[i][0] - z[i][1];
+                Z[i][3] = -z[i][1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * i + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Z[i][j], V[i][j], acc[4 * i + j], 0, 0, 0);
         }
     }
     // the two tile groups of a block: group 1 hands its sums over through LDS, group 0 adds and writes the workgroup's partial
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float* ex = reinterpret_cast<float*>(smem);
-    if (grp == 1) {
+    if (grp2 == 1) {
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ex[(((bo * 2 + bi) * 16 + p) * 4 + r) * 64 + lane] = acc[p][r];
     }
     __syncthreads();
-    if (grp == 0) {
+    if (grp2 == 0) {
         float* out = a.part + (long long)blockIdx.x * 16 * CO * CI;
 #pragma unroll
         for (int p = 0; p < 16; ++p)
@@ -197,8 +203,8 @@ static void reference(const std::vector<float>& x, const std::vector<float>& dy,
 }
 
 int main() {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    printf("LDS per workgroup: %d bytes (stage %d)\n", 2 * STAGE_BYTES, STAGE_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * STAGE_BYTES);
+    printf("LDS per workgroup: %d bytes (stage %d, %d stages)\n", NBUF * STAGE_BYTES, STAGE_BYTES, NBUF);
     // ---- correctness on a small case
     {
         const int B = 2, H = 32, W = 64;
@@ -215,7 +221,7 @@ int main() {
         hipMemcpy(dx_, x.data(), x.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(ddy, dy.data(), dy.size() * 4, hipMemcpyHostToDevice);
         Args a{dx_, ddy, part, B, H, W};
-        hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), 2 * STAGE_BYTES, 0, a);
+        hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), NBUF * STAGE_BYTES, 0, a);
         hipLaunchKernelGGL(finish_kernel, dim3((CO * CI + 255) / 256), dim3(256), 0, 0, part, grid, dw);
         std::vector<float> got((size_t)CO * CI * 9);
         hipMemcpy(got.data(), dw, got.size() * 4, hipMemcpyDeviceToHost);
@@ -245,9 +251,9 @@ int main() {
         Args a{dx_, ddy, part, B, H, W};
         hipEvent_t e0, e1, e2;
         hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
-        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), 2 * STAGE_BYTES, 0, a);
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), NBUF * STAGE_BYTES, 0, a);
         hipEventRecord(e0);
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), 2 * STAGE_BYTES, 0, a);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), NBUF * STAGE_BYTES, 0, a);
         hipEventRecord(e1);
         for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(finish_kernel, dim3((CO * CI + 255) / 256), dim3(256), 0, 0, part, grid, dw);
         hipEventRecord(e2);
