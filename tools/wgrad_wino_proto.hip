@@ -3,9 +3,11 @@
 // i.e. 16 multiplies per 2x2 output block and channel pair instead of the direct form's 36 -- the K dimension of the MFMAs is the TILE index, and
 // between the MFMAs there is nothing but the two transforms.  Measures what DESIGN.md section 8 item 2a prices against wgrad_roll_kernel.
 //   hipcc -O3 --offload-arch=gfx950 tools/wgrad_wino_proto.hip -o /tmp/wgrad_wino_proto && /tmp/wgrad_wino_proto
-// Layout: a workgroup of 8 waves = 4 blocks (16 co x 16 ci) x 2 tile groups; a STAGE is two units (one per group) of one row pair x 32 columns = 16 tiles;
-// all waves stage the next stage by LDS-DMA (rows as [row][channel] groups with a pitch of an odd number of 16-byte units: conflict-free 8-byte reads
-// for lanes = (channel, tile)), one barrier per stage.
+// Layout (version 3): a workgroup of 8 waves = 4 blocks (16 co x 16 ci) x 2 tile groups; a STAGE is FOUR output rows x 32 columns -- two vertically adjacent row pairs, one
+// per tile group, sharing two of their input rows: six input rows + four rows of the output gradient = 52 KB, three stages in flight; all waves issue the LDS-DMAs of the stage two
+// ahead (rows as [row][channel] groups with a pitch of an odd number of 16-byte units: conflict-free 8-byte reads for lanes = (channel, tile)), one barrier per stage.
+// Measured (MI355X, B 32, 32 -> 32): 74 us at 128^2, 282 us at 256^2 = 130-137 TFLOP/s direct-equivalent (wgrad_roll_kernel: 100-119); version 1 (two stages, both operands per
+// unit): 114 / 434 us.  The launch is below the ridge (13-16 executed FLOP per byte): its floor is HBM time.  DESIGN.md section 8, item 2a.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
