@@ -569,7 +569,18 @@ def main():
     # model, templates, scene: built by the PACKAGE (the oracle is imported further down, inside the cpu_baseline / parity_check legs only)
     model = build_model(cfg, dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    dp = D.DataParallel(model.parameters()) if world > 1 else None
+    # YNET_DP_FORCE=1 with --gpus 1: a process group of ONE rank (RCCL) and every collective of the N-rank step issued for real --
+    # the split-graph step with the eager all-reduce between its two hipGraphs (or the one-shot kernel inside one graph) on a 1-GPU box
+    forced_dp = world == 1 and os.environ.get("YNET_DP_FORCE") == "1"
+    if forced_dp and not dist.is_initialized():
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            free_port = sock.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port))
+        dist.init_process_group(backend=os.environ.get("YNET_DIST_BACKEND") or "nccl", rank=0, world_size=1)
+    dp = D.DataParallel(model.parameters()) if (world > 1 or forced_dp) else None
     crit = trainer.HipBCEWithLogitsLoss()
     in_t, gt_t = templates(cfg, dev)
     images = {"scene0": synthetic_scene(cfg, H, W, 0)[0].to(dev)}
@@ -691,7 +702,7 @@ def main():
     # proof of the process group the step ran on: size and backend as torch.distributed reports them, and every rank's device
     mine = {"rank": rank, "device": str(dev), "name": torch.cuda.get_device_name(dev),
             "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")), "pid": os.getpid()}
-    if world > 1:
+    if dp is not None:
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
         out["world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
@@ -811,7 +822,7 @@ def main():
                 v["form"] = "Winograd F(2x2, 3x3), csrc/conv_wino.hip: tflops = the direct form's 2 * 9 * Cin * Cout per pixel over the time"
         total_conv_ms = sum(v["ms"] for v in agg.values())
         out["conv_share_of_step"] = total_conv_ms / out["ms_per_step"]
-    if world > 1:
+    if dp is not None:
         # ---- the collective on its own and the split of a replayed step around it (graph A = forward / backward, eager
         # all-reduce of the flat gradient buffer, graph B = optimizer / read-out), HIP events on the step's stream
         sgm = pkg("utils.step_graph")
@@ -914,7 +925,7 @@ def main():
         out["parity_check"] = parity_check(first, gpu_steps, launched)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -441,7 +441,9 @@ int ynet_adam_step(const long long* table, const int* chunk_tensor, const long l
  *                                                      out of band (motion-style-transfer_amd/dist.py: all_gather_object)
  *   ynet_comm_connect(comm, handles)                   `world` handles in rank order (the own entry is ignored)
  *   ynet_allreduce_sum(comm, buf, n, stream)           in place, n <= max_floats; collective: every rank calls it the same
- *                                                      number of times; NOT capturable into a hipGraph (epoch argument)
+ *                                                      number of times; the call number lives on the device, so the
+ *                                                      launch has no per-call argument and CAN be captured into a
+ *                                                      hipGraph (utils/step_graph.py does); world == 1 launches too (sum = input)
  *   ynet_comm_status(comm)                             1 if a wait for a peer ever timed out (~20 s), else 0; synchronises.
  *                                                      A timed-out call does NOT leave buf un-reduced silently: the parts that
  *                                                      could not be reduced and the last element (the loss slot of

@@ -200,7 +200,8 @@ int ynet_allreduce_sum(void* comm, float* buf, long long n, void* stream) {
     YNET_REQUIRE(c && buf, "allreduce_sum: null pointer");
     YNET_REQUIRE(c->world == 1 || c->connected, "allreduce_sum: ynet_comm_connect has not been called");
     YNET_REQUIRE(n > 0 && n <= c->capacity, "allreduce_sum: %lld floats exceed the mailbox capacity %lld", n, c->capacity);
-    if (c->world == 1) return 0;
+    // (a world of one rank still launches: publish, no peer to wait for, sum = the input bit for bit -- the forced
+    // single-rank runs of dist.DataParallel(force=True) record this launch into the step's graph like N ranks do)
     AllreduceArgs a{};
     a.buf = buf;
     a.n = n;

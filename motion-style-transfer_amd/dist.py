@@ -25,8 +25,13 @@ def _close_comm(lib, comm):
 
 
 class DataParallel:
-    def __init__(self, params, group=None, collective=None):
-        """``collective``: "rccl" (torch.distributed all_reduce: RCCL over xGMI, or gloo in tests; the default) or "oneshot"
+    def __init__(self, params, group=None, collective=None, force=None):
+        """``force`` (default: YNET_DP_FORCE=1): issue every collective even in a world of ONE rank -- all-reduce, scalar
+        sum, seed broadcast all go through torch.distributed / the one-shot kernel and the captured step takes the same
+        shape as on N ranks (two graphs around an eager RCCL all-reduce, or the one-shot kernel recorded inside one graph).
+        The sums of one rank are the inputs, so results equal ``dp=None`` bit for bit; it is how the RCCL stream hand-off is
+        exercised on a box with a single GPU (tests/test_gpu_dp.py, `bench.py --gpus 1` under YNET_DP_FORCE=1).
+        ``collective``: "rccl" (torch.distributed all_reduce: RCCL over xGMI, or gloo in tests; the default) or "oneshot"
         (ynet_allreduce_sum: every rank reads its peers' buffers through HIP IPC in one hop, rank-ordered sums; one node,
         <= 16 ranks; default when YNET_ALLREDUCE=oneshot).  torch.distributed stays the control plane either way."""
         if not dist.is_initialized():
@@ -36,6 +41,9 @@ class DataParallel:
         self._comm = None
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        if force is None:
+            force = os.environ.get("YNET_DP_FORCE", "0") == "1"
+        self.active = self.world > 1 or bool(force)       # do the collectives run at all?
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
@@ -49,7 +57,7 @@ class DataParallel:
             off += p.numel()
         self.bind()
         self.transport_note = None          # why the requested transport was not used (bench.py prints it)
-        if self.collective == "oneshot" and self.world > 1:
+        if self.collective == "oneshot" and self.active:
             self._connect_oneshot()
             self._self_test_oneshot()
         if self._comm is not None:
@@ -169,7 +177,7 @@ class DataParallel:
 
     def allreduce(self):
         """The ONE collective of a step: SUM all-reduce of the flat buffer, in place, on the current stream."""
-        if self.world > 1:
+        if self.active:
             if self._comm is not None:
                 from . import _lib as L
                 L.check(self._lib.ynet_allreduce_sum(self._comm, self.flat.data_ptr(), self.flat.numel(),
@@ -195,14 +203,14 @@ class DataParallel:
 
     def sum_scalar(self, t: torch.Tensor) -> torch.Tensor:
         self.check()          # (the epoch's synchronisation point)
-        if self.world > 1:
+        if self.active:
             t = t.clone()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def gather_rows(self, t: torch.Tensor, sizes: List[int]) -> torch.Tensor:
         """Concatenate per-rank row blocks of (possibly different) length sizes[r] on every rank."""
-        if self.world == 1:
+        if not self.active:
             return t
         m = max(sizes)
         pad = torch.zeros((m,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
@@ -218,7 +226,7 @@ class DataParallel:
         t = torch.zeros(1, dtype=torch.int64, device=dev)
         if self.rank == 0:
             t[0] = int(torch.randint(0, 2 ** 62, (1,)).item())
-        if self.world > 1:
+        if self.active:
             dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
         return int(t.item())
 

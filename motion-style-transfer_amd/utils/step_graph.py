@@ -88,7 +88,7 @@ def step_key(scene_image, n_local, n_global, obs_len, pred_len, waypoints, loss_
              gt_template, input_template, optimizer, dp, model_token=None):
     return (tuple(scene_image.shape), n_local, n_global, obs_len, pred_len, tuple(waypoints), float(loss_scale),
             float(resize_factor), network, id(criterion), gt_template.data_ptr(), input_template.data_ptr(),
-            _hyper(optimizer), None if dp is None else (id(dp), dp.world, dp.rank), model_token)
+            _hyper(optimizer), None if dp is None else (id(dp), dp.world, dp.rank, dp.active), model_token)
 
 
 def cache_for(model, optimizer, device):
@@ -300,8 +300,8 @@ class CapturedStep:
             self.dp = dp
             # the one-shot all-reduce (ynet_allreduce_sum) keeps its call counter on the device: it is recorded INTO the graph, one
             # graph per step; a torch.distributed collective stays between two graphs
-            self.collective_in_graph = dp is not None and dp.world > 1 and dp.capturable_collective()
-            self.split = dp is not None and dp.world > 1 and not self.collective_in_graph
+            self.collective_in_graph = dp is not None and dp.active and dp.capturable_collective()
+            self.split = dp is not None and dp.active and not self.collective_in_graph
             self.params = [p for g in optimizer.param_groups for p in g["params"]]
             # Under a process group other threads (the NCCL / RCCL watchdog) may query events while this thread captures:
             # only the capturing thread is held to capture-safe calls then.
@@ -323,7 +323,7 @@ class CapturedStep:
                     dp.stage(loss)
                 if not self.split:
                     if dp is not None:
-                        dp.allreduce()               # (captured: the one-shot kernel; nothing at world 1)
+                        dp.allreduce()               # (captured: the one-shot kernel; nothing at world 1 unless forced)
                         loss = dp.loss_value()
                     opt_step()
                     ade, fde = finish(fb)

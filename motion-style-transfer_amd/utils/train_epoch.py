@@ -269,7 +269,7 @@ def train_epoch(model, train_loader, train_images, optimizer, criterion, loss_sc
                     train_FDE.append(fde)
 
         train_ADE, train_FDE = torch.cat(train_ADE), torch.cat(train_FDE)
-        if dp is not None and dp.world > 1:
+        if dp is not None and dp.active:
             # per-trajectory errors stay local during the epoch; one (sum, sum, count) reduction at its end
             stats = torch.stack([train_ADE.sum(), train_FDE.sum(),
                                  torch.tensor(float(train_ADE.numel()), device=train_ADE.device)])
