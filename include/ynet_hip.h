@@ -417,6 +417,16 @@ int ynet_seg_onehot_pad(const int* labels, float* y, int H, int W, int Hp, int W
  * out[y][x] = labels[min(floor(y * (1 / fy)), H - 1)][min(floor(x * (1 / fx)), W - 1)], products in double -- OpenCV's published
  * nearest-neighbour rule.  PARITY UNPINNED: cv2 is not in the image; restated from the published algorithm, known-answer tests only. */
 int ynet_resize_nearest(const int* labels, int* out, int H, int W, int Ho, int Wo, double fx, double fy, void* stream);
+/* augment_data's image side (utils/data_utils.py:113-170): cv2.rotate(image, ROTATE_90_COUNTERCLOCKWISE) applied k times (rot(),
+ * lines 133-134) followed, if `flip`, by cv2.flip(image, 1) (fliplr(), line 162) -- pure index permutations, = np.rot90(image, k) and
+ * np.fliplr: N planes [H][W] of 32-bit words (int32 label maps or fp32 planes) -> [Ho][Wo], (Ho, Wo) = (W, H) for odd k.
+ * Bit-exact by construction; src and dst must not overlap. */
+int ynet_rot90_flip(const void* src, void* dst, long long N, int H, int W, int k, int flip, void* stream);
+/* augment_data's coordinate side (utils/data_utils.py:127-131,140-141 and 158-161,169-170), float64 like the DataFrame columns, in place
+ * on xy [n][2]: (x, y) <- ((x - cx, y - cy) . [[r00, r01], [r10, r11]]) + (ox, oy).  rot(): c = cos(-k pi / 2), s = sin(-k pi / 2) as NumPy
+ * evaluates them (passed in: c is 6.1e-17, not 0, for odd k), R = [[c, s], [-s, c]], (cx, cy) = half the image size before, (ox, oy) half
+ * the size after the rotation; fliplr(): R = [[-1, 0], [0, 1]]. */
+int ynet_rot_coords(double* xy, long long n, double cx, double cy, double r00, double r01, double r10, double r11, double ox, double oy, void* stream);
 
 /* y[i] = sum over b of x[b * batch_stride + i], i < n, in batch order (bitwise reproducible): the backward of `semantic_img.expand(B, ...)`
  * (utils/train_epoch.py:87) and of the batch-broadcast scene features of Y-Net-Mod -- the gradient of a one-image tensor that every

@@ -99,6 +99,8 @@ SIGNATURES = {
     "ynet_pad2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_seg_onehot_pad": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_resize_nearest": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_double, c_fp]),
+    "ynet_rot90_flip": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_rot_coords": (c_i, [c_fp, c_ll] + [ctypes.c_double] * 8 + [c_fp]),
     "ynet_sigmoid_temp": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, PI, c_i, c_f, c_fp]),
     "ynet_gather_patch": (c_i, [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "ynet_heatmap_analytic": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, ctypes.c_double, c_fp, c_i, c_fp, c_fp]),

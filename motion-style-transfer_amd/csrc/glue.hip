@@ -1294,6 +1294,40 @@ __global__ __launch_bounds__(256) void resize_nearest_kernel(const int* __restri
     }
 }
 
+// augment_data's image side (utils/data_utils.py:113-170): cv2.rotate(im, ROTATE_90_COUNTERCLOCKWISE) applied k times (= np.rot90(im, k))
+// and cv2.flip(im, 1) (= np.fliplr) are pure index permutations -- N planes [H][W] of 32-bit words (int32 label maps, fp32 planes alike) ->
+// [Ho][Wo], (Ho, Wo) = (W, H) for odd k.  One rotation: out[i][j] = in[j][W - 1 - i]; the flip is applied after the rotations.
+__global__ __launch_bounds__(256) void rot90_flip_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long long N, int H, int W, int k, int flip) {
+    const int Wo = (k & 1) ? H : W;
+    const long long plane = (long long)H * W, total = N * plane;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long n = t / plane;
+        const int r = (int)(t - n * plane), i = r / Wo;
+        int j = r - i * Wo;
+        if (flip) j = Wo - 1 - j;
+        int sy, sx;
+        switch (k & 3) {
+            case 0: sy = i; sx = j; break;
+            case 1: sy = j; sx = W - 1 - i; break;
+            case 2: sy = H - 1 - i; sx = W - 1 - j; break;
+            default: sy = H - 1 - j; sx = i; break;
+        }
+        dst[t] = src[n * plane + (long long)sy * W + sx];
+    }
+}
+
+// augment_data's coordinate side: rot() maps (x, y) -> ((x - x0 / 2, y - y0 / 2) . R) + (x0' / 2, y0' / 2) with R = [[c, s], [-s, c]],
+// c = cos(-k pi / 2), s = sin(-k pi / 2) AS NumPy EVALUATES THEM (c is 6.1e-17, not 0, for odd k: the caller passes the doubles), fliplr()
+// the same with R = [[-1, 0], [0, 1]]; float64 like the DataFrame columns.  xy [n][2] in place.
+__global__ __launch_bounds__(256) void rot_coords_kernel(double* __restrict__ xy, long long n, double cx, double cy, double r00, double r01, double r10, double r11,
+                                                         double ox, double oy) {
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+        const double x = xy[2 * t] - cx, y = xy[2 * t + 1] - cy;
+        xy[2 * t] = (x * r00 + y * r10) + ox;
+        xy[2 * t + 1] = (x * r01 + y * r11) + oy;
+    }
+}
+
 extern "C" {
 
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
@@ -1641,6 +1675,20 @@ int ynet_resize_nearest(const int* labels, int* out, int H, int W, int Ho, int W
     hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for((long long)Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream,
                        labels, out, H, W, Ho, Wo, 1.0 / fx, 1.0 / fy);
     return ynet_check_launch("resize_nearest");
+}
+
+int ynet_rot90_flip(const void* src, void* dst, long long N, int H, int W, int k, int flip, void* stream) {
+    YNET_REQUIRE(src && dst && src != dst && N > 0 && H > 0 && W > 0 && k >= 0, "rot90_flip: bad arguments");
+    YNET_REQUIRE(N * (long long)H * W < (1ll << 40), "rot90_flip: too many elements");
+    hipLaunchKernelGGL(rot90_flip_kernel, dim3(grid_for(N * (long long)H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned*)src, (unsigned*)dst, N, H, W, k & 3, flip ? 1 : 0);
+    return ynet_check_launch("rot90_flip");
+}
+
+int ynet_rot_coords(double* xy, long long n, double cx, double cy, double r00, double r01, double r10, double r11, double ox, double oy, void* stream) {
+    YNET_REQUIRE(xy && n > 0, "rot_coords: bad arguments");
+    hipLaunchKernelGGL(rot_coords_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, xy, n, cx, cy, r00, r01, r10, r11, ox, oy);
+    return ynet_check_launch("rot_coords");
 }
 
 static void pred_softargmax_plan(int H, int W, int* gpw, int* nchunk) {

@@ -24,14 +24,14 @@ def _stream():
     return _VP(torch.cuda.current_stream().cuda_stream)
 
 
-def _need_gpu(t: torch.Tensor, what: str):
+def _need_gpu(t: torch.Tensor, what: str, dtypes=(torch.float32,)):
     if not torch.is_tensor(t):
         raise TypeError(f"{what}: expected a torch.Tensor, got {type(t)}")
     if not t.is_cuda:
         raise RuntimeError(f"{what}: tensor is on {t.device}; the MI355X path runs on HIP devices only "
                            f"(no CPU fallback exists by design)")
-    if t.dtype != torch.float32:
-        raise TypeError(f"{what}: fp32 expected, got {t.dtype}")
+    if dtypes is not None and t.dtype not in dtypes:
+        raise TypeError(f"{what}: {' / '.join(str(d).replace('torch.', '') for d in dtypes)} expected, got {t.dtype}")
     # kernels are enqueued on the CURRENT device's stream: a tensor of another GPU would be addressed from the wrong
     # device's queue.  (YNetTrainer and dist.init_from_env select the device; one process drives one GPU.)
     if t.device.index != torch.cuda.current_device():
@@ -1915,6 +1915,37 @@ def resize_nearest(labels: torch.Tensor, factor: float) -> torch.Tensor:
     lib = _lib()
     L.check(lib.ynet_resize_nearest(lab.data_ptr(), out.data_ptr(), H, W, Ho, Wo, float(factor), float(factor), _stream()), lib)
     return out.to(labels.dtype)
+
+
+def rot90_flip(image: torch.Tensor, k: int = 0, flip: bool = False) -> torch.Tensor:
+    """k times cv2.rotate(image, ROTATE_90_COUNTERCLOCKWISE), then (flip) cv2.flip(image, 1) -- utils/data_utils.py:133-134, 162 -- of a
+    device tensor [H, W] or [..., H, W] with 4-byte elements (int32 label maps, fp32 planes): np.rot90(image, k) / np.fliplr over the last two
+    dimensions, bit-exact (an index permutation, ynet_rot90_flip)."""
+    _need_gpu(image, "rot90_flip", None)
+    if image.dim() < 2 or image.element_size() != 4:
+        raise ValueError("rot90_flip: expected [..., H, W] with 4-byte elements (int32 / float32)")
+    k = int(k) % 4
+    src = image.contiguous()
+    H, W = src.shape[-2:]
+    out = torch.empty(tuple(src.shape[:-2]) + ((W, H) if k & 1 else (H, W)), device=src.device, dtype=src.dtype)
+    if src.numel() == 0:
+        return out
+    lib = _lib()
+    L.check(lib.ynet_rot90_flip(src.data_ptr(), out.data_ptr(), src.numel() // (H * W), H, W, k, 1 if flip else 0, _stream()), lib)
+    return out
+
+
+def rot_coords(xy: torch.Tensor, center, matrix, offset) -> torch.Tensor:
+    """(xy - center) @ matrix + offset on a float64 device tensor [n, 2], in place (the coordinate side of rot() / fliplr(),
+    utils/data_utils.py:127-131,140-141,158-161,169-170; ynet_rot_coords)."""
+    _need_gpu(xy, "rot_coords", (torch.float64,))
+    if xy.dtype != torch.float64 or xy.dim() != 2 or xy.shape[1] != 2 or not xy.is_contiguous():
+        raise ValueError("rot_coords: expected a contiguous float64 tensor [n, 2]")
+    if xy.shape[0]:
+        lib = _lib()
+        L.check(lib.ynet_rot_coords(xy.data_ptr(), xy.shape[0], float(center[0]), float(center[1]), float(matrix[0][0]), float(matrix[0][1]),
+                                    float(matrix[1][0]), float(matrix[1][1]), float(offset[0]), float(offset[1]), _stream()), lib)
+    return xy
 
 
 def kmeans2d(points: torch.Tensor, init_idx: torch.Tensor, tol: float = 1e-3, iter_limit: int = 1000):

@@ -29,6 +29,7 @@ from utils.evaluate import evaluate as ref_evaluate                      # noqa:
 from utils.image_utils import (create_dist_mat, create_gaussian_heatmap_template,   # noqa: E402
                                get_patch as ref_get_patch)
 from utils.softargmax import SoftArgmax2D as RefSoftArgmax               # noqa: E402
+from utils import data_utils as ref_data_utils                            # noqa: E402  (reference: rot / fliplr / augment_data)
 
 from oracle import ynet_oracle as O                                      # noqa: E402
 
@@ -425,6 +426,142 @@ def trained_case(tag, cfg, H, W, B, seed, steps, lr, step_cfg=None, n_goal=20):
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def augment_case():
+    """SURVEY 8(f)-4, the pinnable piece: the REFERENCE's rot / fliplr / augment_data (utils/data_utils.py:113-233)
+    on small label maps and a 3-channel image, with cv2.rotate / cv2.flip / cv2.imread served by oracle/_stubs/cv2.py as their NumPy
+    equivalents (np.rot90 / np.fliplr / an in-memory dict) -- the permutations are OpenCV's documented ones, but OpenCV itself is absent:
+    PARITY UNPINNED at that boundary, and the fixture says so."""
+    import cv2 as stub
+    rng = np.random.RandomState(7)
+    scenes = {"sceneA": rng.randint(0, 6, size=(6, 10)).astype(np.uint8), "sceneB": rng.randint(0, 6, size=(8, 4)).astype(np.uint8)}
+    rows = []
+    meta = 0
+    for sid, im in scenes.items():
+        for _ in range(3):
+            for f in range(4):
+                rows.append({"frame": f, "trackId": meta, "x": float(rng.uniform(0, im.shape[1])), "y": float(rng.uniform(0, im.shape[0])),
+                             "sceneId": sid, "metaId": meta})
+            meta += 1
+    df = pd.DataFrame(rows)
+    stub.FILES.clear()
+    for sid, im in scenes.items():
+        stub.FILES[os.path.join("mem", sid, "oracle.png")] = im
+    out_df, out_images = ref_data_utils.augment_data(df.copy(), image_path="mem", images={}, image_file="oracle.png", seg_mask=True)
+    store = {"meta": np.array(repr({"cv2": "oracle/_stubs/cv2.py: rotate = np.rot90(., 1), flip = np.fliplr (NumPy equivalents, PARITY UNPINNED against OpenCV)"})),
+             "in/x": df["x"].to_numpy(), "in/y": df["y"].to_numpy(), "in/metaId": df["metaId"].to_numpy(), "in/frame": df["frame"].to_numpy(),
+             "in/sceneId": np.array(df["sceneId"].tolist()),
+             "out/x": out_df["x"].to_numpy(), "out/y": out_df["y"].to_numpy(), "out/metaId": out_df["metaId"].to_numpy(),
+             "out/sceneId": np.array(out_df["sceneId"].tolist()), "out/keys": np.array(list(out_images.keys()))}
+    for sid, im in scenes.items():
+        store["in/image/" + sid] = im
+    for key, im in out_images.items():
+        store["out/image/" + key] = im
+    # rot / fliplr on their own, on a 3-channel image, every k
+    img3 = rng.randint(0, 255, size=(5, 7, 3)).astype(np.uint8)
+    pts = pd.DataFrame({"x": rng.uniform(0, 7, 6), "y": rng.uniform(0, 5, 6)})
+    store["rot/image"], store["rot/x"], store["rot/y"] = img3, pts["x"].to_numpy(), pts["y"].to_numpy()
+    for k in (1, 2, 3):
+        d, im = ref_data_utils.rot(pts.copy(), img3.copy(), k)
+        store[f"rot/k{k}/image"], store[f"rot/k{k}/x"], store[f"rot/k{k}/y"] = im, d["x"].to_numpy(), d["y"].to_numpy()
+        assert np.array_equal(im, np.rot90(img3, k))
+    d, im = ref_data_utils.fliplr(pts.copy(), img3.copy())
+    store["flip/image"], store["flip/x"], store["flip/y"] = im, d["x"].to_numpy(), d["y"].to_numpy()
+    path = os.path.join(OUT, "augment.npz")
+    np.savez_compressed(path, **store)
+    print(f"  wrote {path}: {len(df)} -> {len(out_df)} rows, {len(out_images)} scenes")
+
+
+class RecordingBCE(torch.nn.Module):
+    """nn.BCEWithLogitsLoss that remembers every value it returned (train_epoch calls it twice per step: goal, trajectory)."""
+
+    def __init__(self):
+        super().__init__()
+        self.inner = torch.nn.BCEWithLogitsLoss()
+        self.values = []
+
+    def forward(self, x, t):
+        v = self.inner(x, t)
+        self.values.append(float(v.detach()))
+        return v
+
+
+def trajectory_case(tag, cfg, H, W, B, seed, epochs, steps_per_epoch, lr, milestones, lora_b_std=0.0, n_eval=32, n_goal=20):
+    """a multi-step TRAINING TRAJECTORY of the reference (every other fixture is <= 3 consecutive steps).
+    The reference's own loop (models/trainer.py:222-235: per epoch train_epoch(...), then lr_scheduler.step(); Adam + MultiStepLR
+    as models/trainer.py:197-201) runs `epochs` epochs of `steps_per_epoch` steps of batch B; stored: every step's loss
+    (goal + trajectory, x loss_scale, as utils/train_epoch.py:94,106-107 sums them), every epoch's (ADE, FDE, loss) return value,
+    the trajectories, and a K-sample sweep of the FINAL weights over `n_eval` held-out trajectories (mean best-of-K ADE / FDE).
+    The run is done TWICE, with 8 and with 3 intra-op threads: MKL-DNN then sums in a different order, and the difference between
+    the two runs is the reference's OWN fp32 noise along the trajectory -- the yardstick the product's deviation is held against.
+    The initial weights are O.make_state_dict(cfg, seed, lora_b_std) (stored as a checksum; the trajectories are stored)."""
+    if ONLY and not any(o in tag for o in ONLY):
+        return
+    import time
+    n_steps = epochs * steps_per_epoch
+    print(f"[{tag}] {epochs} x {steps_per_epoch} reference Adam steps of batch {B} at {H}x{W}, lr {lr}, milestones {milestones}")
+    sd0 = O.make_state_dict(cfg, seed=seed, lora_b_std=lora_b_std)
+    names = O.trainable_names(cfg, sd0)
+    scene = O.synthetic_scene(cfg, H, W, seed)
+    images = {"scene0": scene[0].clone()}
+    S = cfg.template_size
+    in_t, gt_t = O.dist_template(S), O.gaussian_template(S, cfg.kernlen, cfg.nsig)
+    trajs = [O.synthetic_trajectories(cfg, steps_per_epoch * B, H, W, seed + 100 + e) for e in range(epochs)]
+    eval_traj = O.synthetic_trajectories(cfg, n_eval, H, W, seed + 90)
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        model = fresh_reference(cfg, sd0, B, lr, names)
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=list(milestones), gamma=0.1)
+        crit = RecordingBCE()
+        rets, lrs = [], []
+        t0 = time.time()
+        for e in range(epochs):
+            lrs.append(opt.param_groups[0]["lr"])
+            rets.append(ref_train_epoch(model, loader_for(trajs[e]), images, opt, crit, cfg.loss_scale, torch.device("cpu"), "sdd", None,
+                                        gt_t, in_t, list(cfg.waypoints), e, cfg.obs_len, cfg.pred_len, B, 10000, cfg.resize_factor,
+                                        cfg.network, False))
+            sched.step()
+        v = np.array(crit.values, dtype=np.float64).reshape(n_steps, 2)
+        losses = v.sum(axis=1) * cfg.loss_scale
+        print(f"  {threads} threads: {time.time() - t0:.0f} s; loss step 1 {losses[0]:.3f} -> step {n_steps} {losses[-1]:.3f}; "
+              f"epoch returns {[tuple(round(float(x), 3) for x in r) for r in rets]}")
+        torch.manual_seed(seed + 3)
+        ade, fde, df, td = ref_evaluate(model, loader_for(eval_traj), images, torch.device("cpu"), "sdd", None, in_t, list(cfg.waypoints),
+                                        "test", n_goal, 1, cfg.obs_len, n_eval, cfg.resize_factor, cfg.temperature, False, False,
+                                        0.01, None, return_preds=True, return_samples=True, network=cfg.network)
+        wps = torch.from_numpy(td["waypoint_sample"]).permute(2, 0, 1, 3).contiguous()       # [K, n_eval, nwp, 2]: the draws of this sweep
+        final = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("semantic_segmentation")}
+        return (losses, np.array([[float(x) for x in r] for r in rets]), np.array(lrs), (float(ade), float(fde)), final, wps.numpy(),
+                df["ade"].to_numpy(), df["fde"].to_numpy())
+
+    a = run(8)
+    b = run(3)
+    torch.set_num_threads(8)
+    noise = np.abs(a[0] - b[0]) / np.abs(a[0])
+    print(f"  the reference against itself (8 vs 3 threads): per-step loss differs by max {noise[:10].max():.2e} in steps 1-10, "
+          f"{noise.max():.2e} overall, {noise[-1]:.2e} at the last step; sweep ADE {a[3][0]:.4f} vs {b[3][0]:.4f}")
+    meta = dict(obs_len=cfg.obs_len, pred_len=cfg.pred_len, waypoints=list(cfg.waypoints), enc=list(cfg.enc), dec=list(cfg.dec),
+                network=cfg.network, n_fusion=cfg.n_fusion or 0, train_net=cfg.train_net, position=list(cfg.position),
+                resize_factor=cfg.resize_factor, temperature=cfg.temperature, loss_scale=cfg.loss_scale, H=H, W=W, B=B, seed=seed, lr=lr,
+                epochs=epochs, steps_per_epoch=steps_per_epoch, milestones=list(milestones), lora_b_std=lora_b_std, n_eval=n_eval,
+                n_goal=n_goal, lora_source="oracle/_stubs/loralib (restated 0.1.1, PARITY UNPINNED)")
+    store = {"meta": np.array(repr(meta)),
+             "weight_checksum": np.array(sum(float(v.double().abs().sum()) for v in sd0.values())),
+             "traj": torch.stack(trajs).numpy(), "eval_traj": eval_traj.numpy(),
+             "loss_per_step": a[0], "loss_per_step_other_threads": b[0],
+             "epoch_returns": a[1], "epoch_returns_other_threads": b[1], "lr_per_epoch": a[2],
+             "sweep_ade_fde": np.array(a[3]), "sweep_ade_fde_other_threads": np.array(b[3]),
+             "sweep_waypoint_samples": a[5], "sweep_ade_per_traj": a[6], "sweep_fde_per_traj": a[7],
+             "final_weight_l2": np.array([float(a[4][n].double().norm()) for n in names]),
+             "final_weight_moved_l2": np.array([float((a[4][n] - sd0[n]).double().norm()) for n in names]),
+             "final_weight_self_noise_l2": np.array([float((a[4][n] - b[4][n]).double().norm()) for n in names]),
+             "trainable": np.array(names)}
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def fresh_reference(cfg, sd0, B, lr, trainable):
     with contextlib.redirect_stdout(io.StringIO()):
         t = YNetTrainer(ref_params(cfg, B, lr), device=torch.device("cpu"))
@@ -537,6 +674,8 @@ def main():
     pos5 = ["0", "1", "2", "3", "4"]
     if not ONLY or "kernels" in ONLY:
         kernel_vectors()
+    if not ONLY or "augment" in ONLY:
+        augment_case()
     make_case("tiny_short_train", O.sdd_short(train_net="train", **tiny), 32, 64, 2, seed=1)
     make_case("tiny_short_mosa1", O.sdd_short(train_net="mosa_1", position=pos5, **tiny), 32, 64, 2, seed=2)
     make_case("tiny_short_mosa4_partial", O.sdd_short(train_net="mosa_4", position=["0", "2", "4"], **tiny), 64, 32, 3, seed=3, do_eval=False)
@@ -565,6 +704,13 @@ def main():
     trained_case("trained_tiny_long", O.sdd_long(train_net="train", **tiny), 64, 64, 4, seed=31, steps=300, lr=2e-3)
     trained_case("trained_short_full", O.sdd_short(train_net="train"), 256, 256, 4, seed=32, steps=200, lr=1e-3,
                  step_cfg=O.sdd_short(train_net="mosa_1", position=pos5))
+    # multi-step training trajectories: 4 epochs x 50 steps, the learning rate x 0.1 from epoch 2 on
+    trajectory_case("trajectory_tiny_long", O.sdd_long(train_net="train", **tiny), 64, 64, 4, seed=41, epochs=4, steps_per_epoch=50, lr=2e-3,
+                    milestones=[2])
+    trajectory_case("trajectory_short_mosa1", O.sdd_short(train_net="mosa_1", position=pos5), 256, 256, 4, seed=43, epochs=4, steps_per_epoch=50,
+                    lr=1e-3, milestones=[2], lora_b_std=0.05)
+    trajectory_case("trajectory_short_full", O.sdd_short(train_net="train"), 256, 256, 4, seed=42, epochs=4, steps_per_epoch=50, lr=1e-3,
+                    milestones=[2])
     if not ONLY or "fullsize" in ONLY:
         fullsize_scalars()
 

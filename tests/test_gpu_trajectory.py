@@ -1,0 +1,92 @@
+"""A 200-step TRAINING TRAJECTORY against the reference (missing 5 / next 6).
+
+Every other parity test is <= 3 consecutive steps; bugs that need tens of steps -- a stale packed / Winograd / LoRA-composed filter
+after an Adam update, optimizer state that a graph replay does not see, a step graph captured for one learning rate and replayed for
+another -- are invisible to them.  tests/golden/trajectory_*.npz (oracle/gen_goldens.py::trajectory_case) hold what the imported
+REFERENCE did over 4 epochs x 50 Adam steps of batch 4 (models/trainer.py:197-201,222-235: Adam, MultiStepLR x 0.1 from epoch 2 on,
+utils/train_epoch.py:44-126 per step): every step's loss, every epoch's (ADE, FDE, loss) return value, a K = 20 sweep of the final
+weights with the way-points it drew -- and the same run on 3 instead of 8 intra-op threads, whose distance from the first is the
+reference's OWN fp32 noise along the trajectory.
+
+The product runs the same 200 batches through its train_epoch with the step graph on (one call per step, so that each step's loss is
+visible: the sequence per learning rate is [eager, capture + replay, replay ...], and the decay at epoch 2 makes it capture again).
+Bounds: the first 10 steps within 1e-4 relative (they are the 3-step tests' bound, extended); every step and the last one within
+max(2 %, 3 x the reference's self-noise there); each epoch's mean train ADE / FDE within max(1 %, 3 x self-noise); the sweep of the
+PRODUCT's final weights through the product's evaluate(), fed the reference's way-point draws, within 1 % of the reference's mean
+ADE / FDE."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import Golden, build_model, pkg
+from oracle import ynet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def loader_for(traj):
+    return [(traj.clone(), [pd.DataFrame({"metaId": np.arange(traj.shape[0])})], "scene0")]
+
+
+@pytest.mark.parametrize("tag", ["trajectory_tiny_long", "trajectory_short_mosa1", "trajectory_short_full"])
+def test_training_trajectory_follows_the_reference(dev, tag):
+    g = Golden(tag)
+    m, cfg = g.meta, g.cfg()
+    H, W, B = m["H"], m["W"], m["B"]
+    sd0 = O.make_state_dict(cfg, seed=m["seed"], lora_b_std=m["lora_b_std"])
+    checksum = sum(float(v.double().abs().sum()) for v in sd0.values())
+    assert abs(checksum - float(g.z["weight_checksum"])) <= 1e-9 * checksum, "the box's torch RNG differs from the fixture's: not a kernel bug"
+    scene = O.synthetic_scene(cfg, H, W, m["seed"])
+    S = cfg.template_size
+    in_t, gt_t = O.dist_template(S).to(dev), O.gaussian_template(S, cfg.kernlen, cfg.nsig).to(dev)
+    te, trn, sg, ev = pkg("utils.train_epoch"), pkg("models.trainer"), pkg("utils.step_graph"), pkg("utils.evaluate")
+    model = build_model(cfg, sd0, dev)
+    opt = torch.optim.Adam(model.parameters(), lr=m["lr"])
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=list(m["milestones"]), gamma=0.1)
+    crit = trn.HipBCEWithLogitsLoss()
+    images = {"scene0": scene[0].to(dev)}
+    trajs = g.t("traj")                                   # [epochs, steps * B, T, 2]
+    E, n = m["epochs"], m["steps_per_epoch"]
+    losses, ades, fdes, launched = [], [], [], []
+    for e in range(E):
+        assert abs(opt.param_groups[0]["lr"] - float(g.z["lr_per_epoch"][e])) <= 1e-12
+        for i in range(n):
+            a, f, l = te.train_epoch(model, loader_for(trajs[e, i * B:(i + 1) * B]), images, opt, crit, cfg.loss_scale, dev, "sdd", None,
+                                     gt_t, in_t, list(cfg.waypoints), e, cfg.obs_len, cfg.pred_len, B, 10000, cfg.resize_factor,
+                                     cfg.network, False)
+            losses.append(l)
+            ades.append(a)
+            fdes.append(f)
+        sched.step()
+        entries = [x for c in sg._caches.get(model, {}).values() for x in c.entries.values()]
+        launched.append((sum(1 for x in entries if x.ready), sum(1 for x in entries if x.failed)))
+    if sg.enabled(None, dev):
+        # one captured step per learning rate (the decay at the milestone is a new key), none failed
+        assert launched[-1] == (2, 0), launched
+    want, other = g.z["loss_per_step"], g.z["loss_per_step_other_threads"]
+    got = np.array(losses, dtype=np.float64)
+    rel = np.abs(got - want) / np.abs(want)
+    noise = np.abs(other - want) / np.abs(want)
+    assert rel[:10].max() <= 1e-4, f"first ten steps: {rel[:10]}"
+    bound = np.maximum(0.02, 3.0 * np.maximum.accumulate(noise))
+    worst = int(np.argmax(rel / bound))
+    assert (rel <= bound).all(), f"step {worst + 1}: loss {got[worst]:.4f} vs {want[worst]:.4f} ({rel[worst]:.3e} > {bound[worst]:.3e}; reference self-noise {noise[worst]:.3e})"
+    # per epoch: the loss sum and the mean train ADE / FDE the reference's train_epoch returned
+    ret, ret_o = g.z["epoch_returns"], g.z["epoch_returns_other_threads"]
+    for e in range(E):
+        sl = slice(e * n, (e + 1) * n)
+        for k, val in ((0, float(np.mean(ades[sl]))), (1, float(np.mean(fdes[sl]))), (2, float(np.sum(got[sl])))):
+            tol = max(0.01 if k < 2 else 0.02, 3.0 * abs(ret_o[e, k] - ret[e, k]) / abs(ret[e, k]))
+            assert abs(val - ret[e, k]) <= tol * abs(ret[e, k]), (e, ("ADE", "FDE", "loss")[k], val, float(ret[e, k]), tol)
+    # the sweep of the product's OWN final weights, with the reference's draws
+    wps = g.t("sweep_waypoint_samples").float()          # [K, n_eval, nwp, 2]
+    eval_traj = g.t("eval_traj")
+    ade, fde, df, _ = ev.evaluate(model, loader_for(eval_traj), images, dev, "sdd", None, in_t, list(cfg.waypoints), "test", m["n_goal"], 1,
+                                  cfg.obs_len, m["n_eval"], cfg.resize_factor, cfg.temperature, forced_samples={0: wps})
+    ref_ade, ref_fde = (float(x) for x in g.z["sweep_ade_fde"])
+    oth_ade, oth_fde = (float(x) for x in g.z["sweep_ade_fde_other_threads"])
+    assert abs(ade - ref_ade) <= max(0.01, 3.0 * abs(oth_ade - ref_ade) / ref_ade) * ref_ade, (ade, ref_ade, oth_ade)
+    assert abs(fde - ref_fde) <= max(0.01, 3.0 * abs(oth_fde - ref_fde) / ref_fde) * ref_fde, (fde, ref_fde, oth_fde)
+    print(f"[{tag}] loss deviation: first ten {rel[:10].max():.2e}, max {rel.max():.2e} (reference self-noise {noise.max():.2e}), last {rel[-1]:.2e}; "
+          f"sweep ADE {ade:.4f} vs {ref_ade:.4f}, FDE {fde:.4f} vs {ref_fde:.4f}")
