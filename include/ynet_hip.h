@@ -199,6 +199,84 @@ int ynet_upsample2x_conv2d_winograd_supported(int B, int H, int W, int cin, int 
 int ynet_upsample2x_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout, int B,
                                     int H, int W, int relu, void* stream);
 
+/* ---- ONE dispatching convolution entry (round 6) ----------------------------------------------------------------------------------
+ * ynet_conv2d_auto = nn.Conv2d(K x K, padding K / 2) [+ nn.ReLU] (models/ynet.py:150,192-211,420-451,464,467) or its data gradient
+ * (convolution_backward -> grad_input), with -- all optional -- the concatenation of its inputs (ynet.py:387,466,574), the bilinear x2 in
+ * FRONT of it (`upsample2x`: F.interpolate(scale_factor=2) + upsample_conv, ynet.py:463-464; src is the low-resolution map, H x W the
+ * up-sampled size), the MaxPool2d(2, 2) BEHIND it (`pooled`, ynet.py:202,215), the ReLU backward of the layer below a data gradient
+ * (`relu_of`, or one of the 1-bit forms), and a precomputed additive term (`addend`, utils/evaluate.py:248-283).  This is SURVEY 8(b)'s
+ * `ynet_conv2d_fwd(x, w, b, y, ..., x2, Cin2, pre_op)` / `ynet_conv2d_dgrad(dy, w, y_for_relu_mask, dx, ...)`: the caller describes the
+ * operation, the library picks the kernel family (implicit GEMM / Winograd F(2x2,3x3) / its concatenated-source, slice and up-convolution
+ * forms: every ynet_conv2d_* entry point above), splits wide layers into the launches those kernels serve, and keeps the TRANSFORMED filters
+ * in a cache the caller owns.  It is the path bench.py measures: motion-style-transfer_amd/ops.py::conv2d_raw is a thin call of it.
+ *
+ *   operands     src / dst / mask / wp / bias / workspace: as ynet_conv2d (wp = ynet_pack_weight mode 0, or mode 1 for a data gradient);
+ *                dst[i] may be NULL (those output channels are not wanted: a way-point map's gradient).
+ *   filter cache `cache`: 16-byte aligned device memory of ynet_conv2d_auto_cache_floats(desc) floats (0: this call needs none);
+ *                `cache_tag`: two 64-bit words in HOST memory, zero before the first call; `wp_version`: any number the caller changes
+ *                whenever the contents of wp change.  The transforms run on `stream` when the tag does not match (first call, new
+ *                version, or a plan that differs: another batch / raster size can choose another family); a cache belongs to ONE
+ *                (layer, direction) and one stream order -- a caller that shares it between streams orders them itself (taken->transformed
+ *                tells when a transform was enqueued).
+ *   flags        YNET_AUTO_* below: development switches that restrict the choice (results then differ by fp32 rounding only).
+ *   taken        (optional) what ran: the family, the launches with the template arguments their rocprofv3 kernel names carry, whether
+ *                the optional outputs wbits_out / pool_code were WRITTEN (they are only when the launch taken is the Winograd one they
+ *                belong to; a caller keeps them only then).
+ *   errors       non-zero + ynet_last_error(): operand combinations no kernel serves (upsample2x outside
+ *                ynet_upsample2x_conv2d_winograd_supported, addend outside ynet_conv2d_add_supported and the Winograd forms, ...). */
+#define YNET_AUTO_NO_WINOGRAD 1u        /* implicit GEMM only */
+#define YNET_AUTO_NO_WINOGRAD16 2u      /* no slice-form launches */
+#define YNET_AUTO_WINOGRAD16_FOR_16 4u  /* 16-output launches on the slice form too (measured slower) */
+#define YNET_AUTO_NO_POOL_CODE 8u       /* pool_code is never written */
+#define YNET_AUTO_NO_RELU_WBITS 16u     /* wbits_out is never written, relu_wbits never read (relu_of's float activation instead) */
+typedef struct YnetConvAuto {
+    const float* src[4];
+    int src_c[4];
+    long long src_bs[4];
+    int src_bmod[4];
+    int nsrc;
+    const float* mask;
+    long long mask_bs;
+    const float* wp;
+    const float* bias;
+    float* dst[4];
+    int dst_c[4];
+    long long dst_bs[4];
+    int ndst;
+    int B, H, W, K, relu;
+    int upsample2x;
+    const float* relu_of;
+    long long relu_of_bs;
+    float* pooled;
+    long long pooled_bs;
+    unsigned char* pool_code;
+    const float* addend;
+    long long addend_bs;
+    int addend_bmod;
+    unsigned* bits_out;
+    const unsigned* relu_bits;
+    unsigned* wbits_out;
+    const unsigned* relu_wbits;
+    float* cache;
+    long long cache_floats;
+    unsigned long long* cache_tag;
+    unsigned long long wp_version;
+    float* workspace;
+    long long workspace_floats;
+    unsigned flags;
+} YnetConvAuto;
+typedef struct YnetConvTaken {
+    int family;            /* 0 implicit GEMM (conv_mfma_kernel / conv_dma_*), 1 conv_wino_kernel, 2 conv_wino_cat_kernel, 3 conv_wino16_kernel,
+                              4 conv_wino_up_kernel, 5 conv_wino16_up_kernel */
+    int variant;           /* the dispatcher's branch (csrc/conv_auto.cpp) */
+    int nlaunch;
+    int tmpl[4][3];        /* per launch: family 1 <NCB, NCH, EM>; family 2 <2, EPI>; family 3 <EPI> */
+    int wrote_wbits, wrote_pool_code, transformed;
+} YnetConvTaken;
+long long ynet_conv2d_auto_cache_floats(const YnetConvAuto* desc);
+long long ynet_conv2d_auto_workspace_floats(const YnetConvAuto* desc);
+int ynet_conv2d_auto(const YnetConvAuto* desc, YnetConvTaken* taken, void* stream);
+
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,
  * rows, CC, mask, m16>, or with dma the LDS-DMA generation conv_dma_kernel<tiles, rows, CC, mask, x4, fold>, in a

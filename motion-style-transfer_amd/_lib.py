@@ -19,6 +19,27 @@ PP = ctypes.POINTER(ctypes.c_void_p)
 PI = ctypes.POINTER(ctypes.c_int)
 PLL = ctypes.POINTER(ctypes.c_longlong)
 
+class ConvAuto(ctypes.Structure):
+    """YnetConvAuto of include/ynet_hip.h (the descriptor of ynet_conv2d_auto)."""
+    _fields_ = [("src", c_fp * 4), ("src_c", c_i * 4), ("src_bs", c_ll * 4), ("src_bmod", c_i * 4), ("nsrc", c_i),
+                ("mask", c_fp), ("mask_bs", c_ll), ("wp", c_fp), ("bias", c_fp),
+                ("dst", c_fp * 4), ("dst_c", c_i * 4), ("dst_bs", c_ll * 4), ("ndst", c_i),
+                ("B", c_i), ("H", c_i), ("W", c_i), ("K", c_i), ("relu", c_i), ("upsample2x", c_i),
+                ("relu_of", c_fp), ("relu_of_bs", c_ll), ("pooled", c_fp), ("pooled_bs", c_ll), ("pool_code", c_fp),
+                ("addend", c_fp), ("addend_bs", c_ll), ("addend_bmod", c_i),
+                ("bits_out", c_fp), ("relu_bits", c_fp), ("wbits_out", c_fp), ("relu_wbits", c_fp),
+                ("cache", c_fp), ("cache_floats", c_ll), ("cache_tag", ctypes.POINTER(ctypes.c_ulonglong)), ("wp_version", ctypes.c_ulonglong),
+                ("workspace", c_fp), ("workspace_floats", c_ll), ("flags", ctypes.c_uint)]
+
+
+class ConvTaken(ctypes.Structure):
+    """YnetConvTaken: what ynet_conv2d_auto ran."""
+    _fields_ = [("family", c_i), ("variant", c_i), ("nlaunch", c_i), ("tmpl", (c_i * 3) * 4), ("wrote_wbits", c_i), ("wrote_pool_code", c_i),
+                ("transformed", c_i)]
+
+
+AUTO_NO_WINOGRAD, AUTO_NO_WINOGRAD16, AUTO_WINOGRAD16_FOR_16, AUTO_NO_POOL_CODE, AUTO_NO_RELU_WBITS = 1, 2, 4, 8, 16
+
 # name -> (restype, argtypes); must list every function of include/ynet_hip.h
 SIGNATURES = {
     "ynet_abi_version": (c_i, []),
@@ -57,6 +78,9 @@ SIGNATURES = {
     "ynet_winograd16_filter_floats": (c_ll, [PI, c_i, c_i]),
     "ynet_winograd16_filter": (c_i, [c_fp, c_fp, PI, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd16": (c_i, [PP, PI, PLL, c_i, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_fp, c_ll, c_i, c_fp, c_ll, c_fp]),
+    "ynet_conv2d_auto_cache_floats": (c_ll, [ctypes.POINTER(ConvAuto)]),
+    "ynet_conv2d_auto_workspace_floats": (c_ll, [ctypes.POINTER(ConvAuto)]),
+    "ynet_conv2d_auto": (c_i, [ctypes.POINTER(ConvAuto), ctypes.POINTER(ConvTaken), c_fp]),
     "ynet_conv2d_add_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_add": (c_i, [PP, PI, PLL, PI, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp]),
     "ynet_conv2d_plan": (c_i, [c_i, c_i, c_i, c_i, c_i]),
