@@ -483,8 +483,122 @@ def _pad4(c):
     return (c + 3) & ~3
 
 
+# YNET_CONV_AUTO=0: the launches of a convolution are composed HERE (_conv2d_raw_py, the round-5 dispatcher, kept as the instrumentable
+# twin: bench.py's ConvTimer brackets every launch of a call with its own HIP-event pair through it) instead of by ynet_conv2d_auto in the
+# library.  Both choose the same kernels for the same operands (tests/test_gpu_kernels.py::test_conv2d_auto_takes_the_launches_of_the_python_dispatcher).
+conv_auto = _os.environ.get("YNET_CONV_AUTO", "1") != "0"
+_AUTO_TAG_CAT = {10: ("winograd_cat:2,3", "winograd_cat:2,6|code"), 40: ("winograd_cat:2,2", "winograd_cat:2,5|wbits"), 41: ("winograd_cat:2,0", "winograd_cat:2,4|wbits"),
+                 30: ("winograd_cat:2,2", "winograd_cat:2,5|wbits")}
+
+
+def _auto_tag(tk):
+    """The tag the Python dispatcher returns for the same launches (callers and bench.py read it), from a YnetConvTaken."""
+    if tk.family == 0:
+        return None
+    if tk.family == 1:
+        return "winograd:" + "+".join("%d,%d,%d" % tuple(tk.tmpl[i]) for i in range(tk.nlaunch)) + ("|wbits" if tk.wrote_wbits else "")
+    if tk.family == 2:
+        return _AUTO_TAG_CAT[tk.variant][1 if (tk.wrote_wbits or tk.wrote_pool_code) else 0]
+    if tk.family == 3:
+        return "winograd16:" + "+".join("%d" % tk.tmpl[i][0] for i in range(tk.nlaunch))
+    return "winograd_up:%d" % tk.family
+
+
+def conv2d_auto_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
+                    relu_wbits=None, pool_code=None, addend=None, upsample2x=False, wp_version=1):
+    """ONE call of ynet_conv2d_auto (include/ynet_hip.h): the library chooses the kernel family, splits wide layers and keeps the transformed
+    filters in a cache that lives in the layer's filter cache `wino[0]` under "auto_<direction>".  Operands as conv2d_raw; addend: (ptr,
+    image_stride, modulus); upsample2x: the source is the low-resolution map (H, W are the up-sampled size).  Returns (tag, YnetConvTaken)."""
+    lib = _lib()
+    d = L.ConvAuto()
+    d.nsrc, d.ndst = len(srcs), len(dsts)
+    for i, s_ in enumerate(srcs):
+        d.src[i], d.src_c[i], d.src_bs[i] = s_[0], s_[1], s_[2]
+        d.src_bmod[i] = s_[3] if len(s_) > 3 else 0
+    for i, t_ in enumerate(dsts):
+        d.dst[i], d.dst_c[i], d.dst_bs[i] = t_[0], t_[1], t_[2]
+    if mask:
+        d.mask, d.mask_bs = mask[0], mask[1]
+    d.wp, d.bias = wp.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.B, d.H, d.W, d.K, d.relu, d.upsample2x = B, H, W, K, 1 if relu else 0, 1 if upsample2x else 0
+    if relu_of is not None:
+        d.relu_of, d.relu_of_bs = relu_of[0], relu_of[1]
+    if pooled is not None:
+        d.pooled, d.pooled_bs = pooled[0], pooled[1]
+        if pool_code is not None:
+            d.pool_code = pool_code.data_ptr()
+    if addend is not None:
+        d.addend, d.addend_bs, d.addend_bmod = addend[0], addend[1], addend[2]
+    d.bits_out, d.relu_bits = bits_out, relu_bits
+    if wbits_out is not None:
+        d.wbits_out = wbits_out.data_ptr()
+    if relu_wbits is not None:
+        d.relu_wbits = relu_wbits.data_ptr()
+    flags = 0
+    if wino is None or not _wino_allowed:
+        flags |= L.AUTO_NO_WINOGRAD
+    if not _wino16_allowed:
+        flags |= L.AUTO_NO_WINOGRAD16
+    if _wino16_for_16:
+        flags |= L.AUTO_WINOGRAD16_FOR_16
+    if not _pool_code_allowed:
+        flags |= L.AUTO_NO_POOL_CODE
+    d.flags = flags
+    ent = None
+    if wino is not None and not (flags & L.AUTO_NO_WINOGRAD):
+        cache, what = wino
+        need = lib.ynet_conv2d_auto_cache_floats(ctypes.byref(d))
+        if need < 0:
+            L.check(1, lib)
+        if need > 0:
+            key = "auto_" + what
+            ent = cache.get(key)
+            if ent is None or ent[0] is not wp or ent[1].numel() < need:
+                ent = cache[key] = [wp, torch.empty(need, device=wp.device, dtype=torch.float32), (ctypes.c_ulonglong * 2)(0, 0), None, None]
+            elif ent[4] is not None and not torch.cuda.is_current_stream_capturing():
+                # (made on another stream a few microseconds ago -- evaluate()'s two sweep streams: wait for the maker's event, as _wino_ready)
+                cur = torch.cuda.current_stream()
+                if cur.cuda_stream != ent[3] and not ent[4].query():
+                    cur.wait_event(ent[4])
+            d.cache, d.cache_floats, d.cache_tag, d.wp_version = ent[1].data_ptr(), ent[1].numel(), ent[2], int(wp_version)
+    if B * H * W <= 65536:                                       # small maps only (see ynet_conv2d_workspace_floats)
+        nws = lib.ynet_conv2d_auto_workspace_floats(ctypes.byref(d))
+        if nws > 0:
+            key = (wp.device, torch.cuda.current_stream().cuda_stream)   # grow-only scratch per stream (stream-ordered reuse)
+            ws = _conv_ws.get(key)
+            if ws is None or ws.numel() < nws:
+                ws = _conv_ws[key] = torch.empty(nws, device=wp.device, dtype=torch.float32)
+            d.workspace, d.workspace_floats = ws.data_ptr(), nws
+    tk = L.ConvTaken()
+    L.check(lib.ynet_conv2d_auto(ctypes.byref(d), ctypes.byref(tk), _stream()), lib)
+    if tk.transformed and ent is not None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        ev.record()
+        ent[3], ent[4] = torch.cuda.current_stream().cuda_stream, ev
+    if tk.family:
+        wino_stats["launches"] += tk.nlaunch
+        if tk.family in (3, 5):
+            wino_stats["launches16"] = wino_stats.get("launches16", 0) + tk.nlaunch
+    return _auto_tag(tk), tk
+
+
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
                relu_wbits=None, pool_code=None):
+    """The convolution / data-gradient launch set of one layer: srcs / dsts lists of (ptr, channels, batch_stride[, batch modulus]); the operands
+    are those of _conv2d_raw_py below (the round-5 dispatcher, whose docstring describes them and the returned tag).  Since round 6 the
+    composition happens in the library (ynet_conv2d_auto, csrc/conv_auto.cpp); this function only applies evaluate()'s development gates."""
+    if not conv_auto:
+        return _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits, wino=wino,
+                              wbits_out=wbits_out, relu_wbits=relu_wbits, pool_code=pool_code)
+    if wino is not None and not torch.is_grad_enabled() and (
+            H * W < _wino_eval_min_hw or not (_wino_plain_eval if len(srcs) == 1 and srcs[0][1] in (16, 32) else _wino_cat_eval)):
+        wino = None
+    return conv2d_auto_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits, wino=wino,
+                           wbits_out=wbits_out, relu_wbits=relu_wbits, pool_code=pool_code)[0]
+
+
+def _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
+                   relu_wbits=None, pool_code=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None.  pooled: (ptr,
     batch_stride) of a second output, the 2 x 2 max-pooled copy of the single destination (ynet_conv2d_pool), or None.

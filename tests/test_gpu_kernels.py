@@ -1841,3 +1841,210 @@ def test_conv_with_batch_shared_term(dev, Bs, times, H, W, cx, cf, cw, cout):
     close(got, want, msg="shared-term conv")
     close(got, full, rtol=2e-5, atol=1e-5, msg="vs the full conv on the same device")
     assert not ops.conv2d_add_supported(B, 8, 8, cout, 3)          # small maps keep the plain kernels
+
+
+# ---- ynet_conv2d_auto: the dispatcher inside the library (round 6) -----------------------------------------------------------------------
+AUTO_CASES = {
+    # name: (B, H, W, [source channels], [destination channels, None = not wanted], K, relu, bias, operands)
+    "plain_32_32": (8, 256, 256, [32], [32], 3, True, True, {}),
+    "plain_16_32_no_relu": (16, 128, 128, [16], [32], 3, False, True, {}),
+    "dgrad_pieces_32_16_unwanted": (8, 256, 256, [32], [32, 16, None], 3, False, False, {}),
+    "dgrad_first_unwanted": (8, 256, 256, [16], [None, 32], 3, False, False, {}),
+    "dgrad_relu_of": (8, 256, 256, [32], [32], 3, False, False, {"relu_of": True}),
+    "dgrad_relu_wbits": (8, 256, 256, [32], [32], 3, False, False, {"relu_of": True, "relu_wbits": True}),
+    "fwd_wbits_out": (8, 256, 256, [32], [32], 3, True, True, {"wbits_out": True}),
+    "cat_48": (4, 256, 256, [32, 16], [32], 3, True, True, {}),
+    "cat_49_wbits": (4, 256, 256, [32, 16, 1], [32], 3, True, True, {"wbits_out": True}),
+    "split_65": (16, 128, 128, [64, 1], [32], 3, True, True, {"wbits_out": True}),
+    "pool_code_first_layer": (4, 256, 256, [6, 8], [32], 3, True, True, {"pooled": True, "pool_code": True, "src0_shared": True}),
+    "pool_64_slice_form": (10, 64, 64, [64], [64], 3, True, True, {"pooled": True}),
+    "slice_64_64": (10, 64, 64, [64], [64], 3, True, True, {}),
+    "slice_dgrad_32_64_relu_of": (16, 128, 128, [32], [64], 3, False, False, {"relu_of": True}),
+    "slice_cat_97_64": (10, 64, 64, [32, 64, 1], [64], 3, True, True, {}),
+    "small_map_workspace": (4, 16, 16, [64], [64], 3, True, True, {}),
+    "small_map_dgrad_relu_of": (4, 32, 32, [64], [64], 3, False, False, {"relu_of": True}),
+    "predictor_1x1": (4, 64, 64, [32], [12], 1, False, True, {}),
+    "direct_bits_out": (8, 32, 32, [64], [64], 3, True, True, {"bits_out": True}),
+    "masked_input": (4, 32, 32, [64], [32, 64], 3, False, False, {"mask": True}),
+}
+
+
+@pytest.mark.parametrize("name", list(AUTO_CASES))
+def test_conv2d_auto_takes_the_launches_of_the_python_dispatcher(dev, name):
+    """the composition of a layer's launches (kernel family, destination pieces, two-launch forms, filter transforms and
+    their cache) moved from ops.conv2d_raw into the library: ynet_conv2d_auto (csrc/conv_auto.cpp).  For every operand combination the
+    model produces, the C dispatcher must take exactly the launches the round-5 Python dispatcher took -- same tag, same number of Winograd
+    launches, optional outputs written in the same cases -- and give bit-identical results (they ARE the same kernels); a second call with the
+    same cache does not transform the filter again, a new filter version does."""
+    ops, L = pkg("ops"), pkg("_lib")
+    B, H, W, cs, couts, K, relu, with_bias, opts = AUTO_CASES[name]
+    lib = ops._lib()
+    cin, sizes = sum(cs), [c if c is not None else 16 for c in couts]
+    ctot = sum(sizes)
+    xs = [rnd(1 if (i == 0 and opts.get("src0_shared")) else B, c, H, W, seed=20 + i).to(dev) for i, c in enumerate(cs)]
+    srcs = [(x.data_ptr(), c, 0 if x.shape[0] == 1 and B > 1 else c * H * W) for x, c in zip(xs, cs)]
+    dgrad = not with_bias and not relu
+    w = rnd(cin, ctot, K, K, seed=2, scale=0.2).to(dev) if dgrad else rnd(ctot, cin, K, K, seed=2, scale=0.2).to(dev)
+    wp = ops.pack_weight(w, 1 if dgrad else 0)
+    bias = rnd(ctot, seed=3).to(dev) if with_bias else None
+    act = torch.relu(rnd(B, ctot, H, W, seed=4)).to(dev) if opts.get("relu_of") else None
+    mask_t = torch.relu(rnd(B, cin, H, W, seed=6)).to(dev) if opts.get("mask") else None
+    n_words = lib.ynet_winograd_relu_bits_words(B, H, W)
+    wb_in = None
+    if opts.get("relu_wbits"):      # a mask word tensor as a forward launch leaves it
+        wb_in = torch.empty(n_words, device=dev, dtype=torch.int32)
+        y_prev = torch.empty(B, 32, H, W, device=dev)
+        ops._conv2d_raw_py([(rnd(B, 32, H, W, seed=8).to(dev).data_ptr(), 32, 32 * H * W)], None, ops.pack_weight(rnd(32, 32, 3, 3, seed=9, scale=0.2).to(dev), 0), None,
+                           [(y_prev.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True, wino=({}, "fwd"), wbits_out=wb_in)
+        act = y_prev
+
+    def run(fn, tag_only=False, cache=None):
+        outs = [torch.full((B, c, H, W), float("nan"), device=dev) for c in sizes]
+        dsts = [(t.data_ptr() if c is not None else None, t.shape[1], t.shape[1] * H * W if c is not None else 0) for t, c in zip(outs, couts)]
+        kw = {"wino": (cache if cache is not None else {}, "dgrad" if dgrad else "fwd")}
+        extra = {}
+        if act is not None:
+            kw["relu_of"] = (act.data_ptr(), ctot * H * W)
+        if wb_in is not None:
+            kw["relu_wbits"] = wb_in
+        if opts.get("wbits_out"):
+            extra["wbits"] = kw["wbits_out"] = torch.full((n_words,), -1, device=dev, dtype=torch.int32)
+        if opts.get("pooled"):
+            extra["pooled"] = torch.full((B, ctot, H // 2, W // 2), float("nan"), device=dev)
+            kw["pooled"] = (extra["pooled"].data_ptr(), ctot * (H // 2) * (W // 2))
+        if opts.get("pool_code"):
+            extra["code"] = kw["pool_code"] = torch.full((B, ctot, H // 2, W // 2), 255, device=dev, dtype=torch.uint8)
+        if opts.get("bits_out"):
+            words = lib.ynet_conv2d_relu_bits_words(B, H, W, ctot, K)
+            assert words > 0
+            extra["bits"] = torch.full((words,), -1, device=dev, dtype=torch.int32)
+            kw["bits_out"] = extra["bits"].data_ptr()
+            kw.pop("wino")
+        n0 = ops.wino_stats["launches"]
+        tag = fn(srcs, (mask_t.data_ptr(), cin * H * W) if mask_t is not None else None, wp, bias, dsts, B, H, W, K, relu, **kw)
+        return tag, ops.wino_stats["launches"] - n0, outs, extra
+
+    t_py, n_py, o_py, e_py = run(ops._conv2d_raw_py)
+    cache = {}
+    t_c, n_c, o_c, e_c = run(lambda *a, **k: ops.conv2d_auto_raw(*a, **k)[0], cache=cache)
+    assert t_c == t_py and n_c == n_py, (name, t_c, t_py, n_c, n_py)
+    for a_, b_ in zip(o_py, o_c):
+        assert torch.equal(torch.nan_to_num(a_, nan=12345.0), torch.nan_to_num(b_, nan=12345.0)), name      # (an unwanted destination stays NaN in both)
+    assert set(e_py) == set(e_c)
+    for k in e_py:
+        assert torch.equal(torch.nan_to_num(e_py[k].float(), nan=12345.0), torch.nan_to_num(e_c[k].float(), nan=12345.0)), (name, k)
+    if t_c is not None:
+        # the transformed filter is cached: the second call transforms nothing, a new version does
+        kw = {"wino": (cache, "dgrad" if dgrad else "fwd")}
+        if act is not None and wb_in is None:
+            kw["relu_of"] = (act.data_ptr(), ctot * H * W)
+        if opts.get("pooled"):
+            kw["pooled"] = (e_c["pooled"].data_ptr(), ctot * (H // 2) * (W // 2))
+        dsts = [(t.data_ptr() if c is not None else None, t.shape[1], t.shape[1] * H * W if c is not None else 0) for t, c in zip(o_c, couts)]
+        if wb_in is None and not opts.get("wbits_out") and not opts.get("pool_code"):
+            _, tk = ops.conv2d_auto_raw(srcs, None, wp, bias, dsts, B, H, W, K, relu, **kw)
+            assert tk.transformed == 0
+            _, tk = ops.conv2d_auto_raw(srcs, None, wp, bias, dsts, B, H, W, K, relu, wp_version=2, **kw)
+            assert tk.transformed == 1
+            for a_, b_ in zip(o_py, o_c):
+                assert torch.equal(torch.nan_to_num(a_, nan=12345.0), torch.nan_to_num(b_, nan=12345.0)), name
+
+
+def test_conv2d_auto_reports_what_no_kernel_serves(dev):
+    ops, L = pkg("ops"), pkg("_lib")
+    import ctypes
+    lib = ops._lib()
+    x = rnd(2, 8, 16, 16, seed=1).to(dev)
+    wp = ops.pack_weight(rnd(16, 8, 3, 3, seed=2).to(dev), 0)
+    y = torch.empty(2, 16, 32, 32, device=dev)
+    with pytest.raises(RuntimeError, match="upsample2x"):      # 8 -> 16 at 32^2 is below every up-convolution kernel's range
+        ops.conv2d_auto_raw([(x.data_ptr(), 8, 8 * 256)], None, wp, None, [(y.data_ptr(), 16, 16 * 1024)], 2, 32, 32, 3, False, wino=({}, "fwd"), upsample2x=True)
+    d = L.ConvAuto()
+    assert lib.ynet_conv2d_auto(ctypes.byref(d), None, None) != 0 and b"conv2d_auto" in lib.ynet_last_error()
+    assert lib.ynet_conv2d_auto(None, None, None) != 0
+
+
+def test_a_decoder_level_through_the_c_abi_alone(dev):
+    """A reference maintainer who binds include/ynet_hip.h with ctypes -- no ops.py -- reaches the benchmarked kernels: the last level of a decoder
+    (models/ynet.py:463-467: bilinear x2 -> upsample_conv[4] (32 -> 16, no ReLU) -> cat with the skip features -> decoder[4] = two conv + ReLU)
+    as THREE ynet_conv2d_auto calls on raw device pointers, against torch's fp64 result of the same modules, and at the Python path's speed."""
+    import ctypes
+    L = pkg("_lib")
+    lib = L.load()
+    B, H, W = 8, 256, 256
+    stream = torch.cuda.current_stream().cuda_stream
+    x_low = torch.relu(rnd(B, 32, H // 2, W // 2, seed=1)).to(dev)
+    skip = torch.relu(rnd(B, 16, H, W, seed=2)).to(dev)
+    ws = [rnd(16, 32, 3, 3, seed=3, scale=0.1).to(dev), rnd(32, 32, 3, 3, seed=4, scale=0.1).to(dev), rnd(32, 32, 3, 3, seed=5, scale=0.1).to(dev)]
+    bs = [rnd(16, seed=6).to(dev), rnd(32, seed=7).to(dev), rnd(32, seed=8).to(dev)]
+
+    def packed(w):
+        cout, cin, k, _ = w.shape
+        wp = torch.zeros(lib.ynet_packed_weight_floats(cout, cin, k, 0), device=dev)
+        L.check(lib.ynet_pack_weight(w.data_ptr(), wp.data_ptr(), cout, cin, k, 0, stream), lib)
+        return wp
+
+    wps = [packed(w) for w in ws]
+    up = torch.empty(B, 16, H, W, device=dev)
+    h1, h2 = torch.empty(B, 32, H, W, device=dev), torch.empty(B, 32, H, W, device=dev)
+    keep = []
+
+    def call(srcs, wp, bias, dst, cout, relu, upsample2x=0):
+        d = L.ConvAuto()
+        d.nsrc, d.ndst = len(srcs), 1
+        for i, (t, c) in enumerate(srcs):
+            d.src[i], d.src_c[i], d.src_bs[i] = t.data_ptr(), c, t.stride(0)
+        d.wp, d.bias = wp.data_ptr(), bias.data_ptr()
+        d.dst[0], d.dst_c[0], d.dst_bs[0] = dst.data_ptr(), cout, dst.stride(0)
+        d.B, d.H, d.W, d.K, d.relu, d.upsample2x = B, H, W, 3, relu, upsample2x
+        need = lib.ynet_conv2d_auto_cache_floats(ctypes.byref(d))
+        assert need > 0
+        cache, tag = torch.empty(need, device=dev), (ctypes.c_ulonglong * 2)(0, 0)
+        d.cache, d.cache_floats, d.cache_tag, d.wp_version = cache.data_ptr(), need, tag, 1
+        keep.append((cache, tag))
+        return d
+
+    descs = [call([(x_low, 32)], wps[0], bs[0], up, 16, 0, upsample2x=1), call([(up, 16), (skip, 16)], wps[1], bs[1], h1, 32, 1), call([(h1, 32)], wps[2], bs[2], h2, 32, 1)]
+    taken = [L.ConvTaken() for _ in descs]
+
+    def level():
+        for d, tk in zip(descs, taken):
+            L.check(lib.ynet_conv2d_auto(ctypes.byref(d), ctypes.byref(tk), stream), lib)
+
+    level()
+    assert [tk.family for tk in taken] == [4, 2, 1] and [tk.transformed for tk in taken] == [1, 1, 1]
+    ref = F.interpolate(x_low.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    ref = F.conv2d(ref, ws[0].double(), bs[0].double(), padding=1)
+    ref = torch.relu(F.conv2d(torch.cat([ref, skip.double()], 1), ws[1].double(), bs[1].double(), padding=1))
+    ref = torch.relu(F.conv2d(ref, ws[2].double(), bs[2].double(), padding=1))
+    close(h2, ref, rtol=1e-5, scale_rel=3e-6, msg="decoder level through ynet_conv2d_auto vs torch fp64")
+    level()
+    assert [tk.transformed for tk in taken] == [0, 0, 0]
+
+    # the same level through the package's Python path (ops.upsample2x_conv2d_raw / conv2d_raw): the same kernels, the same speed
+    ops = pkg("ops")
+    cache_py = [{}, {}, {}]
+    u0 = ops.winograd_filter(wps[0], 32, 16, 0, 16)
+
+    def level_py():
+        ops.upsample2x_conv2d_raw((x_low.data_ptr(), x_low.stride(0)), u0, bs[0], (up.data_ptr(), up.stride(0)), 32, 16, B, H, W)
+        ops.conv2d_raw([(up.data_ptr(), 16, up.stride(0)), (skip.data_ptr(), 16, skip.stride(0))], None, wps[1], bs[1], [(h1.data_ptr(), 32, h1.stride(0))], B, H, W, 3, True,
+                       wino=(cache_py[1], "fwd"))
+        ops.conv2d_raw([(h1.data_ptr(), 32, h1.stride(0))], None, wps[2], bs[2], [(h2.data_ptr(), 32, h2.stride(0))], B, H, W, 3, True, wino=(cache_py[2], "fwd"))
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    h2_c = h2.clone()
+    level_py()
+    assert torch.equal(h2, h2_c)
+    t_c, t_py = min(timed(level) for _ in range(3)), min(timed(level_py) for _ in range(3))
+    assert abs(t_c - t_py) <= 0.03 * t_py + 0.005, (t_c, t_py)
