@@ -276,6 +276,10 @@ typedef struct YnetConvTaken {
 long long ynet_conv2d_auto_cache_floats(const YnetConvAuto* desc);
 long long ynet_conv2d_auto_workspace_floats(const YnetConvAuto* desc);
 int ynet_conv2d_auto(const YnetConvAuto* desc, YnetConvTaken* taken, void* stream);
+/* The choice ynet_conv2d_auto WOULD make for this descriptor (family, variant, number of launches), without launching anything: pointers are
+ * looked at for their alignment and for NULL only.  A caller that must decide earlier what a later call will do -- the forward pass of a
+ * conv -> ReLU -> conv chain leaves the mask in the layout of the kernel family that will write the data gradient -- asks the dispatcher itself. */
+int ynet_conv2d_auto_plan(const YnetConvAuto* desc, YnetConvTaken* taken);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ynet_conv2d_auto_cache_floats": (c_ll, [ctypes.POINTER(ConvAuto)]),
     "ynet_conv2d_auto_workspace_floats": (c_ll, [ctypes.POINTER(ConvAuto)]),
     "ynet_conv2d_auto": (c_i, [ctypes.POINTER(ConvAuto), ctypes.POINTER(ConvTaken), c_fp]),
+    "ynet_conv2d_auto_plan": (c_i, [ctypes.POINTER(ConvAuto), ctypes.POINTER(ConvTaken)]),
     "ynet_conv2d_add_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_add": (c_i, [PP, PI, PLL, PI, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_ll, c_i, c_fp]),
     "ynet_conv2d_plan": (c_i, [c_i, c_i, c_i, c_i, c_i]),

@@ -336,6 +336,18 @@ long long ynet_conv2d_auto_workspace_floats(const YnetConvAuto* a) {
     return ynet_conv2d_workspace_floats(a->B, a->H, a->W, ctot);
 }
 
+int ynet_conv2d_auto_plan(const YnetConvAuto* a, YnetConvTaken* taken) {
+    YNET_REQUIRE(a != nullptr && taken != nullptr, "conv2d_auto_plan: null pointer");
+    YNET_REQUIRE(a->nsrc >= 1 && a->nsrc <= 4 && a->ndst >= 1 && a->ndst <= 4, "conv2d_auto_plan: 1..4 sources and destinations are required");
+    Plan p;
+    if (int rc = make_plan(a, p)) return rc;
+    memset(taken, 0, sizeof(*taken));
+    taken->family = p.family;
+    taken->variant = p.variant;
+    taken->nlaunch = p.family ? (p.npieces > 0 ? p.npieces : (p.nl > 0 ? p.nl : 1)) : 1;
+    return 0;
+}
+
 int ynet_conv2d_auto(const YnetConvAuto* a, YnetConvTaken* taken, void* stream) {
     YNET_REQUIRE(a != nullptr, "conv2d_auto: null descriptor");
     YNET_REQUIRE(a->nsrc >= 1 && a->nsrc <= 4 && a->ndst >= 1 && a->ndst <= 4 && a->wp, "conv2d_auto: 1..4 sources, 1..4 destinations and a packed filter are required");

@@ -582,6 +582,31 @@ def conv2d_auto_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, 
     return _auto_tag(tk), tk
 
 
+_dgrad_family_memo = {}
+
+
+def dgrad_relu_family(B, H, W, dy_c, dx_c, K=3):
+    """The kernel family (YnetConvTaken.family: 0 implicit GEMM, 1 conv_wino_kernel, 3 conv_wino16_kernel) that will write the data gradient
+    [B, dx_c, H, W] of a dy_c-channel gradient THROUGH the ReLU backward of the layer below -- asked of the dispatcher itself
+    (ynet_conv2d_auto_plan with the operands of that launch: one aligned source, one aligned destination, relu_of), so that the forward pass of
+    a conv -> ReLU -> conv chain and the backward pass agree with the launch that is finally taken."""
+    key = (B, H, W, dy_c, dx_c, K, _wino_allowed, _wino16_allowed, _wino16_for_16)
+    fam = _dgrad_family_memo.get(key)
+    if fam is None:
+        d, tk = L.ConvAuto(), L.ConvTaken()
+        d.nsrc = d.ndst = 1
+        d.src[0], d.src_c[0], d.src_bs[0] = 256, dy_c, dy_c * H * W          # (alignment stand-ins: the callers check the real tensors)
+        d.dst[0], d.dst_c[0], d.dst_bs[0] = 256, dx_c, dx_c * H * W
+        d.relu_of, d.relu_of_bs = 256, dx_c * H * W
+        d.wp = 256
+        d.B, d.H, d.W, d.K = B, H, W, K
+        d.flags = (0 if _wino_allowed else L.AUTO_NO_WINOGRAD) | (0 if _wino16_allowed else L.AUTO_NO_WINOGRAD16) | (L.AUTO_WINOGRAD16_FOR_16 if _wino16_for_16 else 0)
+        lib = _lib()
+        L.check(lib.ynet_conv2d_auto_plan(ctypes.byref(d), ctypes.byref(tk)), lib)
+        fam = _dgrad_family_memo[key] = int(tk.family)
+    return fam
+
+
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
                relu_wbits=None, pool_code=None):
     """The convolution / data-gradient launch set of one layer: srcs / dsts lists of (ptr, channels, batch_stride[, batch modulus]); the operands
@@ -1082,6 +1107,7 @@ class fold_skip_gradients:
         join_wgrad_branch()
         _relu_outputs.clear()
         _premasked.clear()
+        _blob_targets.clear()      # (holds the positions and the template of every Gaussian target of the step: nothing of a finished step stays alive)
         # gradients handed over to a pool whose backward never ran (an exception, a pruned graph) must not linger
         for k in [k for k, e in _skip_registry.items() if e.consumed or e.ref() is None or e.stash]:
             del _skip_registry[k]
@@ -1143,9 +1169,9 @@ class _Conv2dFn(torch.autograd.Function):
             # the next module is MaxPool2d(2, 2): its output comes out of this launch's epilogue (see _MaxPool2Fn.forward)
             pooled = torch.empty((B, cout, H // 2, W // 2), device=weight.device, dtype=torch.float32)
         bits = None
-        consumer_wino = (isinstance(meta.get("bits"), int) and not isinstance(meta.get("bits"), bool) and meta.get("wino") and _wino_allowed and k == 3
-                         and ((cout in (16, 32) and bool(_lib().ynet_conv2d_winograd_supported(B, H, W, int(meta["bits"]), cout, k)))
-                              or _wino16_supported([int(meta["bits"])], cout, B, H, W, k)))
+        # (will the consumer's data gradient -- meta["bits"] = its output channels -- be a Winograd launch?  The dispatcher that will take it answers)
+        consumer_wino = (isinstance(meta.get("bits"), int) and not isinstance(meta.get("bits"), bool) and bool(meta.get("wino")) and _wino_allowed and k == 3
+                         and dgrad_relu_family(B, H, W, int(meta["bits"]), cout, k) != 0)
         if (meta.get("bits") and not consumer_wino and relu and premask and _relu_bits_allowed and pooled is None and not meta.get("repeat")
                 and all(d[0] % 16 == 0 and d[2] % 4 == 0 for d in descs)):
             # the next conv of a conv -> ReLU -> conv chain will write its data gradient THROUGH this ReLU's backward: leave it the
@@ -1242,9 +1268,8 @@ class _Conv2dFn(torch.autograd.Function):
                     ebits = e0[2]          # (written by s0's own forward launch, for exactly this tiling)
             # (where the Winograd generation serves the launch it applies the float mask itself -- faster than the implicit GEMM with
             #  the 1-bit mask, whose layout belongs to that kernel's tiles)
-            wino_em = (emask is not None and mask is None and meta.get("wino") and _wino_allowed and k == 3 and dy.data_ptr() % 16 == 0
-                       and d_srcs[0].data_ptr() % 8 == 0 and (_lib().ynet_conv2d_winograd_supported(B, H, W, cout, int(s0.shape[1]), int(k))
-                                                               or _wino16_supported([cout], int(s0.shape[1]), B, H, W, int(k))))
+            wino_em = (emask is not None and mask is None and bool(meta.get("wino")) and _wino_allowed and k == 3 and dy.data_ptr() % 16 == 0
+                       and d_srcs[0].data_ptr() % 8 == 0 and s0.data_ptr() % 8 == 0 and dgrad_relu_family(B, H, W, cout, int(s0.shape[1]), int(k)) != 0)
             ewbits = None
             if wino_em and _wino_relu_bits_allowed and int(s0.shape[1]) == 32:
                 e0 = _relu_outputs.get(s0.data_ptr())

@@ -208,6 +208,31 @@ int main() {
     EXPECT_REJECT(ynet_cws_prior(cfp, 4, 1, cfp, cfp, 1, 2, 2, 0.f, 1.f, 0, fp, fp, nullptr));
     EXPECT_REJECT(ynet_resize_nearest(nullptr, (int*)dummy, 4, 4, 2, 2, 0.5, 0.5, nullptr));
     EXPECT_REJECT(ynet_resize_nearest((const int*)dummy, (int*)dummy, 4, 4, 2, 2, 0.0, 0.5, nullptr));      // factor 0
+    EXPECT_REJECT(ynet_rot90_flip(nullptr, dummy, 1, 4, 4, 1, 0, nullptr));
+    EXPECT_REJECT(ynet_rot90_flip(dummy, dummy, 1, 4, 4, 1, 0, nullptr));      // in place
+    EXPECT_REJECT(ynet_rot_coords(nullptr, 4, 0, 0, 1, 0, 0, 1, 0, 0, nullptr));
+    {   // ynet_conv2d_auto: the host half -- descriptor checks, the plan, the cache size -- without a launch
+        EXPECT_REJECT(ynet_conv2d_auto(nullptr, nullptr, nullptr));
+        YnetConvAuto d;
+        memset(&d, 0, sizeof(d));
+        EXPECT_REJECT(ynet_conv2d_auto(&d, nullptr, nullptr));                   // no sources / filter
+        d.nsrc = 1; d.ndst = 1; d.src[0] = cfp; d.src_c[0] = 32; d.src_bs[0] = 32ll * 256 * 256; d.wp = cfp;
+        d.dst[0] = fp; d.dst_c[0] = 32; d.dst_bs[0] = 32ll * 256 * 256; d.B = 8; d.H = 256; d.W = 256; d.K = 3; d.relu = 1;
+        const long long need = ynet_conv2d_auto_cache_floats(&d);
+        if (need != ynet_winograd_filter_floats(32, 32)) { fprintf(stderr, "conv2d_auto cache floats %lld\n", need); ++failures; }
+        EXPECT_REJECT(ynet_conv2d_auto(&d, nullptr, nullptr));                   // a Winograd plan without a cache
+        d.flags = YNET_AUTO_NO_WINOGRAD;
+        if (ynet_conv2d_auto_cache_floats(&d) != 0) { fprintf(stderr, "conv2d_auto: implicit GEMM needs no cache\n"); ++failures; }
+        d.flags = 0; d.K = 4;
+        EXPECT_REJECT(ynet_conv2d_auto(&d, nullptr, nullptr));                   // K
+        d.K = 3; d.upsample2x = 1; d.src_c[0] = 8; d.H = 32; d.W = 32;
+        EXPECT_REJECT(ynet_conv2d_auto(&d, nullptr, nullptr));                   // no up-convolution kernel serves 8 channels at 32^2
+        d.upsample2x = 0; d.H = 256; d.W = 256; d.src_c[0] = 32; d.addend = cfp; d.pooled = fp;
+        EXPECT_REJECT(ynet_conv2d_auto(&d, nullptr, nullptr));                   // addend + pooled
+        d.addend = nullptr; d.dst_c[0] = 64; d.dst_bs[0] = 64ll * 256 * 256; d.pooled = nullptr;
+        if (ynet_conv2d_auto_cache_floats(&d) <= 0) { fprintf(stderr, "conv2d_auto: 32 -> 64 at 256^2 is a Winograd plan\n"); ++failures; }
+        if (ynet_conv2d_auto_workspace_floats(&d) != 0) { fprintf(stderr, "conv2d_auto: no workspace for a large map\n"); ++failures; }
+    }
     void* comm = nullptr;
     EXPECT_REJECT(ynet_comm_create(3, 2, 16, &comm));
     EXPECT_REJECT(ynet_comm_create(0, 99, 16, &comm));
