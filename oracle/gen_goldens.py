@@ -485,7 +485,7 @@ class RecordingBCE(torch.nn.Module):
         return v
 
 
-def trajectory_case(tag, cfg, H, W, B, seed, epochs, steps_per_epoch, lr, milestones, lora_b_std=0.0, n_eval=32, n_goal=20):
+def trajectory_case(tag, cfg, H, W, B, seed, epochs, steps_per_epoch, lr, milestones, lora_b_std=0.0, n_eval=32, n_goal=20, init_from=None):
     """a multi-step TRAINING TRAJECTORY of the reference (every other fixture is <= 3 consecutive steps).
     The reference's own loop (models/trainer.py:222-235: per epoch train_epoch(...), then lr_scheduler.step(); Adam + MultiStepLR
     as models/trainer.py:197-201) runs `epochs` epochs of `steps_per_epoch` steps of batch B; stored: every step's loss
@@ -500,6 +500,13 @@ def trajectory_case(tag, cfg, H, W, B, seed, epochs, steps_per_epoch, lr, milest
     n_steps = epochs * steps_per_epoch
     print(f"[{tag}] {epochs} x {steps_per_epoch} reference Adam steps of batch {B} at {H}x{W}, lr {lr}, milestones {milestones}")
     sd0 = O.make_state_dict(cfg, seed=seed, lora_b_std=lora_b_std)
+    if init_from is not None:
+        # start from the weights of another fixture (trained_short_full: 200 reference Adam steps from scratch): the run then is a smooth
+        # continuation -- a from-scratch run at lr 1e-3 oscillates in its first dozen steps and amplifies every rounding difference
+        z0 = np.load(os.path.join(OUT, init_from + ".npz"), allow_pickle=False)
+        for k in sd0:
+            sd0[k] = torch.from_numpy(np.array(z0["sd/" + k]))
+        seed = int(eval(str(z0["meta"]))["seed"])            # (the scene those weights were trained on)
     names = O.trainable_names(cfg, sd0)
     scene = O.synthetic_scene(cfg, H, W, seed)
     images = {"scene0": scene[0].clone()}
@@ -544,7 +551,7 @@ def trajectory_case(tag, cfg, H, W, B, seed, epochs, steps_per_epoch, lr, milest
     meta = dict(obs_len=cfg.obs_len, pred_len=cfg.pred_len, waypoints=list(cfg.waypoints), enc=list(cfg.enc), dec=list(cfg.dec),
                 network=cfg.network, n_fusion=cfg.n_fusion or 0, train_net=cfg.train_net, position=list(cfg.position),
                 resize_factor=cfg.resize_factor, temperature=cfg.temperature, loss_scale=cfg.loss_scale, H=H, W=W, B=B, seed=seed, lr=lr,
-                epochs=epochs, steps_per_epoch=steps_per_epoch, milestones=list(milestones), lora_b_std=lora_b_std, n_eval=n_eval,
+                epochs=epochs, steps_per_epoch=steps_per_epoch, milestones=list(milestones), lora_b_std=lora_b_std, n_eval=n_eval, init_from=init_from or "",
                 n_goal=n_goal, lora_source="oracle/_stubs/loralib (restated 0.1.1, PARITY UNPINNED)")
     store = {"meta": np.array(repr(meta)),
              "weight_checksum": np.array(sum(float(v.double().abs().sum()) for v in sd0.values())),
@@ -711,6 +718,8 @@ def main():
                     lr=1e-3, milestones=[2], lora_b_std=0.05)
     trajectory_case("trajectory_short_full", O.sdd_short(train_net="train"), 256, 256, 4, seed=42, epochs=4, steps_per_epoch=50, lr=1e-3,
                     milestones=[2])
+    trajectory_case("trajectory_short_full_continued", O.sdd_short(train_net="train"), 256, 256, 4, seed=44, epochs=4, steps_per_epoch=50, lr=1e-4,
+                    milestones=[2], init_from="trained_short_full")
     if not ONLY or "fullsize" in ONLY:
         fullsize_scalars()
 

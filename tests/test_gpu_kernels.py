@@ -2052,19 +2052,22 @@ def test_a_decoder_level_through_the_c_abi_alone(dev):
     assert abs(t_c - t_py) <= 0.03 * t_py + 0.005, (t_c, t_py, rounds)
 
 
-@pytest.mark.parametrize("case", [(16, 128, 128, [16, 1], 32, 4), (20, 64, 64, [32, 1], 64, 10), (8, 32, 32, [64, 1], 64, 4)], ids=str)
+@pytest.mark.parametrize("case", [(16, 128, 128, [16, 1], 32, 4, 2), (20, 64, 64, [32, 1], 64, 10, 3), (16, 128, 128, [16, 1], 32, 4, 0)], ids=str)
 def test_conv2d_auto_with_an_additive_term(dev, case):
     """ynet_conv2d_auto's `addend` operand (the shared skip term of utils/evaluate.py:248-283: y = relu(conv(cat(rest)) + bias + term[b % modulus])) on its three
     routes -- the concatenated-source Winograd launch, the slice form, the implicit GEMM -- against torch in fp64."""
     ops = pkg("ops")
-    B, H, W, cs, cout, mod = case
+    B, H, W, cs, cout, mod, family = case
     xs = [rnd(B, c, H, W, seed=30 + i).to(dev) for i, c in enumerate(cs)]
     w, bias = rnd(cout, sum(cs), 3, 3, seed=2, scale=0.2).to(dev), rnd(cout, seed=3).to(dev)
     term = rnd(mod, cout, H, W, seed=4).to(dev)
     y = torch.full((B, cout, H, W), float("nan"), device=dev)
     tag, tk = ops.conv2d_auto_raw([(x.data_ptr(), c, c * H * W) for x, c in zip(xs, cs)], None, ops.pack_weight(w, 0), bias, [(y.data_ptr(), cout, cout * H * W)], B, H, W, 3, True,
-                                  wino=({}, "fwd"), addend=(term.data_ptr(), cout * H * W, mod))
-    assert tk.family == {128: 2, 64: 3, 32: 0}[H], (tag, tk.family)
+                                  wino=({}, "fwd") if family else None, addend=(term.data_ptr(), cout * H * W, mod))
+    assert tk.family == family, (tag, tk.family)
+    with pytest.raises(RuntimeError, match="additive term is not served"):      # (the implicit GEMM takes an additive term on its large-map tiles only)
+        ops.conv2d_auto_raw([(xs[0].data_ptr(), cs[0], cs[0] * 1024)], None, ops.pack_weight(w, 0), bias, [(y.data_ptr(), cout, cout * 1024)], 2, 32, 32, 3, True,
+                            addend=(term.data_ptr(), cout * 1024, 1))
     ref = torch.relu(F.conv2d(torch.cat(xs, 1).double(), w.double(), bias.double(), padding=1) + term.double().repeat(B // mod + 1, 1, 1, 1)[:B])
     close(y, ref, rtol=1e-5, scale_rel=3e-6, msg="conv + additive term")
 
