@@ -804,7 +804,7 @@ def main():
                            "direct_equiv_note": "SURVEY 8d's algorithmic work (2 * 9 * Cin * Cout per pixel, what the reference computes) over the same time: "
                                                 "above 1.0 of the peak is the algorithmic saving of the Winograd form, not a roofline fraction",
                            "traffic_source": None if traffic is None else
-                           f"{traffic_src} (2 x FETCH_SIZE + WRITE_SIZE of this launch shape, rocprofv3 --pmc passes of this command on an earlier run "
+                           f"{traffic_src} (FETCH_SIZE, doubled for the 16-byte LDS-DMA kernels, + WRITE_SIZE of this launch shape, rocprofv3 --pmc passes of this command on an earlier run "
                            "of the same build; NOT measured in this run)",
                            "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                            "event_pair_floor_us": floor_us,
@@ -812,9 +812,9 @@ def main():
                            "algorithmic_mb_per_launch": dom["algorithmic_mb_per_launch"], "algorithmic_hbm_gbs": dom["algorithmic_hbm_gbs"],
                            "hbm_frac": dom["hbm_frac"],
                            "top_shapes": top,
-                           "profile": "profiles/r05_conv_shapes_C2.json: every launch shape of one step with rocprofv3's kernel-only duration "
+                           "profile": (traffic_src or "profiles/r06_conv_shapes_C2.json") + ": every launch shape of one step with rocprofv3's kernel-only duration "
                                       "(--kernel-trace of this command with YNET_STEP_GRAPH=0 YNET_SERIAL_DECODERS=1), its executed FLOPs and counter "
-                                      "traffic; profiles/r05_bench_C2_serial_kernel_stats.csv is the --stats table of the same trace",
+                                      "traffic; the *_bench_C2_serial_kernel_stats.csv of the same round is the --stats table of the same trace",
                            "note": "per-launch HIP-event timing of 3 instrumented EAGER steps on one stream, run before the warm-up of the timed "
                                    "region; a HIP-event pair also reads the marker / dispatch latency around the kernel (`event_pair_floor_us` "
                                    "around a 1-element fill), so `avg_launch_us` sits that much above rocprofv3's kernel-only duration and "
