@@ -157,6 +157,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: it brings its own HIP runtime (torch/lib/libamdhip64.so); a library loaded before it binds the system's one, and a process with two
+    # HIP runtimes launches this library's kernels on a runtime that never saw torch's device ("no ROCm-capable device is detected" -- found by
+    # running __graft_entry__.build() and smoke() in one process).  Loaded after torch the dependency resolves to the runtime already in the process.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension is not built and there is no fallback path. "
