@@ -363,6 +363,23 @@ int ynet_upsample2x_bwd_relu(const float* dy, float* dx, const float* relu_of, l
  * outs[i-1] receives level i; H, W multiples of 32. */
 int ynet_avgpool_pyramid(const float* x, float* const* outs, int nlev, long long N, int H, int W, void* stream);
 
+/* ---- the serial adapters' element-wise tail (round 6; SURVEY 8(f)-2, outside every BASELINE configuration) ------------------------------ */
+/* nn.BatchNorm2d of AdapterBlock / AdapterLayer.serial_layer[0] (models/ynet.py:24-26,64-66): F.batch_norm's rule on x [B][C][HW] contiguous.
+ * train != 0: batch statistics (biased variance for the normalisation; running_mean / running_var, if given, move by `momentum` towards the batch
+ * mean / the UNBIASED batch variance); train == 0: the running statistics.  save_mean / save_invstd [C] are written either way (what the backward
+ * needs; in evaluation mode save_mean is not written: pass running_mean to the backward).  gamma / beta may be NULL (affine = False).  Sums are
+ * fp64 over 64 fixed slices per channel: bitwise reproducible.  workspace: ynet_batchnorm_workspace_doubles(C) doubles. */
+long long ynet_batchnorm_workspace_doubles(int C);
+int ynet_batchnorm2d_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                         double* workspace, int B, int C, long long HW, int train, double momentum, double eps, void* stream);
+/* native_batch_norm_backward: dgamma = sum dy * xhat, dbeta = sum dy (either may be NULL), dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)) in
+ * training mode, dy * gamma * invstd in evaluation mode (mean = the running mean then). */
+int ynet_batchnorm2d_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta, double* workspace,
+                         int B, int C, long long HW, int train, void* stream);
+/* y = [relu](a + b): the adapters' residual add and the ReLU behind it (models/ynet.py:66,117-131); dx = y > 0 ? dy : 0 for both addends. */
+int ynet_add_relu(const float* a, const float* b, float* y, long long n, int relu, void* stream);
+int ynet_relu_bwd(const float* dy, const float* y, float* dx, long long n, void* stream);
+
 /* ---- loss ----------------------------------------------------------------------------------- */
 /* nn.BCEWithLogitsLoss() (models/trainer.py:206; utils/train_epoch.py:94,106): loss[0] = mean.
  * workspace: ynet_bce_workspace_bytes() bytes.  bwd: dx = (sigmoid(x) - t) * grad_out[0] / n. */

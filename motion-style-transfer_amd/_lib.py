@@ -124,6 +124,11 @@ SIGNATURES = {
     "ynet_pad2d": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_seg_onehot_pad": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_resize_nearest": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, ctypes.c_double, ctypes.c_double, c_fp]),
+    "ynet_batchnorm_workspace_doubles": (c_ll, [c_i]),
+    "ynet_batchnorm2d_fwd": (c_i, [c_fp] * 9 + [c_i, c_i, c_ll, c_i, ctypes.c_double, ctypes.c_double, c_fp]),
+    "ynet_batchnorm2d_bwd": (c_i, [c_fp] * 9 + [c_i, c_i, c_ll, c_i, c_fp]),
+    "ynet_add_relu": (c_i, [c_fp, c_fp, c_fp, c_ll, c_i, c_fp]),
+    "ynet_relu_bwd": (c_i, [c_fp, c_fp, c_fp, c_ll, c_fp]),
     "ynet_rot90_flip": (c_i, [c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_rot_coords": (c_i, [c_fp, c_ll] + [ctypes.c_double] * 8 + [c_fp]),
     "ynet_sigmoid_temp": (c_i, [c_fp, c_fp, c_ll, c_i, c_ll, PI, c_i, c_f, c_fp]),

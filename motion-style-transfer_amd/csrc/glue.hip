@@ -1328,6 +1328,111 @@ __global__ __launch_bounds__(256) void rot_coords_kernel(double* __restrict__ xy
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The serial adapters' element-wise tail (models/ynet.py:24-26,64-66,117-131: nn.BatchNorm2d in front of the adapter's 1x1 conv, the residual add,
+// the ReLU behind the sum) -- SURVEY 8(f)-2, outside every BASELINE configuration; round 6 moves them off ATen.
+//   bn_reduce_kernel   per channel the sums a training-mode BatchNorm2d needs, over B x HW elements, as fp64 partials of 64 fixed slices per
+//                      channel (bitwise reproducible): MODE 0 (sum x, sum x^2), MODE 1 (sum dy, sum dy * xhat)
+//   bn_finish_kernel   mean, 1 / sqrt(var + eps) and the running statistics (momentum, unbiased variance) from the partials: F.batch_norm's rule
+//   bn_apply_kernel    y = (x - mean) * invstd * gamma + beta
+//   bn_bwd_kernel      training: dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)); evaluation: dx = dy * gamma * invstd
+//   add_relu_kernel / relu_bwd_kernel   y = [relu](a + b); dx = y > 0 ? dy : 0
+// ------------------------------------------------------------------------------------------------
+#define BN_PARTS 64
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, double* __restrict__ partial, int B, int C, long long HW) {
+    __shared__ double w0[4], w1[4];
+    const int c = blockIdx.x / BN_PARTS, part = blockIdx.x % BN_PARTS;
+    const long long per = ((long long)B * HW + BN_PARTS - 1) / BN_PARTS, lo = part * per, hi = min(lo + per, (long long)B * HW);
+    const float m = MODE == 1 ? mean[c] : 0.f, is = MODE == 1 ? invstd[c] : 0.f;
+    double s0 = 0.0, s1 = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const long long b = i / HW, p = i - b * HW;
+        const float xv = x[(b * C + c) * HW + p];
+        if (MODE == 0) {
+            s0 += (double)xv;
+            s1 += (double)xv * (double)xv;
+        } else {
+            const float g = dy[(b * C + c) * HW + p];
+            s0 += (double)g;
+            s1 += (double)g * (double)((xv - m) * is);
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) { w0[threadIdx.x >> 6] = s0; w1[threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (w0[0] + w0[1]) + (w0[2] + w0[3]);
+        partial[2 * blockIdx.x + 1] = (w1[0] + w1[1]) + (w1[2] + w1[3]);
+    }
+}
+
+__global__ void bn_finish_kernel(const double* __restrict__ partial, float* mean, float* invstd, float* running_mean, float* running_var, int C, double n, double eps,
+                                 double momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int p = 0; p < BN_PARTS; ++p) { s0 += partial[2 * (c * BN_PARTS + p)]; s1 += partial[2 * (c * BN_PARTS + p) + 1]; }
+    const double m = s0 / n;
+    double var = s1 / n - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + eps));
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+    if (running_var) running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * (n > 1.0 ? var * n / (n - 1.0) : var));
+}
+
+__global__ void bn_invstd_kernel(const float* __restrict__ running_var, float* invstd, int C, double eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = (float)(1.0 / sqrt((double)running_var[c] + eps));
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, long long planes, int C,
+                                                       long long HW) {
+    const long long plane = blockIdx.y;
+    if (plane >= planes) return;
+    const int c = (int)(plane % C);
+    const float m = mean[c], sc = invstd[c] * (gamma ? gamma[c] : 1.f), sh = beta ? beta[c] : 0.f;
+    for (long long p = blockIdx.x * 256ll + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) y[plane * HW + p] = (x[plane * HW + p] - m) * sc + sh;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const double* __restrict__ partial, float* __restrict__ dx, float* dgamma, float* dbeta,
+                                                     long long planes, int C, long long HW, double n, int train) {
+    const long long plane = blockIdx.y;
+    if (plane >= planes) return;
+    const int c = (int)(plane % C);
+    double s0 = 0.0, s1 = 0.0;
+    if (partial) {
+        for (int p = 0; p < BN_PARTS; ++p) { s0 += partial[2 * (c * BN_PARTS + p)]; s1 += partial[2 * (c * BN_PARTS + p) + 1]; }
+        if (plane < C && blockIdx.x == 0 && threadIdx.x == 0) {
+            if (dgamma) dgamma[c] = (float)s1;
+            if (dbeta) dbeta[c] = (float)s0;
+        }
+    }
+    const float m = mean[c], is = invstd[c], g = (gamma ? gamma[c] : 1.f) * is;
+    const float mdy = train ? (float)(s0 / n) : 0.f, mdx = train ? (float)(s1 / n) : 0.f;
+    for (long long p = blockIdx.x * 256ll + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+        const float gy = dy[plane * HW + p];
+        dx[plane * HW + p] = train ? g * (gy - mdy - (x[plane * HW + p] - m) * is * mdx) : g * gy;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long n, int relu) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = a[i] + b[i];
+        y[i] = relu ? (v < 0.f ? 0.f : v) : v;      // (a NaN stays a NaN, as torch.relu)
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
 extern "C" {
 
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
@@ -1675,6 +1780,52 @@ int ynet_resize_nearest(const int* labels, int* out, int H, int W, int Ho, int W
     hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for((long long)Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream,
                        labels, out, H, W, Ho, Wo, 1.0 / fx, 1.0 / fy);
     return ynet_check_launch("resize_nearest");
+}
+
+long long ynet_batchnorm_workspace_doubles(int C) { return C > 0 ? 2ll * C * BN_PARTS : 0; }
+
+static inline dim3 bn_plane_grid(long long planes, long long HW) {
+    long long gx = (HW + 1023) / 1024;
+    return dim3((unsigned)(gx < 1 ? 1 : (gx > 64 ? 64 : gx)), (unsigned)planes);
+}
+
+int ynet_batchnorm2d_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                         double* workspace, int B, int C, long long HW, int train, double momentum, double eps, void* stream) {
+    YNET_REQUIRE(x && y && save_mean && save_invstd && B > 0 && C > 0 && HW > 0 && (long long)B * C < 65536, "batchnorm2d_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (train) {
+        YNET_REQUIRE(workspace != nullptr, "batchnorm2d_fwd: training mode needs ynet_batchnorm_workspace_doubles(C) doubles of workspace");
+        hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(C * BN_PARTS), dim3(256), 0, st, x, nullptr, nullptr, nullptr, workspace, B, C, HW);
+        hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, st, workspace, save_mean, save_invstd, running_mean, running_var, C, (double)B * (double)HW, eps, momentum);
+        hipLaunchKernelGGL(bn_apply_kernel, bn_plane_grid((long long)B * C, HW), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, (long long)B * C, C, HW);
+    } else {
+        YNET_REQUIRE(running_mean && running_var, "batchnorm2d_fwd: evaluation mode needs the running statistics");
+        hipLaunchKernelGGL(bn_invstd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, running_var, save_invstd, C, eps);
+        hipLaunchKernelGGL(bn_apply_kernel, bn_plane_grid((long long)B * C, HW), dim3(256), 0, st, x, running_mean, save_invstd, gamma, beta, y, (long long)B * C, C, HW);
+    }
+    return ynet_check_launch("batchnorm2d_fwd");
+}
+
+int ynet_batchnorm2d_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta, double* workspace,
+                         int B, int C, long long HW, int train, void* stream) {
+    YNET_REQUIRE(dy && x && mean && invstd && dx && workspace && B > 0 && C > 0 && HW > 0 && (long long)B * C < 65536, "batchnorm2d_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(C * BN_PARTS), dim3(256), 0, st, x, dy, mean, invstd, workspace, B, C, HW);
+    hipLaunchKernelGGL(bn_bwd_kernel, bn_plane_grid((long long)B * C, HW), dim3(256), 0, st, dy, x, mean, invstd, gamma, workspace, dx, dgamma, dbeta, (long long)B * C, C, HW,
+                       (double)B * (double)HW, train ? 1 : 0);
+    return ynet_check_launch("batchnorm2d_bwd");
+}
+
+int ynet_add_relu(const float* a, const float* b, float* y, long long n, int relu, void* stream) {
+    YNET_REQUIRE(a && b && y && n > 0, "add_relu: bad arguments");
+    hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, relu ? 1 : 0);
+    return ynet_check_launch("add_relu");
+}
+
+int ynet_relu_bwd(const float* dy, const float* y, float* dx, long long n, void* stream) {
+    YNET_REQUIRE(dy && y && dx && n > 0, "relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+    return ynet_check_launch("relu_bwd");
 }
 
 int ynet_rot90_flip(const void* src, void* dst, long long N, int H, int W, int k, int flip, void* stream) {

@@ -11,7 +11,8 @@ The arithmetic runs in the hand-written gfx950 kernels behind ``..ops``:
   * MaxPool2d, bilinear x2, soft-argmax, sigmoid -> dedicated HBM-bound kernels
 
   * serial / parallel adapters (AdapterBlock, AdapterLayer), Embedding -> the same conv kernels (1x1, 3x3, 5x5,
-    no bias) around torch's BatchNorm2d / add / ReLU (variants outside the BASELINE configs)
+    no bias); BatchNorm2d, the residual adds and the ReLU behind them on ynet_batchnorm2d_* / ynet_add_relu (round 6;
+    variants outside the BASELINE configs)
 
 Reference: models/ynet.py:15-131 (Adapter, AdapterBlock, AdapterLayer), 134-151 (get_conv2d), 154-167
 (Embedding), 170-283 (YNetEncoder/L/B), 286-395 (YNetEncoderFusion), 398-471 (YNetDecoder), 474-600 (YNet).
@@ -93,6 +94,22 @@ class HipMaxPool2d(nn.MaxPool2d):
         return ops.max_pool2(x)
 
 
+class HipBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (the serial adapters' first layer, models/ynet.py:24,64) on ynet_batchnorm2d_fwd / _bwd: same parameters, buffers and
+    state-dict keys, nn.BatchNorm2d's own rule for the exponential average factor and num_batches_tracked."""
+
+    def forward(self, x):
+        self._check_input_dim(x)
+        factor = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:      # cumulative moving average (needs the count on the host: not capturable, as in torch)
+                factor = 1.0 / float(self.num_batches_tracked)
+        train = self.training or (self.running_mean is None and self.running_var is None)
+        return ops.batch_norm2d(x, self.weight, self.bias, self.running_mean if (not self.training or self.track_running_stats) else None,
+                                self.running_var if (not self.training or self.track_running_stats) else None, train, factor, self.eps)
+
+
 def _plain_conv(in_channels, out_channels=None, kernel_size=1, stride=1, padding=None, is_bias=False):
     """models/ynet.py:8-12."""
     if out_channels is None:
@@ -112,7 +129,7 @@ class _AdapterMixin:
         self.adapter_size = adapter_name.split("_")[1:]
         self.is_multiple = len(self.adapter_size) >= 2
         if "serial" in adapter_name:
-            self.serial_layer = nn.Sequential(nn.BatchNorm2d(serial_channels), _plain_conv(serial_channels, is_bias=is_bias))
+            self.serial_layer = nn.Sequential(HipBatchNorm2d(serial_channels), _plain_conv(serial_channels, is_bias=is_bias))
         elif "parallel" in adapter_name and not self.is_multiple:
             k = int(self.adapter_size[0].split("x")[0]) if self.adapter_size else 1
             self.parallel_layer = _plain_conv(in_channels, out_channels, k, stride, is_bias=is_bias)
@@ -141,7 +158,7 @@ class _AdapterMixin:
             y = None
             for layer in self.parallel_layer:
                 z = layer(x_in)
-                y = z if y is None else y + z
+                y = z if y is None else ops.add_relu(y, z)
             return y
         return self.parallel_layer(x_in)
 
@@ -155,7 +172,7 @@ class AdapterBlock(nn.Module, _AdapterMixin):
 
     def forward(self, x):
         if "serial" in self.adapter_name:
-            return self._branch(None, x) + x
+            return ops.add_relu(self._branch(None, x), x)
         return self._branch(x, None)
 
 
@@ -169,8 +186,7 @@ class AdapterLayer(HipConv2d, _AdapterMixin):
 
     def forward(self, x, relu=False):
         out = ops.conv2d(x, self.weight, self.bias, False, self._packed)
-        y = self._branch(x, out) + out
-        return torch.relu(y) if relu else y
+        return ops.add_relu(self._branch(x, out), out, relu)
 
 
 class FusedSequential(nn.Sequential):
@@ -304,7 +320,7 @@ class YNetEncoderB(YNetEncoder):
             elif parallel:
                 seen = stage[0](x) if isinstance(stage[0], nn.MaxPool2d) else x      # (pooled twice: once here, once inside the stage -- as the reference)
                 x = stage(x)
-                x = x + next(blocks)(seen) if adapted else x
+                x = ops.add_relu(x, next(blocks)(seen)) if adapted else x
             else:
                 following = self.stages[i + 1] if i + 1 < len(self.stages) else None
                 x = stage(x, pool_next=following is not None and isinstance(following[0], HipMaxPool2d))

@@ -1611,6 +1611,81 @@ def avgpool_pyramid(x: torch.Tensor, n_levels: int) -> List[torch.Tensor]:
 
 
 # ------------------------------------------------------------------------------------------------
+# The serial adapters' element-wise tail (models/ynet.py:24-26,64-66,117-131): BatchNorm2d, residual add, ReLU (round 6: off ATen)
+# ------------------------------------------------------------------------------------------------
+class _BatchNorm2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, train, factor, eps):
+        _need_gpu(x, "batch_norm2d input")
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        lib = _lib()
+        y = torch.empty_like(x)
+        mean, invstd = torch.empty(C, device=x.device, dtype=torch.float32), torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.ynet_batchnorm_workspace_doubles(C), device=x.device, dtype=torch.float64)
+        ptr = lambda t: None if t is None else t.data_ptr()      # noqa: E731
+        L.check(lib.ynet_batchnorm2d_fwd(x.data_ptr(), y.data_ptr(), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), mean.data_ptr(), invstd.data_ptr(),
+                                         ws.data_ptr(), B, C, H * W, 1 if train else 0, float(factor), float(eps), _stream()), lib)
+        ctx.train = bool(train)
+        ctx.save_for_backward(x, gamma, mean if train else running_mean.detach().clone(), invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        lib = _lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, device=x.device, dtype=torch.float32) if gamma is not None else None
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if gamma is not None else None
+        ws = torch.empty(lib.ynet_batchnorm_workspace_doubles(C), device=x.device, dtype=torch.float64)
+        L.check(lib.ynet_batchnorm2d_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr() if gamma is not None else None, dx.data_ptr(),
+                                         dg.data_ptr() if dg is not None else None, db.data_ptr() if db is not None else None, ws.data_ptr(), B, C, H * W,
+                                         1 if ctx.train else 0, _stream()), lib)
+        return dx, dg, db, None, None, None, None, None
+
+
+def batch_norm2d(x, gamma, beta, running_mean, running_var, train: bool, factor: float, eps: float):
+    """F.batch_norm of a [B, C, H, W] device tensor (ynet_batchnorm2d_fwd / _bwd): batch statistics and the running-statistics update when `train`, the running
+    statistics otherwise; `factor` = the exponential average factor nn.BatchNorm2d computes (momentum, or 1 / num_batches_tracked)."""
+    return _BatchNorm2dFn.apply(x, gamma, beta, running_mean, running_var, train, factor, eps)
+
+
+class _AddReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, relu):
+        _need_gpu(a, "add_relu")
+        _need_gpu(b, "add_relu")
+        if a.shape != b.shape:
+            raise ValueError(f"add_relu: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        lib = _lib()
+        L.check(lib.ynet_add_relu(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), 1 if relu else 0, _stream()), lib)
+        ctx.relu = bool(relu)
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.relu:
+            return dy, dy, None
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        lib = _lib()
+        L.check(lib.ynet_relu_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), _stream()), lib)
+        return dx, dx, None
+
+
+def add_relu(a, b, relu: bool = False):
+    """[relu](a + b) in one launch: the adapters' residual add and the ReLU behind the sum (models/ynet.py:66,117-131)."""
+    return _AddReluFn.apply(a, b, relu)
+
+
+# ------------------------------------------------------------------------------------------------
 # BCE-with-logits (mean)
 # ------------------------------------------------------------------------------------------------
 class _BCEFn(torch.autograd.Function):
