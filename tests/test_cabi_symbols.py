@@ -72,3 +72,44 @@ def test_argument_validation_without_gpu():
     plan = lib.ynet_conv2d_plan(32, 256, 256, 32, 3)
     assert plan & 255 == 4 and (plan >> 8) & 255 == 2 and (plan >> 16) & 1 == 1      # 4 rows, two 16-wide tiles
     assert (plan >> 21) == 4 and (lib.ynet_conv2d_plan(32, 16, 16, 64, 3) >> 21) == 8   # chunk depth: large tiles 4, small tiles 8
+
+
+def test_conv2d_auto_plans_the_benchmarked_layers_without_a_gpu():
+    """ynet_conv2d_auto_plan is host code (csrc/conv_auto.cpp): which kernel family the dispatcher takes for the layers of a C2 step (B 32, 256^2;
+    models/ynet.py:192-211,420-467) is decided -- and checked here -- without a device.  Families: 0 implicit GEMM, 1 conv_wino_kernel,
+    2 conv_wino_cat_kernel, 3 conv_wino16_kernel, 4 / 5 the up-convolution forms."""
+    import ctypes
+    L = pkg("_lib")
+    lib = L.load()
+
+    def plan(B, H, W, srcs, dsts, K=3, relu=True, flags=0, **ops):
+        d, tk = L.ConvAuto(), L.ConvTaken()
+        d.nsrc, d.ndst = len(srcs), len(dsts)
+        for i, c in enumerate(srcs):
+            d.src[i], d.src_c[i], d.src_bs[i] = 256, c, c * H * W
+        for i, c in enumerate(dsts):
+            d.dst[i], d.dst_c[i], d.dst_bs[i] = (256 if c > 0 else None), abs(c), abs(c) * H * W
+        d.wp, d.B, d.H, d.W, d.K, d.relu, d.flags = 256, B, H, W, K, int(relu), flags
+        for k, v in ops.items():
+            setattr(d, k, v)
+        assert lib.ynet_conv2d_auto_plan(ctypes.byref(d), ctypes.byref(tk)) == 0, lib.ynet_last_error()
+        need = lib.ynet_conv2d_auto_cache_floats(ctypes.byref(d))
+        assert (need > 0) == (tk.family != 0)
+        return tk.family, tk.variant, tk.nlaunch
+
+    B = 32
+    assert plan(B, 256, 256, [6, 8], [32], pooled=256)[0] == 2                       # encoder.0 + ReLU + MaxPool (conv_wino_cat_kernel<2, 3 | 6>)
+    assert plan(B, 128, 128, [32], [32])[0] == 1                                     # encoder stage 1
+    assert plan(B, 64, 64, [32], [64])[0] == 3 and plan(B, 64, 64, [64], [64], pooled=256)[0] == 3      # stage 2: the slice form
+    assert plan(B, 32, 32, [64], [64])[0] == 0 and plan(B, 8, 8, [64], [128])[0] == 0                   # small maps: implicit GEMM
+    assert plan(B, 256, 256, [32], [16], relu=False, upsample2x=1)[0] == 4          # bilinear x2 + upsample_conv[4]
+    assert plan(B, 128, 128, [64], [32], relu=False, upsample2x=1)[0] == 5
+    assert plan(B, 256, 256, [16, 32, 1], [32])[0] == 2                              # decoder[4][0] over cat(up, skip, way-point map)
+    assert plan(B, 128, 128, [32, 32, 1], [32])[:2] == (2, 40)                       # 65 channels: 32 first, the rest added in place
+    assert plan(B, 256, 256, [32], [32])[0] == 1                                     # decoder[4][2]
+    assert plan(B, 256, 256, [32], [32], relu=False, relu_of=256) == (1, 21, 1)      # its data gradient through the ReLU backward
+    assert plan(B, 256, 256, [32], [16, 32, -1], relu=False) == (1, 21, 2)           # decoder[4][0]'s data gradient: 16 + 32, the way-point map's not wanted
+    assert plan(B, 128, 128, [32], [64], relu=False) == (3, 22, 1)                   # a 64-channel destination: one launch of the slice form
+    assert plan(B, 256, 256, [32], [12], K=1, relu=False)[0] == 0                    # the 1x1 predictor
+    assert plan(B, 256, 256, [32], [32], flags=L.AUTO_NO_WINOGRAD)[0] == 0
+    assert plan(10, 128, 128, [32], [32])[0] == 1 and plan(4, 64, 64, [32], [32])[0] == 0      # batch 10 still Winograd at 128^2; too few pixels -> implicit GEMM
