@@ -304,8 +304,6 @@ class YNetTrainer:
             raise ValueError(f"{name} dataset is not supported")
         if name == "eth":
             raise NotImplementedError("ETH/UCY homographies are read from data files: out of the MI355X hot path")
-        if augment:
-            raise NotImplementedError("image augmentation (cv2) is out of the MI355X hot path")
         if not isinstance(image_path, dict):
             raise ImportError("decoding scene images needs OpenCV + segmentation_models_pytorch (out of scope here): "
                               "pass a dict {scene_id: float tensor [C,H,W]} (pre-processed, padded to a multiple "
@@ -314,6 +312,18 @@ class YNetTrainer:
         # preprocess_image_for_segmentation(seg_mask=True) (image_utils.py:74-81) run on the device; decoding image files,
         # cv2.resize and the RGB normalisation of the segmentation backbone stay outside (no OpenCV / smp in this image)
         images = dict(image_path)
+        if augment:
+            # models/trainer.py:566-571: augment_data BEFORE resize / pad / encode -- every scene rotated by 90 / 180 / 270 degrees, then everything
+            # flipped (utils/data_utils.py:176-233; the index permutations and the coordinate transforms run on the device).  Raw label maps only:
+            # pre-processed planes arrive padded, and the reference pads AFTER it rotates (the border stays at the bottom / right)
+            if any((im.dim() if torch.is_tensor(im) else np.asarray(im).ndim) != 2 for im in images.values()):
+                raise ValueError("augment=True needs the raw label maps [H, W] (the reference augments before it pads and encodes); "
+                                 "pre-processed planes [C, H, W] cannot be rotated correctly here")
+            from ..utils.data_utils import augment_data
+            df, images = augment_data(df, images=images, seg_mask=True)
+            print("Augmented data and images")
+        else:
+            print("No data and images augmentation")
         for k, im in images.items():
             t = im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im))
             if t.dim() == 2:            # a label map [H, W]: padded with label 0, then one-hot planes

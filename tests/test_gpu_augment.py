@@ -77,3 +77,43 @@ def test_augment_data_matches_the_reference_fixture(dev):
         du.augment_data(df.copy(), images={})
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pkg("ops").rot90_flip(torch.zeros(4, 4, dtype=torch.int32), 1)
+
+
+def test_trainer_prepare_data_with_augmentation(dev):
+    """models/trainer.py:559-583 with augment=True on raw label maps: augment_data (8x the scenes and trajectories, on the device), then pad to a
+    multiple of 32 and the one-hot planes -- every scene of the dict against np.rot90 / np.fliplr of its source followed by the reference's own
+    pad + one-hot rule (class 0 border)."""
+    import contextlib
+    import io
+    trn = pkg("models.trainer")
+    params = dict(obs_len=8, pred_len=12, segmentation_model_fp=None, use_features_only=False, n_semantic_classes=6,
+                  encoder_channels=[8, 8, 16, 16, 16], decoder_channels=[16, 16, 16, 8, 8], waypoints=[11],
+                  train_net="mosa_1", position=["0"], network="original", n_fusion=None, resize_factor=0.25)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        t = trn.YNetTrainer(params, device=dev)
+    rng = np.random.RandomState(3)
+    maps = {"s0": rng.randint(0, 6, size=(40, 70)).astype(np.uint8), "s1": rng.randint(0, 6, size=(33, 33)).astype(np.uint8)}
+    rows = []
+    for m, (sid, im) in enumerate(maps.items()):
+        for f in range(20):
+            rows.append({"frame": f, "trackId": m, "x": float(rng.uniform(0, im.shape[1])), "y": float(rng.uniform(0, im.shape[0])), "sceneId": sid, "metaId": m})
+    df = pd.DataFrame(rows)
+    with contextlib.redirect_stdout(out):
+        images, loader, homo = t.prepare_data(df, dict(maps), "sdd", "train", 8, 12, 0.25, False, augment=True)
+    assert "Augmented data and images" in out.getvalue() and homo is None
+    assert len(images) == 16 and len(loader.dataset) == 16
+    for key, planes in images.items():
+        src = maps[key.split("_")[0]]
+        lab = src
+        for suffix in key.split("_")[1:]:
+            lab = np.rot90(lab, {"rot90": 1, "rot180": 2, "rot270": 3}[suffix]) if suffix.startswith("rot") else np.fliplr(lab)
+        H, W = lab.shape
+        Hp, Wp = -(-H // 32) * 32, -(-W // 32) * 32
+        padded = np.zeros((Hp, Wp), dtype=np.int64)
+        padded[:H, :W] = lab
+        want = torch.nn.functional.one_hot(torch.from_numpy(padded), 6).permute(2, 0, 1).float()
+        assert planes.shape == (6, Hp, Wp) and torch.equal(planes.cpu(), want), key
+    with pytest.raises(ValueError, match="raw label maps"):
+        with contextlib.redirect_stdout(out):
+            t.prepare_data(df, {k: torch.zeros(6, 64, 96) for k in maps}, "sdd", "train", 8, 12, 0.25, False, augment=True)
