@@ -370,8 +370,33 @@ class CapturedStep:
         return {"graph_a": med([e[0].elapsed_time(e[1]) for e in ev]), "allreduce": med([e[1].elapsed_time(e[2]) for e in ev]),
                 "graph_b": med([e[2].elapsed_time(e[3]) for e in ev]), "replays": n}
 
+    PIN_RING = 4
+
+    def _upload_coords(self, batch):
+        """The step's only host input, [n, obs + pred, 2] coordinates: through a small ring of PINNED staging buffers and an asynchronous copy.  A
+        copy from pageable memory blocks the host until the stream has drained -- the previous step -- and the launch latency of the graph (~40 us
+        in the trace: profiles/r06_bench_C2_b32_overlap.txt's idle share) then sits between every two steps; from pinned memory the host runs a
+        step ahead and the latency hides under the previous step's kernels."""
+        if not (torch.is_tensor(batch) and batch.device.type == "cpu" and not batch.is_pinned()) or os.environ.get("YNET_PINNED_COORDS", "1") == "0":
+            self.coords.copy_(batch)
+            return
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None:
+            ring = self._pin_ring = {"bufs": [None] * self.PIN_RING, "evs": [None] * self.PIN_RING, "i": 0}
+        i = ring["i"]
+        ring["i"] = (i + 1) % self.PIN_RING
+        buf, ev = ring["bufs"][i], ring["evs"][i]
+        if buf is None or buf.shape != batch.shape or buf.dtype != self.coords.dtype:
+            buf = ring["bufs"][i] = torch.empty(tuple(batch.shape), dtype=self.coords.dtype, pin_memory=True)
+            ev = ring["evs"][i] = torch.cuda.Event()
+        else:
+            ev.synchronize()              # (the copy that last read this buffer, four steps ago)
+        buf.copy_(batch)
+        self.coords.copy_(buf, non_blocking=True)
+        ev.record()
+
     def replay(self, batch, scene_image):
-        self.coords.copy_(batch)
+        self._upload_coords(batch)
         if self.scene_src is not scene_image:      # a new scene tensor (next epoch, next scene of the same size)
             self.scene.copy_(scene_image)
             self.scene_src = scene_image
