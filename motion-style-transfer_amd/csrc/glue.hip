@@ -613,6 +613,13 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
 #pragma unroll
                     for (int e = 0; e < PX; ++e) xpos[e] |= (v[k][e] > 0.f ? 1u : 0u) << ((c0 + k) & 31);
             }
+#if defined(YNET_PRED_BCE_DIAG) && (YNET_PRED_BCE_DIAG & 1)
+            // (development build, WRONG results: the forward products replaced by one add per plane -- what does the launch cost without its FMAs?)
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+#pragma unroll
+                for (int e = 0; e < PX; ++e) acc[k % CT][e] += v[k][e];
+#else
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 if (c0 + k < a.cin) {
@@ -624,6 +631,7 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
                     }
                 }
             }
+#endif
         }
         const long long obase = (long long)b * a.cout * hwv + p;
         float s = 0.f;
@@ -657,7 +665,12 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
 #pragma unroll
                 for (int e = 0; e < PX; ++e) {
                     float de;
+#if defined(YNET_PRED_BCE_DIAG) && (YNET_PRED_BCE_DIAG & 4)
+                    de = acc[co][e] - tv[e];      // (development build, WRONG results: no exp / log / rcp)
+                    s += de;
+#else
                     s += bce_element<true>(acc[co][e], tv[e], a.gs, de);
+#endif
                     d[e] = de;
                 }
                 acc[co] = d;        // the accumulator now holds dy
@@ -675,12 +688,17 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
                 vec_t o;
 #pragma unroll
                 for (int e = 0; e < PX; ++e) o[e] = 0.f;
+#if defined(YNET_PRED_BCE_DIAG) && (YNET_PRED_BCE_DIAG & 2)
+#pragma unroll
+                for (int e = 0; e < PX; ++e) o[e] = acc[ci % CT][e];      // (development build, WRONG results: no dgrad products)
+#else
 #pragma unroll
                 for (int co = 0; co < CT; ++co) {
                     const float wv = w[ci * a.cout_pad + co];      // (zero in the padded columns)
 #pragma unroll
                     for (int e = 0; e < PX; ++e) o[e] = __builtin_fmaf(acc[co][e], wv, o[e]);
                 }
+#endif
                 if (a.relu_mask) {
 #pragma unroll
                     for (int e = 0; e < PX; ++e) o[e] = ((xpos[e] >> (ci & 31)) & 1u) ? o[e] : 0.f;
