@@ -595,7 +595,11 @@ __global__ __launch_bounds__(256, (CT * PX <= 48 ? 4 : (CT * PX <= 60 ? 3 : 2)))
         }
         // NB input planes are fetched before their FMAs start: a streaming kernel lives on bytes in flight (with two
         // loads per thread outstanding it reached 3.3 TB/s -- Little's law at ~2.5 us of loaded HBM latency)
+#ifdef YNET_PRED_BCE_NB
+        constexpr int NB = YNET_PRED_BCE_NB;      // (development builds: tools/ab_pred_bce.sh)
+#else
         constexpr int NB = 8;
+#endif
         unsigned xpos[PX];          // bit ci: x[ci] > 0 at this thread's pixel e (cin <= 32): the ReLU mask for dx, kept while x streams by
 #pragma unroll
         for (int e = 0; e < PX; ++e) xpos[e] = 0u;
