@@ -126,6 +126,10 @@ long long ynet_winograd_filter_floats(int cin, int cout);
 int ynet_winograd_filter(const float* wp, float* u, int cin, int cout, int col0, int cols_total, void* stream);
 int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
                          int B, int H, int W, int relu, void* stream);
+/*   ynet_conv2d_winograd_s2d    (round 6) the plain data gradient with its output stored SPACE-TO-DEPTH: dst [4 cout][H / 2][W / 2] per image, element (2 i + r, 2 j + c)
+ *                               of channel ch at plane (2 r + c) * cout + ch, position (i, j) -- a lane of this tiling holds exactly one such 2 x 2 block.  It is the layout
+ *                               in which the gradient of an up-convolution's OUTPUT is consumed without the up-sampled tensor (see ynet_upconv_dgrad_ring). */
+int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u, float* dst, long long dst_bs, int cin, int cout, int B, int H, int W, void* stream);
 /*   ynet_conv2d_winograd_dgrad_relu   the data gradient written THROUGH the ReLU backward of the layer below, as ynet_conv2d_dgrad_relu:
  *                               dx = relu_of > 0 ? conv3x3(dy, mode-1 filter) : 0, relu_of = that layer's post-ReLU output [B][dx_c][H][W]
  *                               (8-byte aligned), read by the epilogue at the addresses it stores to. */
@@ -264,6 +268,10 @@ typedef struct YnetConvAuto {
     float* workspace;
     long long workspace_floats;
     unsigned flags;
+    int dst_s2d[4];        /* dst_s2d[i] != 0: destination i (16 or 32 channels, a plain data gradient) may be written SPACE-TO-DEPTH -- element (2 i + r, 2 j + c) of
+                              channel ch at plane (2 r + c) * dst_c + ch, position (i, j) of [4 dst_c][H / 2][W / 2]: the layout ynet_upconv_dgrad_ring and the
+                              low-resolution data gradient of an up-convolution consume; honoured only where one Winograd launch writes the whole destination
+                              (taken->wrote_s2d tells) */
 } YnetConvAuto;
 typedef struct YnetConvTaken {
     int family;            /* 0 implicit GEMM (conv_mfma_kernel / conv_dma_*), 1 conv_wino_kernel, 2 conv_wino_cat_kernel, 3 conv_wino16_kernel,
@@ -272,6 +280,7 @@ typedef struct YnetConvTaken {
     int nlaunch;
     int tmpl[4][3];        /* per launch: family 1 <NCB, NCH, EM>; family 2 <2, EPI>; family 3 <EPI> */
     int wrote_wbits, wrote_pool_code, transformed;
+    int wrote_s2d;         /* bit i: destination i was written space-to-depth */
 } YnetConvTaken;
 long long ynet_conv2d_auto_cache_floats(const YnetConvAuto* desc);
 long long ynet_conv2d_auto_workspace_floats(const YnetConvAuto* desc);
@@ -280,6 +289,21 @@ int ynet_conv2d_auto(const YnetConvAuto* desc, YnetConvTaken* taken, void* strea
  * looked at for their alignment and for NULL only.  A caller that must decide earlier what a later call will do -- the forward pass of a
  * conv -> ReLU -> conv chain leaves the mask in the layout of the kernel family that will write the data gradient -- asks the dispatcher itself. */
 int ynet_conv2d_auto_plan(const YnetConvAuto* desc, YnetConvTaken* taken);
+
+/* The backward of `upsample_conv[i](F.interpolate(x, scale_factor=2, mode='bilinear'))` (models/ynet.py:463-464) WITHOUT the up-sampled gradient (round 6;
+ * VERDICT r5 item 3).  Up^T . conv^T is itself a 3 x 3 convolution at the LOW resolution over the space-to-depth output gradient D [4 cout][h][w]: output pixel
+ * (2 i + py, 2 j + px) of the forward pass sees the 3 x 3 low-resolution patch around (i, j) through the effective filter
+ *     Keff[(py, px, co)][ci][a][b] = sum_{ty, tx} M_py[a][ty] K[co][ci][ty][tx] M_px[b][tx],   M_0 = [[.75 .25 0] [.25 .75 .75] [0 0 .25]],  M_1 = [[.25 0 0] [.75 .75 .25] [0 .25 .75]]
+ * so dx = the ordinary data gradient of a convolution with weight Keff [4 cout][cin][3][3] applied to D -- one ynet_conv2d_auto call (mode-1 packed Keff, relu_of = x) --
+ * EXCEPT on the outermost ring of dx: there the bilinear clamp (L[-1] = L[0]) and the zero padding of the UP-SAMPLED image differ from that formula.  The difference is again
+ * linear and thin: ynet_upconv_dgrad_ring adds it to the ring pixels of dx (masked by relu_of > 0 when given):
+ *     rows 0 / h-1:  sum_{c', b} tables[s * 3 + b][c'][ci] D[c'][row][j - b + 1],  tables[s*3+b] = sum dM_s[py][ty] K M_px[b][tx]
+ *     columns 0 / w-1:  tables[6 + s * 3 + a] alike;  the four corners additionally tables[12 + 2 sv + sh][c'][ci] D[c'][corner]
+ *     dM_0 = .25 [[-1 1 0] [1 0 0]] (couples to L[0]),  dM_1 = .25 [[0 0 1] [0 1 -1]] (couples to L[h-1])
+ * (motion-style-transfer_amd/ops.py::upconv_s2d_tables builds Keff and the 16 tables from the layer's filter; tests compare with autograd in fp64.)
+ * D: [B][C4 = 4 cout][h][w] (batch stride d_bs); tables: [16][C4][cin] floats; dx [B][cin][h][w] is updated in place. */
+int ynet_upconv_dgrad_ring(const float* D, long long d_bs, const float* tables, const float* relu_of, long long relu_of_bs, float* dx, long long dx_bs,
+                           int B, int C4, int cin, int h, int w, void* stream);
 
 /* Introspection for profiling: the instantiation the dispatcher uses for this problem, encoded as
  * rows | tiles << 8 | m16 << 16 | dma << 17 | x4 << 18 | log2(fold) << 19 | CC << 21  ->  conv_mfma_kernel<K, tiles,

@@ -29,13 +29,13 @@ class ConvAuto(ctypes.Structure):
                 ("addend", c_fp), ("addend_bs", c_ll), ("addend_bmod", c_i),
                 ("bits_out", c_fp), ("relu_bits", c_fp), ("wbits_out", c_fp), ("relu_wbits", c_fp),
                 ("cache", c_fp), ("cache_floats", c_ll), ("cache_tag", ctypes.POINTER(ctypes.c_ulonglong)), ("wp_version", ctypes.c_ulonglong),
-                ("workspace", c_fp), ("workspace_floats", c_ll), ("flags", ctypes.c_uint)]
+                ("workspace", c_fp), ("workspace_floats", c_ll), ("flags", ctypes.c_uint), ("dst_s2d", c_i * 4)]
 
 
 class ConvTaken(ctypes.Structure):
     """YnetConvTaken: what ynet_conv2d_auto ran."""
     _fields_ = [("family", c_i), ("variant", c_i), ("nlaunch", c_i), ("tmpl", (c_i * 3) * 4), ("wrote_wbits", c_i), ("wrote_pool_code", c_i),
-                ("transformed", c_i)]
+                ("transformed", c_i), ("wrote_s2d", c_i)]
 
 
 AUTO_NO_WINOGRAD, AUTO_NO_WINOGRAD16, AUTO_WINOGRAD16_FOR_16, AUTO_NO_POOL_CODE, AUTO_NO_RELU_WBITS = 1, 2, 4, 8, 16
@@ -60,6 +60,8 @@ SIGNATURES = {
     "ynet_winograd_filter_floats": (c_ll, [c_i, c_i]),
     "ynet_winograd_filter": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_conv2d_winograd_s2d": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_upconv_dgrad_ring": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_dgrad_relu": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_cat_supported": (c_i, [c_i, c_i, c_i, PI, c_i, c_i, c_i]),
     "ynet_winograd_filter_cat_floats": (c_ll, [PI, c_i, c_i]),

@@ -22,6 +22,8 @@ struct Piece {
     int n;
     long long bs;
     int col0;
+    int dst;             // index of the destination this piece belongs to
+    int whole;           // the piece IS its destination (all its channels)
 };
 
 enum Kind { K_NONE = 0, K_WINO = 1, K_CAT = 2, K_W16 = 3 };
@@ -163,7 +165,7 @@ int make_plan(const YnetConvAuto* a, Plan& p) {
             const int c = a->dst_c[i];
             while (c - o >= 16 && (c - o) % 16 == 0 && np < 8) {
                 const int n = c - o >= 32 ? 32 : 16;
-                pieces[np++] = Piece{a->dst[i] + o * HW, n, a->dst_bs[i], c0 + o};
+                pieces[np++] = Piece{a->dst[i] + o * HW, n, a->dst_bs[i], c0 + o, i, n == c ? 1 : 0};
                 o += n;
             }
             if (o != c) pieces_ok = false;
@@ -202,7 +204,7 @@ int make_plan(const YnetConvAuto* a, Plan& p) {
         int nw = 0;
         c0 = 0;
         for (int i = 0; i < a->ndst; ++i) {
-            if (a->dst[i]) wanted[nw++] = Piece{a->dst[i], a->dst_c[i], a->dst_bs[i], c0};
+            if (a->dst[i]) wanted[nw++] = Piece{a->dst[i], a->dst_c[i], a->dst_bs[i], c0, i, 1};
             c0 += a->dst_c[i];
         }
         bool w_ok = nw > 0 && (!a->relu_of || nw == 1);
@@ -401,6 +403,15 @@ int ynet_conv2d_auto(const YnetConvAuto* a, YnetConvTaken* taken, void* stream) 
             const float* u = a->cache + p.l[i].offset;
             const float* bias = a->bias ? a->bias + q.col0 : nullptr;
             int rc;
+            // (a destination that asked for its gradient space-to-depth gets it when ONE plain 16 / 32-channel launch writes all of it)
+            const bool s2d = a->dst_s2d[q.dst] && q.whole && em == 0 && !a->bias && !relu;
+            if (s2d) {
+                rc = ynet_conv2d_winograd_s2d(a->src[0], a->src_bs[0], u, q.ptr, q.bs, a->src_c[0], q.n, B, H, W, stream);
+                if (rc) return rc;
+                t.wrote_s2d |= 1 << q.dst;
+                tag(i, q.n / 16, a->src_c[0] / 8, 4);
+                continue;
+            }
             if (wb_out) rc = ynet_conv2d_winograd_relu_bits(a->src[0], a->src_bs[0], u, bias, q.ptr, q.bs, a->src_c[0], B, H, W, wb_out, stream);
             else if (wb_in) rc = ynet_conv2d_winograd_dgrad_relu_bits(a->src[0], a->src_bs[0], u, q.ptr, q.bs, wb_in, a->src_c[0], B, H, W, stream);
             else if (a->relu_of) {

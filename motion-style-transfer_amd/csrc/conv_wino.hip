@@ -79,7 +79,10 @@ __device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, 
 // = "output channel cb * 16 + 4 kq + 2 h + k of this lane's 2 x 2 block is positive"): 1 -- the forward launch of a conv -> ReLU -> conv chain returns
 // the word of its outputs in *wbits; 2 -- the data gradient of the chain's second convolution is gated by that word (*wbits) instead of fetching
 // the 16 activation quads of EPI 1 (268 MB less traffic and no fetch latency in front of the stores of a 32-channel launch at 256^2, B 32).
-template <int NCB, int EPI, int BITS = 0>
+// S2D (round 6): the 2 x 2 block of a lane is stored SPACE-TO-DEPTH -- element (row r, column c) of the block goes to plane (2 r + c) * (16 NCB) + channel of a
+// tensor [4 * 16 NCB][H / 2][W / 2] (st0 / so_t are then the lane's / the unit's offsets in a LOW-resolution plane): the layout in which the gradient of an
+// up-convolution's output is consumed by ynet_upsample2x_conv2d_dgrad (a 3 x 3 convolution at the low resolution).
+template <int NCB, int EPI, int BITS = 0, bool S2D = false>
 __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2 (&bias2)[NCB][2], float floor_v, __amdgpu_buffer_rsrc_t ry,
                                               __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW, unsigned stp = 0,
                                               unsigned* wbits = nullptr, unsigned char* pcode = nullptr) {
@@ -135,6 +138,17 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                 }
                 if constexpr (BITS == 1)      // (v > 0: NaN and -0 count as "not positive", as the float comparison of EPI 1 does)
                     word |= (row0[0] > 0.f ? 1u << bit0 : 0u) | (row0[1] > 0.f ? 2u << bit0 : 0u) | (row1[0] > 0.f ? 4u << bit0 : 0u) | (row1[1] > 0.f ? 8u << bit0 : 0u);
+                if constexpr (S2D) {
+                    const unsigned hw = (unsigned)(HW >> 2), ph = (unsigned)(NCB * 16) * hw * 4u;
+                    const unsigned sc = so_t + (unsigned)(cb * 16 + 2 * h + k) * hw * 4u;
+                    // (scalars first: __builtin_bit_cast applied to a vector-element lvalue reads the vector's FIRST element -- hipcc stored row0[0] twice)
+                    const float e00 = row0[0], e01 = row0[1], e10 = row1[0], e11 = row1[1];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e00), ry, st0, sc, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e01), ry, st0, sc + ph, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e10), ry, st0, sc + 2u * ph, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e11), ry, st0, sc + 3u * ph, 0);
+                    continue;
+                }
                 const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), ry, st0, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), ry, st1, so, 0);
@@ -246,7 +260,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
 #pragma unroll
         for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bias2[cb][h]));
     // static store offsets of this lane: output channel 4 kq (+ the rest by the scalar offset), column 2 n, rows 0 / 1 of the pair
-    const unsigned st0 = (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
+    // (EM 4, the space-to-depth store: the lane's offset in a low-resolution plane -- channel 4 kq, column n)
+    const unsigned st0 = EM == 4 ? (unsigned)((4 * kq * (HW >> 2) + n) * 4) : (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
 
     // all transformed filters -> LDS, once; the workgroup's unit counter
 #pragma unroll
@@ -352,12 +367,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
         {
             const int t = tile_first + (cur >> 3) * gstride;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-            const unsigned so_t = (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            const unsigned so_t = EM == 4 ? (unsigned)(((ty * (WN_TH / 2) + (cur & 7)) * (W >> 1) + tx * (WN_TW / 2)) * 4)
+                                          : (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
             const __amdgpu_buffer_rsrc_t rm =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EM == 1 ? a.emask + (long long)b * a.emask_bs : a.y), 0, y_img, 0x00020000);
-            unsigned* wb = EM >= 2 ? a.wbits + (((long long)b * (H >> 1) + (ty * (WN_TH / 2) + (cur & 7))) * tiles_x + tx) * 64 + lane : nullptr;
-            wino_epilogue<NCB, EM == 1 ? 1 : 0, EM == 2 ? 2 : (EM == 3 ? 1 : 0)>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, so_t, HW, 0, wb);
+            unsigned* wb = (EM == 2 || EM == 3) ? a.wbits + (((long long)b * (H >> 1) + (ty * (WN_TH / 2) + (cur & 7))) * tiles_x + tx) * 64 + lane : nullptr;
+            wino_epilogue<NCB, EM == 1 ? 1 : 0, EM == 2 ? 2 : (EM == 3 ? 1 : 0), EM == 4>(acc, bias2, floor_v, ry, rm, st0, st1, so_t, so_t, HW, 0, wb);
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
@@ -1355,7 +1371,7 @@ int ynet_conv2d_winograd_cat_pool_code(const float* const* src, const int* src_c
 
 static int wino_launch_any(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, const float* emask,
                            long long emask_bs, int cin, int cout, int B, int H, int W, int relu, void* stream, const char* what, unsigned* wbits = nullptr,
-                           bool wbits_apply = false) {
+                           bool wbits_apply = false, bool s2d = false) {
     YNET_REQUIRE(src && u && dst, "%s: null pointer", what);
     YNET_REQUIRE(wino_shape_ok(B, H, W, cin, cout, 3), "%s: shape B=%d %dx%d %d -> %d is not served (ask ynet_conv2d_winograd_supported)", what, B, H, W, cin,
                  cout);
@@ -1374,6 +1390,11 @@ static int wino_launch_any(const float* src, long long src_bs, const float* u, c
         if (wbits_apply) return cin == 32 ? launch_wino<2, 4, 2>(a, st) : launch_wino<2, 2, 2>(a, st);
         return cin == 32 ? launch_wino<2, 4, 3>(a, st) : launch_wino<2, 2, 3>(a, st);
     }
+    if (s2d) {                       // the output stored space-to-depth: [4 cout][H / 2][W / 2] per image (a data gradient on its way through an up-convolution)
+        YNET_REQUIRE(emask == nullptr && bias == nullptr && !relu, "%s: the space-to-depth store is for a plain data gradient", what);
+        if (cout == 32) return cin == 32 ? launch_wino<2, 4, 4>(a, st) : launch_wino<2, 2, 4>(a, st);
+        return cin == 32 ? launch_wino<1, 4, 4>(a, st) : launch_wino<1, 2, 4>(a, st);
+    }
     if (emask != nullptr) {
         if (cout == 32) return cin == 32 ? launch_wino<2, 4, 1>(a, st) : launch_wino<2, 2, 1>(a, st);
         return cin == 32 ? launch_wino<1, 4, 1>(a, st) : launch_wino<1, 2, 1>(a, st);
@@ -1385,6 +1406,10 @@ static int wino_launch_any(const float* src, long long src_bs, const float* u, c
 int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, int cin, int cout,
                          int B, int H, int W, int relu, void* stream) {
     return wino_launch_any(src, src_bs, u, bias, dst, dst_bs, nullptr, 0, cin, cout, B, H, W, relu, stream, "conv2d_winograd");
+}
+
+int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u, float* dst, long long dst_bs, int cin, int cout, int B, int H, int W, void* stream) {
+    return wino_launch_any(src, src_bs, u, nullptr, dst, dst_bs, nullptr, 0, cin, cout, B, H, W, 0, stream, "conv2d_winograd_s2d", nullptr, false, true);
 }
 
 // ---- the Winograd-native 1-bit ReLU mask (round 5): one 32-bit word per lane and unit of the NCB = 2 tiling, i.e. per (image, row pair, 32-column tile, lane)

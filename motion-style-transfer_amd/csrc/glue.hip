@@ -1455,6 +1455,98 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
+// The outermost ring of an up-convolution's low-resolution data gradient (ynet_upconv_dgrad_ring, include/ynet_hip.h): what the bilinear clamp and the zero padding of
+// the up-sampled image add to the effective-filter convolution -- a 1 x 3 (rows 0, h-1) / 3 x 1 (columns 0, w-1) data gradient over D's border lines plus a term at the
+// corners.  A workgroup owns one SEGMENT of 64 consecutive pixels of one border line of one image: the line's three tables [3][C4][cin] and the D tile [C4][66] go to
+// LDS and the 3 C4-deep products run on the fp32 matrix cores (a wave: 16 pixels x 16 input channels per v_mfma_f32_16x16x4_f32 chain).  Row segments
+// cover all columns and also add the column and corner terms of the two corner pixels (computed by the whole workgroup, 3 C4 + C4 products per channel); column
+// segments cover rows 1 .. h-2.  Every ring pixel is written by exactly one workgroup.
+#define RING_SEG 64
+__global__ __launch_bounds__(256) void upconv_ring_kernel(const float* __restrict__ D, long long d_bs, const float* __restrict__ tab, const float* __restrict__ relu_of,
+                                                          long long relu_bs, float* __restrict__ dx, long long dx_bs, int B, int C4, int cin, int h, int w,
+                                                          int nseg_row, int nseg_col) {
+    extern __shared__ float ring_smem[];
+    float* T = ring_smem;                                  // [3][C4][cin]
+    float* Dt = T + 3 * C4 * cin;                          // [C4][RING_SEG + 2]
+    float* red = Dt + C4 * (RING_SEG + 2);                 // [8][cin]: partial sums of a corner's extra terms
+    const int per_image = 2 * nseg_row + 2 * nseg_col;
+    const int b = blockIdx.x / per_image, which = blockIdx.x % per_image;
+    const bool is_row = which < 2 * nseg_row;
+    const int side = is_row ? which / nseg_row : (which - 2 * nseg_row) / nseg_col;          // 0: row 0 / column 0; 1: row h-1 / column w-1
+    const int seg = is_row ? which % nseg_row : (which - 2 * nseg_row) % nseg_col;
+    const int len = is_row ? w : h;                        // pixels of the border line
+    const int q0 = is_row ? seg * RING_SEG : 1 + seg * RING_SEG;      // first pixel of the segment along the line
+    const int q_end = is_row ? w : h - 1;                  // column segments leave the corners to the rows
+    const int fixed = is_row ? (side ? h - 1 : 0) : (side ? w - 1 : 0);
+    const long long hw = (long long)h * w, tstride = (long long)C4 * cin;
+    const float* Db = D + (long long)b * d_bs;
+    const int tid = threadIdx.x;
+    const float* tsrc = tab + (long long)((is_row ? 0 : 6) + side * 3) * tstride;
+    for (int i = tid; i < 3 * C4 * cin; i += 256) T[i] = tsrc[i];
+    for (int i = tid; i < C4 * (RING_SEG + 2); i += 256) {
+        const int c = i / (RING_SEG + 2), k = i - c * (RING_SEG + 2), q = q0 - 1 + k;
+        Dt[i] = (q >= 0 && q < len) ? Db[c * hw + (is_row ? (long long)fixed * w + q : (long long)q * w + fixed)] : 0.f;
+    }
+    __syncthreads();
+    // out[ci][pixel] = sum over k = (tap, c') of table[k][ci] * D[c'][pixel - tap + 1] on the fp32 matrix cores: a wave owns 16 pixels of the segment, the A operand is
+    // the table (row = input channel), the B operand the D tile (column = pixel): lane (m, kq) ends up with channels 4 kq .. 4 kq + 3 of pixel m -- consecutive lanes,
+    // consecutive pixels of a border row
+    const int lane = tid & 63, wv = tid >> 6, m = lane & 15, kq = lane >> 4;
+    const int q = q0 + wv * 16 + m;
+    for (int ct = 0; ct * 16 < cin; ++ct) {                // tiles of 16 input channels
+        const int cia = ct * 16 + m;                       // the A operand's channel
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 3; ++t)
+            for (int s4 = 0; s4 < C4; s4 += 4) {
+                const int c = s4 + kq;
+                const float av = cia < cin ? T[((long long)t * C4 + c) * cin + cia] : 0.f;
+                const float bv = Dt[c * (RING_SEG + 2) + wv * 16 + m + 2 - t];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+        if (q < q_end) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = ct * 16 + 4 * kq + e;
+                if (ci >= cin) break;
+                const long long o = (long long)ci * hw + (is_row ? (long long)fixed * w + q : (long long)q * w + fixed);
+                if (relu_of == nullptr || relu_of[(long long)b * relu_bs + o] > 0.f) dx[(long long)b * dx_bs + o] += acc[e];
+            }
+        }
+    }
+    if (!is_row) return;
+    // ---- the corner pixels of a row segment: + the column term (3 taps along the column) + the corner term, by the whole workgroup
+    for (int corner = 0; corner < 2; ++corner) {
+        const int jc = corner ? w - 1 : 0;
+        if (jc < q0 || jc >= q0 + RING_SEG) continue;      // (workgroup-uniform)
+        const float* tcol = tab + (long long)(6 + corner * 3) * tstride;
+        const float* tx = tab + (long long)(12 + side * 2 + corner) * tstride;
+        const int nterm = 4 * C4;                          // (tap 0..2 of the column term, 3 = the corner term) x c'
+        for (int ci = tid & 31; ci < cin; ci += 32) {
+            float part = 0.f;
+            for (int k = tid >> 5; k < nterm; k += 8) {
+                const int t = k / C4, c = k - t * C4;
+                float d = 0.f;
+                if (t < 3) {
+                    const int ii = fixed - t + 1;
+                    if (ii >= 0 && ii < h) d = Db[c * hw + (long long)ii * w + jc] * tcol[((long long)t * C4 + c) * cin + ci];
+                } else {
+                    d = Db[c * hw + (long long)fixed * w + jc] * tx[(long long)c * cin + ci];
+                }
+                part += d;
+            }
+            __syncthreads();
+            red[(tid >> 5) * 32 + (tid & 31)] = part;
+            __syncthreads();
+            if (tid < 32) {
+                float sum = 0.f;
+                for (int k = 0; k < 8; ++k) sum += red[k * 32 + tid];
+                const long long o = (long long)ci * hw + (long long)fixed * w + jc;
+                if (relu_of == nullptr || relu_of[(long long)b * relu_bs + o] > 0.f) dx[(long long)b * dx_bs + o] += sum;
+            }
+        }
+    }
+}
+
 extern "C" {
 
 int ynet_maxpool2_fwd(const float* x, float* y, long long N, int H, int W, void* stream) {
@@ -1848,6 +1940,21 @@ int ynet_relu_bwd(const float* dy, const float* y, float* dx, long long n, void*
     YNET_REQUIRE(dy && y && dx && n > 0, "relu_bwd: bad arguments");
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
     return ynet_check_launch("relu_bwd");
+}
+
+int ynet_upconv_dgrad_ring(const float* D, long long d_bs, const float* tables, const float* relu_of, long long relu_of_bs, float* dx, long long dx_bs,
+                           int B, int C4, int cin, int h, int w, void* stream) {
+    YNET_REQUIRE(D && tables && dx && B > 0 && C4 > 0 && (C4 & 3) == 0 && cin > 0 && h >= 2 && w >= 2, "upconv_dgrad_ring: bad arguments (C4 = 4 cout)");
+    YNET_REQUIRE(d_bs >= (long long)C4 * h * w && dx_bs >= (long long)cin * h * w && (relu_of == nullptr || relu_of_bs >= (long long)cin * h * w),
+                 "upconv_dgrad_ring: batch strides smaller than the images");
+    const int lds = (3 * C4 * cin + C4 * (RING_SEG + 2) + 8 * 32) * 4;
+    YNET_REQUIRE(lds <= 64 * 1024, "upconv_dgrad_ring: 4 cout %d x cin %d tables do not fit the 64 KB of LDS this kernel uses", C4, cin);
+    const int nseg_row = (w + RING_SEG - 1) / RING_SEG, nseg_col = h > 2 ? (h - 2 + RING_SEG - 1) / RING_SEG : 0;
+    const long long blocks = (long long)B * (2 * nseg_row + 2 * nseg_col);
+    YNET_REQUIRE(blocks < (1ll << 31), "upconv_dgrad_ring: too many workgroups");
+    hipLaunchKernelGGL(upconv_ring_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, D, d_bs, tables, relu_of, relu_of_bs, dx, dx_bs, B, C4, cin, h, w,
+                       nseg_row, nseg_col);
+    return ynet_check_launch("upconv_dgrad_ring");
 }
 
 int ynet_rot90_flip(const void* src, void* dst, long long N, int H, int W, int k, int flip, void* stream) {

@@ -505,7 +505,7 @@ def _auto_tag(tk):
 
 
 def conv2d_auto_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
-                    relu_wbits=None, pool_code=None, addend=None, upsample2x=False, wp_version=1):
+                    relu_wbits=None, pool_code=None, addend=None, upsample2x=False, wp_version=1, dst_s2d=None):
     """ONE call of ynet_conv2d_auto (include/ynet_hip.h): the library chooses the kernel family, splits wide layers and keeps the transformed
     filters in a cache that lives in the layer's filter cache `wino[0]` under "auto_<direction>".  Operands as conv2d_raw; addend: (ptr,
     image_stride, modulus); upsample2x: the source is the low-resolution map (H, W are the up-sampled size).  Returns (tag, YnetConvTaken)."""
@@ -517,6 +517,8 @@ def conv2d_auto_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, 
         d.src_bmod[i] = s_[3] if len(s_) > 3 else 0
     for i, t_ in enumerate(dsts):
         d.dst[i], d.dst_c[i], d.dst_bs[i] = t_[0], t_[1], t_[2]
+        if dst_s2d is not None and dst_s2d[i]:
+            d.dst_s2d[i] = 1
     if mask:
         d.mask, d.mask_bs = mask[0], mask[1]
     d.wp, d.bias = wp.data_ptr(), (bias.data_ptr() if bias is not None else None)
@@ -608,8 +610,10 @@ def dgrad_relu_family(B, H, W, dy_c, dx_c, K=3):
 
 
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
-               relu_wbits=None, pool_code=None):
-    """The convolution / data-gradient launch set of one layer: srcs / dsts lists of (ptr, channels, batch_stride[, batch modulus]); the operands
+               relu_wbits=None, pool_code=None, dst_s2d=None, info=None):
+    """dst_s2d (a list of flags, one per destination) / info (a dict that receives "wrote_s2d", the bit mask of the destinations written space-to-depth):
+    the gradient of an up-convolution's output, see upconv_s2d_tables; honoured by the library's dispatcher only (ignored under YNET_CONV_AUTO=0).
+    The convolution / data-gradient launch set of one layer: srcs / dsts lists of (ptr, channels, batch_stride[, batch modulus]); the operands
     are those of _conv2d_raw_py below (the round-5 dispatcher, whose docstring describes them and the returned tag).  Since round 6 the
     composition happens in the library (ynet_conv2d_auto, csrc/conv_auto.cpp); this function only applies evaluate()'s development gates."""
     if not conv_auto:
@@ -618,8 +622,11 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
     if wino is not None and not torch.is_grad_enabled() and (
             H * W < _wino_eval_min_hw or not (_wino_plain_eval if len(srcs) == 1 and srcs[0][1] in (16, 32) else _wino_cat_eval)):
         wino = None
-    return conv2d_auto_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits, wino=wino,
-                           wbits_out=wbits_out, relu_wbits=relu_wbits, pool_code=pool_code)[0]
+    tag, tk = conv2d_auto_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits, wino=wino,
+                              wbits_out=wbits_out, relu_wbits=relu_wbits, pool_code=pool_code, dst_s2d=dst_s2d)
+    if info is not None:
+        info["wrote_s2d"] = int(tk.wrote_s2d)
+    return tag
 
 
 def _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
@@ -1099,6 +1106,8 @@ class fold_skip_gradients:
         wgrad_branch = _wgrad_branch_allowed and overlap_decoders
         _relu_outputs.clear()
         _premasked.clear()
+        _s2d_wanted.clear()
+        _s2d_grads.clear()
         return self
 
     def __exit__(self, *exc):
@@ -1107,6 +1116,8 @@ class fold_skip_gradients:
         join_wgrad_branch()
         _relu_outputs.clear()
         _premasked.clear()
+        _s2d_wanted.clear()
+        _s2d_grads.clear()
         _blob_targets.clear()      # (holds the positions and the template of every Gaussian target of the step: nothing of a finished step stays alive)
         # gradients handed over to a pool whose backward never ran (an exception, a pruned graph) must not linger
         for k in [k for k, e in _skip_registry.items() if e.consumed or e.ref() is None or e.stash]:
@@ -1242,7 +1253,7 @@ class _Conv2dFn(torch.autograd.Function):
             if ctx.w_key != _weight_key(weight, lora_a, lora_b):
                 raise RuntimeError("conv2d backward: a parameter was modified in place between forward and backward")
             wp_d = _cached(cache, weight, lora_a, lora_b, scale, "dgrad")
-            dsts = []
+            dsts, want_s2d = [], []
             for i, s in enumerate(srcs):
                 c = s.shape[1]
                 if need_src[i]:
@@ -1250,8 +1261,12 @@ class _Conv2dFn(torch.autograd.Function):
                     # backward sums it over the batch, as in the reference's semantic_img.expand(...))
                     d_srcs[i] = torch.empty((B, c, H, W), device=dy.device, dtype=torch.float32)
                     dsts.append((d_srcs[i].data_ptr(), c, c * H * W))
+                    w_ = _s2d_wanted.get(s.data_ptr()) if (premask and _upconv_s2d_allowed) else None
+                    want_s2d.append(bool(w_ is not None and w_[0]() is not None and w_[1] == tuple(s.shape) and c == 16 and H % 2 == 0 and W % 2 == 0))
                 else:
                     dsts.append((None, c, 0))
+                    want_s2d.append(False)
+            s2d_info = {} if any(want_s2d) else None
             # the single input is itself a post-ReLU conv output that no pool folds: apply THAT layer's ReLU backward to the
             # gradient produced here (see `_premasked`)
             s0 = srcs[0]
@@ -1283,7 +1298,11 @@ class _Conv2dFn(torch.autograd.Function):
                 if ewbits is not None:
                     premask_stats["wino_bit_masks"] = premask_stats.get("wino_bit_masks", 0) + 1
                 conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], mask, wp_d, None, dsts, B, H, W, k, False, relu_of=emask,
-                           wino=(cache, "dgrad") if meta.get("wino") else None, relu_wbits=ewbits)
+                           wino=(cache, "dgrad") if meta.get("wino") else None, relu_wbits=ewbits, dst_s2d=want_s2d if s2d_info is not None else None, info=s2d_info)
+                if s2d_info:
+                    for i, g_ in enumerate(d_srcs):      # (written space-to-depth: only the up-convolution's backward may read these tensors)
+                        if g_ is not None and (s2d_info.get("wrote_s2d", 0) >> i) & 1:
+                            _s2d_grads[g_.data_ptr()] = (g_._version, tuple(g_.shape))
             if emask is not None:
                 _premasked[d_srcs[0].data_ptr()] = (s0.data_ptr(), d_srcs[0]._version, tuple(d_srcs[0].shape))
             if skip_fold:
@@ -1531,6 +1550,42 @@ def upsample2x_conv2d_raw(src, u, bias, dst, cin, cout, B, H, W, relu=False):
                                                 1 if relu else 0, _stream()), lib)
 
 
+# ---- the up-convolution's backward without the up-sampled gradient (round 6; include/ynet_hip.h: ynet_upconv_dgrad_ring) ----
+# Up^T . conv^T is a 3 x 3 convolution at the LOW resolution over the space-to-depth output gradient.  Protocol (inside fold_skip_gradients() only, like the other
+# producer / consumer hand-overs): _UpConvFn.forward registers its output; the conv backward that produces that tensor's gradient asks the dispatcher to write it
+# space-to-depth (one plain 16-channel Winograd launch: the decoders' last level) and registers the gradient; _UpConvFn.backward, handed a registered gradient, runs the
+# effective-filter data gradient at the low resolution + the ring correction instead of [data gradient at the up-sampled size -> bilinear backward].
+_upconv_s2d_allowed = _os.environ.get("YNET_UPCONV_S2D", "1") != "0"
+_s2d_wanted = {}       # output of an up-convolution: data_ptr -> (weakref, shape)
+_s2d_grads = {}        # a gradient written space-to-depth: data_ptr -> (version, shape)
+upconv_stats_s2d = {"backwards": 0}
+_S2D_M = ((0.75, 0.25, 0.0), (0.25, 0.75, 0.75), (0.0, 0.0, 0.25)), ((0.25, 0.0, 0.0), (0.75, 0.75, 0.25), (0.0, 0.25, 0.75))
+_S2D_DM = ((-0.25, 0.25, 0.0), (0.25, 0.0, 0.0)), ((0.0, 0.0, 0.25), (0.0, 0.25, -0.25))
+
+
+def upconv_s2d_tables(weight, cache):
+    """(packed effective filter for the low-resolution data gradient, ring tables [16][4 cout][cin]) of an up-convolution's filter [cout][cin][3][3], cached per weight
+    version in the layer's cache.  Keff[(py, px, co)][ci][a][b] = sum M_py[a][ty] K[co][ci][ty][tx] M_px[b][tx]; the tables as include/ynet_hip.h lists them."""
+    key = ("s2d", weight.data_ptr(), weight._version)
+    ent = cache.get("s2d_tables")
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            K = weight.detach().double()
+            cout, cin = K.shape[0], K.shape[1]
+            M = torch.tensor(_S2D_M, dtype=torch.float64, device=K.device)           # [p][a][t]
+            dM = torch.tensor(_S2D_DM, dtype=torch.float64, device=K.device)         # [side][p][t]
+            keff = torch.einsum("pau,oiuv,qbv->pqoiab", M, K, M).reshape(4 * cout, cin, 3, 3).float().contiguous()
+            tabs = []
+            for s_ in range(2):      # rows: [b][c'][ci]
+                tabs.append(torch.einsum("pu,oiuv,qbv->bpqoi", dM[s_], K, M).reshape(3, 4 * cout, cin))
+            for s_ in range(2):      # columns: [a][c'][ci]
+                tabs.append(torch.einsum("pau,oiuv,qv->apqoi", M, K, dM[s_]).reshape(3, 4 * cout, cin))
+            corners = [torch.einsum("pu,oiuv,qv->pqoi", dM[sv], K, dM[sh]).reshape(1, 4 * cout, cin) for sv in range(2) for sh in range(2)]
+            tables = torch.cat(tabs + corners, 0).float().contiguous()
+            ent = cache["s2d_tables"] = (key, pack_weight(keff, 1), tables, {})
+    return ent[1], ent[2], ent[3]
+
+
 class _UpConvFn(torch.autograd.Function):
     """y = conv3x3(upsample2x(x), W) + b without the up-sampled tensor (models/ynet.py:463-464 as one launch).  The filter is frozen (no
     filter gradient needs the up-sampled input); backward = the convolution's data gradient at the up-sampled size, then the bilinear
@@ -1560,6 +1615,10 @@ class _UpConvFn(torch.autograd.Function):
         ctx.w_key = _weight_key(weight, None, None)
         ctx.premask = bool(premask and ctx.needs_input_grad[0] and _is_relu_output(x))
         ctx.save_for_backward(weight, x if ctx.premask else None)
+        if (_upconv_s2d_allowed and conv_auto and premask and ctx.needs_input_grad[0] and cout == 16 and x.data_ptr() % 16 == 0
+                and _wino16_supported([4 * cout], cin, B, Hl, Wl)):
+            # (inside fold_skip_gradients(): the gradient of y may arrive space-to-depth -- see the protocol above)
+            _s2d_wanted[y.data_ptr()] = (weakref.ref(y), tuple(y.shape))
         return y
 
     @staticmethod
@@ -1570,6 +1629,22 @@ class _UpConvFn(torch.autograd.Function):
         if ctx.w_key != _weight_key(weight, None, None):
             raise RuntimeError("upsample2x_conv2d backward: the filter was modified in place between forward and backward")
         dy = dy.contiguous()
+        reg = _s2d_grads.pop(dy.data_ptr(), None)
+        if reg is not None and reg == (dy._version, tuple(dy.shape)):
+            # dy's memory holds the gradient space-to-depth, [B, 4 cout, Hl, Wl]: the data gradient of the effective filter at the low resolution (through the ReLU
+            # backward of x where that is wanted), then what the bilinear clamp and the up-sampled image's zero padding add on the outermost ring
+            wp_eff, tables, wcache = upconv_s2d_tables(weight, ctx.cache)
+            dx = torch.empty((B, cin, Hl, Wl), device=dy.device, dtype=torch.float32)
+            masked = bool(ctx.premask and premask and x is not None)
+            conv2d_raw([(dy.data_ptr(), 4 * cout, 4 * cout * Hl * Wl)], None, wp_eff, None, [(dx.data_ptr(), cin, cin * Hl * Wl)], B, Hl, Wl, 3, False,
+                       relu_of=(x.data_ptr(), cin * Hl * Wl) if masked else None, wino=(wcache, "dgrad"))
+            lib = _lib()
+            L.check(lib.ynet_upconv_dgrad_ring(dy.data_ptr(), 4 * cout * Hl * Wl, tables.data_ptr(), x.data_ptr() if masked else None, cin * Hl * Wl, dx.data_ptr(),
+                                               cin * Hl * Wl, B, 4 * cout, cin, Hl, Wl, _stream()), lib)
+            if masked:
+                _premasked[dx.data_ptr()] = (x.data_ptr(), dx._version, tuple(dx.shape))
+            upconv_stats_s2d["backwards"] += 1
+            return dx, None, None, None
         wp_d = _cached(ctx.cache, weight, None, None, 1.0, "dgrad")
         d_up = torch.empty((B, cin, H, W), device=dy.device, dtype=torch.float32)
         conv2d_raw([(dy.data_ptr(), cout, cout * H * W)], None, wp_d, None, [(d_up.data_ptr(), cin, cin * H * W)], B, H, W, 3, False, wino=(ctx.cache, "dgrad"))

@@ -2210,3 +2210,63 @@ def test_batchnorm2d_and_add_relu_match_torch(dev, case):
     nan = torch.tensor([float("nan"), -1.0, 2.0], device=dev).view(1, 3, 1, 1)
     out = ops.add_relu(nan, torch.zeros_like(nan), True)
     assert bool(torch.isnan(out[0, 0, 0, 0])) and float(out[0, 1, 0, 0]) == 0.0 and float(out[0, 2, 0, 0]) == 2.0
+
+
+@pytest.mark.parametrize("B,Hl,Wl,wmap", [(8, 128, 128, True), (4, 128, 128, False), (6, 64, 160, True)], ids=str)
+def test_up_convolution_backward_without_the_up_sampled_gradient(dev, B, Hl, Wl, wmap):
+    """Round 6: the backward of `upsample_conv[4](F.interpolate(x, scale_factor=2))` (models/ynet.py:463-464) as a 3 x 3 convolution at the LOW
+    resolution over the space-to-depth output gradient (effective filter per bilinear phase) + a correction on the outermost ring -- the up-sampled gradient
+    [B, 32, 2 Hl, 2 Wl] is never written and the bilinear backward launch disappears.  A decoder's last level (conv -> ReLU below, up-convolution, cat with the skip
+    features [and a way-point map], conv + ReLU above) inside fold_skip_gradients(): the gradient of the level's input with the hand-over on and off, and against
+    torch's autograd in fp64; the hand-over is taken (the producer's 16-channel piece written space-to-depth), and only then."""
+    ynet, ops = pkg("models.ynet"), pkg("ops")
+    H, W = 2 * Hl, 2 * Wl
+    below, up = ynet.HipConv2d(32, 32, 3).to(dev), ynet.HipConv2d(32, 16, 3).to(dev)
+    top = ynet.FusedSequential(ynet.HipConv2d(49 if wmap else 48, 32, 3), torch.nn.ReLU(), ynet.HipConv2d(32, 32, 3), torch.nn.ReLU()).to(dev)      # decoder[4]
+    for m in (below, up, top):
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+    x0 = rnd(B, 32, Hl, Wl, seed=1).to(dev)
+    skip = torch.relu(rnd(B, 32, H, W, seed=2)).to(dev)
+    wm = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(3)).to(dev) if wmap else None
+    g = rnd(B, 32, H, W, seed=4).to(dev)
+
+    def run(s2d):
+        old = ops._upconv_s2d_allowed
+        ops._upconv_s2d_allowed = s2d
+        try:
+            xi, sk = x0.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+            n0 = ops.upconv_stats_s2d["backwards"]
+            with ops.fold_skip_gradients():
+                h0 = below(xi, relu=True)                                   # a post-ReLU activation feeds the up-convolution, as in the decoder
+                u_ = ops.upsample2x_conv2d(h0, up)
+                y = top(ops.lazy_cat([u_, sk] + ([wm] if wmap else [])))
+                (y * g).sum().backward()
+            return y.detach(), xi.grad, sk.grad, ops.upconv_stats_s2d["backwards"] - n0
+        finally:
+            ops._upconv_s2d_allowed = old
+
+    y1, gx1, gs1, n1 = run(True)
+    y0, gx0, gs0, n0 = run(False)
+    assert n1 == 1 and n0 == 0, (n1, n0)
+    assert torch.equal(y1, y0) and torch.equal(gs1, gs0)                     # the forward pass and the skip features' gradient do not change
+    xr, sr = x0.double().cpu().requires_grad_(True), skip.double().cpu().requires_grad_(True)
+    dd = lambda m: (m.weight.detach().double().cpu(), m.bias.detach().double().cpu())      # noqa: E731
+    h0 = torch.relu(F.conv2d(xr, *dd(below), padding=1))
+    u_ = F.conv2d(F.interpolate(h0, scale_factor=2, mode="bilinear", align_corners=False), *dd(up), padding=1)
+    yr = torch.relu(F.conv2d(torch.cat([u_, sr] + ([wm.double().cpu()] if wmap else []), 1), *dd(top[0]), padding=1))
+    yr = torch.relu(F.conv2d(yr, *dd(top[2]), padding=1))
+    (yr * g.double().cpu()).sum().backward()
+    # the two device paths share every ReLU mask (the forward pass is bit-identical): they agree to fp32 rounding EVERYWHERE, the outermost ring included
+    close(gx1, gx0, rtol=1e-4, scale_rel=5e-6, msg="low-resolution form vs up-sampled form")
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), -1)):
+        close(gx1[sl], gx0[sl], rtol=1e-4, scale_rel=5e-6, msg="ring")
+    # against torch in fp64: a few pre-activations round to opposite sides of zero on the host and on the device, each flips the 9 x 32 gradients it gates --
+    # all but a few per mille of the entries within rounding (the same entries on both device paths), and the low-resolution form no further from fp64 than the up-sampled one
+    want = xr.grad
+    tol = 5e-6 * float(want.abs().max()) + 1e-4 * want.abs()
+    bad1, bad0 = (gx1.double().cpu() - want).abs() > tol, (gx0.double().cpu() - want).abs() > tol
+    assert float(bad1.double().mean()) <= 5e-3 and int(bad1.sum()) <= int(bad0.sum()) + 16, (int(bad1.sum()), int(bad0.sum()))
+    ok = ~(bad1 | bad0)
+    e1, e0 = float((gx1.double().cpu() - want)[ok].abs().max()), float((gx0.double().cpu() - want)[ok].abs().max())
+    assert e1 <= 2.0 * e0 + 1e-7 * float(want.abs().max()), (e1, e0)

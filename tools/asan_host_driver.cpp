@@ -208,6 +208,19 @@ int main() {
     EXPECT_REJECT(ynet_cws_prior(cfp, 4, 1, cfp, cfp, 1, 2, 2, 0.f, 1.f, 0, fp, fp, nullptr));
     EXPECT_REJECT(ynet_resize_nearest(nullptr, (int*)dummy, 4, 4, 2, 2, 0.5, 0.5, nullptr));
     EXPECT_REJECT(ynet_resize_nearest((const int*)dummy, (int*)dummy, 4, 4, 2, 2, 0.0, 0.5, nullptr));      // factor 0
+    EXPECT_REJECT(ynet_upconv_dgrad_ring(nullptr, 0, cfp, nullptr, 0, fp, 0, 1, 64, 32, 8, 8, nullptr));
+    EXPECT_REJECT(ynet_upconv_dgrad_ring(cfp, 64 * 64, cfp, nullptr, 0, fp, 32 * 64, 1, 62, 32, 8, 8, nullptr));        // C4 not a multiple of 4
+    EXPECT_REJECT(ynet_upconv_dgrad_ring(cfp, 8, cfp, nullptr, 0, fp, 32 * 64, 1, 64, 32, 8, 8, nullptr));               // batch stride below the image
+    EXPECT_REJECT(ynet_upconv_dgrad_ring(cfp, 512 * 64, cfp, nullptr, 0, fp, 64 * 64, 1, 512, 64, 8, 8, nullptr));       // tables beyond 64 KB of LDS
+    EXPECT_REJECT(ynet_conv2d_winograd_s2d(nullptr, 0, cfp, fp, 0, 32, 16, 8, 256, 256, nullptr));
+    EXPECT_REJECT(ynet_conv2d_winograd_s2d(cfp, 32ll * 64 * 64, cfp, fp, 16ll * 64 * 64, 32, 16, 1, 64, 64, nullptr));   // too few pixels for the Winograd kernels
+    EXPECT_REJECT(ynet_batchnorm2d_fwd(nullptr, fp, nullptr, nullptr, nullptr, nullptr, fp, fp, nullptr, 1, 4, 16, 1, 0.1, 1e-5, nullptr));
+    EXPECT_REJECT(ynet_batchnorm2d_fwd(cfp, fp, nullptr, nullptr, nullptr, nullptr, fp, fp, nullptr, 1, 4, 16, 1, 0.1, 1e-5, nullptr));      // training mode without a workspace
+    EXPECT_REJECT(ynet_batchnorm2d_fwd(cfp, fp, nullptr, nullptr, nullptr, nullptr, fp, fp, nullptr, 1, 4, 16, 0, 0.1, 1e-5, nullptr));      // evaluation mode without running statistics
+    EXPECT_REJECT(ynet_batchnorm2d_bwd(cfp, cfp, cfp, cfp, nullptr, fp, nullptr, nullptr, nullptr, 1, 4, 16, 1, nullptr));
+    EXPECT_REJECT(ynet_add_relu(nullptr, cfp, fp, 4, 1, nullptr));
+    EXPECT_REJECT(ynet_relu_bwd(cfp, cfp, nullptr, 4, nullptr));
+    if (ynet_batchnorm_workspace_doubles(16) != 2ll * 16 * 64 || ynet_batchnorm_workspace_doubles(0) != 0) { fprintf(stderr, "batchnorm workspace\n"); ++failures; }
     EXPECT_REJECT(ynet_rot90_flip(nullptr, dummy, 1, 4, 4, 1, 0, nullptr));
     EXPECT_REJECT(ynet_rot90_flip(dummy, dummy, 1, 4, 4, 1, 0, nullptr));      // in place
     EXPECT_REJECT(ynet_rot_coords(nullptr, 4, 0, 0, 1, 0, 0, 1, 0, 0, nullptr));
