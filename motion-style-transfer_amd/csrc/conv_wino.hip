@@ -143,10 +143,15 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                     const unsigned sc = so_t + (unsigned)(cb * 16 + 2 * h + k) * hw * 4u;
                     // (scalars first: __builtin_bit_cast applied to a vector-element lvalue reads the vector's FIRST element -- hipcc stored row0[0] twice)
                     const float e00 = row0[0], e01 = row0[1], e10 = row1[0], e11 = row1[1];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e00), ry, st0, sc, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e01), ry, st0, sc + ph, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e10), ry, st0, sc + 2u * ph, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e11), ry, st0, sc + 3u * ph, 0);
+                    // Two neighbouring lanes (low-resolution columns j, j + 1) trade one element per row so that the even one holds the column-phase-0 pair and the
+                    // odd one the column-phase-1 pair: 2 eight-byte stores per lane instead of 4 four-byte ones (same 64-byte segments, half the instructions).
+                    const bool odd = __lane_id() & 1u;
+                    const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? e00 : e01), 0xB1, 0xF, 0xF, false));
+                    const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? e10 : e11), 0xB1, 0xF, 0xF, false));
+                    const f32x2 p0 = odd ? f32x2{g0, e01} : f32x2{e00, g0}, p1 = odd ? f32x2{g1, e11} : f32x2{e10, g1};
+                    const unsigned vo = st0 + (odd ? ph - 4u : 0u);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p0), ry, vo, sc, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p1), ry, vo, sc + 2u * ph, 0);
                     continue;
                 }
                 const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
