@@ -165,14 +165,15 @@ class ConvTimer:
         #  because only there every launch of a call can be bracketed by its own event pair)
         self.ops.conv_auto = False
 
-        def timed_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None, wbits_out=None, relu_wbits=None):
+        def timed_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None, wbits_out=None, relu_wbits=None, s2d=False):
             # one Winograd launch (a convolution with 48 / 64 outputs is two of them): its own event pair, rocprof's kernel name
-            # (third template argument: 0 plain, 1 through a ReLU backward with the float activation, 2 with the 1-bit mask, 3 plain + mask written)
+            # (third template argument: 0 plain, 1 through a ReLU backward with the float activation, 2 with the 1-bit mask, 3 plain + mask written,
+            #  4 plain, stored space-to-depth: the gradient of an up-convolution's output)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=relu_of, wbits_out=wbits_out, relu_wbits=relu_wbits)
+            self.orig_wino(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=relu_of, wbits_out=wbits_out, relu_wbits=relu_wbits, s2d=s2d)
             e1.record()
-            em = 3 if wbits_out is not None else (2 if relu_wbits is not None else (1 if relu_of is not None else 0))
+            em = 4 if s2d else (3 if wbits_out is not None else (2 if relu_wbits is not None else (1 if relu_of is not None else 0)))
             name = f"conv_wino_kernel<{cout // 16}, {cin // 8}, {em}, 8>"
             self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin + cout * (2 if em == 1 else (1 + 1 / 32 if em >= 2 else 1))),
                              (B, H, W, cin, cout, 3, False)))

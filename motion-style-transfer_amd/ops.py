@@ -370,12 +370,17 @@ def winograd_filter(wp: torch.Tensor, cin: int, cout: int, col0: int = 0, cols_t
     return u
 
 
-def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None, wbits_out=None, relu_wbits=None):
+def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=None, wbits_out=None, relu_wbits=None, s2d=False):
     """src / dst: (ptr, batch_stride in floats); u: winograd_filter(...) of the layer's packed filter; relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to dst (ynet_conv2d_winograd_dgrad_relu: a data gradient, no bias / ReLU).  wbits_out: an
     int32 tensor of ynet_winograd_relu_bits_words(B, H, W) words that receives the 1-bit mask of the (ReLU, 32-channel) output; relu_wbits:
     such a mask, applied to a data gradient in place of relu_of's activation fetch."""
     lib = _lib()
+    if s2d:      # the plain data gradient stored space-to-depth (ynet_conv2d_winograd_s2d: the gradient of an up-convolution's output)
+        if bias is not None or relu or relu_of is not None or wbits_out is not None or relu_wbits is not None:
+            raise ValueError("conv2d_winograd_raw: s2d is for a plain data gradient")
+        L.check(lib.ynet_conv2d_winograd_s2d(src[0], src[1], u.data_ptr(), dst[0], dst[1], cin, cout, B, H, W, _stream()), lib)
+        return
     if wbits_out is not None:
         if cout != 32 or not relu or relu_of is not None or relu_wbits is not None:
             raise ValueError("conv2d_winograd_raw: wbits_out is for a forward ReLU launch with 32 outputs")
@@ -612,13 +617,13 @@ def dgrad_relu_family(B, H, W, dy_c, dx_c, K=3):
 def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
                relu_wbits=None, pool_code=None, dst_s2d=None, info=None):
     """dst_s2d (a list of flags, one per destination) / info (a dict that receives "wrote_s2d", the bit mask of the destinations written space-to-depth):
-    the gradient of an up-convolution's output, see upconv_s2d_tables; honoured by the library's dispatcher only (ignored under YNET_CONV_AUTO=0).
+    the gradient of an up-convolution's output, see upconv_s2d_tables; honoured where ONE plain Winograd launch writes the whole destination.
     The convolution / data-gradient launch set of one layer: srcs / dsts lists of (ptr, channels, batch_stride[, batch modulus]); the operands
     are those of _conv2d_raw_py below (the round-5 dispatcher, whose docstring describes them and the returned tag).  Since round 6 the
     composition happens in the library (ynet_conv2d_auto, csrc/conv_auto.cpp); this function only applies evaluate()'s development gates."""
     if not conv_auto:
         return _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=relu_of, pooled=pooled, bits_out=bits_out, relu_bits=relu_bits, wino=wino,
-                              wbits_out=wbits_out, relu_wbits=relu_wbits, pool_code=pool_code)
+                              wbits_out=wbits_out, relu_wbits=relu_wbits, pool_code=pool_code, dst_s2d=dst_s2d, info=info)
     if wino is not None and not torch.is_grad_enabled() and (
             H * W < _wino_eval_min_hw or not (_wino_plain_eval if len(srcs) == 1 and srcs[0][1] in (16, 32) else _wino_cat_eval)):
         wino = None
@@ -630,7 +635,7 @@ def conv2d_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, poole
 
 
 def _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, pooled=None, bits_out=None, relu_bits=None, wino=None, wbits_out=None,
-                   relu_wbits=None, pool_code=None):
+                   relu_wbits=None, pool_code=None, dst_s2d=None, info=None):
     """srcs / dsts: lists of (ptr, channels, batch_stride); mask: (ptr, batch_stride) or None.  relu_of: (ptr, batch_stride) of the
     post-ReLU activation whose backward is applied to the single destination (ynet_conv2d_dgrad_relu), or None.  pooled: (ptr,
     batch_stride) of a second output, the 2 x 2 max-pooled copy of the single destination (ynet_conv2d_pool), or None.
@@ -647,6 +652,8 @@ def _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, p
     concatenated sources (tag "winograd_cat:2,6|code": the caller keeps the tensor only then)."""
     lib = _lib()
     sp, sc, sb = _arrays(srcs)
+    if info is not None:
+        info["wrote_s2d"] = 0
     if wino is not None and not torch.is_grad_enabled() and (
             H * W < _wino_eval_min_hw or not (_wino_plain_eval if len(srcs) == 1 and srcs[0][1] in (16, 32) else _wino_cat_eval)):
         wino = None
@@ -695,8 +702,8 @@ def _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, p
         # destination channels in pieces of 32 / 16 (a 48- or 64-channel data gradient is two launches over slices of the filter; the
         # input is read once per piece -- from L2 --, pieces nobody wants are not computed)
         cin, ctot, HW = srcs[0][1], sum(d[1] for d in dsts), H * W
-        pieces, c0 = [], 0
-        for ptr, c, bs in dsts:
+        pieces, piece_dst, c0 = [], [], 0      # piece_dst: (index of the piece's destination, "the piece is that whole destination")
+        for di, (ptr, c, bs) in enumerate(dsts):
             if ptr is None:          # (nobody wants these channels -- e.g. the way-point map's gradient --: not computed)
                 c0 += c
                 continue
@@ -704,6 +711,7 @@ def _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, p
             while c - o >= 16 and (c - o) % 16 == 0:
                 n = 32 if c - o >= 32 else 16
                 pieces.append((ptr + 4 * o * HW, n, bs, c0 + o))
+                piece_dst.append((di, n == c))
                 o += n
             if o != c:
                 pieces = None
@@ -723,15 +731,20 @@ def _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, p
             wb_out = wbits_out if (one32 and relu and relu_of is None) else None      # the forward launch of a conv -> ReLU -> conv chain writes the mask word
             wb_in = relu_wbits if (one32 and relu_of is not None and not relu and bias is None) else None      # ... and the chain's data gradient applies it
             em = 3 if wb_out is not None else (2 if wb_in is not None else (1 if relu_of is not None else 0))
-            tag = "winograd:" + "+".join("%d,%d,%d" % (p_[1] // 16, cin // 8, em) for p_ in pieces) + ("|wbits" if wb_out is not None else "")
-            for ptr, n, bs, col0 in pieces:
+            # (the gradient of an up-convolution's output, stored space-to-depth: csrc/conv_auto.cpp's rule -- a plain launch that writes the whole destination)
+            s2ds = [bool(dst_s2d and dst_s2d[di] and whole and em == 0 and bias is None and not relu) for di, whole in piece_dst]
+            tag = ("winograd:" + "+".join("%d,%d,%d" % (p_[1] // 16, cin // 8, 4 if f_ else em) for p_, f_ in zip(pieces, s2ds))
+                   + ("|wbits" if wb_out is not None else ""))
+            for (ptr, n, bs, col0), (di, whole), s2d in zip(pieces, piece_dst, s2ds):
                 key = "wino_%s_%d_%d" % (what, col0, n)
                 ent = cache.get(key)
                 if ent is None or ent[0] is not wp:
                     ent = cache[key] = _wino_made((wp, winograd_filter(wp, cin, n, col0, ctot)))
                 _wino_ready(ent)
                 conv2d_winograd_raw((srcs[0][0], srcs[0][2]), ent[1], None if bias is None else bias[col0:col0 + n], (ptr, bs), cin, n, B, H, W, relu,
-                                    relu_of=None if wb_in is not None else relu_of, wbits_out=wb_out, relu_wbits=wb_in)
+                                    relu_of=None if wb_in is not None else relu_of, wbits_out=wb_out, relu_wbits=wb_in, **({"s2d": True} if s2d else {}))
+                if s2d and info is not None:
+                    info["wrote_s2d"] |= 1 << di
                 wino_stats["launches"] += 1
             return tag
         # the slice form for what the kernels above do not serve: 64 input channels, destinations of 64 channels (one launch per
@@ -1615,7 +1628,7 @@ class _UpConvFn(torch.autograd.Function):
         ctx.w_key = _weight_key(weight, None, None)
         ctx.premask = bool(premask and ctx.needs_input_grad[0] and _is_relu_output(x))
         ctx.save_for_backward(weight, x if ctx.premask else None)
-        if (_upconv_s2d_allowed and conv_auto and premask and ctx.needs_input_grad[0] and cout == 16 and x.data_ptr() % 16 == 0
+        if (_upconv_s2d_allowed and premask and ctx.needs_input_grad[0] and cout == 16 and x.data_ptr() % 16 == 0
                 and _wino16_supported([4 * cout], cin, B, Hl, Wl)):
             # (inside fold_skip_gradients(): the gradient of y may arrive space-to-depth -- see the protocol above)
             _s2d_wanted[y.data_ptr()] = (weakref.ref(y), tuple(y.shape))

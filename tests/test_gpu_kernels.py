@@ -1866,6 +1866,8 @@ AUTO_CASES = {
     "predictor_1x1": (4, 64, 64, [32], [12], 1, False, True, {}),
     "direct_bits_out": (8, 32, 32, [64], [64], 3, True, True, {"bits_out": True}),
     "masked_input": (4, 32, 32, [64], [32, 64], 3, False, False, {"mask": True}),
+    "dgrad_s2d_16_of_16_32": (8, 256, 256, [32], [16, 32, None], 3, False, False, {"s2d": [1, 0, 0]}),
+    "dgrad_s2d_asked_of_two_pieces": (8, 256, 256, [32], [48], 3, False, False, {"s2d": [1]}),      # (not one launch: stays row-major)
 }
 
 
@@ -1898,7 +1900,7 @@ def test_conv2d_auto_takes_the_launches_of_the_python_dispatcher(dev, name):
                            [(y_prev.data_ptr(), 32, 32 * H * W)], B, H, W, 3, True, wino=({}, "fwd"), wbits_out=wb_in)
         act = y_prev
 
-    def run(fn, tag_only=False, cache=None):
+    def run(fn, tag_only=False, cache=None, s2d=True):
         outs = [torch.full((B, c, H, W), float("nan"), device=dev) for c in sizes]
         dsts = [(t.data_ptr() if c is not None else None, t.shape[1], t.shape[1] * H * W if c is not None else 0) for t, c in zip(outs, couts)]
         kw = {"wino": (cache if cache is not None else {}, "dgrad" if dgrad else "fwd")}
@@ -1920,6 +1922,8 @@ def test_conv2d_auto_takes_the_launches_of_the_python_dispatcher(dev, name):
             extra["bits"] = torch.full((words,), -1, device=dev, dtype=torch.int32)
             kw["bits_out"] = extra["bits"].data_ptr()
             kw.pop("wino")
+        if opts.get("s2d") and s2d:
+            kw["dst_s2d"] = opts["s2d"]
         n0 = ops.wino_stats["launches"]
         tag = fn(srcs, (mask_t.data_ptr(), cin * H * W) if mask_t is not None else None, wp, bias, dsts, B, H, W, K, relu, **kw)
         return tag, ops.wino_stats["launches"] - n0, outs, extra
@@ -1933,6 +1937,20 @@ def test_conv2d_auto_takes_the_launches_of_the_python_dispatcher(dev, name):
     assert set(e_py) == set(e_c)
     for k in e_py:
         assert torch.equal(torch.nan_to_num(e_py[k].float(), nan=12345.0), torch.nan_to_num(e_c[k].float(), nan=12345.0)), (name, k)
+    if opts.get("s2d"):
+        # a destination that asked for it AND is written whole by one plain launch holds its gradient space-to-depth (element (2 i + r, 2 j + c) of channel ch at
+        # plane (2 r + c) * C + ch, position (i, j)): the same numbers as the row-major launch, bit for bit; every other destination is row-major as ever
+        t_rm, _, o_rm, _ = run(ops._conv2d_raw_py, s2d=False)
+        took = "4" in [g.split(",")[2] for g in t_c.split(":")[1].split("|")[0].split("+")]
+        assert took == (name == "dgrad_s2d_16_of_16_32"), t_c
+        for i, (a_, b_) in enumerate(zip(o_rm, o_c)):
+            if couts[i] is None:
+                continue
+            if took and opts["s2d"][i]:
+                C = a_.shape[1]
+                a_ = a_.view(B, C, H // 2, 2, W // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(B, 4 * C, H // 2, W // 2)
+                b_ = b_.view(B, 4 * C, H // 2, W // 2)
+            assert torch.equal(a_, b_), (name, i)
     if t_c is not None:
         # the transformed filter is cached: the second call transforms nothing, a new version does
         kw = {"wino": (cache, "dgrad" if dgrad else "fwd")}
@@ -1940,6 +1958,8 @@ def test_conv2d_auto_takes_the_launches_of_the_python_dispatcher(dev, name):
             kw["relu_of"] = (act.data_ptr(), ctot * H * W)
         if opts.get("pooled"):
             kw["pooled"] = (e_c["pooled"].data_ptr(), ctot * (H // 2) * (W // 2))
+        if opts.get("s2d"):
+            kw["dst_s2d"] = opts["s2d"]
         dsts = [(t.data_ptr() if c is not None else None, t.shape[1], t.shape[1] * H * W if c is not None else 0) for t, c in zip(o_c, couts)]
         if wb_in is None and not opts.get("wbits_out") and not opts.get("pool_code"):
             _, tk = ops.conv2d_auto_raw(srcs, None, wp, bias, dsts, B, H, W, K, relu, **kw)
