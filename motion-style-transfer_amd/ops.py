@@ -1121,6 +1121,7 @@ class fold_skip_gradients:
         _premasked.clear()
         _s2d_wanted.clear()
         _s2d_grads.clear()
+        _s2d_produced.clear()
         return self
 
     def __exit__(self, *exc):
@@ -1131,6 +1132,7 @@ class fold_skip_gradients:
         _premasked.clear()
         _s2d_wanted.clear()
         _s2d_grads.clear()
+        _s2d_produced.clear()
         _blob_targets.clear()      # (holds the positions and the template of every Gaussian target of the step: nothing of a finished step stays alive)
         # gradients handed over to a pool whose backward never ran (an exception, a pruned graph) must not linger
         for k in [k for k, e in _skip_registry.items() if e.consumed or e.ref() is None or e.stash]:
@@ -1316,6 +1318,10 @@ class _Conv2dFn(torch.autograd.Function):
                     for i, g_ in enumerate(d_srcs):      # (written space-to-depth: only the up-convolution's backward may read these tensors)
                         if g_ is not None and (s2d_info.get("wrote_s2d", 0) >> i) & 1:
                             _s2d_grads[g_.data_ptr()] = (g_._version, tuple(g_.shape))
+                            # (one hand-over per up-convolution output: a second consumer of that tensor gets a row-major gradient, and the sum autograd
+                            #  forms of the two is then refused by _UpConvFn.backward instead of being read in the wrong layout)
+                            _s2d_wanted.pop(srcs[i].data_ptr(), None)
+                            _s2d_produced.add(srcs[i].data_ptr())
             if emask is not None:
                 _premasked[d_srcs[0].data_ptr()] = (s0.data_ptr(), d_srcs[0]._version, tuple(d_srcs[0].shape))
             if skip_fold:
@@ -1571,6 +1577,7 @@ def upsample2x_conv2d_raw(src, u, bias, dst, cin, cout, B, H, W, relu=False):
 _upconv_s2d_allowed = _os.environ.get("YNET_UPCONV_S2D", "1") != "0"
 _s2d_wanted = {}       # output of an up-convolution: data_ptr -> (weakref, shape)
 _s2d_grads = {}        # a gradient written space-to-depth: data_ptr -> (version, shape)
+_s2d_produced = set()  # outputs of up-convolutions (data_ptr) for which a gradient WAS written space-to-depth: their backward must be handed exactly that tensor
 upconv_stats_s2d = {"backwards": 0}
 _S2D_M = ((0.75, 0.25, 0.0), (0.25, 0.75, 0.75), (0.0, 0.0, 0.25)), ((0.25, 0.0, 0.0), (0.75, 0.75, 0.25), (0.0, 0.25, 0.75))
 _S2D_DM = ((-0.25, 0.25, 0.0), (0.25, 0.0, 0.0)), ((0.0, 0.0, 0.25), (0.0, 0.25, -0.25))
@@ -1632,6 +1639,7 @@ class _UpConvFn(torch.autograd.Function):
                 and _wino16_supported([4 * cout], cin, B, Hl, Wl)):
             # (inside fold_skip_gradients(): the gradient of y may arrive space-to-depth -- see the protocol above)
             _s2d_wanted[y.data_ptr()] = (weakref.ref(y), tuple(y.shape))
+        ctx.y_ptr = y.data_ptr()
         return y
 
     @staticmethod
@@ -1643,7 +1651,13 @@ class _UpConvFn(torch.autograd.Function):
             raise RuntimeError("upsample2x_conv2d backward: the filter was modified in place between forward and backward")
         dy = dy.contiguous()
         reg = _s2d_grads.pop(dy.data_ptr(), None)
-        if reg is not None and reg == (dy._version, tuple(dy.shape)):
+        handed = reg is not None and reg == (dy._version, tuple(dy.shape))
+        if ctx.y_ptr in _s2d_produced:
+            _s2d_produced.discard(ctx.y_ptr)
+            if not handed:
+                raise RuntimeError("upsample2x_conv2d backward: a gradient of this up-convolution's output was written space-to-depth for it, but the gradient that "
+                                   "arrived is another tensor (the output has a second consumer, or a hook replaced its gradient): set YNET_UPCONV_S2D=0 for such a graph")
+        if handed:
             # dy's memory holds the gradient space-to-depth, [B, 4 cout, Hl, Wl]: the data gradient of the effective filter at the low resolution (through the ReLU
             # backward of x where that is wanted), then what the bilinear clamp and the up-sampled image's zero padding add on the outermost ring
             wp_eff, tables, wcache = upconv_s2d_tables(weight, ctx.cache)

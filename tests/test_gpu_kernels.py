@@ -2290,3 +2290,37 @@ def test_up_convolution_backward_without_the_up_sampled_gradient(dev, B, Hl, Wl,
     ok = ~(bad1 | bad0)
     e1, e0 = float((gx1.double().cpu() - want)[ok].abs().max()), float((gx0.double().cpu() - want)[ok].abs().max())
     assert e1 <= 2.0 * e0 + 1e-7 * float(want.abs().max()), (e1, e0)
+
+
+def test_a_second_consumer_of_an_up_convolution_output_is_refused(dev):
+    """The space-to-depth hand-over is between ONE producer and the up-convolution's backward.  If the up-convolution's output feeds two operations, autograd sums
+    their gradients into a tensor the protocol never saw -- one of them in the other layout.  That must fail loudly, not return numbers."""
+    ynet, ops = pkg("models.ynet"), pkg("ops")
+    B, Hl, Wl = 4, 128, 128
+    H, W = 2 * Hl, 2 * Wl
+    below, up, other = ynet.HipConv2d(32, 32, 3).to(dev), ynet.HipConv2d(32, 16, 3).to(dev), ynet.HipConv2d(16, 16, 3).to(dev)
+    top = ynet.FusedSequential(ynet.HipConv2d(48, 32, 3), torch.nn.ReLU(), ynet.HipConv2d(32, 32, 3), torch.nn.ReLU()).to(dev)
+    for m in (below, up, other, top):
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+    xi = rnd(B, 32, Hl, Wl, seed=1).to(dev).requires_grad_(True)
+    skip = torch.relu(rnd(B, 32, H, W, seed=2)).to(dev)
+    if not ops._upconv_s2d_allowed:
+        pytest.skip("YNET_UPCONV_S2D=0")
+    with pytest.raises(RuntimeError, match="second consumer"):
+        with ops.fold_skip_gradients():
+            u_ = ops.upsample2x_conv2d(below(xi, relu=True), up)
+            loss = top(ops.lazy_cat([u_, skip])).sum() + other(u_).sum()
+            loss.backward()
+    assert not ops._s2d_produced and not ops._s2d_grads and not ops._s2d_wanted      # (the registries do not outlive the context)
+    # ... and the same graph with the hand-over off is served as ever
+    old = ops._upconv_s2d_allowed
+    ops._upconv_s2d_allowed = False
+    try:
+        xi.grad = None
+        with ops.fold_skip_gradients():
+            u_ = ops.upsample2x_conv2d(below(xi, relu=True), up)
+            (top(ops.lazy_cat([u_, skip])).sum() + other(u_).sum()).backward()
+        assert torch.isfinite(xi.grad).all() and float(xi.grad.abs().max()) > 0
+    finally:
+        ops._upconv_s2d_allowed = old
