@@ -2324,3 +2324,44 @@ def test_a_second_consumer_of_an_up_convolution_output_is_refused(dev):
         assert torch.isfinite(xi.grad).all() and float(xi.grad.abs().max()) > 0
     finally:
         ops._upconv_s2d_allowed = old
+
+
+@pytest.mark.parametrize("B,cin,cout,h,w", [(2, 3, 2, 5, 7), (1, 32, 16, 2, 2), (3, 8, 4, 16, 70), (2, 20, 16, 130, 9), (2, 32, 16, 64, 64)], ids=str)
+def test_upconv_dgrad_ring_and_the_effective_filter_at_any_shape(dev, B, cin, cout, h, w):
+    """ynet_upconv_dgrad_ring through the C ABI, away from the shapes the decoders use (odd sizes, a 2 x 2 map where every pixel is a corner, border lines longer
+    and shorter than a 64-pixel segment, channel counts that are no multiple of 16): [data gradient of the effective filter over the space-to-depth gradient] +
+    [ring] must be the gradient torch's fp64 autograd gives for conv2d(F.interpolate(x, scale_factor=2, mode='bilinear'), K) -- with and without a ReLU gate."""
+    import torch.nn.functional as F
+    ops = pkg("ops")
+    lib = ops._lib()
+    K = rnd(cout, cin, 3, 3, seed=1, scale=0.3)
+    x = rnd(B, cin, h, w, seed=2).double().requires_grad_(True)
+    dy = rnd(B, cout, 2 * h, 2 * w, seed=3)
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), K.double(), padding=1)
+    (want,) = torch.autograd.grad(y, x, dy.double())
+    D = dy.view(B, cout, h, 2, w, 2).permute(0, 3, 5, 1, 2, 4).reshape(B, 4 * cout, h, w).contiguous().to(dev)      # plane (2 r + c) * cout + ch
+    wp_eff, tables, _ = ops.upconv_s2d_tables(K.to(dev), {})
+    assert tuple(tables.shape) == (16, 4 * cout, cin)
+    gate = torch.relu(rnd(B, cin, h, w, seed=4)).to(dev)
+    for masked in (False, True):
+        dx = torch.full((B, cin, h, w), float("nan"), device=dev)
+        fused_gate = masked and (cin * h * w) % 4 == 0      # (the convolution's ReLU-gated epilogue wants 16-byte aligned images; the ring kernel does not care)
+        ops.conv2d_raw([(D.data_ptr(), 4 * cout, 4 * cout * h * w)], None, wp_eff, None, [(dx.data_ptr(), cin, cin * h * w)], B, h, w, 3, False,
+                       relu_of=(gate.data_ptr(), cin * h * w) if fused_gate else None)
+        if masked and not fused_gate:
+            dx.mul_(gate > 0)
+        pkg("_lib").check(lib.ynet_upconv_dgrad_ring(D.data_ptr(), 4 * cout * h * w, tables.data_ptr(), gate.data_ptr() if masked else None, cin * h * w,
+                                                     dx.data_ptr(), cin * h * w, B, 4 * cout, cin, h, w, None), lib)
+        ref = want * (gate.cpu() > 0) if masked else want
+        err = (dx.double().cpu() - ref).abs()
+        scale = float(want.abs().max())
+        assert float(err.max()) <= 2e-5 * scale, (masked, float(err.max()), scale, [int(v) for v in torch.nonzero(err == err.max())[0]])
+    # the interior alone (no ring) is NOT the gradient: the correction is doing something on every border line
+    inner = torch.empty((B, cin, h, w), device=dev)
+    ops.conv2d_raw([(D.data_ptr(), 4 * cout, 4 * cout * h * w)], None, wp_eff, None, [(inner.data_ptr(), cin, cin * h * w)], B, h, w, 3, False)
+    diff = (inner.double().cpu() - want).abs()
+    assert float(diff[:, :, 0, :].max()) > 1e-3 * scale and float(diff[:, :, :, -1].max()) > 1e-3 * scale
+    if h > 2 and w > 2:
+        assert float(diff[:, :, 1:-1, 1:-1].max()) <= 2e-5 * scale
+    with pytest.raises(RuntimeError, match="upconv_dgrad_ring"):
+        pkg("_lib").check(lib.ynet_upconv_dgrad_ring(D.data_ptr(), 4 * cout * h * w, tables.data_ptr(), None, 0, dx.data_ptr(), cin * h * w, B, 4 * cout + 2, cin, h, w, None), lib)
