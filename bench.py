@@ -157,6 +157,7 @@ class ConvTimer:
         self.orig_cat = ops.conv2d_winograd_cat_raw
         self.orig_16 = ops.conv2d_winograd16_raw
         self.orig_up = ops.upsample2x_conv2d_raw
+        self.orig_split = ops.conv2d_winograd_split_raw
         self.orig_auto = getattr(ops, "conv_auto", False)
 
     def __enter__(self):
@@ -178,6 +179,16 @@ class ConvTimer:
             self.rec.append((name, e0, e1, 2.0 * B * H * W * cin * cout * 9, 4.0 * B * H * W * (cin + cout * (2 if em == 1 else (1 + 1 / 32 if em >= 2 else 1))),
                              (B, H, W, cin, cout, 3, False)))
         self.ops.conv2d_winograd_raw = timed_wino
+
+        def timed_split(src, u, dst0, dst0_s2d, dst1, cin, B, H, W):
+            # the [16, 32]-channel data gradient in one launch (three output blocks per wave, four waves per workgroup); EM 5 row-major, 6 = the 16 channels space-to-depth
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig_split(src, u, dst0, dst0_s2d, dst1, cin, B, H, W)
+            e1.record()
+            self.rec.append((f"conv_wino_kernel<3, {cin // 8}, {6 if dst0_s2d else 5}, 4>", e0, e1, 2.0 * B * H * W * cin * 48 * 9, 4.0 * B * H * W * (cin + 48),
+                             (B, H, W, cin, 48, 3, False)))
+        self.ops.conv2d_winograd_split_raw = timed_split
 
         def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None, pool_code=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -263,6 +274,7 @@ class ConvTimer:
         self.ops.conv2d_winograd_cat_raw = self.orig_cat
         self.ops.conv2d_winograd16_raw = self.orig_16
         self.ops.upsample2x_conv2d_raw = self.orig_up
+        self.ops.conv2d_winograd_split_raw = self.orig_split
 
     def layers(self, steps):
         """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, direct-form TFLOP/s,

@@ -130,6 +130,14 @@ int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, con
  *                               of channel ch at plane (2 r + c) * cout + ch, position (i, j) -- a lane of this tiling holds exactly one such 2 x 2 block.  It is the layout
  *                               in which the gradient of an up-convolution's OUTPUT is consumed without the up-sampled tensor (see ynet_upconv_dgrad_ring). */
 int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u, float* dst, long long dst_bs, int cin, int cout, int B, int H, int W, void* stream);
+/*   ynet_conv2d_winograd_split  (round 6) the plain data gradient of a convolution whose input was the concatenation [16 channels, 32 channels]
+ *                               (models/ynet.py:466: cat(up-sampled features, skip features)) in ONE launch that reads and transforms dy once: u = the 48-column
+ *                               transformed filter (ynet_winograd_filter(wp, u, cin, 48, col0, cols_total)); output channels 0..15 go to dst0 (row-major, or
+ *                               space-to-depth as ynet_conv2d_winograd_s2d when dst0_s2d != 0), channels 16..47 to dst1.  Three output blocks per wave = 192
+ *                               accumulator registers: four waves per workgroup, one per SIMD.  cin = 32; bit-identical to the two launches it replaces. */
+int ynet_conv2d_winograd_split_supported(int B, int H, int W, int cin);
+int ynet_conv2d_winograd_split(const float* src, long long src_bs, const float* u, float* dst0, long long dst0_bs, int dst0_s2d, float* dst1, long long dst1_bs, int cin,
+                               int B, int H, int W, void* stream);
 /*   ynet_conv2d_winograd_dgrad_relu   the data gradient written THROUGH the ReLU backward of the layer below, as ynet_conv2d_dgrad_relu:
  *                               dx = relu_of > 0 ? conv3x3(dy, mode-1 filter) : 0, relu_of = that layer's post-ReLU output [B][dx_c][H][W]
  *                               (8-byte aligned), read by the epilogue at the addresses it stores to. */
@@ -233,6 +241,7 @@ int ynet_upsample2x_conv2d_winograd(const float* src, long long src_bs, const fl
 #define YNET_AUTO_WINOGRAD16_FOR_16 4u  /* 16-output launches on the slice form too (measured slower) */
 #define YNET_AUTO_NO_POOL_CODE 8u       /* pool_code is never written */
 #define YNET_AUTO_NO_RELU_WBITS 16u     /* wbits_out is never written, relu_wbits never read (relu_of's float activation instead) */
+#define YNET_AUTO_NO_SPLIT48 32u        /* a [16, 32]-channel data gradient as two launches, not ynet_conv2d_winograd_split */
 typedef struct YnetConvAuto {
     const float* src[4];
     int src_c[4];

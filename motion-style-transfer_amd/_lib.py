@@ -38,7 +38,7 @@ class ConvTaken(ctypes.Structure):
                 ("transformed", c_i), ("wrote_s2d", c_i)]
 
 
-AUTO_NO_WINOGRAD, AUTO_NO_WINOGRAD16, AUTO_WINOGRAD16_FOR_16, AUTO_NO_POOL_CODE, AUTO_NO_RELU_WBITS = 1, 2, 4, 8, 16
+AUTO_NO_WINOGRAD, AUTO_NO_WINOGRAD16, AUTO_WINOGRAD16_FOR_16, AUTO_NO_POOL_CODE, AUTO_NO_RELU_WBITS, AUTO_NO_SPLIT48 = 1, 2, 4, 8, 16, 32
 
 # name -> (restype, argtypes); must list every function of include/ynet_hip.h
 SIGNATURES = {
@@ -61,6 +61,8 @@ SIGNATURES = {
     "ynet_winograd_filter": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_s2d": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "ynet_conv2d_winograd_split_supported": (c_i, [c_i, c_i, c_i, c_i]),
+    "ynet_conv2d_winograd_split": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_i, c_fp, c_ll, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_upconv_dgrad_ring": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_dgrad_relu": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_cat_supported": (c_i, [c_i, c_i, c_i, PI, c_i, c_i, c_i]),

@@ -189,6 +189,18 @@ int make_plan(const YnetConvAuto* a, Plan& p) {
         for (int i = 0; i < a->ndst; ++i) wide = wide || (a->dst[i] && a->dst_c[i] >= 64);
         bool all_sup = np > 0 && np <= (a->relu_of ? 1 : 2) && piece_al(np);
         for (int i = 0; i < np && all_sup; ++i) all_sup = ynet_conv2d_winograd_supported(B, H, W, cin, pieces[i].n, K) != 0;
+        // [16 channels, 32 channels] of a plain data gradient (the decoders' first convolution at the last level: cat(up-sampled 16, skip 32[, way-point map])):
+        // ONE launch with three output blocks per wave -- dy is read and transformed once (ynet_conv2d_winograd_split)
+        if (all_sup && !wide && np == 2 && !a->relu_of && !a->bias && !a->relu && !(a->flags & YNET_AUTO_NO_SPLIT48) && pieces[0].n == 16 && pieces[0].whole &&
+            pieces[1].n == 32 && pieces[1].whole && pieces[1].col0 == pieces[0].col0 + 16 && ynet_conv2d_winograd_split_supported(B, H, W, cin)) {
+            p.family = 1;
+            p.variant = 23;
+            p.npieces = 2;
+            p.pieces[0] = pieces[0];
+            p.pieces[1] = pieces[1];
+            add_launch(p, K_WINO, 0, cs, 1, 48, pieces[0].col0, ctot);
+            return 0;
+        }
         if (all_sup && !wide) {
             p.family = 1;
             p.variant = 21;
@@ -346,7 +358,7 @@ int ynet_conv2d_auto_plan(const YnetConvAuto* a, YnetConvTaken* taken) {
     memset(taken, 0, sizeof(*taken));
     taken->family = p.family;
     taken->variant = p.variant;
-    taken->nlaunch = p.family ? (p.npieces > 0 ? p.npieces : (p.nl > 0 ? p.nl : 1)) : 1;
+    taken->nlaunch = p.family ? (p.variant == 23 ? 1 : (p.npieces > 0 ? p.npieces : (p.nl > 0 ? p.nl : 1))) : 1;
     return 0;
 }
 
@@ -394,6 +406,15 @@ int ynet_conv2d_auto(const YnetConvAuto* a, YnetConvTaken* taken, void* stream) 
         tag(0, p.family == 4 ? 4 : 0, 0, 0);
         return done(ynet_upsample2x_conv2d_winograd(a->src[0], a->src_bs[0], u0, a->bias, a->dst[0], a->dst_bs[0], a->src_c[0], ctot, B, H, W, relu, stream));
     case 1: {      // conv_wino_kernel<NCB, NCH, EM>, one launch per destination piece
+        if (p.variant == 23) {      // two destinations, one launch (conv_wino_kernel<3, 4, 5 | 6, 4>)
+            const Piece &q0 = p.pieces[0], &q1 = p.pieces[1];
+            const int s2d = a->dst_s2d[q0.dst] ? 1 : 0;
+            const int rc = ynet_conv2d_winograd_split(a->src[0], a->src_bs[0], u0, q0.ptr, q0.bs, s2d, q1.ptr, q1.bs, a->src_c[0], B, H, W, stream);
+            if (rc) return rc;
+            if (s2d) t.wrote_s2d |= 1 << q0.dst;
+            tag(0, 3, a->src_c[0] / 8, s2d ? 6 : 5);
+            return done(0);
+        }
         const bool one32 = p.npieces == 1 && p.pieces[0].n == 32;
         unsigned* wb_out = (one32 && relu && !a->relu_of && !(a->flags & YNET_AUTO_NO_RELU_WBITS)) ? a->wbits_out : nullptr;
         const unsigned* wb_in = (one32 && a->relu_of && !relu && !a->bias && !(a->flags & YNET_AUTO_NO_RELU_WBITS)) ? a->relu_wbits : nullptr;

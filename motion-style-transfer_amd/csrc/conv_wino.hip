@@ -57,6 +57,8 @@ struct WinoArgs {
     const float* emask;    // EM: [B] x (emask_bs floats), cout planes -- the post-ReLU activation whose backward is applied to y (y = emask > 0 ? y : 0)
     long long emask_bs;
     unsigned* wbits;       // the Winograd-native 1-bit mask [B][H / 2][W / 32][64 lanes] (NCB = 2): written (EM 3) or applied (EM 2)
+    float* y2;             // EM 5 / 6 (NCB = 3): the destination of output blocks 1 and 2 (32 planes); block 0 goes to y (16 planes)
+    long long y2_bs;
 };
 
 __device__ __forceinline__ f32x2 wn_v01(f32x2 tl, f32x2 th) {      // (t0 - t2, t1 + t2)
@@ -82,21 +84,25 @@ __device__ __forceinline__ f32x2 wn_v23(f32x2 tl, f32x2 th) {      // (t2 - t1, 
 // S2D (round 6): the 2 x 2 block of a lane is stored SPACE-TO-DEPTH -- element (row r, column c) of the block goes to plane (2 r + c) * (16 NCB) + channel of a
 // tensor [4 * 16 NCB][H / 2][W / 2] (st0 / so_t are then the lane's / the unit's offsets in a LOW-resolution plane): the layout in which the gradient of an
 // up-convolution's output is consumed by ynet_upsample2x_conv2d_dgrad (a 3 x 3 convolution at the low resolution).
-template <int NCB, int EPI, int BITS = 0, bool S2D = false>
+// CB0 / CB1: the output blocks [CB0, CB1) of the accumulators go to this destination, as its channels 0 .. 16 (CB1 - CB0) - 1 (the 48-channel launch of a data
+// gradient with two destinations calls the epilogue once per destination).
+template <int NCB, int EPI, int BITS = 0, bool S2D = false, int CB0 = 0, int CB1 = NCB>
 __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2 (&bias2)[NCB][2], float floor_v, __amdgpu_buffer_rsrc_t ry,
                                               __amdgpu_buffer_rsrc_t rm, unsigned st0, unsigned st1, unsigned so_t, unsigned sm_t, int HW, unsigned stp = 0,
                                               unsigned* wbits = nullptr, unsigned char* pcode = nullptr) {
     unsigned word = 0u;
     if constexpr (BITS == 2) word = *wbits;
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
+    for (int cb = CB0; cb < CB1; ++cb) {
+        constexpr int NB = CB1 - CB0;      // blocks of this destination
+        const int cd = cb - CB0;           // the block's index there
         u32x2 mk[2][2][2];
         if constexpr (EPI == 1 || EPI == 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const unsigned sm = sm_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
+                    const unsigned sm = sm_t + (unsigned)((cd * 16 + 2 * h + k) * HW * 4);
                     mk[h][k][0] = __builtin_amdgcn_raw_buffer_load_b64(rm, st0, sm, 0);
                     mk[h][k][1] = __builtin_amdgcn_raw_buffer_load_b64(rm, st1, sm, 0);
                 }
@@ -139,8 +145,8 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                 if constexpr (BITS == 1)      // (v > 0: NaN and -0 count as "not positive", as the float comparison of EPI 1 does)
                     word |= (row0[0] > 0.f ? 1u << bit0 : 0u) | (row0[1] > 0.f ? 2u << bit0 : 0u) | (row1[0] > 0.f ? 4u << bit0 : 0u) | (row1[1] > 0.f ? 8u << bit0 : 0u);
                 if constexpr (S2D) {
-                    const unsigned hw = (unsigned)(HW >> 2), ph = (unsigned)(NCB * 16) * hw * 4u;
-                    const unsigned sc = so_t + (unsigned)(cb * 16 + 2 * h + k) * hw * 4u;
+                    const unsigned hw = (unsigned)(HW >> 2), ph = (unsigned)(NB * 16) * hw * 4u;
+                    const unsigned sc = so_t + (unsigned)(cd * 16 + 2 * h + k) * hw * 4u;
                     // (scalars first: __builtin_bit_cast applied to a vector-element lvalue reads the vector's FIRST element -- hipcc stored row0[0] twice)
                     const float e00 = row0[0], e01 = row0[1], e10 = row1[0], e11 = row1[1];
                     // Two neighbouring lanes (low-resolution columns j, j + 1) trade one element per row so that the even one holds the column-phase-0 pair and the
@@ -154,13 +160,13 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p1), ry, vo, sc + 2u * ph, 0);
                     continue;
                 }
-                const unsigned so = so_t + (unsigned)((cb * 16 + 2 * h + k) * HW * 4);
+                const unsigned so = so_t + (unsigned)((cd * 16 + 2 * h + k) * HW * 4);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), ry, st0, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), ry, st1, so, 0);
                 if constexpr (EPI == 3) {      // max over the block, NaN if any element is (torch's max_pool2d)
                     float pm = fmaxf(fmaxf(row0[0], row0[1]), fmaxf(row1[0], row1[1]));
                     if (__builtin_isunordered(row0[0], row0[1]) || __builtin_isunordered(row1[0], row1[1])) pm = __builtin_nanf("");
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pm), rm, stp, sm_t + (unsigned)((cb * 16 + 2 * h + k) * (HW >> 2) * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pm), rm, stp, sm_t + (unsigned)((cd * 16 + 2 * h + k) * (HW >> 2) * 4), 0);
                     if constexpr (BITS == 3) {      // what the pool's backward needs of this block, in one byte: bits 0..1 the arg-max (first maximum in scan
                         float mx = row0[0];         // order, a NaN wins: maxpool2_bwd_add_kernel's rule), bits 2..5 "element is positive" (the ReLU backward)
                         unsigned arg = 0u;
@@ -168,7 +174,7 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
                         if (row1[0] > mx || row1[0] != row1[0]) { mx = row1[0]; arg = 2u; }
                         if (row1[1] > mx || row1[1] != row1[1]) { mx = row1[1]; arg = 3u; }
                         const unsigned code = arg | (row0[0] > 0.f ? 4u : 0u) | (row0[1] > 0.f ? 8u : 0u) | (row1[0] > 0.f ? 16u : 0u) | (row1[1] > 0.f ? 32u : 0u);
-                        pcode[(cb * 16 + 2 * h + k) * (HW >> 2)] = (unsigned char)code;
+                        pcode[(cd * 16 + 2 * h + k) * (HW >> 2)] = (unsigned char)code;
                     }
                 }
             }
@@ -266,7 +272,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
         for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(bias2[cb][h]));
     // static store offsets of this lane: output channel 4 kq (+ the rest by the scalar offset), column 2 n, rows 0 / 1 of the pair
     // (EM 4, the space-to-depth store: the lane's offset in a low-resolution plane -- channel 4 kq, column n)
-    const unsigned st0 = EM == 4 ? (unsigned)((4 * kq * (HW >> 2) + n) * 4) : (unsigned)((4 * kq * HW + 2 * n) * 4), st1 = st0 + (unsigned)(W * 4);
+    // (EM 5 / 6, NCB = 3: block 0 to a.y -- row-major / space-to-depth --, blocks 1 and 2 row-major to a.y2)
+    const unsigned st_s2d = (unsigned)((4 * kq * (HW >> 2) + n) * 4), st_rm = (unsigned)((4 * kq * HW + 2 * n) * 4);
+    const unsigned st0 = EM == 4 ? st_s2d : st_rm, st1 = st0 + (unsigned)(W * 4);
 
     // all transformed filters -> LDS, once; the workgroup's unit counter
 #pragma unroll
@@ -372,8 +380,20 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
         {
             const int t = tile_first + (cur >> 3) * gstride;
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-            const unsigned so_t = EM == 4 ? (unsigned)(((ty * (WN_TH / 2) + (cur & 7)) * (W >> 1) + tx * (WN_TW / 2)) * 4)
-                                          : (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            const unsigned so_s2d = (unsigned)(((ty * (WN_TH / 2) + (cur & 7)) * (W >> 1) + tx * (WN_TW / 2)) * 4);
+            const unsigned so_rm = (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            if constexpr (EM == 5 || EM == 6) {
+                static_assert(EM < 5 || NCB == 3, "the two-destination epilogue is the 48-channel launch's");
+                const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, (unsigned)(16 * HW * 4), 0x00020000);
+                const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(a.y2 + (long long)b * a.y2_bs, 0, (unsigned)(32 * HW * 4), 0x00020000);
+                if constexpr (EM == 6) wino_epilogue<NCB, 0, 0, true, 0, 1>(acc, bias2, floor_v, r0, r0, st_s2d, st_s2d, so_s2d, so_s2d, HW);
+                else wino_epilogue<NCB, 0, 0, false, 0, 1>(acc, bias2, floor_v, r0, r0, st_rm, st_rm + (unsigned)(W * 4), so_rm, so_rm, HW);
+                wino_epilogue<NCB, 0, 0, false, 1, 3>(acc, bias2, floor_v, r1, r1, st_rm, st_rm + (unsigned)(W * 4), so_rm, so_rm, HW);
+                cur = nxt;
+                if (cur < total_units) nxt = next_unit();
+                continue;
+            }
+            const unsigned so_t = EM == 4 ? so_s2d : so_rm;
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
             const __amdgpu_buffer_rsrc_t rm =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EM == 1 ? a.emask + (long long)b * a.emask_bs : a.y), 0, y_img, 0x00020000);
@@ -1178,8 +1198,9 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
     static const int on = getenv("YNET_WINOGRAD") ? atoi(getenv("YNET_WINOGRAD")) : 1;
     if (!on || K != 3 || B <= 0) return false;
     if (H % WN_TH || W % WN_TW || H < WN_TH || W < WN_TW) return false;
-    if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return false;
-    if (32ll * H * W * 4 + (W + 4) * 4 >= (1ll << 31)) return false;      // one image per buffer descriptor, below 2 GB (the batch is unbounded)
+    static const int on48 = getenv("YNET_WINOGRAD48") ? atoi(getenv("YNET_WINOGRAD48")) : 1;      // (48 outputs: three blocks per wave, one wave per SIMD -- the two-destination data gradient)
+    if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32 && !(cout == 48 && on48))) return false;
+    if (48ll * H * W * 4 + (W + 4) * 4 >= (1ll << 31)) return false;      // one image per buffer descriptor, below 2 GB (the batch is unbounded)
     static const int min_pixels = getenv("YNET_WINOGRAD_MIN") ? atoi(getenv("YNET_WINOGRAD_MIN")) : 128 * 128 * 8;      // (round 4: 16 -> 8 -- batch 10 at 128^2 is 320 tiles: 3.15 -> 3.00 ms per step there, nothing lost at batch 32)
     return (long long)B * H * W >= min_pixels;      // (one workgroup of eight waves per CU: small launches stay with the direct tiles)
 }
@@ -1376,7 +1397,7 @@ int ynet_conv2d_winograd_cat_pool_code(const float* const* src, const int* src_c
 
 static int wino_launch_any(const float* src, long long src_bs, const float* u, const float* bias, float* dst, long long dst_bs, const float* emask,
                            long long emask_bs, int cin, int cout, int B, int H, int W, int relu, void* stream, const char* what, unsigned* wbits = nullptr,
-                           bool wbits_apply = false, bool s2d = false) {
+                           bool wbits_apply = false, bool s2d = false, float* dst2 = nullptr, long long dst2_bs = 0, int split_mode = 0) {
     YNET_REQUIRE(src && u && dst, "%s: null pointer", what);
     YNET_REQUIRE(wino_shape_ok(B, H, W, cin, cout, 3), "%s: shape B=%d %dx%d %d -> %d is not served (ask ynet_conv2d_winograd_supported)", what, B, H, W, cin,
                  cout);
@@ -1384,11 +1405,15 @@ static int wino_launch_any(const float* src, long long src_bs, const float* u, c
                      (src_bs & 3) == 0 && (dst_bs & 1) == 0,
                  "%s: planes must be 16-byte (input, filters) / 8-byte (output) aligned", what);
     const long long HW = (long long)H * W;
-    YNET_REQUIRE((src_bs == 0 || src_bs >= cin * HW) && dst_bs >= cout * HW, "%s: batch strides smaller than the images (input: 0 = one image for the batch)", what);
+    YNET_REQUIRE((src_bs == 0 || src_bs >= cin * HW) && dst_bs >= (split_mode ? 16 : cout) * HW, "%s: batch strides smaller than the images (input: 0 = one image for the batch)", what);
+    if (split_mode)
+        YNET_REQUIRE(cout == 48 && dst2 != nullptr && (reinterpret_cast<uintptr_t>(dst2) & 7) == 0 && (dst2_bs & 1) == 0 && dst2_bs >= 32 * HW && bias == nullptr && !relu &&
+                         wbits == nullptr && !s2d,
+                     "%s: two destinations are for the plain 48-channel data gradient (16 + 32 planes, 8-byte aligned)", what);
     if (emask != nullptr)
         YNET_REQUIRE((reinterpret_cast<uintptr_t>(emask) & 7) == 0 && (emask_bs & 1) == 0 && emask_bs >= cout * HW,
                      "%s: the activation must be 8-byte aligned, its batch stride not smaller than the image", what);
-    WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW), emask, emask_bs, wbits};
+    WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dst, src_bs, dst_bs, B, H, W, relu ? 1 : 0, B * (H / WN_TH) * (W / WN_TW), emask, emask_bs, wbits, dst2, dst2_bs};
     hipStream_t st = (hipStream_t)stream;
     if (wbits != nullptr) {          // the 1-bit mask: 32 output channels only (one word per lane and unit)
         YNET_REQUIRE(cout == 32 && emask == nullptr && (reinterpret_cast<uintptr_t>(wbits) & 3) == 0, "%s: the 1-bit mask serves 32 output channels and excludes the float mask", what);
@@ -1399,6 +1424,12 @@ static int wino_launch_any(const float* src, long long src_bs, const float* u, c
         YNET_REQUIRE(emask == nullptr && bias == nullptr && !relu, "%s: the space-to-depth store is for a plain data gradient", what);
         if (cout == 32) return cin == 32 ? launch_wino<2, 4, 4>(a, st) : launch_wino<2, 2, 4>(a, st);
         return cin == 32 ? launch_wino<1, 4, 4>(a, st) : launch_wino<1, 2, 4>(a, st);
+    }
+    if (cout == 48) {                // three output blocks per wave: 192 accumulator registers, FOUR waves per workgroup (one per SIMD, 512 registers each)
+        YNET_REQUIRE(emask == nullptr && cin == 32, "%s: the 48-channel form is plain, from 32 input channels", what);
+        if (split_mode == 1) return launch_wino_nw<3, 4, 5, 4>(a, st);
+        if (split_mode == 2) return launch_wino_nw<3, 4, 6, 4>(a, st);
+        return launch_wino_nw<3, 4, 0, 4>(a, st);
     }
     if (emask != nullptr) {
         if (cout == 32) return cin == 32 ? launch_wino<2, 4, 1>(a, st) : launch_wino<2, 2, 1>(a, st);
@@ -1415,6 +1446,14 @@ int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, con
 
 int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u, float* dst, long long dst_bs, int cin, int cout, int B, int H, int W, void* stream) {
     return wino_launch_any(src, src_bs, u, nullptr, dst, dst_bs, nullptr, 0, cin, cout, B, H, W, 0, stream, "conv2d_winograd_s2d", nullptr, false, true);
+}
+
+int ynet_conv2d_winograd_split_supported(int B, int H, int W, int cin) { return (cin == 32 && wino_shape_ok(B, H, W, cin, 48, 3)) ? 1 : 0; }
+
+int ynet_conv2d_winograd_split(const float* src, long long src_bs, const float* u, float* dst0, long long dst0_bs, int dst0_s2d, float* dst1, long long dst1_bs, int cin,
+                               int B, int H, int W, void* stream) {
+    return wino_launch_any(src, src_bs, u, nullptr, dst0, dst0_bs, nullptr, 0, cin, 48, B, H, W, 0, stream, "conv2d_winograd_split", nullptr, false, false, dst1, dst1_bs,
+                           dst0_s2d ? 2 : 1);
 }
 
 // ---- the Winograd-native 1-bit ReLU mask (round 5): one 32-bit word per lane and unit of the NCB = 2 tiling, i.e. per (image, row pair, 32-column tile, lane)

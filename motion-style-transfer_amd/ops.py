@@ -401,6 +401,13 @@ def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=Non
                                      cin, cout, B, H, W, 1 if relu else 0, _stream()), lib)
 
 
+def conv2d_winograd_split_raw(src, u, dst0, dst0_s2d, dst1, cin, B, H, W):
+    """The plain data gradient with the destinations [16 channels, 32 channels] in one launch (ynet_conv2d_winograd_split): src / dst0 / dst1 = (ptr, batch_stride),
+    u = winograd_filter(wp, cin, 48, col0, cols_total); dst0 space-to-depth when dst0_s2d."""
+    lib = _lib()
+    L.check(lib.ynet_conv2d_winograd_split(src[0], src[1], u.data_ptr(), dst0[0], dst0[1], 1 if dst0_s2d else 0, dst1[0], dst1[1], cin, B, H, W, _stream()), lib)
+
+
 def conv2d_winograd_cat_raw(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None, pool_code=None):
     """srcs: [(ptr, channels, batch_stride)] (at most three, 56 padded channels); dst: (ptr, batch_stride), 32 channels; u: the filter in
     ynet_winograd_filter_cat's layout for these sources; addend: (ptr, image_stride, modulus) of a term added in front of the ReLU;
@@ -437,6 +444,7 @@ _wino16_allowed = _os.environ.get("YNET_WINOGRAD16", "1") != "0"     # YNET_WINO
 # YNET_WINOGRAD16_SLICE16=1: 16-output-channel launches (32 -> 16 at 256^2) on the slice form too -- measured SLOWER there than
 # conv_wino_kernel<1, 4> (141 against 134 us at B 32: the launch streams 402 MB, and six staged rows per unit do not pay for one slice)
 _wino16_for_16 = _os.environ.get("YNET_WINOGRAD16_SLICE16", "0") != "0"
+_split48_allowed = _os.environ.get("YNET_WINOGRAD_SPLIT48", "1") != "0"      # a [16, 32]-channel data gradient as ONE launch (ynet_conv2d_winograd_split)
 
 
 def conv2d_winograd16_raw(srcs, u, bias, dst, cout, B, H, W, relu, relu_of=None, addend=None, pool=None):
@@ -550,6 +558,8 @@ def conv2d_auto_raw(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, 
         flags |= L.AUTO_WINOGRAD16_FOR_16
     if not _pool_code_allowed:
         flags |= L.AUTO_NO_POOL_CODE
+    if not _split48_allowed:
+        flags |= L.AUTO_NO_SPLIT48
     d.flags = flags
     ent = None
     if wino is not None and not (flags & L.AUTO_NO_WINOGRAD):
@@ -724,6 +734,23 @@ def _conv2d_raw_py(srcs, mask, wp, bias, dsts, B, H, W, K, relu, relu_of=None, p
             _wino16(wino, wp, 0, srcs, bias, (ptr, bs), 16, col0, ctot, B, H, W, relu, relu_of=relu_of)
             return "winograd16:%d" % (1 if relu_of is not None else 0)
         wide = any(d_[0] is not None and d_[1] >= 64 for d_ in dsts)      # (a 64-channel destination: one launch of the slice form, below)
+        if (_split48_allowed and pieces and not wide and len(pieces) == 2 and relu_of is None and bias is None and not relu and pieces[0][1] == 16 and piece_dst[0][1]
+                and pieces[1][1] == 32 and piece_dst[1][1] and pieces[1][3] == pieces[0][3] + 16 and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
+                and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces) and lib.ynet_conv2d_winograd_split_supported(B, H, W, cin)):
+            # [16, 32] channels of a plain data gradient (cat(up-sampled 16, skip 32[, way-point map]) at the decoders' last level): one launch, dy read once
+            cache, what = wino
+            col0 = pieces[0][3]
+            key = "wino_%s_%d_48" % (what, col0)
+            ent = cache.get(key)
+            if ent is None or ent[0] is not wp:
+                ent = cache[key] = _wino_made((wp, winograd_filter(wp, cin, 48, col0, ctot)))
+            _wino_ready(ent)
+            s2d = bool(dst_s2d and dst_s2d[piece_dst[0][0]])
+            conv2d_winograd_split_raw((srcs[0][0], srcs[0][2]), ent[1], (pieces[0][0], pieces[0][2]), s2d, (pieces[1][0], pieces[1][2]), cin, B, H, W)
+            if s2d and info is not None:
+                info["wrote_s2d"] |= 1 << piece_dst[0][0]
+            wino_stats["launches"] += 1
+            return "winograd:3,%d,%d" % (cin // 8, 6 if s2d else 5)
         if (pieces and not wide and len(pieces) <= (2 if relu_of is None else 1) and all(p_[0] % 8 == 0 and p_[2] % 2 == 0 for p_ in pieces)
                 and all(lib.ynet_conv2d_winograd_supported(B, H, W, cin, p_[1], K) for p_ in pieces)):
             cache, what = wino

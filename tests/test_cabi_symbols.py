@@ -108,7 +108,8 @@ def test_conv2d_auto_plans_the_benchmarked_layers_without_a_gpu():
     assert plan(B, 128, 128, [32, 32, 1], [32])[:2] == (2, 40)                       # 65 channels: 32 first, the rest added in place
     assert plan(B, 256, 256, [32], [32])[0] == 1                                     # decoder[4][2]
     assert plan(B, 256, 256, [32], [32], relu=False, relu_of=256) == (1, 21, 1)      # its data gradient through the ReLU backward
-    assert plan(B, 256, 256, [32], [16, 32, -1], relu=False) == (1, 21, 2)           # decoder[4][0]'s data gradient: 16 + 32, the way-point map's not wanted
+    assert plan(B, 256, 256, [32], [16, 32, -1], relu=False) == (1, 23, 1)           # decoder[4][0]'s data gradient: 16 + 32 in ONE launch (ynet_conv2d_winograd_split), the way-point map's not wanted
+    assert plan(B, 256, 256, [32], [32, 16, -1], relu=False) == (1, 21, 2)           # (the other order: two launches)
     assert plan(B, 128, 128, [32], [64], relu=False) == (3, 22, 1)                   # a 64-channel destination: one launch of the slice form
     assert plan(B, 256, 256, [32], [12], K=1, relu=False)[0] == 0                    # the 1x1 predictor
     assert plan(B, 256, 256, [32], [32], flags=L.AUTO_NO_WINOGRAD)[0] == 0

@@ -1866,7 +1866,9 @@ AUTO_CASES = {
     "predictor_1x1": (4, 64, 64, [32], [12], 1, False, True, {}),
     "direct_bits_out": (8, 32, 32, [64], [64], 3, True, True, {"bits_out": True}),
     "masked_input": (4, 32, 32, [64], [32, 64], 3, False, False, {"mask": True}),
-    "dgrad_s2d_16_of_16_32": (8, 256, 256, [32], [16, 32, None], 3, False, False, {"s2d": [1, 0, 0]}),
+    "dgrad_s2d_16_of_16_32": (8, 256, 256, [32], [16, 32, None], 3, False, False, {"s2d": [1, 0, 0]}),      # (one launch: conv_wino_kernel<3, 4, 6, 4>)
+    "dgrad_split_16_32": (8, 256, 256, [32], [16, 32], 3, False, False, {"split": True}),                  # (one launch: conv_wino_kernel<3, 4, 5, 4>)
+    "dgrad_s2d_16_alone": (8, 256, 256, [32], [16, None], 3, False, False, {"s2d": [1, 0]}),               # (conv_wino_kernel<1, 4, 4, 8>)
     "dgrad_s2d_asked_of_two_pieces": (8, 256, 256, [32], [48], 3, False, False, {"s2d": [1]}),      # (not one launch: stays row-major)
 }
 
@@ -1941,8 +1943,9 @@ def test_conv2d_auto_takes_the_launches_of_the_python_dispatcher(dev, name):
         # a destination that asked for it AND is written whole by one plain launch holds its gradient space-to-depth (element (2 i + r, 2 j + c) of channel ch at
         # plane (2 r + c) * C + ch, position (i, j)): the same numbers as the row-major launch, bit for bit; every other destination is row-major as ever
         t_rm, _, o_rm, _ = run(ops._conv2d_raw_py, s2d=False)
-        took = "4" in [g.split(",")[2] for g in t_c.split(":")[1].split("|")[0].split("+")]
-        assert took == (name == "dgrad_s2d_16_of_16_32"), t_c
+        took = any(g.split(",")[2] in ("4", "6") for g in t_c.split(":")[1].split("|")[0].split("+"))
+        assert took == (name != "dgrad_s2d_asked_of_two_pieces"), t_c
+        assert t_c == {"dgrad_s2d_16_of_16_32": "winograd:3,4,6", "dgrad_s2d_16_alone": "winograd:1,4,4", "dgrad_s2d_asked_of_two_pieces": "winograd:2,4,0+1,4,0"}[name]
         for i, (a_, b_) in enumerate(zip(o_rm, o_c)):
             if couts[i] is None:
                 continue
@@ -1951,6 +1954,19 @@ def test_conv2d_auto_takes_the_launches_of_the_python_dispatcher(dev, name):
                 a_ = a_.view(B, C, H // 2, 2, W // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(B, 4 * C, H // 2, W // 2)
                 b_ = b_.view(B, 4 * C, H // 2, W // 2)
             assert torch.equal(a_, b_), (name, i)
+    if opts.get("split") or name == "dgrad_s2d_16_of_16_32":
+        # [16, 32] channels in ONE launch (three output blocks per wave): the numbers of the two launches it replaces, bit for bit
+        assert n_c == 1 and t_c.startswith("winograd:3,4,")
+        old = ops._split48_allowed
+        ops._split48_allowed = False
+        try:
+            t_two, n_two, o_two, _ = run(ops._conv2d_raw_py)
+            t_two_c, n_two_c, o_two_c, _ = run(lambda *a, **k: ops.conv2d_auto_raw(*a, **k)[0], cache={})
+        finally:
+            ops._split48_allowed = old
+        assert n_two == 2 and n_two_c == 2 and t_two == t_two_c and "+" in t_two, (t_two, t_two_c)
+        for a_, b_, c_ in zip(o_two, o_c, o_two_c):
+            assert torch.equal(torch.nan_to_num(a_, nan=12345.0), torch.nan_to_num(b_, nan=12345.0)) and torch.equal(torch.nan_to_num(a_, nan=12345.0), torch.nan_to_num(c_, nan=12345.0)), name
     if t_c is not None:
         # the transformed filter is cached: the second call transforms nothing, a new version does
         kw = {"wino": (cache, "dgrad" if dgrad else "fwd")}
