@@ -158,6 +158,7 @@ class ConvTimer:
         self.orig_16 = ops.conv2d_winograd16_raw
         self.orig_up = ops.upsample2x_conv2d_raw
         self.orig_split = ops.conv2d_winograd_split_raw
+        self.orig_predbce = ops.conv2d_winograd_pred_bce_raw
         self.orig_auto = getattr(ops, "conv_auto", False)
 
     def __enter__(self):
@@ -189,6 +190,17 @@ class ConvTimer:
             self.rec.append((f"conv_wino_kernel<3, {cin // 8}, {6 if dst0_s2d else 5}, 4>", e0, e1, 2.0 * B * H * W * cin * 48 * 9, 4.0 * B * H * W * (cin + 48),
                              (B, H, W, cin, 48, 3, False)))
         self.ops.conv2d_winograd_split_raw = timed_split
+
+        def timed_predbce(src, u, bias, pred_wp, pred_bias, pred_cout, pos, tmpl, logits, loss, dx, ws, B, H, W, expected_grad):
+            # the last decoder convolution with the predictor, the criterion and the predictor's data gradient in its epilogue: the convolution's FLOPs + the two
+            # 1 x 1 products; bytes = the input, the logits and dX (the convolution's own output is never written)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig_predbce(src, u, bias, pred_wp, pred_bias, pred_cout, pos, tmpl, logits, loss, dx, ws, B, H, W, expected_grad)
+            e1.record()
+            self.rec.append(("conv_wino_kernel<2, 4, 7, 8>", e0, e1, 2.0 * B * H * W * 32 * (32 * 9 + 2 * pred_cout), 4.0 * B * H * W * (32 + pred_cout + 32),
+                             (B, H, W, 32, 32, 3, False)))
+        self.ops.conv2d_winograd_pred_bce_raw = timed_predbce
 
         def timed_cat(srcs, u, bias, dst, B, H, W, relu, addend=None, pool=None, wbits_out=None, pool_code=None):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -275,6 +287,7 @@ class ConvTimer:
         self.ops.conv2d_winograd16_raw = self.orig_16
         self.ops.upsample2x_conv2d_raw = self.orig_up
         self.ops.conv2d_winograd_split_raw = self.orig_split
+        self.ops.conv2d_winograd_pred_bce_raw = self.orig_predbce
 
     def layers(self, steps):
         """The launches of one step in call order: [kernel, (B, H, W, cin, cout, K, masked), median microseconds, direct-form TFLOP/s,

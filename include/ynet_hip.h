@@ -135,6 +135,18 @@ int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u,
  *                               transformed filter (ynet_winograd_filter(wp, u, cin, 48, col0, cols_total)); output channels 0..15 go to dst0 (row-major, or
  *                               space-to-depth as ynet_conv2d_winograd_s2d when dst0_s2d != 0), channels 16..47 to dst1.  Three output blocks per wave = 192
  *                               accumulator registers: four waves per workgroup, one per SIMD.  cin = 32; bit-identical to the two launches it replaces. */
+/*   ynet_conv2d_winograd_pred_bce_blob  (round 6) the LAST decoder convolution with everything behind it in its epilogue:
+ *                               y = relu(conv3x3(src, filter) + bias)  (32 -> 32, never written),  logits = pred_bias + pred_w y  (the 1 x 1 predictor, <= 16 outputs,
+ *                               models/ynet.py:450-451,469),  loss = mean BCE-with-logits(logits, target)  (utils/train_epoch.py:93-94,105-106; the target in the blob form
+ *                               of ynet_pred_bce_blob),  dx = y > 0 ? pred_w^T (sigmoid(logits) - target) expected_grad / n : 0  (the gradient of the loss with respect
+ *                               to the convolution's PRE-activation output: what its data gradient consumes).  Replaces [ynet_conv2d_winograd -> ynet_pred_bce_blob]: the
+ *                               32 activation planes are neither written nor read back; the predictor products run on the matrix cores.  u = ynet_winograd_filter(...,
+ *                               32, 32, ...); pred_wp = ynet_pack_weight(1 x 1 filter, mode 0); workspace as ynet_pred_bce_workspace_bytes() (ticket zero before the
+ *                               first launch); loss partials are summed in a fixed order (bitwise reproducible). */
+int ynet_conv2d_winograd_pred_bce_supported(int B, int H, int W, int cin, int cout, int pred_cout);
+int ynet_conv2d_winograd_pred_bce_blob(const float* src, long long src_bs, const float* u, const float* bias, const float* pred_wp, const float* pred_bias, int pred_cout,
+                                       const float* target_xy, const float* blob, int kernlen, int S, float* logits, float* loss, float* dx, long long dx_bs,
+                                       void* workspace, int B, int H, int W, float expected_grad, void* stream);
 int ynet_conv2d_winograd_split_supported(int B, int H, int W, int cin);
 int ynet_conv2d_winograd_split(const float* src, long long src_bs, const float* u, float* dst0, long long dst0_bs, int dst0_s2d, float* dst1, long long dst1_bs, int cin,
                                int B, int H, int W, void* stream);

@@ -30,6 +30,7 @@
 //               Wider convolutions are composed by the caller (ops.conv2d_raw): output-channel slices, or a second launch that adds onto
 //               the first one's output.
 #include "ynet_common.h"
+#include "bce_element.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -59,6 +60,20 @@ struct WinoArgs {
     unsigned* wbits;       // the Winograd-native 1-bit mask [B][H / 2][W / 32][64 lanes] (NCB = 2): written (EM 3) or applied (EM 2)
     float* y2;             // EM 5 / 6 (NCB = 3): the destination of output blocks 1 and 2 (32 planes); block 0 goes to y (16 planes)
     long long y2_bs;
+    // EM 7 (NCB = 2): the 1 x 1 predictor + BCE-with-logits + the predictor's data gradient in the epilogue (wino_epilogue_pred) -- y receives dX, the convolution's own
+    // output is never written
+    const float* pw;       // the predictor's packed filter [32 padded rows][pco_pad] (ynet_pack_weight, forward layout of a 1 x 1 filter)
+    const float* pb;       // its bias or NULL
+    int pco, pco_pad;      // predictor outputs (<= 16) and the packed filter's column padding
+    const float* t_xy;     // the BLOB form of the target (pred_bce_kernel): plane (b, o) = the kernlen x kernlen blob at the rounded position t_xy[2 (b pco + o) ..]
+    const float* t_blob;
+    int t_m, t_S;
+    float* logits;         // [B][pco][H][W]
+    double* partial;       // [gridDim.x] loss partials, summed in a fixed order by the last workgroup
+    unsigned* ticket;
+    float* loss;
+    long long n_loss;      // B pco H W
+    float gs;              // expected upstream gradient / n_loss
 };
 
 __device__ __forceinline__ f32x2 wn_v01(f32x2 tl, f32x2 th) {      // (t0 - t2, t1 + t2)
@@ -183,6 +198,116 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
     if constexpr (BITS == 1) *wbits = word;
 }
 
+// EM 7: the last decoder convolution + ReLU with the predictor, the criterion and the predictor's data gradient in its epilogue (models/ynet.py:467,469
+// `self.predictor(x)`, utils/train_epoch.py:93-94,105-106 `criterion(pred_map, gt_map) * loss_scale`) -- what pred_bce_kernel (glue.hip) does in a pass of its own
+// over the 32 activation planes, done where those activations are still in registers: the convolution's output is never written, never read back.
+//   y[c]       = relu(A^T M A + bias)                                 lane (n, kq): channels cb 16 + 4 kq + j (j = 0..3) of the 2 x 2 block n, 8 x 4 values
+//   z[o]       = pb[o] + sum_c pw[o][c] y[c]                          on the matrix cores: k-step (cb, j) takes channel cb 16 + 4 kq' + j from lane group kq' -- the
+//                                                                     lane's own value is the B operand; the result lands as o = 4 kq + i per lane
+//   loss      += BCE-with-logits(z[o], t[o]);  dz[o] = (sigmoid(z[o]) - t[o]) gs
+//   dX[c]      = y[c] > 0 ? sum_o pw[o][c] dz[o] : 0                  again on the matrix cores (k-step i takes o = 4 kq' + i), landing in y's own layout
+// 64 matrix instructions per unit on top of the 256 of the convolution; the logits and dX leave through the stores the plain epilogue uses.
+// wa / wb: the lane's A operands, [cb][j] = pw[o = lane & 15][c = cb 16 + 4 (lane >> 4) + j] and [cb][i] = pw[o = 4 (lane >> 4) + i][c = cb 16 + (lane & 15)].
+__device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f32x2 (&bias2)[2][2], const f32x4 (&wa)[2], const f32x4 (&wb)[2], const f32x4 pbv,
+                                                    const WinoArgs& a, __amdgpu_buffer_rsrc_t rdx, __amdgpu_buffer_rsrc_t rlog, unsigned st_rm, unsigned so_rm, int b,
+                                                    int py0, int px0, int kq, int H, int W) {
+    const int HW = H * W;
+    float yv[2][4][4];      // [cb][j = 2 h + k][p = 2 r + c]
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2 m[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                m[e] = h == 0 ? __builtin_shufflevector(acc[e][cb], acc[e][cb], 0, 1) : __builtin_shufflevector(acc[e][cb], acc[e][cb], 2, 3);
+            m[5] = m[5] + bias2[cb][h];
+            f32x2 r0[4], r1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r0[j] = m[j] + m[4 + j] + m[8 + j];
+                r1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+            }
+            const f32x2 o00 = r0[0] + r0[1] + r0[2], o01 = r0[1] - r0[2] - r0[3];
+            const f32x2 o10 = r1[0] + r1[1] + r1[2], o11 = r1[1] - r1[2] - r1[3];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float v00 = o00[k], v01 = o01[k], v10 = o10[k], v11 = o11[k];
+                // (v < 0 ? 0 : v -- a NaN stays a NaN as in torch's relu)
+                yv[cb][2 * h + k][0] = v00 < 0.f ? 0.f : v00;
+                yv[cb][2 * h + k][1] = v01 < 0.f ? 0.f : v01;
+                yv[cb][2 * h + k][2] = v10 < 0.f ? 0.f : v10;
+                yv[cb][2 * h + k][3] = v11 < 0.f ? 0.f : v11;
+            }
+        }
+    // ---- the predictor: four independent accumulator chains (one per pixel of the block)
+    f32x4 z[4] = {pbv, pbv, pbv, pbv};
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) z[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][j], yv[cb][j][p], z[p], 0, 0, 0);
+    // ---- the criterion on the lane's 4 outputs x 4 pixels; the target is the Gaussian blob at the rounded position (pred_bce_kernel's BLOB form)
+    float s = 0.f;
+    f32x4 dz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = 4 * kq + i;
+        const bool valid = o < a.pco;
+        int rx = 0, ry = 0;
+        bool inside = false;
+        if (valid) {
+            const float* pos = a.t_xy + 2ll * ((long long)b * a.pco + o);
+            rx = (int)rintf(pos[0]);
+            ry = (int)rintf(pos[1]);
+            const int ox = a.t_S / 2 - rx, oy = a.t_S / 2 - ry;
+            inside = !(ox < 0 || oy < 0 || ox + W > a.t_S || oy + H > a.t_S);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int by = py0 + (p >> 1) - ry + a.t_m / 2, bx = px0 + (p & 1) - rx + a.t_m / 2;
+            const float t = (inside && by >= 0 && by < a.t_m && bx >= 0 && bx < a.t_m) ? a.t_blob[by * a.t_m + bx] : 0.f;
+            float de;
+            const float l = bce_element<true>(z[p][i], t, a.gs, de);
+            s += valid ? l : 0.f;
+            dz[p][i] = valid ? de : 0.f;
+        }
+    }
+    // ---- the predictor's data gradient, into y's layout; the ReLU backward of y applied here
+    f32x4 dx[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dx[cb][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) dx[cb][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[cb][i], dz[p][i], dx[cb][p], 0, 0, 0);
+    const unsigned st1 = st_rm + (unsigned)(W * 4);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 row0 = {yv[cb][j][0] > 0.f ? dx[cb][0][j] : 0.f, yv[cb][j][1] > 0.f ? dx[cb][1][j] : 0.f};
+            const f32x2 row1 = {yv[cb][j][2] > 0.f ? dx[cb][2][j] : 0.f, yv[cb][j][3] > 0.f ? dx[cb][3][j] : 0.f};
+            const unsigned so = so_rm + (unsigned)((cb * 16 + j) * HW * 4);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), rdx, st_rm, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), rdx, st1, so, 0);
+        }
+    // the logits: plane o = 4 kq + i at the lane's static offset (channel 4 kq) + i planes; planes >= pco are beyond the descriptor (dropped by the range check)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 row0 = {z[0][i], z[1][i]}, row1 = {z[2][i], z[3][i]};
+        const unsigned so = so_rm + (unsigned)(i * HW * 4);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), rlog, st_rm, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), rlog, st1, so, 0);
+    }
+    return s;
+}
+
 // one k-step of 4 input channels: V = B^T d B of the lane's patch (rows dl / dh), then 16 NCB MFMAs against the filter fragments at wl
 template <int NCB, bool FIRST>
 __device__ __forceinline__ void wino_kstep(f32x4 (&acc)[16][NCB], const f32x2 (&dl)[4], const f32x2 (&dh)[4], const f32x4* wl, int lane) {
@@ -252,7 +377,22 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
     const int gstride = xcd_walk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
     const int tile_first = xcd_walk ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int tile_end = xcd_walk ? min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : a.ntiles;
-    if (tile_first >= tile_end) return;
+    if (tile_first >= tile_end) {
+        if constexpr (EM == 7) {      // (a workgroup without tiles still takes its ticket: the last one to arrive sums the loss partials)
+            if (tid == 0) {
+                a.partial[blockIdx.x] = 0.0;
+                __threadfence();
+                if (atomicAdd(a.ticket, 1u) == gridDim.x - 1) {
+                    __threadfence();
+                    double t = 0.0;
+                    for (unsigned i = 0; i < gridDim.x; ++i) t += ((volatile double*)a.partial)[i];
+                    a.loss[0] = (float)(t / (double)a.n_loss);
+                    *a.ticket = 0u;
+                }
+            }
+        }
+        return;
+    }
     const int my_tiles = (tile_end - tile_first + gstride - 1) / gstride;
     const int total_units = my_tiles * 8;
 
@@ -284,6 +424,30 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
                                                      (unsigned)((j * NT + tid) * 16), 0, 0, 0);
     unsigned* unit_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(smem) + NCH * WQ * 16 + NW * WN_RING_BYTES);
     if (tid == 0) *unit_ctr = (unsigned)NW;
+    // EM 7: the predictor's filter as the lanes' matrix operands (see wino_epilogue_pred), [5][64 lanes] x 16 bytes behind the unit counter: units 0 / 1 = wa[cb], 2 / 3 = wb[cb],
+    // 4 = the bias of the lane's four outputs; then 8 doubles for the workgroup's loss partial
+    f32x4* ptab = reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(smem) + NCH * WQ * 16 + NW * WN_RING_BYTES + 16);
+    if constexpr (EM == 7) {
+        if (tid < 64) {
+            const int o_a = tid & 15, g = tid >> 4;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                f32x4 va, vb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    va[j] = o_a < a.pco ? a.pw[(cb * 16 + 4 * g + j) * a.pco_pad + o_a] : 0.f;
+                    vb[j] = 4 * g + j < a.pco ? a.pw[(cb * 16 + o_a) * a.pco_pad + 4 * g + j] : 0.f;
+                }
+                ptab[cb * 64 + tid] = va;
+                ptab[(2 + cb) * 64 + tid] = vb;
+            }
+            f32x4 vp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vp[j] = (a.pb != nullptr && 4 * g + j < a.pco) ? a.pb[4 * g + j] : 0.f;
+            ptab[4 * 64 + tid] = vp;
+        }
+    }
+    double acc_loss = 0.0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     auto next_unit = [&]() {
@@ -382,6 +546,19 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
             const unsigned so_s2d = (unsigned)(((ty * (WN_TH / 2) + (cur & 7)) * (W >> 1) + tx * (WN_TW / 2)) * 4);
             const unsigned so_rm = (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
+            if constexpr (EM == 7) {
+                static_assert(EM != 7 || NCB == 2, "the predictor epilogue is the 32-channel launch's");
+                const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rlog =
+                    __builtin_amdgcn_make_buffer_rsrc(a.logits + (long long)b * a.pco * HW, 0, (unsigned)(a.pco * HW * 4), 0x00020000);
+                const f32x4 wa[2] = {ptab[lane], ptab[64 + lane]}, wb[2] = {ptab[128 + lane], ptab[192 + lane]};
+                const float s_ = wino_epilogue_pred(acc, bias2, wa, wb, ptab[256 + lane], a, rdx, rlog, st_rm, so_rm, b, ty * WN_TH + 2 * (cur & 7), tx * WN_TW + 2 * n,
+                                                    kq, H, W);
+                acc_loss += (double)s_;
+                cur = nxt;
+                if (cur < total_units) nxt = next_unit();
+                continue;
+            }
             if constexpr (EM == 5 || EM == 6) {
                 static_assert(EM < 5 || NCB == 3, "the two-destination epilogue is the 48-channel launch's");
                 const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, (unsigned)(16 * HW * 4), 0x00020000);
@@ -402,6 +579,38 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
         }
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
+    }
+    if constexpr (EM == 7) {
+        // the loss: lanes -> wave -> workgroup partial (fp64) -> the last workgroup to arrive sums the partials in index order (bitwise reproducible) and resets the ticket
+        double* wsd = reinterpret_cast<double*>(ptab + 5 * 64);
+        unsigned* last = reinterpret_cast<unsigned*>(wsd + NW);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc_loss += __shfl_xor(acc_loss, o, 64);
+        if (lane == 0) wsd[wave] = acc_loss;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int i = 0; i < NW; ++i) t += wsd[i];
+            a.partial[blockIdx.x] = t;
+            __threadfence();
+            *last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*last) {
+            __threadfence();
+            double t = 0.0;
+            for (unsigned i = tid; i < gridDim.x; i += NT) t += ((volatile double*)a.partial)[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane == 0) wsd[wave] = t;
+            __syncthreads();
+            if (tid == 0) {
+                double tt = 0.0;
+                for (int i = 0; i < NW; ++i) tt += wsd[i];
+                a.loss[0] = (float)(tt / (double)a.n_loss);
+                *a.ticket = 0u;
+            }
+        }
     }
 }
 
@@ -1207,7 +1416,7 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
 
 template <int NCB, int NCH, int EM, int NW>
 static int launch_wino_nw(WinoArgs& a, hipStream_t st) {
-    constexpr int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16;
+    constexpr int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16 + (EM == 7 ? 5 * 64 * 16 + NW * 8 + 16 : 0);      // (EM 7: + the predictor tables and the loss scratch)
     static bool attr_dev[YNET_MAX_DEV] = {false};
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
@@ -1446,6 +1655,40 @@ int ynet_conv2d_winograd(const float* src, long long src_bs, const float* u, con
 
 int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u, float* dst, long long dst_bs, int cin, int cout, int B, int H, int W, void* stream) {
     return wino_launch_any(src, src_bs, u, nullptr, dst, dst_bs, nullptr, 0, cin, cout, B, H, W, 0, stream, "conv2d_winograd_s2d", nullptr, false, true);
+}
+
+int ynet_conv2d_winograd_pred_bce_supported(int B, int H, int W, int cin, int cout, int pred_cout) {
+    static const int on = getenv("YNET_CONV_PRED_BCE") ? atoi(getenv("YNET_CONV_PRED_BCE")) : 1;
+    return (on && cin == 32 && cout == 32 && pred_cout >= 1 && pred_cout <= 16 && wino_shape_ok(B, H, W, cin, cout, 3)) ? 1 : 0;
+}
+
+int ynet_conv2d_winograd_pred_bce_blob(const float* src, long long src_bs, const float* u, const float* bias, const float* pred_wp, const float* pred_bias, int pred_cout,
+                                       const float* target_xy, const float* blob, int kernlen, int S, float* logits, float* loss, float* dx, long long dx_bs,
+                                       void* workspace, int B, int H, int W, float expected_grad, void* stream) {
+    YNET_REQUIRE(src && u && pred_wp && target_xy && blob && logits && loss && dx && workspace, "conv2d_winograd_pred_bce_blob: null pointer");
+    YNET_REQUIRE(ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, pred_cout), "conv2d_winograd_pred_bce_blob: B=%d %dx%d with %d predictor outputs is not served (32 -> 32, <= 16 outputs; ask ..._supported)",
+                 B, H, W, pred_cout);
+    YNET_REQUIRE(kernlen > 0 && kernlen <= S && S >= H && S >= W, "conv2d_winograd_pred_bce_blob: the target needs a blob table with 0 < kernlen <= S and S >= H, W (got kernlen %d, S %d, %dx%d)", kernlen, S, H, W);
+    const long long HW = (long long)H * W;
+    YNET_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 && (reinterpret_cast<uintptr_t>(dx) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(logits) & 7) == 0 && (src_bs & 3) == 0 && (dx_bs & 1) == 0 && (src_bs == 0 || src_bs >= 32 * HW) && dx_bs >= 32 * HW,
+                 "conv2d_winograd_pred_bce_blob: planes must be 16-byte (input, filters) / 8-byte (outputs) aligned, batch strides not smaller than the images");
+    WinoArgs a{src, reinterpret_cast<const f32x4*>(u), bias, dx, src_bs, dx_bs, B, H, W, 1, B * (H / WN_TH) * (W / WN_TW), nullptr, 0, nullptr, nullptr, 0};
+    a.pw = pred_wp;
+    a.pb = pred_bias;
+    a.pco = pred_cout;
+    a.pco_pad = ceil_div(pred_cout, 64) * 64;
+    a.t_xy = target_xy;
+    a.t_blob = blob;
+    a.t_m = kernlen;
+    a.t_S = S;
+    a.logits = logits;
+    a.partial = (double*)workspace;
+    a.ticket = (unsigned*)((char*)workspace + 1024 * sizeof(double));      // (the layout of ynet_pred_bce_workspace_bytes(): 1024 partials, then the ticket)
+    a.loss = loss;
+    a.n_loss = (long long)B * pred_cout * HW;
+    a.gs = expected_grad / (float)a.n_loss;
+    return launch_wino_nw<2, 4, 7, 8>(a, (hipStream_t)stream);
 }
 
 int ynet_conv2d_winograd_split_supported(int B, int H, int W, int cin) { return (cin == 32 && wino_shape_ok(B, H, W, cin, 48, 3)) ? 1 : 0; }

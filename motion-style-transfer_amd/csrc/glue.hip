@@ -3,6 +3,7 @@
 // (16-byte where alignment allows), wavefront (64-lane) shuffles for reductions.
 // Reference call sites are cited per kernel; the public C ABI is include/ynet_hip.h.
 #include "ynet_common.h"
+#include "bce_element.h"
 #include <stdlib.h>
 
 // Plane-wise kernels: blockIdx.y walks the (b,c) planes, blockIdx.x the items of a plane -- the item index stays
@@ -485,23 +486,7 @@ __device__ __forceinline__ float wave_max(float v) {
 //   l = (1 - t) * x - log_sigmoid(x),  log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
 //   dl/dx = (sigmoid(x) - t) * g / n
 // ------------------------------------------------------------------------------------------------
-// One element of the loss (and of its gradient).  e = exp(-|x|) is shared by both:
-//   log1p(e) = log(w) * e / (w - 1), w = fl(1 + e)   (w - 1 is exact; the ratio undoes the rounding of 1 + e)
-//   sigmoid(x) = x >= 0 ? 1 / w' : e / w'            (w' = 1 + e)
-// exp and the two reciprocals are the hardware approximations (<= 1 ulp each; the element's absolute
-// error stays below 1e-7, and the mean is accumulated in fp64) -- with libm's expf / log1pf and IEEE
-// divisions the kernel is VALU bound at half the HBM rate.
-template <bool GRAD>
-__device__ __forceinline__ float bce_element(float x, float t, float gs, float& d) {
-    const float e = __expf(-fabsf(x));
-    const float w = 1.f + e;
-    const float r = __frcp_rn(w);
-    const float wm1 = w - 1.f;
-    const float l1p = wm1 == 0.f ? e : logf(w) * (e * __frcp_rn(wm1));
-    if (GRAD) d = ((x >= 0.f ? r : e * r) - t) * gs;
-    return (1.f - t) * x - (fminf(x, 0.f) - l1p);
-}
-
+// (one element of the loss and of its gradient: bce_element.h)
 // GRAD: also writes dx = (sigmoid(x) - t) * gs in the same pass (gs = the expected upstream gradient / n).
 template <bool GRAD>
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,

@@ -52,8 +52,9 @@ class HipConv2d(nn.Conv2d):
         super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
         self._packed = {}
 
-    def forward(self, x, relu=False, pool=False, bits=False):
-        return ops.conv2d(x, self.weight, self.bias, relu, self._packed, pool=pool, bits=bits)
+    def forward(self, x, relu=False, pool=False, bits=False, defer=False):
+        """defer: the caller hands the (post-ReLU) result to ops.pred_bce next -- where the fused launch applies the convolution runs inside it (ops.conv2d)."""
+        return ops.conv2d(x, self.weight, self.bias, relu, self._packed, pool=pool, bits=bits, defer=defer)
 
 
 class LoRAConv2d(HipConv2d):
@@ -192,9 +193,10 @@ class AdapterLayer(HipConv2d, _AdapterMixin):
 class FusedSequential(nn.Sequential):
     """nn.Sequential with the reference's child indices, executing Conv2d+ReLU pairs as one launch."""
 
-    def forward(self, x, pool_next=False):
+    def forward(self, x, pool_next=False, defer_last=False):
         """pool_next: the caller feeds the result to a MaxPool2d(2, 2) next (the following encoder stage opens with one): the last
-        conv + ReLU of this sequence is asked to write the pooled copy too (ops.conv2d(pool=True))."""
+        conv + ReLU of this sequence is asked to write the pooled copy too (ops.conv2d(pool=True)).  defer_last: the caller feeds the result to the fused
+        predictor + criterion next (ops.pred_bce): the last conv + ReLU may run inside that launch (ops.conv2d(defer=True))."""
         mods = list(self)
         i = 0
         while i < len(mods):
@@ -210,6 +212,8 @@ class FusedSequential(nn.Sequential):
                     x = m(x, relu=fuse, pool=True)
                 elif chain:
                     x = m(x, relu=fuse, bits=int(mods[i + 2].out_channels) if mods[i + 2].out_channels > 1 else True)
+                elif defer_last and last and fuse and type(m) is HipConv2d:
+                    x = m(x, relu=True, defer=True)
                 else:
                     x = m(x, relu=fuse)
                 i += 2 if fuse else 1
@@ -458,7 +462,10 @@ class YNetDecoder(nn.Module):
             #  the shape is served and the filter is frozen -- the up-sampled tensor is never written, ops.upsample2x_conv2d)
             x = ops.upsample2x_conv2d(x, up) if type(up) is HipConv2d else up(ops.upsample2x(x))
             y = self._first_conv_shared(lvl, d, x, f)
-            x = d[2](y, relu=True) if y is not None else d(ops.lazy_cat([x, f]))
+            # (the last level's second convolution may run INSIDE the fused predictor + criterion launch below: ops.conv2d(defer=True))
+            defer = (lvl == len(self.decoder) - 1 and not readout and self._bce is not None and torch.is_grad_enabled() and type(self.predictor) is HipConv2d
+                     and type(d) is FusedSequential and not d._forward_hooks and not d[2]._forward_hooks and not d[3]._forward_hooks)
+            x = d[2](y, relu=True) if y is not None else (d(ops.lazy_cat([x, f]), defer_last=True) if defer else d(ops.lazy_cat([x, f])))
         if readout:
             if (FUSED_READOUT and not torch.is_grad_enabled() and type(self.predictor) is HipConv2d
                     and ops.pred_softargmax_supported(x, self.predictor.weight)):
@@ -471,7 +478,7 @@ class YNetDecoder(nn.Module):
             y, loss = ops.pred_bce(x, self.predictor.weight, self.predictor.bias, target, expected, self.predictor._packed)
             y._ynet_fused_bce = (target, loss, float(expected))
             return y
-        return self.predictor(x)
+        return self.predictor(ops.materialize_deferred(x))
 
 
     def _first_conv_shared(self, lvl, d, x, f):

@@ -401,6 +401,16 @@ def conv2d_winograd_raw(src, u, bias, dst, cin, cout, B, H, W, relu, relu_of=Non
                                      cin, cout, B, H, W, 1 if relu else 0, _stream()), lib)
 
 
+def conv2d_winograd_pred_bce_raw(src, u, bias, pred_wp, pred_bias, pred_cout, pos, tmpl, logits, loss, dx, ws, B, H, W, expected_grad):
+    """[conv3x3 32 -> 32 + ReLU -> 1 x 1 predictor -> BCE-with-logits -> predictor's data gradient] in one launch (ynet_conv2d_winograd_pred_bce_blob): src = (ptr, channels,
+    batch_stride) of the convolution's input, u its Winograd-domain filter; pos / tmpl the blob form of the target (see _blob_target)."""
+    lib = _lib()
+    L.check(lib.ynet_conv2d_winograd_pred_bce_blob(src[0], src[2], u.data_ptr(), bias.data_ptr() if bias is not None else None, pred_wp.data_ptr(),
+                                                   pred_bias.data_ptr() if pred_bias is not None else None, pred_cout, pos.data_ptr(), tmpl.blob.data_ptr(),
+                                                   tmpl.blob.shape[0], tmpl.size, logits.data_ptr(), loss.data_ptr(), dx.data_ptr(), 32 * H * W, ws.data_ptr(), B, H, W,
+                                                   expected_grad, _stream()), lib)
+
+
 def conv2d_winograd_split_raw(src, u, dst0, dst0_s2d, dst1, cin, B, H, W):
     """The plain data gradient with the destinations [16 channels, 32 channels] in one launch (ynet_conv2d_winograd_split): src / dst0 / dst1 = (ptr, batch_stride),
     u = winograd_filter(wp, cin, 48, col0, cols_total); dst0 space-to-depth when dst0_s2d."""
@@ -1149,6 +1159,8 @@ class fold_skip_gradients:
         _s2d_wanted.clear()
         _s2d_grads.clear()
         _s2d_produced.clear()
+        _deferred.clear()
+        _unmaterialized.clear()
         return self
 
     def __exit__(self, *exc):
@@ -1160,6 +1172,8 @@ class fold_skip_gradients:
         _s2d_wanted.clear()
         _s2d_grads.clear()
         _s2d_produced.clear()
+        _deferred.clear()
+        _unmaterialized.clear()
         _blob_targets.clear()      # (holds the positions and the template of every Gaussian target of the step: nothing of a finished step stays alive)
         # gradients handed over to a pool whose backward never ran (an exception, a pruned graph) must not linger
         for k in [k for k, e in _skip_registry.items() if e.consumed or e.ref() is None or e.stash]:
@@ -1244,10 +1258,22 @@ class _Conv2dFn(torch.autograd.Function):
         pcode = None
         if pooled is not None and relu and cout == 32 and _pool_code_allowed and any(ctx.needs_input_grad) and meta.get("wino"):
             pcode = torch.empty((B, cout, H // 2, W // 2), device=weight.device, dtype=torch.uint8)
-        took = conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu,
-                          pooled=None if pooled is None else (pooled.data_ptr(), cout * (H // 2) * (W // 2)),
-                          bits_out=None if bits is None else bits.data_ptr(), wino=(cache, "fwd") if meta.get("wino") else None, wbits_out=wbits,
-                          pool_code=pcode)
+        # (the last decoder convolution, asked to wait for the fused predictor + criterion: see `_deferred`)
+        defer = bool(meta.get("defer") and _conv_pred_bce_allowed and premask and relu and pooled is None and bits is None and wbits is None and len(descs) == 1
+                     and len(descs[0]) == 3 and (cin, cout, k) == (32, 32, 3) and lora_a is None and not any(ctx.needs_input_grad[1:5]) and ctx.needs_input_grad[5]
+                     and meta.get("wino") and _wino_allowed and descs[0][0] % 16 == 0 and descs[0][2] % 4 == 0 and keep[0].shape[0] == B
+                     and _lib().ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, 1))
+        if defer:
+            def run(descs=descs, wp=wp, b=b, y=y, dims=(B, H, W), cache=cache):
+                conv2d_raw(descs, None, wp, b, [(y.data_ptr(), 32, 32 * dims[1] * dims[2])], dims[0], dims[1], dims[2], 3, True, wino=(cache, "fwd"))
+            _deferred[y.data_ptr()] = {"ref": weakref.ref(y), "shape": tuple(y.shape), "run": run, "src": descs[0], "wp": wp, "bias": b, "cache": cache,
+                                       "dims": (B, H, W), "keep": keep[0]}
+            took = None
+        else:
+            took = conv2d_raw(descs, None, wp, b, [(y.data_ptr(), cout, cout * H * W)], B, H, W, k, relu,
+                              pooled=None if pooled is None else (pooled.data_ptr(), cout * (H // 2) * (W // 2)),
+                              bits_out=None if bits is None else bits.data_ptr(), wino=(cache, "fwd") if meta.get("wino") else None, wbits_out=wbits,
+                              pool_code=pcode)
         if not (isinstance(took, str) and took.endswith("|wbits")):
             wbits = None
         if not (isinstance(took, str) and took.endswith("|code")):
@@ -1280,6 +1306,9 @@ class _Conv2dFn(torch.autograd.Function):
             if _premasked.pop(dy.data_ptr(), None) == (y.data_ptr(), dy._version, tuple(dy.shape)):
                 mask = None
                 premask_stats["unmasked_backwards"] += 1
+        if relu and mask is not None and _unmaterialized.get(y.data_ptr()) == tuple(y.shape):
+            raise RuntimeError("conv2d backward: this convolution ran inside the fused predictor + criterion launch (its output was never written), but the gradient that "
+                               "arrived does not carry its ReLU backward -- the output has another consumer, or a hook replaced its gradient: set YNET_CONV_PRED_BCE=0")
         need = ctx.needs_input_grad
         need_src = list(need[5:5 + ctx.n_src])
         d_srcs = [None] * ctx.n_src
@@ -1453,7 +1482,7 @@ def lora_conv2d_wgrad_raw(srcs, dy, mask, weight, lora_a, lora_b, scale):
 
 
 def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, scale: float = 1.0, pool: bool = False,
-           bits=False):
+           bits=False, defer: bool = False):
     """[ReLU](conv(cat(x), W_eff) + bias); x is a tensor or a LazyCat.  pool: the caller applies max_pool2 to the result next --
     where the kernel can, the pooled copy is written by this launch and that max_pool2 call finds it (no kernel).  bits: the
     caller feeds the (post-ReLU) result to another convolution next -- inside fold_skip_gradients() this launch then also writes
@@ -1468,7 +1497,7 @@ def conv2d(x, weight, bias, relu: bool, cache: dict, lora_a=None, lora_b=None, s
     # (max 6e-5 / 3e-5 either way), while single coordinates of single goal samples -- 0.3 % of them, where the decoded heat-map is
     # diffuse -- move by up to 5e-3 px instead of 4e-5.  YNET_WINOGRAD_EVAL=0 keeps evaluate() on the implicit GEMM.
     meta = {"relu": bool(relu), "scale": float(scale), "cache": cache, "pool": bool(pool), "bits": bits if torch.is_grad_enabled() else False,
-            "wino": torch.is_grad_enabled() or _wino_eval}
+            "wino": torch.is_grad_enabled() or _wino_eval, "defer": bool(defer) and torch.is_grad_enabled()}
     if any(isinstance(p, BatchRepeat) for p in parts):
         if torch.is_grad_enabled() and any(t.requires_grad for t in (weight, bias, lora_a, lora_b) if t is not None):
             raise NotImplementedError("conv2d: batch-repeated inputs are for inference (torch.no_grad) only")
@@ -1604,6 +1633,30 @@ def upsample2x_conv2d_raw(src, u, bias, dst, cin, cout, B, H, W, relu=False):
 _upconv_s2d_allowed = _os.environ.get("YNET_UPCONV_S2D", "1") != "0"
 _s2d_wanted = {}       # output of an up-convolution: data_ptr -> (weakref, shape)
 _s2d_grads = {}        # a gradient written space-to-depth: data_ptr -> (version, shape)
+# ---- the last decoder convolution inside the fused predictor + criterion (round 6; ynet_conv2d_winograd_pred_bce_blob) -------------------------------------------
+# `conv2d(..., defer=True)` (a frozen 32 -> 32 conv + ReLU under fold_skip_gradients()) builds its autograd node but launches nothing: its output tensor is registered
+# here, and the pred_bce call that consumes it runs [convolution -> predictor -> criterion -> predictor's data gradient] as ONE launch -- the 32 activation planes are
+# never written.  Anything else that wants the tensor calls materialize_deferred() first (pred_bce itself does when the fused launch does not apply).  The convolution's
+# backward receives the fused launch's dx, which carries that convolution's ReLU backward already (`_premasked`); a backward that would need the activation itself
+# (its mask was not applied by the producer) is refused loudly.
+_conv_pred_bce_allowed = _os.environ.get("YNET_CONV_PRED_BCE", "1") != "0"
+_deferred = {}         # data_ptr of y -> dict(ref, shape, run) : convolutions not yet launched
+_unmaterialized = {}   # data_ptr of y -> shape : outputs whose convolution ran inside the fused launch (the memory holds nothing)
+conv_pred_bce_stats = {"fused": 0, "materialized": 0}
+
+
+def materialize_deferred(t):
+    """Launch the convolution behind `t` if it was deferred (see above); a no-op for every other tensor."""
+    if not _deferred or not torch.is_tensor(t):
+        return t
+    e = _deferred.get(t.data_ptr())
+    if e is not None and e["ref"]() is not None and e["shape"] == tuple(t.shape):
+        del _deferred[t.data_ptr()]
+        e["run"]()
+        conv_pred_bce_stats["materialized"] += 1
+    return t
+
+
 _s2d_produced = set()  # outputs of up-convolutions (data_ptr) for which a gradient WAS written space-to-depth: their backward must be handed exactly that tensor
 upconv_stats_s2d = {"backwards": 0}
 _S2D_M = ((0.75, 0.25, 0.0), (0.25, 0.75, 0.75), (0.0, 0.0, 0.25)), ((0.25, 0.0, 0.0), (0.75, 0.75, 0.25), (0.0, 0.25, 0.75))
@@ -1874,6 +1927,9 @@ class _PredBCEFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, target, expected_grad, cache):
         _need_gpu(x, "pred_bce input")
         _need_gpu(target, "pred_bce target")
+        dfr = _deferred.get(x.data_ptr()) if _deferred else None      # x = the output of a convolution that has not been launched yet (see `_deferred`)
+        if dfr is not None and not (dfr["ref"]() is not None and dfr["shape"] == tuple(x.shape) and x.is_contiguous()):
+            dfr = None
         x, target = x.contiguous(), target.contiguous()
         B, cin, H, W = x.shape
         cout = weight.shape[0]
@@ -1881,6 +1937,45 @@ class _PredBCEFn(torch.autograd.Function):
             raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({(B, cout, H, W)})")
         lib = _lib()
         wp = _cached(cache, weight, None, None, 1.0, "fwd")
+        if dfr is not None:
+            need_w_ = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
+            blob_t_ = _blob_target(target, B, cout, H, W)
+            if (ctx.needs_input_grad[0] and not need_w_ and blob_t_ is not None and premask and cin == 32 and dfr["dims"] == (B, H, W)
+                    and lib.ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, cout)):
+                # ONE launch: the convolution, its ReLU, the predictor, the criterion and the predictor's data gradient (through that ReLU's backward)
+                del _deferred[x.data_ptr()]
+                pos, tmpl = blob_t_
+                pos.record_stream(torch.cuda.current_stream(x.device))
+                y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+                loss = torch.empty((), device=x.device, dtype=torch.float32)
+                key = (x.device, torch.cuda.current_stream().cuda_stream)
+                ws = _pred_bce_ws.get(key)
+                if ws is None:
+                    ws = _pred_bce_ws[key] = torch.zeros(lib.ynet_pred_bce_workspace_bytes() // 8 + 1, device=x.device, dtype=torch.float64)
+                expected_grad = float(expected_grad)
+                if not (expected_grad != 0.0 and abs(expected_grad) < float("inf")):
+                    expected_grad = 1.0
+                ccache = dfr["cache"]
+                ent = ccache.get("wino_fwd_0_32")       # (the entry ops.conv2d_raw keeps for the unfused launch of the same layer)
+                if ent is None or ent[0] is not dfr["wp"]:
+                    ent = ccache["wino_fwd_0_32"] = _wino_made((dfr["wp"], winograd_filter(dfr["wp"], 32, 32, 0, 32)))
+                _wino_ready(ent)
+                ctx.dx = torch.empty_like(x)
+                ctx.dy = None
+                conv2d_winograd_pred_bce_raw(dfr["src"], ent[1], dfr["bias"], wp, bias.detach() if bias is not None else None, cout, pos, tmpl, y, loss, ctx.dx, ws,
+                                             B, H, W, expected_grad)
+                bce_blob_stats["launches"] += 1
+                conv_pred_bce_stats["fused"] += 1
+                _unmaterialized[x.data_ptr()] = tuple(x.shape)
+                ctx.premask_y = x.data_ptr()
+                ctx.blob_keep = (pos, tmpl, dfr["keep"])
+                ctx.expected = expected_grad
+                ctx.has_bias = bias is not None
+                ctx.save_for_backward(x, weight)
+                ctx.mark_non_differentiable(y)
+                ctx.set_materialize_grads(False)
+                return y, loss
+            materialize_deferred(x)
         y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
         loss = torch.empty((), device=x.device, dtype=torch.float32)
         key = (x.device, torch.cuda.current_stream().cuda_stream)

@@ -2381,3 +2381,73 @@ def test_upconv_dgrad_ring_and_the_effective_filter_at_any_shape(dev, B, cin, co
         assert float(diff[:, :, 1:-1, 1:-1].max()) <= 2e-5 * scale
     with pytest.raises(RuntimeError, match="upconv_dgrad_ring"):
         pkg("_lib").check(lib.ynet_upconv_dgrad_ring(D.data_ptr(), 4 * cout * h * w, tables.data_ptr(), None, 0, dx.data_ptr(), cin * h * w, B, 4 * cout + 2, cin, h, w, None), lib)
+
+
+@pytest.mark.parametrize("B,cout,H,W,S", [(8, 12, 128, 128, 400), (13, 12, 64, 160, 400), (8, 5, 128, 128, 300), (2, 16, 256, 256, 600)], ids=str)
+def test_last_decoder_convolution_inside_the_predictor_and_criterion(dev, B, cout, H, W, S):
+    """Round 6: decoder[4][2] + ReLU, the 1 x 1 predictor, BCEWithLogitsLoss and the predictor's data gradient as ONE launch (ynet_conv2d_winograd_pred_bce_blob;
+    models/ynet.py:467,469, utils/train_epoch.py:93-94) -- the 32 activation planes between the convolution and the predictor are never written.  Against the two
+    launches it replaces (same kernels' arithmetic for the convolution; the predictor's products run on the matrix cores instead of an FMA chain: fp32 rounding
+    differences only) and against torch autograd in fp64: logits, loss, the gradient of the level's input."""
+    import torch.nn.functional as F
+    ynet, ops, iu = pkg("models.ynet"), pkg("ops"), pkg("utils.image_utils")
+    below = ynet.HipConv2d(32, 32, 3).to(dev)
+    last = ynet.FusedSequential(ynet.HipConv2d(32, 32, 3), torch.nn.ReLU(), ynet.HipConv2d(32, 32, 3), torch.nn.ReLU()).to(dev)
+    pred = ynet.HipConv2d(32, cout, 1).to(dev)
+    for m in (below, last, pred):
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+    tmpl = iu.analytic_gaussian_template(S, 31, 4, True, dev)
+    gen = torch.Generator().manual_seed(B + cout)
+    xy = torch.rand(B * cout, 2, generator=gen) * torch.tensor([W * 1.0, H * 1.0])
+    xy[0] = torch.tensor([0.5, 1.5])
+    xy[1] = torch.tensor([W - 0.5, H - 1.49])
+    x0 = rnd(B, 32, H, W, seed=1).to(dev)
+    scale = 1000.0
+    expected = scale
+
+    def run(fused):
+        old = ops._conv_pred_bce_allowed
+        ops._conv_pred_bce_allowed = fused
+        try:
+            xi = x0.clone().requires_grad_(True)
+            n0, m0 = ops.conv_pred_bce_stats["fused"], ops.premask_stats["unmasked_backwards"]
+            with ops.fold_skip_gradients():
+                target = ops.gather_patches(tmpl, xy.to(dev), H, W).view(B, cout, H, W)
+                h = last(below(xi, relu=True), defer_last=True)
+                y, loss = ops.pred_bce(h, pred.weight, pred.bias, target, expected, pred._packed)
+                (loss * scale).backward()
+            return y.detach(), loss.detach().clone(), xi.grad, ops.conv_pred_bce_stats["fused"] - n0
+        finally:
+            ops._conv_pred_bce_allowed = old
+
+    y1, l1, g1, n1 = run(True)
+    y0, l0, g0, n0 = run(False)
+    assert (n1, n0) == (1, 0)
+    # fp64 autograd of the same graph
+    xd = x0.double().cpu().requires_grad_(True)
+    c = lambda m_, t: F.conv2d(t, m_.weight.double().cpu(), m_.bias.double().cpu(), padding=m_.kernel_size[0] // 2)
+    hd = torch.relu(c(last[2], torch.relu(c(last[0], torch.relu(c(below, xd))))))
+    zd = c(pred, hd)
+    td = ops.gather_patches(tmpl, xy.to(dev), H, W).view(B, cout, H, W).double().cpu()
+    ld = F.binary_cross_entropy_with_logits(zd, td)
+    (ld * scale).backward()
+    zs, gs = float(zd.detach().abs().max()), float(xd.grad.abs().max())
+    e1, e0 = float((y1.double().cpu() - zd.detach()).abs().max()), float((y0.double().cpu() - zd.detach()).abs().max())
+    assert e1 <= 2.0 * e0 + 1e-6 * zs, (e1, e0, zs)
+    assert abs(float(l1) - float(ld)) <= 2e-6 * abs(float(ld)) and abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0)), (float(l1), float(l0), float(ld))
+    # the gradient: a ReLU whose pre-activation is within rounding of zero may flip between the two device paths -- isolated elements; everything else to fp32 rounding
+    d1, d0 = (g1.double().cpu() - xd.grad).abs(), (g0.double().cpu() - xd.grad).abs()
+    tol = 2e-4 * gs
+    f1, f0 = float((d1 > tol).double().mean()), float((d0 > tol).double().mean())
+    assert f1 <= max(5e-4, 1.25 * f0) and f0 <= 2e-3, (f1, f0)      # (the fused launch has no more of them than the two launches it replaces)
+    assert float((g1 - g0).abs().median()) <= 1e-6 * gs and float(((g1 - g0).abs() > tol).double().mean()) <= 5e-4
+    # a consumer that is not the fused criterion gets the tensor itself: the deferred convolution is launched for it
+    with ops.fold_skip_gradients():
+        xi = x0.clone().requires_grad_(True)
+        h = last(below(xi, relu=True), defer_last=True)
+        m0 = ops.conv_pred_bce_stats["materialized"]
+        hm = ops.materialize_deferred(h)
+        assert hm is h and ops.conv_pred_bce_stats["materialized"] == m0 + 1
+        ref = last(below(x0, relu=True))
+        assert torch.equal(h.detach(), ref.detach())
