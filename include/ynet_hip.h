@@ -143,7 +143,7 @@ int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u,
  *                               32 activation planes are neither written nor read back; the predictor products run on the matrix cores.  u = ynet_winograd_filter(...,
  *                               32, 32, ...); pred_wp = ynet_pack_weight(1 x 1 filter, mode 0); workspace as ynet_pred_bce_workspace_bytes() (ticket zero before the
  *                               first launch); loss partials are summed in a fixed order (bitwise reproducible). */
-int ynet_conv2d_winograd_pred_bce_supported(int B, int H, int W, int cin, int cout, int pred_cout);
+int ynet_conv2d_winograd_pred_bce_supported(int B, int H, int W, int cin, int cout, int pred_cout, int kernlen);
 int ynet_conv2d_winograd_pred_bce_blob(const float* src, long long src_bs, const float* u, const float* bias, const float* pred_wp, const float* pred_bias, int pred_cout,
                                        const float* target_xy, const float* blob, int kernlen, int S, float* logits, float* loss, float* dx, long long dx_bs,
                                        void* workspace, int B, int H, int W, float expected_grad, void* stream);

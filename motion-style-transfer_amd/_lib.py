@@ -61,7 +61,7 @@ SIGNATURES = {
     "ynet_winograd_filter": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "ynet_conv2d_winograd_s2d": (c_i, [c_fp, c_ll, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp]),
-    "ynet_conv2d_winograd_pred_bce_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "ynet_conv2d_winograd_pred_bce_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "ynet_conv2d_winograd_pred_bce_blob": (c_i, [c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_ll, c_fp, c_i, c_i, c_i,
                                                  c_f, c_fp]),
     "ynet_conv2d_winograd_split_supported": (c_i, [c_i, c_i, c_i, c_i]),

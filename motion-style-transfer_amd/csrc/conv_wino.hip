@@ -210,7 +210,7 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
 // wa / wb: the lane's A operands, [cb][j] = pw[o = lane & 15][c = cb 16 + 4 (lane >> 4) + j] and [cb][i] = pw[o = 4 (lane >> 4) + i][c = cb 16 + (lane & 15)].
 __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f32x2 (&bias2)[2][2], const f32x4 (&wa)[2], const f32x4 (&wb)[2], const f32x4 pbv,
                                                     const WinoArgs& a, __amdgpu_buffer_rsrc_t rdx, __amdgpu_buffer_rsrc_t rlog, unsigned st_rm, unsigned so_rm, int b,
-                                                    int py0, int px0, int kq, int H, int W) {
+                                                    int py0, int px0, int kq, int H, int W, const float* blob_lds, const int* pos_lds) {
     const int HW = H * W;
     float yv[2][4][4];      // [cb][j = 2 h + k][p = 2 r + c]
 #pragma unroll
@@ -255,19 +255,12 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
     for (int i = 0; i < 4; ++i) {
         const int o = 4 * kq + i;
         const bool valid = o < a.pco;
-        int rx = 0, ry = 0;
-        bool inside = false;
-        if (valid) {
-            const float* pos = a.t_xy + 2ll * ((long long)b * a.pco + o);
-            rx = (int)rintf(pos[0]);
-            ry = (int)rintf(pos[1]);
-            const int ox = a.t_S / 2 - rx, oy = a.t_S / 2 - ry;
-            inside = !(ox < 0 || oy < 0 || ox + W > a.t_S || oy + H > a.t_S);
-        }
+        // (rounded position of plane (b, o) from LDS -- far outside for a plane whose window leaves the template --, the blob table from LDS)
+        const int rx = valid ? pos_lds[2 * (b * a.pco + o)] : (1 << 20), ry = valid ? pos_lds[2 * (b * a.pco + o) + 1] : (1 << 20);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int by = py0 + (p >> 1) - ry + a.t_m / 2, bx = px0 + (p & 1) - rx + a.t_m / 2;
-            const float t = (inside && by >= 0 && by < a.t_m && bx >= 0 && bx < a.t_m) ? a.t_blob[by * a.t_m + bx] : 0.f;
+            const float t = (by >= 0 && by < a.t_m && bx >= 0 && bx < a.t_m) ? blob_lds[by * a.t_m + bx] : 0.f;
             float de;
             const float l = bce_element<true>(z[p][i], t, a.gs, de);
             s += valid ? l : 0.f;
@@ -446,6 +439,18 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
             for (int j = 0; j < 4; ++j) vp[j] = (a.pb != nullptr && 4 * g + j < a.pco) ? a.pb[4 * g + j] : 0.f;
             ptab[4 * 64 + tid] = vp;
         }
+        // ... then the blob table and the rounded position of every target plane (pred_bce_kernel's BLOB form: an all-zero plane when the H x W window around the
+        // position would leave the S x S template -- encoded as a position far away)
+        float* blob_w = reinterpret_cast<float*>(ptab + 5 * 64) + 2 * NW + 4;
+        int* pos_w = reinterpret_cast<int*>(blob_w + a.t_m * a.t_m);
+        for (int i = tid; i < a.t_m * a.t_m; i += NT) blob_w[i] = a.t_blob[i];
+        for (int i = tid; i < a.B * a.pco; i += NT) {
+            const int rx = (int)rintf(a.t_xy[2 * i]), ry = (int)rintf(a.t_xy[2 * i + 1]);
+            const int ox = a.t_S / 2 - rx, oy = a.t_S / 2 - ry;
+            const bool inside = !(ox < 0 || oy < 0 || ox + W > a.t_S || oy + H > a.t_S);
+            pos_w[2 * i] = inside ? rx : (1 << 20);
+            pos_w[2 * i + 1] = inside ? ry : (1 << 20);
+        }
     }
     double acc_loss = 0.0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -552,8 +557,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
                 const __amdgpu_buffer_rsrc_t rlog =
                     __builtin_amdgcn_make_buffer_rsrc(a.logits + (long long)b * a.pco * HW, 0, (unsigned)(a.pco * HW * 4), 0x00020000);
                 const f32x4 wa[2] = {ptab[lane], ptab[64 + lane]}, wb[2] = {ptab[128 + lane], ptab[192 + lane]};
+                const float* blob_lds = reinterpret_cast<const float*>(ptab + 5 * 64) + 2 * NW + 4;
                 const float s_ = wino_epilogue_pred(acc, bias2, wa, wb, ptab[256 + lane], a, rdx, rlog, st_rm, so_rm, b, ty * WN_TH + 2 * (cur & 7), tx * WN_TW + 2 * n,
-                                                    kq, H, W);
+                                                    kq, H, W, blob_lds, reinterpret_cast<const int*>(blob_lds + a.t_m * a.t_m));
                 acc_loss += (double)s_;
                 cur = nxt;
                 if (cur < total_units) nxt = next_unit();
@@ -1416,12 +1422,13 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
 
 template <int NCB, int NCH, int EM, int NW>
 static int launch_wino_nw(WinoArgs& a, hipStream_t st) {
-    constexpr int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16 + (EM == 7 ? 5 * 64 * 16 + NW * 8 + 16 : 0);      // (EM 7: + the predictor tables and the loss scratch)
+    // (EM 7: + the predictor tables, the loss scratch, the blob table and the positions of the target planes -- wino_pred_lds_bytes)
+    const int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16 + (EM == 7 ? 5 * 64 * 16 + NW * 8 + 16 + (a.t_m * a.t_m + 2 * a.B * a.pco) * 4 : 0);
     static bool attr_dev[YNET_MAX_DEV] = {false};
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
     if (!attr_dev[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH, EM, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH, EM, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, EM == 7 ? 160 * 1024 : lds);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1657,17 +1664,20 @@ int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u,
     return wino_launch_any(src, src_bs, u, nullptr, dst, dst_bs, nullptr, 0, cin, cout, B, H, W, 0, stream, "conv2d_winograd_s2d", nullptr, false, true);
 }
 
-int ynet_conv2d_winograd_pred_bce_supported(int B, int H, int W, int cin, int cout, int pred_cout) {
+// (the blob table and two ints per target plane live in LDS next to the filters and the staging rings: kernlen^2 + 2 B pred_cout words in what the 160 KB leave)
+int ynet_conv2d_winograd_pred_bce_supported(int B, int H, int W, int cin, int cout, int pred_cout, int kernlen) {
     static const int on = getenv("YNET_CONV_PRED_BCE") ? atoi(getenv("YNET_CONV_PRED_BCE")) : 1;
-    return (on && cin == 32 && cout == 32 && pred_cout >= 1 && pred_cout <= 16 && wino_shape_ok(B, H, W, cin, cout, 3)) ? 1 : 0;
+    if (!(on && cin == 32 && cout == 32 && pred_cout >= 1 && pred_cout <= 16 && kernlen >= 1 && wino_shape_ok(B, H, W, cin, cout, 3))) return 0;
+    const long long lds = 4ll * 8 * 2 * 64 * 16 + 8ll * WN_RING_BYTES + 16 + 5 * 64 * 16 + 8 * 8 + 16 + ((long long)kernlen * kernlen + 2ll * B * pred_cout) * 4;
+    return lds <= 160 * 1024 ? 1 : 0;
 }
 
 int ynet_conv2d_winograd_pred_bce_blob(const float* src, long long src_bs, const float* u, const float* bias, const float* pred_wp, const float* pred_bias, int pred_cout,
                                        const float* target_xy, const float* blob, int kernlen, int S, float* logits, float* loss, float* dx, long long dx_bs,
                                        void* workspace, int B, int H, int W, float expected_grad, void* stream) {
     YNET_REQUIRE(src && u && pred_wp && target_xy && blob && logits && loss && dx && workspace, "conv2d_winograd_pred_bce_blob: null pointer");
-    YNET_REQUIRE(ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, pred_cout), "conv2d_winograd_pred_bce_blob: B=%d %dx%d with %d predictor outputs is not served (32 -> 32, <= 16 outputs; ask ..._supported)",
-                 B, H, W, pred_cout);
+    YNET_REQUIRE(ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, pred_cout, kernlen), "conv2d_winograd_pred_bce_blob: B=%d %dx%d with %d predictor outputs and a %d x %d blob is not served (32 -> 32, <= 16 outputs, tables within LDS; ask ..._supported)",
+                 B, H, W, pred_cout, kernlen, kernlen);
     YNET_REQUIRE(kernlen > 0 && kernlen <= S && S >= H && S >= W, "conv2d_winograd_pred_bce_blob: the target needs a blob table with 0 < kernlen <= S and S >= H, W (got kernlen %d, S %d, %dx%d)", kernlen, S, H, W);
     const long long HW = (long long)H * W;
     YNET_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0 && (reinterpret_cast<uintptr_t>(dx) & 7) == 0 &&

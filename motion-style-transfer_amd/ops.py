@@ -1262,7 +1262,7 @@ class _Conv2dFn(torch.autograd.Function):
         defer = bool(meta.get("defer") and _conv_pred_bce_allowed and premask and relu and pooled is None and bits is None and wbits is None and len(descs) == 1
                      and len(descs[0]) == 3 and (cin, cout, k) == (32, 32, 3) and lora_a is None and not any(ctx.needs_input_grad[1:5]) and ctx.needs_input_grad[5]
                      and meta.get("wino") and _wino_allowed and descs[0][0] % 16 == 0 and descs[0][2] % 4 == 0 and keep[0].shape[0] == B
-                     and _lib().ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, 1))
+                     and _lib().ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, 1, 1))
         if defer:
             def run(descs=descs, wp=wp, b=b, y=y, dims=(B, H, W), cache=cache):
                 conv2d_raw(descs, None, wp, b, [(y.data_ptr(), 32, 32 * dims[1] * dims[2])], dims[0], dims[1], dims[2], 3, True, wino=(cache, "fwd"))
@@ -1941,7 +1941,7 @@ class _PredBCEFn(torch.autograd.Function):
             need_w_ = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
             blob_t_ = _blob_target(target, B, cout, H, W)
             if (ctx.needs_input_grad[0] and not need_w_ and blob_t_ is not None and premask and cin == 32 and dfr["dims"] == (B, H, W)
-                    and lib.ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, cout)):
+                    and lib.ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, cout, int(blob_t_[1].blob.shape[0]))):
                 # ONE launch: the convolution, its ReLU, the predictor, the criterion and the predictor's data gradient (through that ReLU's backward)
                 del _deferred[x.data_ptr()]
                 pos, tmpl = blob_t_

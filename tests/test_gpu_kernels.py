@@ -2435,6 +2435,7 @@ def test_last_decoder_convolution_inside_the_predictor_and_criterion(dev, B, cou
     zs, gs = float(zd.detach().abs().max()), float(xd.grad.abs().max())
     e1, e0 = float((y1.double().cpu() - zd.detach()).abs().max()), float((y0.double().cpu() - zd.detach()).abs().max())
     assert e1 <= 2.0 * e0 + 1e-6 * zs, (e1, e0, zs)
+    ld = ld.detach()
     assert abs(float(l1) - float(ld)) <= 2e-6 * abs(float(ld)) and abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0)), (float(l1), float(l0), float(ld))
     # the gradient: a ReLU whose pre-activation is within rounding of zero may flip between the two device paths -- isolated elements; everything else to fp32 rounding
     d1, d0 = (g1.double().cpu() - xd.grad).abs(), (g0.double().cpu() - xd.grad).abs()

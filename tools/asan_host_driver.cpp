@@ -214,6 +214,17 @@ int main() {
     EXPECT_REJECT(ynet_upconv_dgrad_ring(cfp, 512 * 64, cfp, nullptr, 0, fp, 64 * 64, 1, 512, 64, 8, 8, nullptr));       // tables beyond 64 KB of LDS
     EXPECT_REJECT(ynet_conv2d_winograd_s2d(nullptr, 0, cfp, fp, 0, 32, 16, 8, 256, 256, nullptr));
     EXPECT_REJECT(ynet_conv2d_winograd_s2d(cfp, 32ll * 64 * 64, cfp, fp, 16ll * 64 * 64, 32, 16, 1, 64, 64, nullptr));   // too few pixels for the Winograd kernels
+    // the [16, 32]-channel data gradient in one launch and the last decoder convolution inside the predictor + criterion (round 6)
+    if (ynet_conv2d_winograd_split_supported(8, 256, 256, 32) != 1 || ynet_conv2d_winograd_split_supported(8, 256, 256, 16) != 0) ++failures;
+    EXPECT_REJECT(ynet_conv2d_winograd_split(nullptr, 0, cfp, fp, 0, 0, fp, 0, 32, 8, 256, 256, nullptr));
+    EXPECT_REJECT(ynet_conv2d_winograd_split(cfp, 32ll * 65536, cfp, fp, 16ll * 65536, 1, nullptr, 0, 32, 8, 256, 256, nullptr));      // no second destination
+    EXPECT_REJECT(ynet_conv2d_winograd_split(cfp, 32ll * 65536, cfp, fp, 16ll * 65536, 0, fp, 8, 32, 8, 256, 256, nullptr));            // its batch stride below the image
+    if (ynet_conv2d_winograd_pred_bce_supported(32, 256, 256, 32, 32, 12, 31) != 1 || ynet_conv2d_winograd_pred_bce_supported(32, 256, 256, 32, 32, 30, 31) != 0 ||
+        ynet_conv2d_winograd_pred_bce_supported(512, 256, 256, 32, 32, 12, 31) != 0 || ynet_conv2d_winograd_pred_bce_supported(8, 256, 256, 16, 32, 12, 31) != 0)
+        ++failures;      // (<= 16 predictor outputs, tables within LDS, 32 -> 32)
+    EXPECT_REJECT(ynet_conv2d_winograd_pred_bce_blob(nullptr, 0, cfp, cfp, cfp, cfp, 12, cfp, cfp, 31, 400, fp, fp, fp, 0, fp, 8, 256, 256, 1.f, nullptr));
+    EXPECT_REJECT(ynet_conv2d_winograd_pred_bce_blob(cfp, 32ll * 65536, cfp, cfp, cfp, cfp, 30, cfp, cfp, 31, 400, fp, fp, fp, 32ll * 65536, fp, 8, 256, 256, 1.f, nullptr));   // 30 outputs
+    EXPECT_REJECT(ynet_conv2d_winograd_pred_bce_blob(cfp, 32ll * 65536, cfp, cfp, cfp, cfp, 12, cfp, cfp, 31, 128, fp, fp, fp, 32ll * 65536, fp, 8, 256, 256, 1.f, nullptr));   // template smaller than the window
     EXPECT_REJECT(ynet_batchnorm2d_fwd(nullptr, fp, nullptr, nullptr, nullptr, nullptr, fp, fp, nullptr, 1, 4, 16, 1, 0.1, 1e-5, nullptr));
     EXPECT_REJECT(ynet_batchnorm2d_fwd(cfp, fp, nullptr, nullptr, nullptr, nullptr, fp, fp, nullptr, 1, 4, 16, 1, 0.1, 1e-5, nullptr));      // training mode without a workspace
     EXPECT_REJECT(ynet_batchnorm2d_fwd(cfp, fp, nullptr, nullptr, nullptr, nullptr, fp, fp, nullptr, 1, 4, 16, 0, 0.1, 1e-5, nullptr));      // evaluation mode without running statistics
