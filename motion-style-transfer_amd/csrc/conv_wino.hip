@@ -260,9 +260,18 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int by = py0 + (p >> 1) - ry + a.t_m / 2, bx = px0 + (p & 1) - rx + a.t_m / 2;
+#if defined(YNET_PRED_EPI_DIAG) && (YNET_PRED_EPI_DIAG & 2)
+            const float t = 0.f;      // (development build, WRONG results: no target lookup -- tools/ab_conv_pred_bce_epi.sh)
+#else
             const float t = (by >= 0 && by < a.t_m && bx >= 0 && bx < a.t_m) ? blob_lds[by * a.t_m + bx] : 0.f;
+#endif
             float de;
-            const float l = bce_element<true>(z[p][i], t, a.gs, de);
+#if defined(YNET_PRED_EPI_DIAG) && (YNET_PRED_EPI_DIAG & 1)
+            de = (z[p][i] - t) * a.gs;      // (development build, WRONG results: no exp / log / rcp)
+            const float l = z[p][i] - t;
+#else
+            const float l = bce_element<true, true>(z[p][i], t, a.gs, de);
+#endif
             s += valid ? l : 0.f;
             dz[p][i] = valid ? de : 0.f;
         }
