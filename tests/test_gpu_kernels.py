@@ -2443,6 +2443,16 @@ def test_last_decoder_convolution_inside_the_predictor_and_criterion(dev, B, cou
     f1, f0 = float((d1 > tol).double().mean()), float((d0 > tol).double().mean())
     assert f1 <= max(5e-4, 1.25 * f0) and f0 <= 2e-3, (f1, f0)      # (the fused launch has no more of them than the two launches it replaces)
     assert float((g1 - g0).abs().median()) <= 1e-6 * gs and float(((g1 - g0).abs() > tol).double().mean()) <= 5e-4
+    # a target that is not the blob form (a clone: no positions behind it) cannot take the fused launch: pred_bce launches the deferred convolution itself, then runs as ever
+    with ops.fold_skip_gradients():
+        xi = x0.clone().requires_grad_(True)
+        target = ops.gather_patches(tmpl, xy.to(dev), H, W).view(B, cout, H, W).clone()
+        f0, m0 = ops.conv_pred_bce_stats["fused"], ops.conv_pred_bce_stats["materialized"]
+        h = last(below(xi, relu=True), defer_last=True)
+        y2, loss2 = ops.pred_bce(h, pred.weight, pred.bias, target, expected, pred._packed)
+        (loss2 * scale).backward()
+        assert (ops.conv_pred_bce_stats["fused"] - f0, ops.conv_pred_bce_stats["materialized"] - m0) == (0, 1)
+    assert torch.equal(y2.detach(), y0) and float(loss2) == float(l0) and torch.equal(xi.grad, g0)
     # a consumer that is not the fused criterion gets the tensor itself: the deferred convolution is launched for it
     with ops.fold_skip_gradients():
         xi = x0.clone().requires_grad_(True)
