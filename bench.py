@@ -198,7 +198,7 @@ class ConvTimer:
             e0.record()
             self.orig_predbce(src, u, bias, pred_wp, pred_bias, pred_cout, pos, tmpl, logits, loss, dx, ws, B, H, W, expected_grad)
             e1.record()
-            self.rec.append(("conv_wino_kernel<2, 4, 7, 8>", e0, e1, 2.0 * B * H * W * 32 * (32 * 9 + 2 * pred_cout), 4.0 * B * H * W * (32 + pred_cout + 32),
+            self.rec.append((f"conv_wino_kernel<2, 4, {7 if pred_cout <= 16 else 8}, 8>", e0, e1, 2.0 * B * H * W * 32 * (32 * 9 + 2 * pred_cout), 4.0 * B * H * W * (32 + pred_cout + 32),
                              (B, H, W, 32, 32, 3, False)))
         self.ops.conv2d_winograd_pred_bce_raw = timed_predbce
 

@@ -207,10 +207,13 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
 //   loss      += BCE-with-logits(z[o], t[o]);  dz[o] = (sigmoid(z[o]) - t[o]) gs
 //   dX[c]      = y[c] > 0 ? sum_o pw[o][c] dz[o] : 0                  again on the matrix cores (k-step i takes o = 4 kq' + i), landing in y's own layout
 // 64 matrix instructions per unit on top of the 256 of the convolution; the logits and dX leave through the stores the plain epilogue uses.
-// wa / wb: the lane's A operands, [cb][j] = pw[o = lane & 15][c = cb 16 + 4 (lane >> 4) + j] and [cb][i] = pw[o = 4 (lane >> 4) + i][c = cb 16 + (lane & 15)].
-__device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f32x2 (&bias2)[2][2], const f32x4 (&wa)[2], const f32x4 (&wb)[2], const f32x4 pbv,
+// wa / wb: the lane's A operands, [mb][cb][j] = pw[o = 16 mb + (lane & 15)][c = cb 16 + 4 (lane >> 4) + j] and [mb][cb][i] = pw[o = 16 mb + 4 (lane >> 4) + i][c = cb 16 + (lane & 15)].
+// MB: blocks of 16 predictor outputs (1: <= 16 outputs, EM 7; 2: <= 32, EM 8 -- the 30 prediction steps of the long-term configs: 128 extra matrix instructions per unit);
+// BLOB_LDS: the blob table is in LDS (MB = 1; with two blocks of tables it no longer fits and is read through the cache).
+template <int MB, bool BLOB_LDS>
+__device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f32x2 (&bias2)[2][2], const f32x4* tab,      // tab: this lane's column of the operand tables in LDS
                                                     const WinoArgs& a, __amdgpu_buffer_rsrc_t rdx, __amdgpu_buffer_rsrc_t rlog, unsigned st_rm, unsigned so_rm, int b,
-                                                    int py0, int px0, int kq, int H, int W, const float* blob_lds, const int* pos_lds) {
+                                                    int py0, int px0, int kq, int H, int W, const float* blob_tab, const int* pos_lds) {
     const int HW = H * W;
     float yv[2][4][4];      // [cb][j = 2 h + k][p = 2 r + c]
 #pragma unroll
@@ -241,39 +244,59 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
             }
         }
     // ---- the predictor: four independent accumulator chains (one per pixel of the block)
-    f32x4 z[4] = {pbv, pbv, pbv, pbv};
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) z[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][j], yv[cb][j][p], z[p], 0, 0, 0);
-    // ---- the criterion on the lane's 4 outputs x 4 pixels; the target is the Gaussian blob at the rounded position (pred_bce_kernel's BLOB form)
+    // (one block of 16 outputs at a time: its four accumulators, the criterion on them, its logits stored -- only dz stays for the data gradient)
+    const unsigned st1 = st_rm + (unsigned)(W * 4);
     float s = 0.f;
-    f32x4 dz[4];
+    f32x4 dz[MB][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int o = 4 * kq + i;
-        const bool valid = o < a.pco;
-        // (rounded position of plane (b, o) from LDS -- far outside for a plane whose window leaves the template --, the blob table from LDS)
-        const int rx = valid ? pos_lds[2 * (b * a.pco + o)] : (1 << 20), ry = valid ? pos_lds[2 * (b * a.pco + o) + 1] : (1 << 20);
+    for (int mb = 0; mb < MB; ++mb) {
+        f32x4 z[4];
+        {
+            const f32x4 pbv = tab[(4 * MB + mb) * 64];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int by = py0 + (p >> 1) - ry + a.t_m / 2, bx = px0 + (p & 1) - rx + a.t_m / 2;
+            for (int p = 0; p < 4; ++p) z[p] = pbv;
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const f32x4 wa = tab[(mb * 2 + cb) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) z[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], yv[cb][j][p], z[p], 0, 0, 0);
+        }
+        // ---- the criterion on the lane's 4 outputs x 4 pixels; the target is the Gaussian blob at the rounded position (pred_bce_kernel's BLOB form)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = 16 * mb + 4 * kq + i;
+            const bool valid = o < a.pco;
+            // (rounded position of plane (b, o) from LDS -- far outside for a plane whose window leaves the template)
+            const int rx = valid ? pos_lds[2 * (b * a.pco + o)] : (1 << 20), ry = valid ? pos_lds[2 * (b * a.pco + o) + 1] : (1 << 20);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int by = py0 + (p >> 1) - ry + a.t_m / 2, bx = px0 + (p & 1) - rx + a.t_m / 2;
 #if defined(YNET_PRED_EPI_DIAG) && (YNET_PRED_EPI_DIAG & 2)
-            const float t = 0.f;      // (development build, WRONG results: no target lookup -- tools/ab_conv_pred_bce_epi.sh)
+                const float t = 0.f;      // (development build, WRONG results: no target lookup -- tools/ab_conv_pred_bce_epi.sh)
 #else
-            const float t = (by >= 0 && by < a.t_m && bx >= 0 && bx < a.t_m) ? blob_lds[by * a.t_m + bx] : 0.f;
+                const float t = (by >= 0 && by < a.t_m && bx >= 0 && bx < a.t_m) ? (BLOB_LDS ? blob_tab[by * a.t_m + bx] : a.t_blob[by * a.t_m + bx]) : 0.f;
 #endif
-            float de;
+                float de;
 #if defined(YNET_PRED_EPI_DIAG) && (YNET_PRED_EPI_DIAG & 1)
-            de = (z[p][i] - t) * a.gs;      // (development build, WRONG results: no exp / log / rcp)
-            const float l = z[p][i] - t;
+                de = (z[p][i] - t) * a.gs;      // (development build, WRONG results: no exp / log / rcp)
+                const float l = z[p][i] - t;
 #else
-            const float l = bce_element<true, true>(z[p][i], t, a.gs, de);
+                const float l = bce_element<true, true>(z[p][i], t, a.gs, de);
 #endif
-            s += valid ? l : 0.f;
-            dz[p][i] = valid ? de : 0.f;
+                s += valid ? l : 0.f;
+                dz[mb][p][i] = valid ? de : 0.f;
+            }
+        }
+        // the logits: plane o = 16 mb + 4 kq + i at the lane's static offset (channel 4 kq) + 16 mb + i planes; planes >= pco are beyond the descriptor (dropped by the range check)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 row0 = {z[0][i], z[1][i]}, row1 = {z[2][i], z[3][i]};
+            const unsigned so = so_rm + (unsigned)((16 * mb + i) * HW * 4);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), rlog, st_rm, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), rlog, st1, so, 0);
         }
     }
     // ---- the predictor's data gradient, into y's layout; the ReLU backward of y applied here
@@ -283,12 +306,15 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
 #pragma unroll
         for (int p = 0; p < 4; ++p) dx[cb][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int mb = 0; mb < MB; ++mb) {
+        const f32x4 wb0 = tab[(2 * MB + mb * 2) * 64], wb1 = tab[(2 * MB + mb * 2 + 1) * 64];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) dx[cb][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[cb][i], dz[p][i], dx[cb][p], 0, 0, 0);
-    const unsigned st1 = st_rm + (unsigned)(W * 4);
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) dx[cb][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb == 0 ? wb0[i] : wb1[i], dz[mb][p][i], dx[cb][p], 0, 0, 0);
+    }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -299,14 +325,6 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), rdx, st_rm, so, 0);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), rdx, st1, so, 0);
         }
-    // the logits: plane o = 4 kq + i at the lane's static offset (channel 4 kq) + i planes; planes >= pco are beyond the descriptor (dropped by the range check)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x2 row0 = {z[0][i], z[1][i]}, row1 = {z[2][i], z[3][i]};
-        const unsigned so = so_rm + (unsigned)(i * HW * 4);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), rlog, st_rm, so, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), rlog, st1, so, 0);
-    }
     return s;
 }
 
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
     const int tile_first = xcd_walk ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int tile_end = xcd_walk ? min(a.ntiles, ((int)(blockIdx.x & 7) + 1) * per_xcd) : a.ntiles;
     if (tile_first >= tile_end) {
-        if constexpr (EM == 7) {      // (a workgroup without tiles still takes its ticket: the last one to arrive sums the loss partials)
+        if constexpr (EM == 7 || EM == 8) {      // (a workgroup without tiles still takes its ticket: the last one to arrive sums the loss partials)
             if (tid == 0) {
                 a.partial[blockIdx.x] = 0.0;
                 __threadfence();
@@ -429,30 +447,35 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
     // EM 7: the predictor's filter as the lanes' matrix operands (see wino_epilogue_pred), [5][64 lanes] x 16 bytes behind the unit counter: units 0 / 1 = wa[cb], 2 / 3 = wb[cb],
     // 4 = the bias of the lane's four outputs; then 8 doubles for the workgroup's loss partial
     f32x4* ptab = reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(smem) + NCH * WQ * 16 + NW * WN_RING_BYTES + 16);
-    if constexpr (EM == 7) {
+    constexpr int PMB = EM == 8 ? 2 : 1;      // blocks of 16 predictor outputs (EM 7: one, EM 8: two); tables: units [mb 2 + cb] = wa, [2 PMB + mb 2 + cb] = wb, [4 PMB + mb] = bias
+    if constexpr (EM == 7 || EM == 8) {
         if (tid < 64) {
             const int o_a = tid & 15, g = tid >> 4;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                f32x4 va, vb;
+            for (int mb = 0; mb < PMB; ++mb) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    va[j] = o_a < a.pco ? a.pw[(cb * 16 + 4 * g + j) * a.pco_pad + o_a] : 0.f;
-                    vb[j] = 4 * g + j < a.pco ? a.pw[(cb * 16 + o_a) * a.pco_pad + 4 * g + j] : 0.f;
+                for (int cb = 0; cb < 2; ++cb) {
+                    f32x4 va, vb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        va[j] = 16 * mb + o_a < a.pco ? a.pw[(cb * 16 + 4 * g + j) * a.pco_pad + 16 * mb + o_a] : 0.f;
+                        vb[j] = 16 * mb + 4 * g + j < a.pco ? a.pw[(cb * 16 + o_a) * a.pco_pad + 16 * mb + 4 * g + j] : 0.f;
+                    }
+                    ptab[(mb * 2 + cb) * 64 + tid] = va;
+                    ptab[(2 * PMB + mb * 2 + cb) * 64 + tid] = vb;
                 }
-                ptab[cb * 64 + tid] = va;
-                ptab[(2 + cb) * 64 + tid] = vb;
-            }
-            f32x4 vp;
+                f32x4 vp;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vp[j] = (a.pb != nullptr && 4 * g + j < a.pco) ? a.pb[4 * g + j] : 0.f;
-            ptab[4 * 64 + tid] = vp;
+                for (int j = 0; j < 4; ++j) vp[j] = (a.pb != nullptr && 16 * mb + 4 * g + j < a.pco) ? a.pb[16 * mb + 4 * g + j] : 0.f;
+                ptab[(4 * PMB + mb) * 64 + tid] = vp;
+            }
         }
-        // ... then the blob table and the rounded position of every target plane (pred_bce_kernel's BLOB form: an all-zero plane when the H x W window around the
+        // ... then the blob table (EM 7) and the rounded position of every target plane (pred_bce_kernel's BLOB form: an all-zero plane when the H x W window around the
         // position would leave the S x S template -- encoded as a position far away)
-        float* blob_w = reinterpret_cast<float*>(ptab + 5 * 64) + 2 * NW + 4;
-        int* pos_w = reinterpret_cast<int*>(blob_w + a.t_m * a.t_m);
-        for (int i = tid; i < a.t_m * a.t_m; i += NT) blob_w[i] = a.t_blob[i];
+        float* blob_w = reinterpret_cast<float*>(ptab + 5 * PMB * 64) + 2 * NW + 4;
+        int* pos_w = reinterpret_cast<int*>(blob_w + (EM == 7 ? a.t_m * a.t_m : 0));
+        if constexpr (EM == 7)
+            for (int i = tid; i < a.t_m * a.t_m; i += NT) blob_w[i] = a.t_blob[i];
         for (int i = tid; i < a.B * a.pco; i += NT) {
             const int rx = (int)rintf(a.t_xy[2 * i]), ry = (int)rintf(a.t_xy[2 * i + 1]);
             const int ox = a.t_S / 2 - rx, oy = a.t_S / 2 - ry;
@@ -560,15 +583,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
             const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
             const unsigned so_s2d = (unsigned)(((ty * (WN_TH / 2) + (cur & 7)) * (W >> 1) + tx * (WN_TW / 2)) * 4);
             const unsigned so_rm = (unsigned)(((ty * WN_TH + 2 * (cur & 7)) * W + tx * WN_TW) * 4);
-            if constexpr (EM == 7) {
-                static_assert(EM != 7 || NCB == 2, "the predictor epilogue is the 32-channel launch's");
+            if constexpr (EM == 7 || EM == 8) {
+                static_assert((EM != 7 && EM != 8) || NCB == 2, "the predictor epilogue is the 32-channel launch's");
                 const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rlog =
                     __builtin_amdgcn_make_buffer_rsrc(a.logits + (long long)b * a.pco * HW, 0, (unsigned)(a.pco * HW * 4), 0x00020000);
-                const f32x4 wa[2] = {ptab[lane], ptab[64 + lane]}, wb[2] = {ptab[128 + lane], ptab[192 + lane]};
-                const float* blob_lds = reinterpret_cast<const float*>(ptab + 5 * 64) + 2 * NW + 4;
-                const float s_ = wino_epilogue_pred(acc, bias2, wa, wb, ptab[256 + lane], a, rdx, rlog, st_rm, so_rm, b, ty * WN_TH + 2 * (cur & 7), tx * WN_TW + 2 * n,
-                                                    kq, H, W, blob_lds, reinterpret_cast<const int*>(blob_lds + a.t_m * a.t_m));
+                const float* blob_lds = reinterpret_cast<const float*>(ptab + 5 * PMB * 64) + 2 * NW + 4;
+                const float s_ = wino_epilogue_pred<PMB, EM == 7>(acc, bias2, ptab + lane, a, rdx, rlog, st_rm, so_rm, b, ty * WN_TH + 2 * (cur & 7), tx * WN_TW + 2 * n, kq, H, W,
+                                                                  blob_lds, reinterpret_cast<const int*>(blob_lds + (EM == 7 ? a.t_m * a.t_m : 0)));
                 acc_loss += (double)s_;
                 cur = nxt;
                 if (cur < total_units) nxt = next_unit();
@@ -595,9 +617,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
         cur = nxt;
         if (cur < total_units) nxt = next_unit();
     }
-    if constexpr (EM == 7) {
+    if constexpr (EM == 7 || EM == 8) {
         // the loss: lanes -> wave -> workgroup partial (fp64) -> the last workgroup to arrive sums the partials in index order (bitwise reproducible) and resets the ticket
-        double* wsd = reinterpret_cast<double*>(ptab + 5 * 64);
+        double* wsd = reinterpret_cast<double*>(ptab + 5 * PMB * 64);
         unsigned* last = reinterpret_cast<unsigned*>(wsd + NW);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc_loss += __shfl_xor(acc_loss, o, 64);
@@ -1432,12 +1454,13 @@ static bool wino_shape_ok(int B, int H, int W, int cin, int cout, int K) {
 template <int NCB, int NCH, int EM, int NW>
 static int launch_wino_nw(WinoArgs& a, hipStream_t st) {
     // (EM 7: + the predictor tables, the loss scratch, the blob table and the positions of the target planes -- wino_pred_lds_bytes)
-    const int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16 + (EM == 7 ? 5 * 64 * 16 + NW * 8 + 16 + (a.t_m * a.t_m + 2 * a.B * a.pco) * 4 : 0);
+    const int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16 +
+                    (EM == 7 ? 5 * 64 * 16 + NW * 8 + 16 + (a.t_m * a.t_m + 2 * a.B * a.pco) * 4 : (EM == 8 ? 10 * 64 * 16 + NW * 8 + 16 + 2 * a.B * a.pco * 4 : 0));
     static bool attr_dev[YNET_MAX_DEV] = {false};
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
     if (!attr_dev[slot]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH, EM, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, EM == 7 ? 160 * 1024 : lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<NCB, NCH, EM, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (EM == 7 || EM == 8) ? 160 * 1024 : lds);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1676,8 +1699,10 @@ int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u,
 // (the blob table and two ints per target plane live in LDS next to the filters and the staging rings: kernlen^2 + 2 B pred_cout words in what the 160 KB leave)
 int ynet_conv2d_winograd_pred_bce_supported(int B, int H, int W, int cin, int cout, int pred_cout, int kernlen) {
     static const int on = getenv("YNET_CONV_PRED_BCE") ? atoi(getenv("YNET_CONV_PRED_BCE")) : 1;
-    if (!(on && cin == 32 && cout == 32 && pred_cout >= 1 && pred_cout <= 16 && kernlen >= 1 && wino_shape_ok(B, H, W, cin, cout, 3))) return 0;
-    const long long lds = 4ll * 8 * 2 * 64 * 16 + 8ll * WN_RING_BYTES + 16 + 5 * 64 * 16 + 8 * 8 + 16 + ((long long)kernlen * kernlen + 2ll * B * pred_cout) * 4;
+    if (!(on && cin == 32 && cout == 32 && pred_cout >= 1 && pred_cout <= 32 && kernlen >= 1 && wino_shape_ok(B, H, W, cin, cout, 3))) return 0;
+    const long long base = 4ll * 8 * 2 * 64 * 16 + 8ll * WN_RING_BYTES + 16 + 8 * 8 + 16;
+    const long long lds = pred_cout <= 16 ? base + 5 * 64 * 16 + ((long long)kernlen * kernlen + 2ll * B * pred_cout) * 4      // one block of tables, the blob in LDS
+                                          : base + 10 * 64 * 16 + 2ll * B * pred_cout * 4;                                     // two blocks, the blob through the cache
     return lds <= 160 * 1024 ? 1 : 0;
 }
 
@@ -1685,7 +1710,7 @@ int ynet_conv2d_winograd_pred_bce_blob(const float* src, long long src_bs, const
                                        const float* target_xy, const float* blob, int kernlen, int S, float* logits, float* loss, float* dx, long long dx_bs,
                                        void* workspace, int B, int H, int W, float expected_grad, void* stream) {
     YNET_REQUIRE(src && u && pred_wp && target_xy && blob && logits && loss && dx && workspace, "conv2d_winograd_pred_bce_blob: null pointer");
-    YNET_REQUIRE(ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, pred_cout, kernlen), "conv2d_winograd_pred_bce_blob: B=%d %dx%d with %d predictor outputs and a %d x %d blob is not served (32 -> 32, <= 16 outputs, tables within LDS; ask ..._supported)",
+    YNET_REQUIRE(ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, pred_cout, kernlen), "conv2d_winograd_pred_bce_blob: B=%d %dx%d with %d predictor outputs and a %d x %d blob is not served (32 -> 32, <= 32 outputs, tables within LDS; ask ..._supported)",
                  B, H, W, pred_cout, kernlen, kernlen);
     YNET_REQUIRE(kernlen > 0 && kernlen <= S && S >= H && S >= W, "conv2d_winograd_pred_bce_blob: the target needs a blob table with 0 < kernlen <= S and S >= H, W (got kernlen %d, S %d, %dx%d)", kernlen, S, H, W);
     const long long HW = (long long)H * W;
@@ -1707,7 +1732,7 @@ int ynet_conv2d_winograd_pred_bce_blob(const float* src, long long src_bs, const
     a.loss = loss;
     a.n_loss = (long long)B * pred_cout * HW;
     a.gs = expected_grad / (float)a.n_loss;
-    return launch_wino_nw<2, 4, 7, 8>(a, (hipStream_t)stream);
+    return pred_cout <= 16 ? launch_wino_nw<2, 4, 7, 8>(a, (hipStream_t)stream) : launch_wino_nw<2, 4, 8, 8>(a, (hipStream_t)stream);
 }
 
 int ynet_conv2d_winograd_split_supported(int B, int H, int W, int cin) { return (cin == 32 && wino_shape_ok(B, H, W, cin, 48, 3)) ? 1 : 0; }

@@ -2383,7 +2383,7 @@ def test_upconv_dgrad_ring_and_the_effective_filter_at_any_shape(dev, B, cin, co
         pkg("_lib").check(lib.ynet_upconv_dgrad_ring(D.data_ptr(), 4 * cout * h * w, tables.data_ptr(), None, 0, dx.data_ptr(), cin * h * w, B, 4 * cout + 2, cin, h, w, None), lib)
 
 
-@pytest.mark.parametrize("B,cout,H,W,S", [(8, 12, 128, 128, 400), (13, 12, 64, 160, 400), (8, 5, 128, 128, 300), (2, 16, 256, 256, 600)], ids=str)
+@pytest.mark.parametrize("B,cout,H,W,S", [(8, 12, 128, 128, 400), (13, 12, 64, 160, 400), (8, 5, 128, 128, 300), (2, 16, 256, 256, 600), (8, 30, 128, 128, 400), (2, 17, 256, 256, 600)], ids=str)
 def test_last_decoder_convolution_inside_the_predictor_and_criterion(dev, B, cout, H, W, S):
     """Round 6: decoder[4][2] + ReLU, the 1 x 1 predictor, BCEWithLogitsLoss and the predictor's data gradient as ONE launch (ynet_conv2d_winograd_pred_bce_blob;
     models/ynet.py:467,469, utils/train_epoch.py:93-94) -- the 32 activation planes between the convolution and the predictor are never written.  Against the two

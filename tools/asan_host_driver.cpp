@@ -219,11 +219,11 @@ int main() {
     EXPECT_REJECT(ynet_conv2d_winograd_split(nullptr, 0, cfp, fp, 0, 0, fp, 0, 32, 8, 256, 256, nullptr));
     EXPECT_REJECT(ynet_conv2d_winograd_split(cfp, 32ll * 65536, cfp, fp, 16ll * 65536, 1, nullptr, 0, 32, 8, 256, 256, nullptr));      // no second destination
     EXPECT_REJECT(ynet_conv2d_winograd_split(cfp, 32ll * 65536, cfp, fp, 16ll * 65536, 0, fp, 8, 32, 8, 256, 256, nullptr));            // its batch stride below the image
-    if (ynet_conv2d_winograd_pred_bce_supported(32, 256, 256, 32, 32, 12, 31) != 1 || ynet_conv2d_winograd_pred_bce_supported(32, 256, 256, 32, 32, 30, 31) != 0 ||
+    if (ynet_conv2d_winograd_pred_bce_supported(32, 256, 256, 32, 32, 12, 31) != 1 || ynet_conv2d_winograd_pred_bce_supported(16, 512, 512, 32, 32, 30, 31) != 1 || ynet_conv2d_winograd_pred_bce_supported(32, 256, 256, 32, 32, 33, 31) != 0 ||
         ynet_conv2d_winograd_pred_bce_supported(512, 256, 256, 32, 32, 12, 31) != 0 || ynet_conv2d_winograd_pred_bce_supported(8, 256, 256, 16, 32, 12, 31) != 0)
-        ++failures;      // (<= 16 predictor outputs, tables within LDS, 32 -> 32)
+        ++failures;      // (<= 32 predictor outputs, tables within LDS, 32 -> 32)
     EXPECT_REJECT(ynet_conv2d_winograd_pred_bce_blob(nullptr, 0, cfp, cfp, cfp, cfp, 12, cfp, cfp, 31, 400, fp, fp, fp, 0, fp, 8, 256, 256, 1.f, nullptr));
-    EXPECT_REJECT(ynet_conv2d_winograd_pred_bce_blob(cfp, 32ll * 65536, cfp, cfp, cfp, cfp, 30, cfp, cfp, 31, 400, fp, fp, fp, 32ll * 65536, fp, 8, 256, 256, 1.f, nullptr));   // 30 outputs
+    EXPECT_REJECT(ynet_conv2d_winograd_pred_bce_blob(cfp, 32ll * 65536, cfp, cfp, cfp, cfp, 33, cfp, cfp, 31, 400, fp, fp, fp, 32ll * 65536, fp, 8, 256, 256, 1.f, nullptr));   // 33 outputs
     EXPECT_REJECT(ynet_conv2d_winograd_pred_bce_blob(cfp, 32ll * 65536, cfp, cfp, cfp, cfp, 12, cfp, cfp, 31, 128, fp, fp, fp, 32ll * 65536, fp, 8, 256, 256, 1.f, nullptr));   // template smaller than the window
     EXPECT_REJECT(ynet_batchnorm2d_fwd(nullptr, fp, nullptr, nullptr, nullptr, nullptr, fp, fp, nullptr, 1, 4, 16, 1, 0.1, 1e-5, nullptr));
     EXPECT_REJECT(ynet_batchnorm2d_fwd(cfp, fp, nullptr, nullptr, nullptr, nullptr, fp, fp, nullptr, 1, 4, 16, 1, 0.1, 1e-5, nullptr));      // training mode without a workspace
