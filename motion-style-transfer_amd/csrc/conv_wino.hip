@@ -198,7 +198,7 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
     if constexpr (BITS == 1) *wbits = word;
 }
 
-// EM 7: the last decoder convolution + ReLU with the predictor, the criterion and the predictor's data gradient in its epilogue (models/ynet.py:467,469
+// EM 7 / 8: the last decoder convolution + ReLU with the predictor, the criterion and the predictor's data gradient in its epilogue (models/ynet.py:467,469
 // `self.predictor(x)`, utils/train_epoch.py:93-94,105-106 `criterion(pred_map, gt_map) * loss_scale`) -- what pred_bce_kernel (glue.hip) does in a pass of its own
 // over the 32 activation planes, done where those activations are still in registers: the convolution's output is never written, never read back.
 //   y[c]       = relu(A^T M A + bias)                                 lane (n, kq): channels cb 16 + 4 kq + j (j = 0..3) of the 2 x 2 block n, 8 x 4 values
@@ -209,11 +209,12 @@ __device__ __forceinline__ void wino_epilogue(f32x4 (&acc)[16][NCB], const f32x2
 // 64 matrix instructions per unit on top of the 256 of the convolution; the logits and dX leave through the stores the plain epilogue uses.
 // wa / wb: the lane's A operands, [mb][cb][j] = pw[o = 16 mb + (lane & 15)][c = cb 16 + 4 (lane >> 4) + j] and [mb][cb][i] = pw[o = 16 mb + 4 (lane >> 4) + i][c = cb 16 + (lane & 15)].
 // MB: blocks of 16 predictor outputs (1: <= 16 outputs, EM 7; 2: <= 32, EM 8 -- the 30 prediction steps of the long-term configs: 128 extra matrix instructions per unit);
-// BLOB_LDS: the blob table is in LDS (MB = 1; with two blocks of tables it no longer fits and is read through the cache).
-template <int MB, bool BLOB_LDS>
+// PosT: the rounded positions of the target planes in LDS -- int, or short where two blocks of operand tables leave the blob table and the positions 5.8 KB (MB = 2;
+// 32767 = "this plane is all zero").
+template <int MB, typename PosT>
 __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f32x2 (&bias2)[2][2], const f32x4* tab,      // tab: this lane's column of the operand tables in LDS
                                                     const WinoArgs& a, __amdgpu_buffer_rsrc_t rdx, __amdgpu_buffer_rsrc_t rlog, unsigned st_rm, unsigned so_rm, int b,
-                                                    int py0, int px0, int kq, int H, int W, const float* blob_tab, const int* pos_lds) {
+                                                    int py0, int px0, int kq, int H, int W, const float* blob_tab, const PosT* pos_lds) {
     const int HW = H * W;
     float yv[2][4][4];      // [cb][j = 2 h + k][p = 2 r + c]
 #pragma unroll
@@ -247,10 +248,13 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
     // (one block of 16 outputs at a time: its four accumulators, the criterion on them, its logits stored -- only dz stays for the data gradient)
     const unsigned st1 = st_rm + (unsigned)(W * 4);
     float s = 0.f;
-    f32x4 dz[MB][4];
+    f32x4 dx[2][4];      // the predictor's data gradient, in y's layout (accumulated block by block)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        f32x4 z[4];
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dx[cb][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto block = [&](const int mb) {
+        f32x4 z[4], dz[4];
         {
             const f32x4 pbv = tab[(4 * MB + mb) * 64];
 #pragma unroll
@@ -270,14 +274,14 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
             const int o = 16 * mb + 4 * kq + i;
             const bool valid = o < a.pco;
             // (rounded position of plane (b, o) from LDS -- far outside for a plane whose window leaves the template)
-            const int rx = valid ? pos_lds[2 * (b * a.pco + o)] : (1 << 20), ry = valid ? pos_lds[2 * (b * a.pco + o) + 1] : (1 << 20);
+            const int rx = valid ? (int)pos_lds[2 * (b * a.pco + o)] : 32767, ry = valid ? (int)pos_lds[2 * (b * a.pco + o) + 1] : 32767;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int by = py0 + (p >> 1) - ry + a.t_m / 2, bx = px0 + (p & 1) - rx + a.t_m / 2;
 #if defined(YNET_PRED_EPI_DIAG) && (YNET_PRED_EPI_DIAG & 2)
                 const float t = 0.f;      // (development build, WRONG results: no target lookup -- tools/ab_conv_pred_bce_epi.sh)
 #else
-                const float t = (by >= 0 && by < a.t_m && bx >= 0 && bx < a.t_m) ? (BLOB_LDS ? blob_tab[by * a.t_m + bx] : a.t_blob[by * a.t_m + bx]) : 0.f;
+                const float t = (by >= 0 && by < a.t_m && bx >= 0 && bx < a.t_m) ? blob_tab[by * a.t_m + bx] : 0.f;
 #endif
                 float de;
 #if defined(YNET_PRED_EPI_DIAG) && (YNET_PRED_EPI_DIAG & 1)
@@ -287,7 +291,7 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
                 const float l = bce_element<true, true>(z[p][i], t, a.gs, de);
 #endif
                 s += valid ? l : 0.f;
-                dz[mb][p][i] = valid ? de : 0.f;
+                dz[p][i] = valid ? de : 0.f;
             }
         }
         // the logits: plane o = 16 mb + 4 kq + i at the lane's static offset (channel 4 kq) + 16 mb + i planes; planes >= pco are beyond the descriptor (dropped by the range check)
@@ -298,23 +302,23 @@ __device__ __forceinline__ float wino_epilogue_pred(f32x4 (&acc)[16][2], const f
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row0), rlog, st_rm, so, 0);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, row1), rlog, st1, so, 0);
         }
-    }
-    // ---- the predictor's data gradient, into y's layout; the ReLU backward of y applied here
-    f32x4 dx[2][4];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) dx[cb][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+        // this block's part of the predictor's data gradient (k-step i takes output 16 mb + 4 kq' + i from lane group kq')
         const f32x4 wb0 = tab[(2 * MB + mb * 2) * 64], wb1 = tab[(2 * MB + mb * 2 + 1) * 64];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) dx[cb][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb == 0 ? wb0[i] : wb1[i], dz[mb][p][i], dx[cb][p], 0, 0, 0);
+                for (int p = 0; p < 4; ++p) dx[cb][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb == 0 ? wb0[i] : wb1[i], dz[p][i], dx[cb][p], 0, 0, 0);
+    };
+    if constexpr (MB == 1) {
+        block(0);
+    } else {
+        // (a real loop over the blocks: unrolled, the two blocks' chains were interleaved and 36 registers spilled -- 754 against 637 us at 512^2, B 16)
+#pragma unroll 1
+        for (int mb = 0; mb < MB; ++mb) block(mb);
     }
+    // ---- the ReLU backward of y applied to the data gradient, stored where y would have been
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -472,16 +476,17 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
         }
         // ... then the blob table (EM 7) and the rounded position of every target plane (pred_bce_kernel's BLOB form: an all-zero plane when the H x W window around the
         // position would leave the S x S template -- encoded as a position far away)
+        typedef typename std::conditional<EM == 7, int, short>::type PosT;
         float* blob_w = reinterpret_cast<float*>(ptab + 5 * PMB * 64) + 2 * NW + 4;
-        int* pos_w = reinterpret_cast<int*>(blob_w + (EM == 7 ? a.t_m * a.t_m : 0));
-        if constexpr (EM == 7)
-            for (int i = tid; i < a.t_m * a.t_m; i += NT) blob_w[i] = a.t_blob[i];
+        PosT* pos_w = reinterpret_cast<PosT*>(blob_w + a.t_m * a.t_m);
+        for (int i = tid; i < a.t_m * a.t_m; i += NT) blob_w[i] = a.t_blob[i];
         for (int i = tid; i < a.B * a.pco; i += NT) {
             const int rx = (int)rintf(a.t_xy[2 * i]), ry = (int)rintf(a.t_xy[2 * i + 1]);
             const int ox = a.t_S / 2 - rx, oy = a.t_S / 2 - ry;
             const bool inside = !(ox < 0 || oy < 0 || ox + W > a.t_S || oy + H > a.t_S);
-            pos_w[2 * i] = inside ? rx : (1 << 20);
-            pos_w[2 * i + 1] = inside ? ry : (1 << 20);
+            // (a position beyond +-32766 cannot be `inside`: the window would leave any template the host admits)
+            pos_w[2 * i] = (PosT)(inside && rx > -32767 && rx < 32767 && ry > -32767 && ry < 32767 ? rx : 32767);
+            pos_w[2 * i + 1] = (PosT)(inside && rx > -32767 && rx < 32767 && ry > -32767 && ry < 32767 ? ry : 32767);
         }
     }
     double acc_loss = 0.0;
@@ -588,9 +593,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_wino_kernel(const WinoArgs a)
                 const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)b * a.y_bs, 0, y_img, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rlog =
                     __builtin_amdgcn_make_buffer_rsrc(a.logits + (long long)b * a.pco * HW, 0, (unsigned)(a.pco * HW * 4), 0x00020000);
+                typedef typename std::conditional<EM == 7, int, short>::type PosT;
                 const float* blob_lds = reinterpret_cast<const float*>(ptab + 5 * PMB * 64) + 2 * NW + 4;
-                const float s_ = wino_epilogue_pred<PMB, EM == 7>(acc, bias2, ptab + lane, a, rdx, rlog, st_rm, so_rm, b, ty * WN_TH + 2 * (cur & 7), tx * WN_TW + 2 * n, kq, H, W,
-                                                                  blob_lds, reinterpret_cast<const int*>(blob_lds + (EM == 7 ? a.t_m * a.t_m : 0)));
+                const float s_ = wino_epilogue_pred<PMB, PosT>(acc, bias2, ptab + lane, a, rdx, rlog, st_rm, so_rm, b, ty * WN_TH + 2 * (cur & 7), tx * WN_TW + 2 * n, kq, H, W,
+                                                               blob_lds, reinterpret_cast<const PosT*>(blob_lds + a.t_m * a.t_m));
                 acc_loss += (double)s_;
                 cur = nxt;
                 if (cur < total_units) nxt = next_unit();
@@ -1455,7 +1461,8 @@ template <int NCB, int NCH, int EM, int NW>
 static int launch_wino_nw(WinoArgs& a, hipStream_t st) {
     // (EM 7: + the predictor tables, the loss scratch, the blob table and the positions of the target planes -- wino_pred_lds_bytes)
     const int lds = NCH * 8 * NCB * 64 * 16 + NW * WN_RING_BYTES + 16 +
-                    (EM == 7 ? 5 * 64 * 16 + NW * 8 + 16 + (a.t_m * a.t_m + 2 * a.B * a.pco) * 4 : (EM == 8 ? 10 * 64 * 16 + NW * 8 + 16 + 2 * a.B * a.pco * 4 : 0));
+                    (EM == 7 ? 5 * 64 * 16 + NW * 8 + 16 + (a.t_m * a.t_m + 2 * a.B * a.pco) * 4
+                             : (EM == 8 ? 10 * 64 * 16 + NW * 8 + 16 + a.t_m * a.t_m * 4 + ((2 * a.B * a.pco * 2 + 15) & ~15) : 0));
     static bool attr_dev[YNET_MAX_DEV] = {false};
     static int cus_dev[YNET_MAX_DEV] = {0};
     const int slot = ynet_device_slot();
@@ -1702,7 +1709,7 @@ int ynet_conv2d_winograd_pred_bce_supported(int B, int H, int W, int cin, int co
     if (!(on && cin == 32 && cout == 32 && pred_cout >= 1 && pred_cout <= 32 && kernlen >= 1 && wino_shape_ok(B, H, W, cin, cout, 3))) return 0;
     const long long base = 4ll * 8 * 2 * 64 * 16 + 8ll * WN_RING_BYTES + 16 + 8 * 8 + 16;
     const long long lds = pred_cout <= 16 ? base + 5 * 64 * 16 + ((long long)kernlen * kernlen + 2ll * B * pred_cout) * 4      // one block of tables, the blob in LDS
-                                          : base + 10 * 64 * 16 + 2ll * B * pred_cout * 4;                                     // two blocks, the blob through the cache
+                                          : base + 10 * 64 * 16 + (long long)kernlen * kernlen * 4 + ((2ll * B * pred_cout * 2 + 15) & ~15ll);      // two blocks, 16-bit positions
     return lds <= 160 * 1024 ? 1 : 0;
 }
 
