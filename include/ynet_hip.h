@@ -136,7 +136,7 @@ int ynet_conv2d_winograd_s2d(const float* src, long long src_bs, const float* u,
  *                               space-to-depth as ynet_conv2d_winograd_s2d when dst0_s2d != 0), channels 16..47 to dst1.  Three output blocks per wave = 192
  *                               accumulator registers: four waves per workgroup, one per SIMD.  cin = 32; bit-identical to the two launches it replaces. */
 /*   ynet_conv2d_winograd_pred_bce_blob  (round 6) the LAST decoder convolution with everything behind it in its epilogue:
- *                               y = relu(conv3x3(src, filter) + bias)  (32 -> 32, never written),  logits = pred_bias + pred_w y  (the 1 x 1 predictor, <= 16 outputs,
+ *                               y = relu(conv3x3(src, filter) + bias)  (32 -> 32, never written),  logits = pred_bias + pred_w y  (the 1 x 1 predictor, <= 32 outputs,
  *                               models/ynet.py:450-451,469),  loss = mean BCE-with-logits(logits, target)  (utils/train_epoch.py:93-94,105-106; the target in the blob form
  *                               of ynet_pred_bce_blob),  dx = y > 0 ? pred_w^T (sigmoid(logits) - target) expected_grad / n : 0  (the gradient of the loss with respect
  *                               to the convolution's PRE-activation output: what its data gradient consumes).  Replaces [ynet_conv2d_winograd -> ynet_pred_bce_blob]: the
