@@ -324,11 +324,21 @@ def _wgrad_stream(device):
     return key, _wgrad_streams[key]
 
 
+_wgrad_adds = {}       # branch key -> [(existing .grad, the gradient to add into it)]: added in ONE launch when the branch is joined
+
+
 def join_wgrad_branch():
-    """The current stream of every device with adapter gradients in flight waits for them."""
+    """The current stream of every device with adapter gradients in flight waits for them.  Gradients that go INTO an existing .grad (the data-parallel flat buffer's
+    views, an accumulation) are added here, on the branch, in one multi-tensor launch -- not as two little launches behind every layer's filter gradient (18 of them on
+    the tail of an N-rank step)."""
     for key, side in list(_wgrad_pending.items()):
+        adds = _wgrad_adds.pop(key, None)
+        if adds:
+            with torch.cuda.stream(side), torch.no_grad():
+                torch._foreach_add_([a for a, _ in adds], [b for _, b in adds])
         torch.cuda.current_stream(torch.device(key[0], key[1])).wait_stream(side)
     _wgrad_pending.clear()
+    _wgrad_adds.clear()
 
 
 _wino_allowed = _os.environ.get("YNET_WINOGRAD", "1") != "0"     # YNET_WINOGRAD=0: every convolution takes the implicit-GEMM kernels
@@ -1407,7 +1417,7 @@ class _Conv2dFn(torch.autograd.Function):
                 # this backward is the only writer of these two parameters' gradients)
                 for p_, g_, want in ((lora_a, d_a, need[3]), (lora_b, d_bm, need[4])):
                     if want and p_.grad is not None:
-                        p_.grad.add_(g_.view_as(p_.grad))
+                        _wgrad_adds.setdefault(bkey, []).append((p_.grad, g_.view_as(p_.grad)))      # (added when the branch is joined: join_wgrad_branch)
             for p_, g_, want in ((lora_a, d_a, need[3]), (lora_b, d_bm, need[4])):
                 g_.record_stream(cur)         # read by the optimizer (and a data-parallel stage) on the step's stream, after the join
                 if want and p_.grad is None:
