@@ -2108,7 +2108,7 @@ def test_conv2d_auto_with_an_additive_term(dev, case):
     close(y, ref, rtol=1e-5, scale_rel=3e-6, msg="conv + additive term")
 
 
-@pytest.mark.parametrize("kind", ["cat_pool_code", "relu_bits", "winograd16_addend", "winograd16_pooled", "up", "up16"])
+@pytest.mark.parametrize("kind", ["cat_pool_code", "relu_bits", "winograd16_addend", "winograd16_pooled", "up", "up16", "split48_s2d", "conv_pred_bce"])
 def test_winograd_epilogue_and_up_paths_beyond_2_and_4_gib(dev, kind):
     """the one-image-per-descriptor addressing of round 5 was only exercised beyond 2 / 4 GiB on the plain, dgrad_relu, cat and cat_add
     paths.  The others -- the pooled copy's descriptor and the code byte index (EPI 3 / 6), the 1-bit mask word index, the slice form's auxiliary
@@ -2154,6 +2154,54 @@ def test_winograd_epilogue_and_up_paths_beyond_2_and_4_gib(dev, kind):
         for b in picks(32 * H * W * 4, B):
             close(y[b:b + 1], torch.relu(F.conv2d(x[b:b + 1].double(), w.double(), bias.double(), padding=1)), rtol=1e-4, scale_rel=2e-6, msg=f"image {b}")
             close(dx[b:b + 1], F.conv_transpose2d(dy[b:b + 1].double(), w2.double(), padding=1) * (y[b:b + 1] > 0), rtol=1e-4, scale_rel=2e-6, msg=f"masked gradient of image {b}")
+        return
+    if kind == "split48_s2d":
+        # round 6: the [16, 32]-channel data gradient in one launch, the 16 channels space-to-depth -- dy 4.4 GB, the two destinations 2.2 and 4.4 GB
+        B, H, W = 520, 256, 256
+        dy = torch.randn(B, 32, H, W, device=dev, generator=g)
+        w = rnd(32, 49, 3, 3, seed=2, scale=0.2).to(dev)          # a forward filter [cout 32][cin 49]: its data gradient maps 32 -> 49 (the 49th not wanted)
+        d0, d1 = torch.full((B, 16, H, W), float("nan"), device=dev), torch.full((B, 32, H, W), float("nan"), device=dev)
+        info = {}
+        tag = ops.conv2d_raw([(dy.data_ptr(), 32, 32 * H * W)], None, ops.pack_weight(w, 1), None, [(d0.data_ptr(), 16, 16 * H * W), (d1.data_ptr(), 32, 32 * H * W), (None, 1, 0)],
+                             B, H, W, 3, False, wino=({}, "dgrad"), dst_s2d=[1, 0, 0], info=info)
+        assert tag == "winograd:3,4,6" and info["wrote_s2d"] == 1
+        for b in picks(32 * H * W * 4, B) + picks(16 * H * W * 4, B):
+            ref = F.conv_transpose2d(dy[b:b + 1].double(), w.double(), padding=1)
+            got0 = d0[b].view(2, 2, 16, H // 2, W // 2).permute(2, 3, 0, 4, 1).reshape(1, 16, H, W)      # plane (2 r + c) * 16 + ch, position (i, j) -> (2 i + r, 2 j + c)
+            close(got0, ref[:, :16], rtol=1e-4, scale_rel=2e-6, msg=f"space-to-depth part of image {b}")
+            close(d1[b:b + 1], ref[:, 16:48], rtol=1e-4, scale_rel=2e-6, msg=f"row-major part of image {b}")
+        assert not bool(torch.isnan(d0).any()) and not bool(torch.isnan(d1).any())
+        return
+    if kind == "conv_pred_bce":
+        # round 6: the last decoder convolution with the predictor + criterion in its epilogue -- x, dX 4.3 GB each, the logits 1.5 GB; the table of target positions
+        # (2 ints per plane in LDS) bounds the batch at 16 outputs to B <= 84, so the images are tall: 512 x 2048
+        iu = pkg("utils.image_utils")
+        B, H, W, pco, S = 66, 512, 2048, 12, 4200
+        assert lib.ynet_conv2d_winograd_pred_bce_supported(B, H, W, 32, 32, pco, 31) == 1
+        x = torch.randn(B, 32, H, W, device=dev, generator=g).relu_()
+        w3, b3 = rnd(32, 32, 3, 3, seed=2, scale=0.1).to(dev), rnd(32, seed=3, scale=0.1).to(dev)
+        w1, b1 = rnd(pco, 32, 1, 1, seed=4, scale=0.3).to(dev), rnd(pco, seed=5, scale=0.1).to(dev)
+        tmpl = iu.analytic_gaussian_template(S, 31, 4, True, dev)
+        pos = (torch.rand(B * pco, 2, generator=torch.Generator().manual_seed(7)) * torch.tensor([W * 1.0, H * 1.0])).to(dev)
+        logits, dx, loss = torch.full((B, pco, H, W), float("nan"), device=dev), torch.full((B, 32, H, W), float("nan"), device=dev), torch.empty((), device=dev)
+        ws = torch.zeros(lib.ynet_pred_bce_workspace_bytes() // 8 + 1, device=dev, dtype=torch.float64)
+        assert x.numel() * 4 > (1 << 32) and dx.numel() * 4 > (1 << 32)
+        ops.conv2d_winograd_pred_bce_raw((x.data_ptr(), 32, 32 * H * W), ops.winograd_filter(ops.pack_weight(w3, 0), 32, 32, 0, 32), b3, ops.pack_weight(w1, 0), b1, pco, pos, tmpl,
+                                         logits, loss, dx, ws, B, H, W, 1000.0)
+        n = B * pco * H * W
+        tot = 0.0
+        for b in range(B):
+            yb = torch.relu(F.conv2d(x[b:b + 1].double(), w3.double(), b3.double(), padding=1))
+            zb = F.conv2d(yb, w1.double(), b1.double())
+            tb = ops.gather_patches(tmpl, pos[b * pco:(b + 1) * pco], H, W).view(1, pco, H, W).double()
+            tot += float(F.binary_cross_entropy_with_logits(zb, tb, reduction="sum"))
+            if b in picks(32 * H * W * 4, B) + picks(pco * H * W * 4, B):
+                close(logits[b:b + 1], zb, rtol=1e-4, scale_rel=2e-6, msg=f"logits of image {b}")
+                gz = (torch.sigmoid(zb) - tb) * (1000.0 / n)
+                gx = F.conv_transpose2d(gz, w1.double()) * (yb > 0)
+                bad = ((dx[b:b + 1].double() - gx).abs() > 1e-4 * float(gx.abs().max())).double().mean()
+                assert float(bad) <= 1e-3, (b, float(bad))      # (isolated ReLU flips where the pre-activation is within fp32 rounding of zero)
+        assert abs(float(loss) - tot / n) <= 2e-6 * tot / n and not bool(torch.isnan(dx).any()) and not bool(torch.isnan(logits).any())
         return
     if kind.startswith("winograd16"):
         B, H, W = 1040, 128, 128              # x, y 4.4 GB each
